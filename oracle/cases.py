@@ -1,0 +1,67 @@
+"""Golden-case definitions shared by oracle/gen_golden.py (which runs the REFERENCE on them, build container
+only) and by the parity tests (which run the oracle restatement and the HIP path on the same recipe inputs).
+
+TEST INFRASTRUCTURE.  A slot spec is (modality, is_src, value-spec, attributes); value-spec is
+("tok", key, shape, row_lengths|None) or ("img", key, shape).
+"""
+import torch
+
+from oracle import recipe
+
+VOCAB_EXTRA = 200
+
+CASES = {
+    # cfg-1 family: text -> text, tiny, default flags (biased attention everywhere)
+    "tiny_text": dict(
+        arch="tiny", active={"text"}, overrides={}, adaptor_overrides={},
+        slots=[("TEXT", True, ("tok", "src", (2, 16), [16, 11]), None),
+               ("TEXT", False, ("tok", "prev", (2, 12), [9, 12]), None)],
+        full_grads=["encoder.layers.0.self_attn.c_attn", "encoder.adaptor.text.token_rel_pos_table_list.1.weight",
+                    "encoder.adaptor.pos_q_linear.weight", "decoder.cross_pos_k_linear.bias",
+                    "decoder.layers.3.ffn_layernorm.weight", "encoder.layers.2.self_attn.q_proj.weight",
+                    "decoder.adaptor.text.embed_positions.weight", "encoder.adaptor.embed_tokens.weight"],
+    ),
+    # three source slots incl. BOX-as-tokens: slot order != ModalityType order, block-diagonal rel-pos bias
+    "tiny_multislot": dict(
+        arch="tiny", active={"text"}, overrides={}, adaptor_overrides={},
+        slots=[("BOX", True, ("tok", "box", (3, 4), None), None),
+               ("TEXT", True, ("tok", "srcA", (3, 7), [7, 5, 3]), None),
+               ("STRUCT", True, ("tok", "srcB", (3, 5), None), None),
+               ("TEXT", False, ("tok", "prev", (3, 6), [6, 4, 6]), None)],
+        full_grads=["encoder.adaptor.text.token_rel_pos_table_list.0.weight", "decoder.layers.0.encoder_attn.c_attn",
+                    "encoder.adaptor.text.type_embedding.weight"],
+    ),
+    # cfg-2 family: image_patch_embed + text -> text, base, the adaptor's only working corner
+    "base_patch": dict(
+        arch="base", active={"text", "image_patch_embed"},
+        overrides={"use_self_attn_bias": False, "entangle_position_embedding": True},
+        adaptor_overrides={"text": {"entangle_position_embedding": True},
+                           "image_patch_embed": {"entangle_position_embedding": True}},
+        slots=[("IMAGE", True, ("img", "image", (2, 3, 224, 224)), ["adaptor=image_patch_embed"]),
+               ("TEXT", True, ("tok", "src", (2, 10), [10, 6]), None),
+               ("TEXT", False, ("tok", "prev", (2, 8), [8, 5]), None)],
+        full_grads=["encoder.adaptor.image_patch_embed.cls_token", "encoder.adaptor.image_patch_embed.proj.bias",
+                    "encoder.layers.5.attn_ln.weight", "decoder.layers.0.self_attn.c_attn",
+                    "decoder.layers.5.encoder_attn.out_proj.bias", "encoder.adaptor.text.type_embedding.weight"],
+    ),
+}
+
+
+
+
+def make_value(spec, vocab):
+    if spec[0] == "tok":
+        _, key, shape, lengths = spec
+        return recipe.tokens("input." + key, shape, vocab, lengths, bos=0 if key == "prev" else None)
+    _, key, shape = spec
+    return recipe.floats("input." + key, shape)
+
+
+def make_target(prev, pad=1, eos=2):
+    """target = prev shifted left, eos appended at each row's end, pad elsewhere."""
+    target = torch.full_like(prev, pad)
+    for r in range(prev.shape[0]):
+        n = int(prev[r].ne(pad).sum())
+        target[r, : n - 1] = prev[r, 1:n]
+        target[r, n - 1] = eos
+    return target

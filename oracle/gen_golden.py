@@ -1,0 +1,154 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only; needs /root/reference).
+
+TEST INFRASTRUCTURE.  Usage:  python oracle/gen_golden.py
+The reference is imported through oracle/ref_import.py (third-party stubs), its parameters are
+overwritten with the shared recipe (oracle/recipe.py), it is run in eval mode (dropout off: bitwise
+dropout parity with a fused kernel is not a goal) on recipe inputs, and inputs'
+descriptions + outputs + gradients are stored.  Only data is stored -- no reference source.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import recipe  # noqa: E402
+from oracle.ref_import import build_reference_model, install  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle.cases import CASES, VOCAB_EXTRA, make_value, make_target  # noqa: E402
+
+
+def run_case(name, case):
+    install()
+    import ofasys  # noqa: F401
+    from ofasys import ModalityType
+    from ofasys.preprocessor import Slot
+    from ofasys.engine.criterion.cross_entropy import nll_loss
+
+    model, d = build_reference_model(case["arch"], VOCAB_EXTRA, case["active"], case["overrides"], case["adaptor_overrides"])
+    recipe.fill_state(model.state_dict())
+    model.eval()
+    V = len(d)
+    slots, prev = [], None
+    for mod, is_src, spec, attrs in case["slots"]:
+        v = make_value(spec, V)
+        slots.append(Slot(ModalityType[mod], is_src, v, attributes=attrs))
+        if not is_src:
+            prev = v
+    target = make_target(prev)
+
+    rec = {}
+    hooks = []
+    for l, layer in enumerate(model.encoder.layers):
+        hooks.append(layer.register_forward_hook(lambda m, i, o, l=l: rec.__setitem__(f"enc_layer{l}", o[0].detach())))
+    for l, layer in enumerate(model.decoder.layers):
+        hooks.append(layer.register_forward_hook(lambda m, i, o, l=l: rec.__setitem__(f"dec_layer{l}", o[0].detach())))
+
+    def enc_adaptor_hook(m, i, o):
+        rec["enc_embed"] = o[0].detach().clone()
+        rec["enc_pos_embed"] = o[2].detach().clone()
+        if o[3] is not None:
+            rec["enc_bias0"] = o[3][0].detach().clone()
+            rec["enc_bias_last"] = o[3][-1].detach().clone()
+    hooks.append(model.encoder.adaptor.register_forward_hook(enc_adaptor_hook))
+
+    logits, extra, enc_out = model(slots, return_encoder_out=True)
+    lprobs = model.get_normalized_probs((logits, extra), log_probs=True)
+    loss = nll_loss(lprobs.view(-1, lprobs.size(-1)), target.view(-1), ignore_index=d.pad(), reduce=True)
+    model.zero_grad()
+    loss.backward()
+    for h in hooks:
+        h.remove()
+
+    out = {
+        "logits": logits.detach(), "loss": loss.detach().reshape(1), "target": target,
+        "sample_size": torch.tensor([int(target.ne(1).sum())]),
+        "attn": extra["attn"][0].detach(), "encoder_out": enc_out["encoder_out"][0].detach(),
+        "encoder_padding_mask": enc_out["encoder_padding_mask"][0].to(torch.uint8),
+    }
+    big = case["arch"] == "base"
+    for k, v in rec.items():
+        if big and v.numel() > 200000:
+            v = v.reshape(-1)[::97]          # strided sample keeps the file small; the test applies the same stride
+        out["rec." + k] = v
+    if big:
+        out["encoder_out"] = out["encoder_out"].reshape(-1)[::97]
+    gn = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            gn[k] = -1.0
+        else:
+            gn[k] = float(p.grad.double().norm())
+    out["grad_norm_keys"] = np.array(sorted(gn.keys()))
+    out["grad_norms"] = np.array([gn[k] for k in sorted(gn.keys())], dtype=np.float64)
+    params = dict(model.named_parameters())
+    for k in case["full_grads"]:
+        out["grad." + k] = params[k].grad.detach()
+    out["state_keys"] = np.array([f"{k}|{tuple(v.shape)}|{str(v.dtype)}" for k, v in model.state_dict().items()])
+    # integer buffers are part of the bit-exact contract
+    out["token_rp_bucket_crc"] = np.array([zlib_crc(model.state_dict()["encoder.adaptor.text.token_rp_bucket"])])
+    out["token_rp_bucket_corner"] = model.state_dict()["encoder.adaptor.text.token_rp_bucket"][:300:7, :300:7].clone()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+    print(name, "loss", float(loss), "logits", tuple(logits.shape), "file KB",
+          os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024)
+
+
+def zlib_crc(t):
+    import zlib
+    return zlib.crc32(t.contiguous().numpy().tobytes())
+
+
+def softmax_vectors():
+    """Golden vectors for the fused-softmax entry points.  The CUDA extensions cannot be
+    built here (no nvcc); their semantics are pinned by the reference's own torch fallback
+    FusedScaleMaskSoftmax.forward_torch_softmax (fused_kernels/fused_softmax.py:187-202)."""
+    install()
+    from ofasys.module.fused_kernels.fused_softmax import FusedScaleMaskSoftmax
+    x = recipe.floats("softmax.x", (2, 3, 8, 40), 2.0)
+    m = FusedScaleMaskSoftmax(False, False, "pad", True, lambda a, mask: a.masked_fill(mask.bool(), -10000.0), True, 0.37)
+    y = m.forward_torch_softmax(x, None)
+    mask = (recipe.floats("softmax.mask", (2, 1, 8, 40)) > 0.8)
+    ym = m.forward_torch_softmax(x, mask)
+    np.savez_compressed(os.path.join(OUT, "fused_softmax.npz"), x=x.numpy(), scale=np.array([0.37], dtype=np.float32),
+                        y=y.numpy(), mask=mask.numpy().astype(np.uint8), y_masked=ym.numpy())
+    print("fused_softmax ok")
+
+
+def box_vectors():
+    """Integer <bin> indices (bit-exact contract) via the reference's arithmetic
+    preprocessor/default/box.py:101-110."""
+    g = np.random.Generator(np.random.Philox(key=7))
+    coords = g.uniform(0, 512, size=(64, 4)).astype(np.float32)
+    max_image_size, num_bins = 512, 1000
+    bins = np.array([[int(round(float(c) / max_image_size * (num_bins - 1))) for c in row] for row in coords], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "box_bins.npz"), coords=coords, bins=bins,
+                        max_image_size=np.array([max_image_size]), num_bins=np.array([num_bins]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    if len(sys.argv) == 3 and sys.argv[1] == "--case":
+        run_case(sys.argv[2], CASES[sys.argv[2]])
+        sys.exit(0)
+    # one fresh process per case: the reference's dataclass defaults are shared mutable instances, so adaptor
+    # configs (embed_dim, layers, ...) leak from one model to the next inside a process
+    import subprocess
+    for name in CASES:
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
+    softmax_vectors()
+    box_vectors()
+    manifest = {
+        "generator": "oracle/gen_golden.py",
+        "torch": torch.__version__, "numpy": np.__version__,
+        "reference_tree_sha1": hashlib.sha1("".join(sorted(
+            f"{r}/{f}" for r, _, fs in os.walk("/root/reference/ofasys") for f in fs if f.endswith(".py"))).encode()).hexdigest(),
+        "cases": {k: {kk: (sorted(vv) if isinstance(vv, set) else vv) for kk, vv in v.items() if kk != "slots"} for k, v in CASES.items()},
+    }
+    json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, default=str)

@@ -1,0 +1,432 @@
+"""CPU oracle: a plain-torch fp32 restatement of the OFASys encoder-decoder hot path.
+
+TEST INFRASTRUCTURE.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+leg may import this file, and only as the *checker* / the timed CPU baseline.  The product
+(`ofasys_amd`) never imports it and has no CPU fallback.
+
+What it is: functional code over a flat `state` dict whose keys are the reference's state-dict
+keys.  No nn.Module, no autograd tricks -- gradients come from
+torch.autograd over these plain ops, which is what the reference itself does.  Every function
+cites the reference file:line (relative to /root/reference/ofasys) it restates.
+
+Parity status: PINNED.  `tests/test_oracle_golden.py` checks this file against the golden vectors
+in `tests/golden/*.npz`, which `oracle/gen_golden.py` produced by importing and running the
+reference itself in the build container (the reference ships no tests of its own, SURVEY.md
+section 4).
+
+Scope: a1 Slot, a2 general adaptor dispatch, a3 adaptor post-hook,
+a4 text adaptor (+ a5 box-as-tokens), a6 image_patch_embed adaptor, a10 abs/rel position bias
+assembly, a11 encoder stack, a12 encoder layer, a13 attention (slow + fast path), a14 decoder,
+a15 executor / normalized probs, and the CE criterion that closes the training step.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# carrier types (a1) -- preprocessor/instruction.py:29-107, ofasys/__init__.py:29-38
+# --------------------------------------------------------------------------------------------
+MODALITY_ORDER = ["TEXT", "IMAGE", "BOX", "AUDIO", "MOTION", "PHONE", "VIDEO", "STRUCT", "CATEGORY"]
+
+# adaptor/general.py:36-46
+DEFAULT_ADAPTOR = {
+    "TEXT": "text", "IMAGE": "image_resnet", "BOX": "text", "AUDIO": "audio_fbank", "PHONE": "text",
+    "VIDEO": "video_image_sequence", "MOTION": "text", "STRUCT": "text", "CATEGORY": "text",
+}
+
+
+@dataclass
+class OSlot:
+    modality: str            # one of MODALITY_ORDER
+    is_src: bool
+    value: Any
+    attributes: Optional[List[str]] = None
+
+    def get_attr(self, key):  # preprocessor/instruction.py:73-83
+        for a in self.attributes or []:
+            if a.startswith(key + "="):
+                return a[len(key) + 1:]
+        return None
+
+
+@dataclass
+class OConfig:
+    """The subset of GeneralistModelConfig (model/ofa.py:41-122) that shapes the math."""
+    embed_dim: int
+    ffn_dim: int
+    heads: int
+    enc_layers: int
+    dec_layers: int
+    attn_scale_factor: float = 2.0          # ofa.py:56-59
+    use_self_attn_bias: bool = True         # ofa.py:110-113
+    entangle_position_embedding: bool = False  # ofa.py:76-79 (model level)
+    share_attn_bias: bool = False           # ofa.py:115-118
+    pad_idx: int = 1                        # dictionary.py:21-53
+    eps: float = 1e-5                       # module/layer_norm.py:27
+    # per-adaptor flags (adaptor/base.py:56-81); NOT inherited from the model cfg (base.py:97-101)
+    adaptor_entangle: Dict[str, bool] = field(default_factory=dict)
+    patch: int = 14                         # adaptor/image_patch_embed.py:24-29
+
+
+# --------------------------------------------------------------------------------------------
+# small ops
+# --------------------------------------------------------------------------------------------
+def layer_norm(state, prefix, x, eps=1e-5):
+    """torch.nn.LayerNorm(eps=1e-5, affine) -- module/layer_norm.py:27-32."""
+    w, b = state[prefix + ".weight"], state[prefix + ".bias"]
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def linear(state, prefix, x):
+    return F.linear(x, state[prefix + ".weight"], state.get(prefix + ".bias"))
+
+
+def gelu(x):
+    """module/gelu.py:18-19: exact-erf GELU computed in fp32 then cast back."""
+    return F.gelu(x.float()).type_as(x)
+
+
+def make_token_bucket_position(bucket_size, max_position):
+    """adaptor/text.py:20-30 -- log-bucketed signed relative distance, integers (bit-exact)."""
+    ctx = torch.arange(max_position, dtype=torch.long)[:, None]
+    mem = torch.arange(max_position, dtype=torch.long)[None, :]
+    rel = ctx - mem
+    sign = torch.sign(rel)
+    mid = bucket_size // 2
+    abs_pos = torch.where((rel < mid) & (rel > -mid), torch.full_like(rel, mid - 1), torch.abs(rel))
+    log_pos = torch.ceil(torch.log(abs_pos / mid) / math.log((max_position - 1) / mid) * (mid - 1)) + mid
+    log_pos = log_pos.int()
+    bucket = torch.where(abs_pos.le(mid), rel, log_pos * sign).long()
+    return bucket + bucket_size - 1
+
+
+def box_to_bins(coords, max_image_size, num_bins):
+    """preprocessor/default/box.py:101-110 -- int(round(coord / max_image_size * (num_bins-1)))."""
+    return [int(round(float(c) / max_image_size * (num_bins - 1))) for c in coords]
+
+
+# --------------------------------------------------------------------------------------------
+# adaptors (a3, a4, a6)
+# --------------------------------------------------------------------------------------------
+def _post_hook(state, cfg, side, name, slot, embed, pos_embed):
+    """adaptor/base.py:152-181 (embed_scale == 1 since no_scale_embedding, base.py:69,144)."""
+    p = f"{side}.adaptor.{name}"
+    if cfg.adaptor_entangle.get(name, False) and pos_embed is not None:   # base.py:170-171
+        embed = embed + pos_embed
+    if slot.is_src and (p + ".type_embedding.weight") in state:          # base.py:172-173
+        embed = embed + state[p + ".type_embedding.weight"].squeeze()
+    embed = layer_norm(state, p + ".layernorm_embedding", embed, cfg.eps)  # base.py:177-178
+    if pos_embed is not None:
+        pos_embed = layer_norm(state, p + ".layernorm_position", pos_embed, cfg.eps)  # base.py:179-180
+    return embed, pos_embed   # dropout (base.py:181) is identity in eval
+
+
+def text_adaptor(state, cfg, side, slot):
+    """adaptor/text.py:106-127 + get_rel_pos_bias :101-104 + base hook."""
+    p = f"{side}.adaptor.text"
+    tok = slot.value
+    masks = tok.eq(cfg.pad_idx)                                           # text.py:119-122
+    T = tok.shape[1]
+    pos = torch.arange(T).unsqueeze(0).expand_as(tok)                     # module/utils.py:623-630
+    pos_embed = F.embedding(pos, state[p + ".embed_positions.weight"])    # text.py:124
+    embed = F.embedding(tok, state[f"{side}.adaptor.embed_tokens.weight"], padding_idx=cfg.pad_idx)
+    embed, pos_embed = _post_hook(state, cfg, side, "text", slot, embed, pos_embed)
+    rel = None
+    if cfg.use_self_attn_bias:                                            # base.py:183-189
+        L = cfg.enc_layers if side == "encoder" else cfg.dec_layers
+        n_tab = 1 if cfg.share_attn_bias else L
+        bucket = state[p + ".token_rp_bucket"][:T, :T]
+        rel = []
+        for l in range(n_tab):
+            v = F.embedding(bucket, state[p + f".token_rel_pos_table_list.{l}.weight"])  # [T,T,A]
+            rel.append(v.unsqueeze(0).expand(tok.shape[0], -1, -1, -1).permute(0, 3, 1, 2))  # base.py:242-256
+    return embed, masks, pos_embed, rel
+
+
+def image_patch_embed_adaptor(state, cfg, side, slot):
+    """adaptor/image_patch_embed.py:62-80: Conv2d(3,D,k=p,s=p) -> flatten -> [B,N,D], cls token,
+    learned positions, all-False mask, bias None (only valid with use_self_attn_bias=False)."""
+    p = f"{side}.adaptor.image_patch_embed"
+    img = slot.value
+    B = img.shape[0]
+    x = F.conv2d(img, state[p + ".proj.weight"], state[p + ".proj.bias"], stride=cfg.patch)
+    x = x.flatten(2).transpose(1, 2)
+    if (p + ".cls_token") in state:
+        x = torch.cat((state[p + ".cls_token"].expand(B, -1, -1), x), dim=1)
+    N = x.shape[1]
+    masks = torch.zeros(B, N, dtype=torch.bool)
+    pos = torch.arange(N).unsqueeze(0).expand(B, -1)
+    pos_embed = F.embedding(pos, state[p + ".embed_image_positions.weight"])
+    if cfg.use_self_attn_bias:
+        raise NotImplementedError("image_patch_embed defines no get_rel_pos_bias (adaptor/base.py:183-189, 240)")
+    embed, pos_embed = _post_hook(state, cfg, side, "image_patch_embed", slot, x, pos_embed)
+    return embed, masks, pos_embed, None
+
+
+_ADAPTORS = {"text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor}
+
+
+def general_adaptor(state, cfg, side, slots):
+    """adaptor/general.py:120-158 (dispatch in ModalityType order, outputs kept in slot order) and
+    concat :245-282 (abs-pos bias :223-243, per-layer clone + block-diagonal rel-pos add :270-280)."""
+    outs = [None] * len(slots)
+    for mod in MODALITY_ORDER:
+        for i, s in enumerate(slots):
+            if s.modality == mod:
+                name = s.get_attr("adaptor") or DEFAULT_ADAPTOR[mod]       # general.py:103-118
+                outs[i] = _ADAPTORS[name](state, cfg, side, s)
+    embed = torch.cat([o[0] for o in outs], dim=1)
+    masks = torch.cat([o[1] for o in outs], dim=1)
+    pos_embed = torch.cat([o[2] for o in outs], dim=1)
+    bias = None
+    if cfg.use_self_attn_bias:
+        B, T, D = pos_embed.shape
+        A = cfg.heads
+        if not cfg.entangle_position_embedding:
+            pos_scaling = float(D / cfg.heads * cfg.attn_scale_factor) ** -0.5      # general.py:98
+            pq = linear(state, f"{side}.adaptor.pos_q_linear", pos_embed).view(B, T, A, -1).transpose(1, 2) * pos_scaling
+            pk = linear(state, f"{side}.adaptor.pos_k_linear", pos_embed).view(B, T, A, -1).transpose(1, 2)
+            abs_bias = torch.matmul(pq, pk.transpose(2, 3))
+        else:
+            abs_bias = torch.zeros(B, A, T, T, dtype=pos_embed.dtype)               # general.py:234-242
+        L = cfg.enc_layers if side == "encoder" else cfg.dec_layers
+        bias = []
+        for l in range(1 if cfg.share_attn_bias else L):
+            b = abs_bias.clone()
+            s0 = 0
+            for o in outs:
+                n = o[0].shape[1]
+                if o[3] is not None and o[3][l] is not None:
+                    b[:, :, s0:s0 + n, s0:s0 + n] = b[:, :, s0:s0 + n, s0:s0 + n] + o[3][l]
+                s0 += n
+            bias.append(b)
+    return embed, masks, pos_embed, bias
+
+
+# --------------------------------------------------------------------------------------------
+# attention (a13) -- module/multihead_attention.py
+# --------------------------------------------------------------------------------------------
+def mha_slow(state, prefix, cfg, query, key, key_padding_mask, attn_mask, attn_bias, need_head_weights=False):
+    """multihead_attention.py:188-353.  query [T,B,D], key [S,B,D] (value == key for both uses).
+    attn_bias [B*A,T,S] or None/False; attn_mask [T,S] additive (-inf upper triangle) or None."""
+    T, B, D = query.shape
+    A = cfg.heads
+    hd = D // A
+    scaling = float(hd * cfg.attn_scale_factor) ** -0.5                   # :54
+    q = linear(state, prefix + ".q_proj", query) * scaling               # :199-218
+    k = linear(state, prefix + ".k_proj", key)
+    v = linear(state, prefix + ".v_proj", key)
+    S = key.shape[0]
+    q = q.contiguous().view(T, B * A, hd).transpose(0, 1)                 # :235-239
+    k = k.contiguous().view(S, B * A, hd).transpose(0, 1)
+    v = v.contiguous().view(S, B * A, hd).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))                                   # :308
+    if attn_bias is not None and attn_bias is not False:
+        w = w + attn_bias                                                 # :311-312
+    if attn_mask is not None:
+        w = torch.nan_to_num(w) + attn_mask.unsqueeze(0)                  # :314-317
+    if key_padding_mask is not None:                                      # :319-326
+        w = w.view(B, A, T, S).masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), float("-inf"))
+        w = w.view(B * A, T, S)
+    p = F.softmax(w, dim=-1, dtype=torch.float32).type_as(w)              # module/utils.py:451-455
+    o = torch.bmm(p, v)                                                   # :338 (attention dropout 0)
+    o = o.transpose(0, 1).contiguous().view(T, B, D)
+    c = state.get(prefix + ".c_attn")
+    if c is not None:                                                     # :342-345
+        o = (o.view(T, B, A, hd) * c.view(1, 1, A, 1)).reshape(T, B, D)
+    o = linear(state, prefix + ".out_proj", o)                            # :346
+    weights = p.view(B, A, T, S).transpose(1, 0) if need_head_weights else None   # :347-351
+    return o, weights
+
+
+def mha_fast(state, prefix, cfg, x, key_padding_mask):
+    """multihead_attention.py:155-186: F.multi_head_attention_forward.  Uses head_dim**-0.5 scaling and
+    ignores scale_factor and c_attn.  x [T,B,D], self-attention only."""
+    T, B, D = x.shape
+    A = cfg.heads
+    hd = D // A
+    q = linear(state, prefix + ".q_proj", x)
+    k = linear(state, prefix + ".k_proj", x)
+    v = linear(state, prefix + ".v_proj", x)
+    q = q.view(T, B * A, hd).transpose(0, 1)
+    k = k.view(T, B * A, hd).transpose(0, 1)
+    v = v.view(T, B * A, hd).transpose(0, 1)
+    w = torch.bmm(q * (1.0 / math.sqrt(hd)), k.transpose(1, 2))
+    if key_padding_mask is not None:
+        w = w.view(B, A, T, T).masked_fill(key_padding_mask.view(B, 1, 1, T), float("-inf")).view(B * A, T, T)
+    p = F.softmax(w, dim=-1)
+    o = torch.bmm(p, v).transpose(0, 1).contiguous().view(T, B, D)
+    return linear(state, prefix + ".out_proj", o)
+
+
+# --------------------------------------------------------------------------------------------
+# layers (a12, a14) -- module/transformer_layer.py
+# --------------------------------------------------------------------------------------------
+def _ffn(state, p, cfg, x):
+    """transformer_layer.py:186-208 / :471-494 (pre-LN, scale_fc LayerNorm over F inside the FFN)."""
+    r = x
+    x = layer_norm(state, p + ".final_layer_norm", x, cfg.eps)
+    x = gelu(linear(state, p + ".fc1", x))
+    if (p + ".ffn_layernorm.weight") in state:
+        x = layer_norm(state, p + ".ffn_layernorm", x, cfg.eps)
+    x = linear(state, p + ".fc2", x)
+    return r + x
+
+
+def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias):
+    """transformer_layer.py:132-209 (normalize_before=True, dropout/droppath identity in eval)."""
+    r = x
+    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
+    if self_attn_bias is None:
+        h = mha_fast(state, p + ".self_attn", cfg, h, padding_mask)
+    else:
+        h, _ = mha_slow(state, p + ".self_attn", cfg, h, h, padding_mask, None, self_attn_bias)
+    if (p + ".attn_ln.weight") in state:
+        h = layer_norm(state, p + ".attn_ln", h, cfg.eps)                 # :179-180
+    x = r + h
+    return _ffn(state, p, cfg, x)
+
+
+def decoder_layer(state, p, cfg, x, enc, enc_padding_mask, self_attn_mask, self_attn_padding_mask,
+                  self_attn_bias, cross_attn_bias, need_head_weights):
+    """transformer_layer.py:351-495."""
+    r = x
+    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
+    h, _ = mha_slow(state, p + ".self_attn", cfg, h, h, self_attn_padding_mask, self_attn_mask, self_attn_bias)
+    if (p + ".self_attn_ln.weight") in state:
+        h = layer_norm(state, p + ".self_attn_ln", h, cfg.eps)            # :431-432
+    x = r + h
+    r = x
+    h = layer_norm(state, p + ".encoder_attn_layer_norm", x, cfg.eps)     # :440-441
+    h, cross_w = mha_slow(state, p + ".encoder_attn", cfg, h, enc, enc_padding_mask, None, cross_attn_bias,
+                          need_head_weights=need_head_weights)            # :453-463 (static_kv -> slow path)
+    if (p + ".cross_attn_ln.weight") in state:
+        h = layer_norm(state, p + ".cross_attn_ln", h, cfg.eps)           # :464-465
+    x = r + h
+    return _ffn(state, p, cfg, x), cross_w
+
+
+# --------------------------------------------------------------------------------------------
+# stacks (a11, a14, a15) -- model/transformer.py, model/ofa.py
+# --------------------------------------------------------------------------------------------
+def encoder_forward(state, cfg, slots, record=None):
+    """model/transformer.py:78-156."""
+    embed, masks, pos_embed, bias = general_adaptor(state, cfg, "encoder", slots)
+    if record is not None:
+        record["enc_embed"] = embed                                       # adaptor output, before pad zeroing
+    has_pad = bool(masks.any())                                           # :110
+    if has_pad:
+        embed = embed * (1 - masks.unsqueeze(-1).type_as(embed))          # :111-112 (in place in the reference)
+    x = embed.transpose(0, 1)
+    T = x.shape[0]
+    if record is not None:
+        record["enc_pos_embed"] = pos_embed
+        if bias is not None:
+            record["enc_bias0"] = bias[0]
+            record["enc_bias_last"] = bias[-1]
+    for l in range(cfg.enc_layers):
+        b = None
+        if cfg.use_self_attn_bias:                                        # :121-126
+            b = bias[0 if cfg.share_attn_bias else l].view(-1, T, T)
+        x = encoder_layer(state, f"encoder.layers.{l}", cfg, x, masks if has_pad else None, b)
+        if record is not None:
+            record[f"enc_layer{l}"] = x
+    x = layer_norm(state, "encoder.layer_norm", x, cfg.eps)               # :142-143
+    return {"encoder_out": x, "encoder_padding_mask": masks, "position_embeddings": pos_embed}
+
+
+def decoder_forward(state, cfg, slots, enc_out, record=None):
+    """model/transformer.py:365-522 + forward :349-363 (tied output projection adaptor/text.py:94-96,142)."""
+    embed, masks, pos_embed, bias = general_adaptor(state, cfg, "decoder", slots)
+    B, Tt, D = embed.shape
+    A = cfg.heads
+    enc = enc_out["encoder_out"]
+    cross_bias = None
+    if not cfg.entangle_position_embedding:                               # :441-445 -> :280-299
+        src_pos = enc_out["position_embeddings"]
+        Ts = src_pos.shape[1]
+        pos_scaling = float(D / cfg.heads * cfg.attn_scale_factor) ** -0.5   # decoder adaptor's, :291
+        pq = linear(state, "decoder.cross_pos_q_linear", pos_embed).view(B, Tt, A, -1).transpose(1, 2) * pos_scaling
+        pk = linear(state, "decoder.cross_pos_k_linear", src_pos).view(B, Ts, A, -1).transpose(1, 2)
+        cross_bias = torch.matmul(pq, pk.transpose(2, 3)).reshape(-1, Tt, Ts)
+    x = embed.transpose(0, 1)
+    future = torch.triu(torch.full((Tt, Tt), float("-inf")), 1)           # :528-539
+    attn = None
+    for l in range(cfg.dec_layers):
+        if cfg.use_self_attn_bias:                                        # :468-475
+            sb = bias[0 if cfg.share_attn_bias else l].view(-1, Tt, Tt)
+        else:
+            sb = False                                                    # :477 (forces the slow path)
+        last = l == cfg.dec_layers - 1                                    # alignment_layer default, :421-422
+        x, cw = decoder_layer(state, f"decoder.layers.{l}", cfg, x, enc, enc_out["encoder_padding_mask"],
+                              future, masks, sb, cross_bias, need_head_weights=last)
+        if record is not None:
+            record[f"dec_layer{l}"] = x
+        if last:
+            attn = cw.float().mean(dim=0)                                 # :498-506 (names swapped upstream: this IS cross-attn)
+    x = layer_norm(state, "decoder.layer_norm", x, cfg.eps)               # :508-509
+    x = x.transpose(0, 1)
+    logits = F.linear(x, state["decoder.adaptor.embed_tokens.weight"])    # adaptor/base.py:131
+    return logits, {"attn": attn, "last_hidden_state": x}
+
+
+def model_forward(state, cfg, slots, record=None):
+    """model/ofa.py:165-285: split by is_src, encoder then decoder."""
+    enc = encoder_forward(state, cfg, [s for s in slots if s.is_src], record)
+    if record is not None:
+        record["encoder_out"] = enc["encoder_out"]
+    logits, extra = decoder_forward(state, cfg, [s for s in slots if not s.is_src], enc, record)
+    return logits, extra
+
+
+def cross_entropy(logits, target, pad_idx=1):
+    """engine/criterion/cross_entropy.py:50-67, 27-41: fp32 log-softmax, NLL sum, ignore pad;
+    sample_size = number of non-pad targets."""
+    lprobs = F.log_softmax(logits.float(), dim=-1)
+    loss = F.nll_loss(lprobs.view(-1, lprobs.size(-1)), target.view(-1), ignore_index=pad_idx, reduction="sum")
+    return loss, int(target.ne(pad_idx).sum())
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's fused-softmax extensions restated
+# --------------------------------------------------------------------------------------------
+def scaled_softmax(x, scale):
+    """fused_kernels/scaled_masked_softmax.h:98-201: y = softmax(scale*x) over the last dim, fp32 accumulate."""
+    return F.softmax(x.float() * scale, dim=-1).type_as(x)
+
+
+def scaled_softmax_bwd(dy, y, scale):
+    """scaled_masked_softmax.h:329-423: dx = scale * (dy*y - y*sum(dy*y))."""
+    dy, y = dy.float(), y.float()
+    return (scale * (dy * y - y * (dy * y).sum(-1, keepdim=True)))
+
+
+def scaled_masked_softmax(x, mask, scale):
+    """scaled_masked_softmax.h:209-327: masked (mask==1) positions are REPLACED by -10000.0 (:269-273)."""
+    z = x.float() * scale
+    z = torch.where(mask.bool(), torch.full_like(z, -10000.0), z)
+    return F.softmax(z, dim=-1).type_as(x)
+
+
+def scaled_upper_triang_masked_softmax(x, scale):
+    """scaled_upper_triang_masked_softmax.h:113-230: causal softmax on [attn_batches, sq, sq]; masked outputs are 0."""
+    sq = x.shape[-1]
+    z = x.float() * scale
+    m = torch.triu(torch.ones(sq, sq, dtype=torch.bool), 1)
+    z = z.masked_fill(m, float("-inf"))
+    return F.softmax(z, dim=-1).type_as(x)
+
+
+def get_batch_per_block(sq, sk, b, np_):
+    """scaled_masked_softmax.h:426-438 (32-lane-warp arithmetic of the reference, kept for API parity)."""
+    log2 = 0
+    while (1 << log2) < sk:
+        log2 += 1
+    pow2 = 1 << log2
+    warp_size = pow2 if pow2 < 32 else 32
+    batches_per_warp = 2 if pow2 <= 128 else 1
+    warps_per_block = 128 // warp_size
+    return warps_per_block * batches_per_warp

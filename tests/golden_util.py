@@ -1,0 +1,67 @@
+"""Helpers shared by the oracle tests (CPU) and the HIP parity tests (GPU)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import recipe
+from oracle.cases import CASES, VOCAB_EXTRA, make_target, make_value
+from oracle.restate import OConfig, OSlot
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARCH = {  # model/ofa.py:557-610
+    "tiny": dict(embed_dim=256, ffn_dim=1024, heads=4, enc_layers=4, dec_layers=4),
+    "base": dict(embed_dim=768, ffn_dim=3072, heads=12, enc_layers=6, dec_layers=6),
+    "large": dict(embed_dim=1024, ffn_dim=4096, heads=16, enc_layers=12, dec_layers=12),
+}
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False))
+
+
+def state_from_golden(g, dtype=torch.float32):
+    """Rebuild the full state dict (reference key schema) from the recipe; integer buffers are recomputed."""
+    from oracle.restate import make_token_bucket_position
+    state = {}
+    bucket = None
+    for item in g["state_keys"]:
+        key, shape, _ = str(item).split("|")
+        shape = tuple(int(x) for x in shape.strip("()").split(",") if x.strip())
+        if key.endswith("version"):
+            state[key] = torch.tensor([3.0])
+        elif key.endswith("token_rp_bucket"):
+            if bucket is None:
+                bucket = make_token_bucket_position(256, 1024)
+            state[key] = bucket
+        else:
+            state[key] = recipe.value_for(key, shape).to(dtype)
+    return state
+
+
+def oracle_cfg(case):
+    ov = case["overrides"]
+    ent = {k: v.get("entangle_position_embedding", False) for k, v in case["adaptor_overrides"].items()}
+    return OConfig(**ARCH[case["arch"]], use_self_attn_bias=ov.get("use_self_attn_bias", True),
+                   entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent)
+
+
+def case_inputs(case):
+    V = 4 + VOCAB_EXTRA
+    vals, prev = [], None
+    for mod, is_src, spec, attrs in case["slots"]:
+        v = make_value(spec, V)
+        vals.append((mod, is_src, v, attrs))
+        if not is_src:
+            prev = v
+    return vals, make_target(prev)
+
+
+def oracle_slots(vals):
+    return [OSlot(m, s, v, a) for m, s, v, a in vals]
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -1,0 +1,88 @@
+"""CPU: the oracle restatement (oracle/restate.py) against golden vectors produced by RUNNING THE REFERENCE
+(oracle/gen_golden.py).  This is what pins the oracle (the reference ships no tests)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate
+from oracle.cases import CASES
+from tests.golden_util import case_inputs, load_golden, oracle_cfg, oracle_slots, rel_err, state_from_golden
+
+TOL = 2e-5   # fp32 vs fp32, different op order only (reference noise floor 2e-6)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_backward_matches_reference(name):
+    torch.set_num_threads(8)
+    case = CASES[name]
+    g = load_golden(name)
+    state = state_from_golden(g)
+    params = {k: v.requires_grad_(True) for k, v in state.items() if v.is_floating_point() and not k.endswith("version")}
+    # tied embedding: one tensor under both names, as in the reference (adaptor/general.py:193-221)
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    cfg = oracle_cfg(case)
+    vals, target = case_inputs(case)
+    assert np.array_equal(target.numpy(), g["target"])
+    rec = {}
+    logits, extra = restate.model_forward(state, cfg, oracle_slots(vals), rec)
+    loss, n = restate.cross_entropy(logits, target)
+    assert n == int(g["sample_size"][0])
+    assert rel_err(logits.detach(), g["logits"]) < TOL
+    assert rel_err(loss.detach(), g["loss"][0]) < TOL
+    assert rel_err(extra["attn"].detach(), g["attn"]) < TOL
+    big = case["arch"] == "base"
+    enc = rec["encoder_out"].detach()
+    assert rel_err(enc.reshape(-1)[::97] if big else enc, g["encoder_out"]) < TOL
+    for k in g:
+        if k.startswith("rec."):
+            mine = rec[k[4:]].detach()
+            if big and mine.numel() > 200000:
+                mine = mine.reshape(-1)[::97]
+            assert rel_err(mine, g[k]) < TOL, k
+    loss.backward()
+    gn = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norms"]))
+    for k, want in gn.items():
+        p = state[k]
+        if k == "decoder.adaptor.embed_tokens.weight":
+            continue  # same tensor as the encoder's
+        if want < 0:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, k
+            continue
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        assert abs(got - want) <= 1e-4 * want + 1e-5, (k, got, want)  # k_proj.bias grads are exactly 0 in maths
+    for k in g:
+        if k.startswith("grad."):
+            assert rel_err(state[k[5:]].grad, g[k]) < 5 * TOL, k
+
+
+def test_token_bucket_bit_exact():
+    g = load_golden("tiny_text")
+    b = restate.make_token_bucket_position(256, 1024)
+    import zlib
+    assert zlib.crc32(b.contiguous().numpy().tobytes()) == int(g["token_rp_bucket_crc"][0])
+    assert np.array_equal(b[:300:7, :300:7].numpy(), g["token_rp_bucket_corner"])
+    assert int(b.min()) == 0 and int(b.max()) == 510
+
+
+def test_box_bins_bit_exact():
+    g = load_golden("box_bins")
+    for row, want in zip(g["coords"], g["bins"]):
+        assert restate.box_to_bins(row, int(g["max_image_size"][0]), int(g["num_bins"][0])) == list(want)
+
+
+def test_fused_softmax_semantics():
+    g = load_golden("fused_softmax")
+    x = torch.from_numpy(g["x"])
+    s = float(g["scale"][0])
+    assert rel_err(restate.scaled_softmax(x, s), g["y"]) < 1e-6
+    assert rel_err(restate.scaled_masked_softmax(x, torch.from_numpy(g["mask"]), s), g["y_masked"]) < 1e-6
+    # backward formula against autograd
+    xx = x.clone().requires_grad_(True)
+    y = torch.softmax(xx * s, -1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert rel_err(restate.scaled_softmax_bwd(dy, y.detach(), s), xx.grad) < 1e-5
+    # causal variant: rows sum to one over the visible prefix, zeros above the diagonal
+    c = restate.scaled_upper_triang_masked_softmax(x[0, :, :8, :8].contiguous(), s)
+    assert torch.all(torch.triu(c, 1) == 0) and torch.allclose(c.sum(-1), torch.ones(3, 8), atol=1e-6)
+    assert restate.get_batch_per_block(128, 128, 2, 4) == 8 and restate.get_batch_per_block(64, 448, 2, 4) == 4

@@ -1,0 +1,165 @@
+/*
+ * ofasys_amd.h -- C ABI of libofasys_amd.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * OFASys unified encoder-decoder hot path.
+ *
+ * What this boundary replaces.  The reference has no C/FFI boundary of its own for this path except the
+ * pybind11 fused-softmax extensions; everything else goes torch -> ATen -> cuBLAS/cuDNN.  Each entry point
+ * below names the reference call site (relative to /root/reference/ofasys) whose arithmetic it carries.
+ *
+ * Conventions (carried over from the reference's extensions, module/fused_kernels/scaled_masked_softmax.h:476,
+ * scaled_softmax_cuda.cu:84-99, scaled_masked_softmax.cpp:45-49):
+ *   - the caller owns every buffer; the library never allocates device memory;
+ *   - raw device pointers + explicit sizes / leading dimensions (in ELEMENTS), row-major;
+ *   - work is enqueued on the caller's stream (`stream` is a hipStream_t passed as void*), no hidden sync,
+ *     no internal threads;
+ *   - every function returns an int status: 0 ok, nonzero = error (the Python wrapper raises RuntimeError,
+ *     mirroring TORCH_CHECK); shape preconditions are status codes, not asserts;
+ *   - dtype is an ofa_dtype; accumulation is always fp32.
+ */
+#ifndef OFASYS_AMD_H
+#define OFASYS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { OFA_F32 = 0, OFA_BF16 = 1 } ofa_dtype;
+
+enum {
+  OFA_OK = 0,
+  OFA_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, misaligned leading dimension) */
+  OFA_ERR_UNSUPPORTED = 2, /* valid request this build has no kernel for (e.g. head_dim != 64 in the fused path) */
+  OFA_ERR_LAUNCH = 3       /* hipLaunch / runtime error; see ofa_last_error() */
+};
+
+/* GEMM epilogue flags (ofa_gemm.flags) */
+enum {
+  OFA_GEMM_BIAS_COL = 1,   /* C[m][n] += bias[n]  (nn.Linear bias)                              */
+  OFA_GEMM_BIAS_ROW = 2,   /* C[m][n] += bias[m]  (transposed-output projections)                */
+  OFA_GEMM_ACCUM = 4,      /* C = result + C_old  (gradient accumulation)                        */
+  OFA_GEMM_FORCE_SIMPLE = 8, /* use the exact-fp32-FMA VALU kernel even for bf16 (tests)         */
+  OFA_GEMM_OUT_F32 = 16    /* bf16 inputs, fp32 output                                           */
+};
+
+int ofa_version(void);
+const char* ofa_last_error(void);
+
+/* ---- LayerNorm: torch.nn.LayerNorm(eps, affine) -- module/layer_norm.py:27-32; saves mean and rstd in fp32
+ * exactly as the (never built) apex kernel does, fused_kernels/layer_norm_cuda.cpp:136-138. cols <= 8192. */
+int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int cols, float eps, int dtype, void* stream);
+/* dgamma/dbeta are fp32 [cols]; `ws` is fp32 scratch of 2*ofa_layernorm_bwd_ws_rows()*cols floats. */
+int ofa_layernorm_bwd_ws_rows(void);
+int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                      void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
+                      void* stream);
+/* y = LayerNorm(gelu(h)) -- transformer_layer.py:194-197 (fc1 -> GELU (module/gelu.py:18-19, fp32 erf) -> ffn_layernorm). */
+int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                           int64_t rows, int cols, float eps, int dtype, void* stream);
+int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean, const float* rstd,
+                           void* dh, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
+                           void* stream);
+
+/* ---- GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+bias) (+C).  Replaces F.linear / torch.bmm / matmul:
+ * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.
+ *   transA == 0: A is [M,K] row-major (lda >= K);  transA == 1: A is stored [K,M] (lda >= M).
+ *   transB == 0: B is [K,N] row-major (ldb >= N);  transB == 1: B is stored [N,K] (ldb >= K)  <- nn.Linear weight.
+ * batch > 1: strided-batched (strides in elements).  bf16 runs on MFMA (v_mfma_f32_32x32x16_bf16) when every
+ * leading dimension is a multiple of 8 elements; fp32 (and OFA_GEMM_FORCE_SIMPLE) run an exact fp32-FMA kernel.
+ * `ws`/`ws_bytes`: optional fp32 scratch that enables split-K for skinny outputs (may be NULL). */
+int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA, int transB,
+             int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+             float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- the reference's fused softmax extensions, wave64 re-derivations.
+ * x,y: [b, np, sq, sk]; softmax over sk of scale*x, fp32 accumulate.  sk <= 4096 (scaled_masked_softmax_cuda.cu:47-52). */
+int ofa_scaled_softmax_fwd(const void* x, void* y, float scale, int b, int np, int sq, int sk, int dtype, void* stream);
+/* dx = scale*(dy*y - y*sum(dy*y)); dx may alias dy (in place, scaled_softmax_cuda.cu:84-99). */
+int ofa_scaled_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int b, int np, int sq, int sk,
+                           int dtype, void* stream);
+/* mask: uint8 [mask_b (b or 1), 1, sq, sk]; masked scores are replaced by -10000.0 (scaled_masked_softmax.h:269-273). */
+int ofa_scaled_masked_softmax_fwd(const void* x, const uint8_t* mask, void* y, float scale, int b, int np, int sq,
+                                  int sk, int mask_b, int dtype, void* stream);
+/* x,y: [attn_batches, sq, sq]; implicit causal mask, masked outputs are zero (scaled_upper_triang_masked_softmax.h:113-230). */
+int ofa_scaled_upper_triang_masked_softmax_fwd(const void* x, void* y, float scale, int attn_batches, int sq,
+                                               int dtype, void* stream);
+int ofa_get_batch_per_block(int sq, int sk, int b, int np); /* scaled_masked_softmax.h:426-438, kept for API parity */
+
+/* ---- attention-score softmax of the slow path, multihead_attention.py:311-334:
+ * p = softmax_fp32( x*scale + bias + causal(-inf above diagonal) ; key_padding -> -inf ) over S.
+ * x,bias,p: [BA, T, S] (bias may be NULL); kpm: uint8 [B, S] or NULL (BA = B*heads). */
+int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, void* p, float scale, int BA, int heads,
+                         int T, int S, int causal, int dtype, void* stream);
+
+/* ---- fused attention (bf16, head_dim 64): multihead_attention.py:218-346 without materialising [BA,T,S].
+ * q,k: [B, T|S, heads*64] rows (ld = ldq/ldk elements); vt: V transposed [B, heads*64, Spad] (key-contiguous);
+ * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional fp32
+ * [heads] per-head output scale (:342-345). out: [B, T, heads*64]; lse: fp32 [B*heads, Tpad].  scale multiplies q.k
+ * (the reference pre-scales q, :218).  Tpad/Spad: multiples of 32 covering T/S; vt must be zero for keys >= S.
+ * Attention dropout is not supported here (the reference default is attention_dropout = 0.0). */
+int ofa_attn_fwd(const void* q, const void* k, const void* vt, const void* bias, const uint8_t* kpm,
+                 const float* c_attn, void* out, float* lse, int B, int heads, int T, int S, int Tpad, int Spad,
+                 int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream);
+/* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
+ * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep.  qt/kt/dot: transposed copies
+ * [B, heads*64, Tpad|Spad] of q, k and dO (ofa_transpose_heads); v: [B,S,heads*64] rows with the same ld as k.
+ * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS. */
+int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
+                      int dtype, void* stream);
+int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* dot,
+                 const void* dout, const void* bias, const uint8_t* kpm, const float* c_attn, const float* lse,
+                 const float* delta, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S,
+                 int Tpad, int Spad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype,
+                 void* stream);
+/* x: [B, T, C] rows (ld elements) -> xt: [B, C, Tpad] (zero-filled for t >= T). */
+int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, int64_t ld, int dtype, void* stream);
+
+/* ---- embeddings: F.embedding gather (adaptor/text.py:119-127) and its dense-gradient scatter-add, deterministic
+ * (one wave per vocabulary row scans the ids with ballots; no atomics). ids: int64. */
+int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
+                      void* stream);
+int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
+                      int64_t padding_idx, int dtype, void* stream);
+
+/* ---- elementwise pieces of the layer (transformer_layer.py:167-208): */
+int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);                  /* module/gelu.py:18-19 */
+int ofa_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+/* y = residual + dropout_p(x); mask is regenerated from (seed, offset) with Philox4x32-10, nothing is stored. */
+int ofa_dropout_add_fwd(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed,
+                        uint64_t offset, int dtype, void* stream);
+int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
+                    void* stream);
+/* y[r][c] = (a[r][c] + (b? b[r][c]:0) + (vec? vec[c]:0)) * (rowmask && rowmask[r] ? 0 : 1)  -- adaptor/base.py:168-173,
+ * model/transformer.py:110-112 */
+int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y, int64_t rows,
+                        int cols, int dtype, void* stream);
+
+/* ---- patch embedding (adaptor/image_patch_embed.py:59-73): im2col of non-overlapping p x p patches.
+ * img [B,C,H,W] -> col [B*(H/p)*(W/p), Kpad] with K = C*p*p in (c,ph,pw) order (= Conv2d weight.view(D,-1)), zero pad. */
+int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype, void* stream);
+
+/* ---- criterion (engine/criterion/cross_entropy.py:27-67): fp32 log-softmax + NLL(sum, ignore_index) per row.
+ * logits [rows, V] (ld elements); writes lse[rows] and row_loss[rows] (0 for ignored rows). */
+int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, int64_t rows,
+                          int64_t V, int64_t ld, int64_t ignore_index, int dtype, void* stream);
+/* dlogits = (softmax - onehot) * grad_scale[0] (device scalar), zero for ignored rows and for columns V..ld-1. */
+int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,
+                          void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,
+                          void* stream);
+
+/* ---- train-step glue (engine/trainer.py:857-884, optim/adam.py:144-218, optim/fp16_optimizer.py): flat arenas. */
+int ofa_sumsq_ws_floats(void);
+int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* ws /* ofa_sumsq_ws_floats() floats */,
+              int64_t n, int dtype, void* stream);
+/* Adam on fp32 master weights with grads of `dtype`; coef[0] = grad multiplier (world/sample_size and clip folded
+ * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p). */
+int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
+                  const float* coef, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int step, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFASYS_AMD_H */

@@ -1,0 +1,117 @@
+// Shared device/host helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ofasys_amd.h"
+
+namespace ofa {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define OFA_REQUIRE(cond, code, ...)     \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::ofa::set_error(__VA_ARGS__);     \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> fp32 (round-to-nearest-even, as torch)
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t x = __float_as_uint(f);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x >> 16) | 0x40);  // quiet NaN
+  x += 0x7fffu + ((x >> 16) & 1u);
+  return (bf16_t)(x >> 16);
+}
+
+template <typename T> struct Vec;  // 16-byte vector of T
+template <> struct Vec<float> { static constexpr int N = 4; typedef float4 type; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; typedef uint4 type; };
+
+// load/store N consecutive elements (16-byte aligned) as floats
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float* out) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
+  *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float* in) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---------------------------------------------------------------- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (counter-based dropout masks)
+struct Philox {
+  uint32_t k0, k1;
+  __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+  __device__ __forceinline__ uint4 operator()(uint64_t ctr) const {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t a = k0, b = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+// keep-probability test on one 32-bit word: keep iff u < (1-p)
+__device__ __forceinline__ bool philox_keep(uint32_t word, float p) {
+  return (float)(word >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ofa

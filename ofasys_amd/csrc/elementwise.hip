@@ -1,0 +1,284 @@
+// HBM-bound pieces of the layer for gfx950: 16-byte vector loads, grid-stride loops, wave64 ballots.
+//   GELU fwd/bwd            module/gelu.py:18-19 (exact erf, fp32 math)
+//   dropout(x) + residual   transformer_layer.py:181-182, 203-206 (Philox4x32-10 counter RNG, mask never stored)
+//   embedding gather        adaptor/text.py:124-125, module/layer.py:8-15
+//   embedding grad          dense scatter-add, deterministic: one wave per vocabulary row scans the ids with ballots
+//   add + row-vector + row mask   adaptor/base.py:168-173, model/transformer.py:110-112
+//   im2col of p x p patches  adaptor/image_patch_embed.py:59-73
+#include "common.h"
+
+namespace ofa {
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ y,
+                                                   int64_t nvec, int64_t n) {
+  constexpr int N = Vec<T>::N;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float a[N], g[N], o[N];
+    load_vec<T>(x + v * N, a);
+    if (BWD) load_vec<T>(dy + v * N, g);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = BWD ? g[j] * gelu_grad_f(a[j]) : gelu_f(a[j]);
+    store_vec<T>(y + v * N, o);
+  }
+  // tail (n not a multiple of the vector width)
+  if (blockIdx.x == 0) {
+    for (int64_t e = nvec * N + threadIdx.x; e < n; e += 256) {
+      const float a = ld1<T>(x + e);
+      st1<T>(y + e, BWD ? ld1<T>(dy + e) * gelu_grad_f(a) : gelu_f(a));
+    }
+  }
+}
+
+// element e uses Philox counter (offset + e/4), word e%4.
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                      int64_t n, float p, uint64_t seed, uint64_t offset) {
+  const Philox rng(seed);
+  const float keep_scale = 1.0f / (1.0f - p);
+  const int64_t nq = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+    const uint4 r = rng(offset + (uint64_t)q);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = q * 4 + j;
+      if (e < n) {
+        float v = philox_keep(w[j], p) ? ld1<T>(x + e) * keep_scale : 0.f;
+        if (ADD) v += ld1<T>(res + e);
+        st1<T>(y + e, v);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowvec_mask_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              const T* __restrict__ vec, const uint8_t* __restrict__ rowmask,
+                                                              T* __restrict__ y, int64_t rows, int cols) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = cols / N;
+  const int64_t total = rows * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    float x[N], t[N];
+    load_vec<T>(a + r * cols + c, x);
+    if (b) {
+      load_vec<T>(b + r * cols + c, t);
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] += t[j];
+    }
+    if (vec) {
+      load_vec<T>(vec + c, t);
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] += t[j];
+    }
+    if (rowmask && rowmask[r]) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = 0.f;
+    }
+    store_vec<T>(y + r * cols + c, x);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict__ w, const int64_t* __restrict__ ids,
+                                                            T* __restrict__ out, int64_t n, int D, int64_t V) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = D / N;
+  const int64_t total = n * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    *reinterpret_cast<typename Vec<T>::type*>(out + r * D + c) =
+        *reinterpret_cast<const typename Vec<T>::type*>(w + id * D + c);
+  }
+}
+
+// dweight[v] += sum_{i : ids[i]==v} dout[i]   -- one wave per vocabulary row; the wave sweeps the id list 64 at a time,
+// ballots the matches and accumulates the matching rows in increasing position order (deterministic, no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                            T* __restrict__ dw, int64_t n, int D, int64_t V,
+                                                            int64_t padding_idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V || v == padding_idx) return;
+  constexpr int MAXC = 32;                 // columns per lane held in registers: D <= 2048
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+  bool any = false;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t idx = base + lane;
+    const bool hit = idx < n && ids[idx] == v;
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      any = true;
+      const T* row = dout + (base + src) * D;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int c = j * 64 + lane;
+        if (c < D) acc[j] += ld1<T>(row + c);
+      }
+    }
+  }
+  if (any) {
+    T* wr = dw + v * D;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      const int c = j * 64 + lane;
+      if (c < D) st1<T>(wr + c, ld1<T>(wr + c) + acc[j]);
+    }
+  }
+}
+
+// col[(b*nph*npw + ph*npw + pw)][c*p*p + i*p + j] = img[b][c][ph*p+i][pw*p+j]; columns K..Kpad-1 are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const T* __restrict__ img, T* __restrict__ col, int B, int C, int H,
+                                                           int W, int p, int Kpad) {
+  const int nph = H / p, npw = W / p, K = C * p * p;
+  const int64_t total = (int64_t)B * nph * npw * Kpad;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % Kpad);
+    const int64_t r = e / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int j = k % p, i = (k / p) % p, c = k / (p * p);
+      const int pw = (int)(r % npw), ph = (int)((r / npw) % nph);
+      const int64_t b = r / ((int64_t)npw * nph);
+      v = ld1<T>(img + ((b * C + c) * H + ph * p + i) * W + pw * p + j);
+    }
+    st1<T>(col + e, v);
+  }
+}
+
+static inline int grid_for(int64_t work) {
+  int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace ofa
+using namespace ofa;
+
+#define OFA_DT_CHECK(name) OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, name ": bad dtype %d", dtype)
+
+extern "C" int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  OFA_DT_CHECK("gelu_fwd");
+  OFA_REQUIRE(n >= 0 && (n == 0 || (x && y)), OFA_ERR_INVALID, "gelu_fwd: bad argument");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((gelu_kernel<float, false>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)nullptr,
+                       (const float*)x, (float*)y, n / 4, n);
+  else
+    hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)nullptr,
+                       (const bf16_t*)x, (bf16_t*)y, n / 8, n);
+  return check_launch("gelu_fwd");
+}
+
+extern "C" int ofa_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) {
+  OFA_DT_CHECK("gelu_bwd");
+  OFA_REQUIRE(n >= 0 && (n == 0 || (dy && x && dx)), OFA_ERR_INVALID, "gelu_bwd: bad argument");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((gelu_kernel<float, true>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy,
+                       (const float*)x, (float*)dx, n / 4, n);
+  else
+    hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)x, (bf16_t*)dx, n / 8, n);
+  return check_launch("gelu_bwd");
+}
+
+extern "C" int ofa_dropout_add_fwd(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed,
+                                   uint64_t offset, int dtype, void* stream) {
+  OFA_DT_CHECK("dropout_add_fwd");
+  OFA_REQUIRE(n >= 0 && p >= 0.f && p < 1.f && (n == 0 || (x && y)), OFA_ERR_INVALID, "dropout_add_fwd: bad argument");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(grid_for((n + 3) / 4)), block(256);
+  if (dtype == OFA_F32) {
+    if (residual) hipLaunchKernelGGL((dropout_kernel<float, true>), grid, block, 0, st, (const float*)x, (const float*)residual, (float*)y, n, p, seed, offset);
+    else hipLaunchKernelGGL((dropout_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (float*)y, n, p, seed, offset);
+  } else {
+    if (residual) hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, p, seed, offset);
+    else hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, p, seed, offset);
+  }
+  return check_launch("dropout_add_fwd");
+}
+
+extern "C" int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
+                               void* stream) {
+  return ofa_dropout_add_fwd(dy, nullptr, dx, n, p, seed, offset, dtype, stream);
+}
+
+extern "C" int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y,
+                                   int64_t rows, int cols, int dtype, void* stream) {
+  OFA_DT_CHECK("add_rowvec_mask");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && a && y, OFA_ERR_INVALID, "add_rowvec_mask: bad argument");
+  OFA_REQUIRE(cols % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "add_rowvec_mask: cols=%d not vectorizable", cols);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((add_rowvec_mask_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)a,
+                       (const float*)b, (const float*)vec, rowmask, (float*)y, rows, cols);
+  else
+    hipLaunchKernelGGL((add_rowvec_mask_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st,
+                       (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)vec, rowmask, (bf16_t*)y, rows, cols);
+  return check_launch("add_rowvec_mask");
+}
+
+extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
+                                 void* stream) {
+  OFA_DT_CHECK("embedding_fwd");
+  OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && weight && ids && out, OFA_ERR_INVALID, "embedding_fwd: bad argument");
+  OFA_REQUIRE(D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "embedding_fwd: D=%d not vectorizable", D);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((embedding_fwd_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)weight, ids,
+                       (float*)out, n, D, V);
+  else
+    hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)weight,
+                       ids, (bf16_t*)out, n, D, V);
+  return check_launch("embedding_fwd");
+}
+
+extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
+                                 int64_t padding_idx, int dtype, void* stream) {
+  OFA_DT_CHECK("embedding_bwd");
+  OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && dout && ids && dweight, OFA_ERR_INVALID, "embedding_bwd: bad argument");
+  OFA_REQUIRE(D <= 2048, OFA_ERR_UNSUPPORTED, "embedding_bwd: D=%d exceeds 2048", D);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((V + 3) / 4)), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((embedding_bwd_kernel<float>), grid, block, 0, st, (const float*)dout, ids, (float*)dweight, n, D, V,
+                       padding_idx);
+  else
+    hipLaunchKernelGGL((embedding_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, n, D,
+                       V, padding_idx);
+  return check_launch("embedding_bwd");
+}
+
+extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype,
+                                void* stream) {
+  OFA_DT_CHECK("im2col_patch");
+  OFA_REQUIRE(img && col && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= C * p * p, OFA_ERR_INVALID,
+              "im2col_patch: bad argument (H=%d W=%d p=%d Kpad=%d)", H, W, p, Kpad);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)B * (H / p) * (W / p) * Kpad;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)img, (float*)col,
+                       B, C, H, W, p, Kpad);
+  else
+    hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img,
+                       (bf16_t*)col, B, C, H, W, p, Kpad);
+  return check_launch("im2col_patch");
+}

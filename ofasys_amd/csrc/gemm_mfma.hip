@@ -1,0 +1,368 @@
+// bf16 MFMA GEMM for gfx950 (CDNA4): C[M,N] = alpha*(op(A) op(B) + bias) (+C), fp32 accumulate.
+//
+// Covers the three contractions of a linear layer without any operand transposes in HBM:
+//   forward   Y  = X  W^T      (A k-major,  B k-major : "NT",  transA=0, transB=1)
+//   dgrad     dX = dY W        (A k-major,  B m-major : "NN",  transA=0, transB=0)
+//   wgrad     dW = dY^T X      (A m-major,  B m-major : "TN",  transA=1, transB=0)
+// (multihead_attention.py:199-217,346; transformer_layer.py:194,202; adaptor/text.py:94-96 output projection).
+//
+// Structure (MI355X_MICROARCH / cdna_hip_programming.md section 5):
+//   * block tile (64*WM) x (64*WN) x 64, one wave per 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators
+//     (64 fp32 accumulator registers per lane);
+//   * operands are staged global -> registers -> LDS with 16-byte vectors; the next K-tile's global loads are issued
+//     before the current tile's MFMAs and written to the other LDS buffer afterwards (one barrier per K-tile);
+//   * k-major tiles sit in LDS as [row][64+8] (144-byte rows: every 16-lane ds_read_b128 group hits 16 distinct
+//     16-byte slots); m-major tiles (contraction index is the slow dimension in memory) sit as [k][rows+32] and are
+//     read with ds_read_b64_tr_b16, the CDNA4 transposing LDS read, so no transpose pass ever touches HBM;
+//   * the MFMA is issued "swapped" (A-operand = weight-side tile, B-operand = activation-side tile) so each lane ends
+//     up with 4 consecutive output columns of ONE output row -> 8-byte (bf16) / 16-byte (fp32) stores;
+//   * workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a contiguous run of tiles;
+//   * skinny outputs (wgrad: M,N ~ 768..3072, K = tokens) use split-K into an fp32 workspace + a reduce/epilogue
+//     kernel (deterministic, no atomics).
+// Roofline: MFMA-bound; algorithmic flops = 2*M*N*K.
+#include "gemm.h"
+
+namespace ofa {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int BK = 64;
+constexpr int KMAJ_LD = BK + 8;  // elements per LDS row of a k-major tile
+
+template <int R, bool KMAJ> struct TileGeom {
+  static constexpr int LD = KMAJ ? KMAJ_LD : (R + 32);
+  static constexpr int ELEMS = KMAJ ? R * KMAJ_LD : BK * (R + 32);
+  static constexpr int NVEC = R * BK / 8;
+};
+
+// Stage one operand tile: global -> registers.
+//  KMAJ: element (r, k) at base[(r0+r)*ld + k];   vectors run along k.
+// !KMAJ: element (r, k) at base[k*ld + r0 + r];   vectors run along r.
+template <int R, bool KMAJ, int NT, int NV>
+__device__ __forceinline__ void stage_load(uint4 (&reg)[NV], const bf16_t* __restrict__ base, int64_t ld, int r0,
+                                           int rmax, int k0, int kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * NT;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (KMAJ) {
+      const int r = v >> 3, c = (v & 7) * 8;
+      int rr = r0 + r;
+      rr = rr < rmax ? rr : rmax - 1;
+      if (k0 + c < kend) val = *reinterpret_cast<const uint4*>(base + (int64_t)rr * ld + k0 + c);
+    } else {
+      constexpr int VPR = R / 8;
+      const int k = v / VPR, c = (v % VPR) * 8;
+      if (k0 + k < kend && r0 + c < rmax) val = *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + k) * ld + r0 + c);
+    }
+    reg[i] = val;
+  }
+}
+
+template <int R, bool KMAJ, int NT, int NV>
+__device__ __forceinline__ void stage_store(const uint4 (&reg)[NV], bf16_t* __restrict__ lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * NT;
+    int off;
+    if (KMAJ) {
+      off = (v >> 3) * KMAJ_LD + (v & 7) * 8;
+    } else {
+      constexpr int VPR = R / 8;
+      off = (v / VPR) * (R + 32) + (v % VPR) * 8;
+    }
+    *reinterpret_cast<uint4*>(lds + off) = reg[i];
+  }
+}
+
+// MFMA operand fragment for rows [rbase, rbase+32) of the tile and k-slice kk (16 wide): lane (i = l&31, hi = l>>5)
+// receives elements (row rbase+i, k = kk*16 + hi*8 + 0..7).
+template <int R, bool KMAJ>
+__device__ __forceinline__ bf16x8 load_frag(const bf16_t* __restrict__ lds, int rbase, int kk, int lane) {
+  if (KMAJ) {
+    const int i = lane & 31, hi = lane >> 5;
+    return *reinterpret_cast<const bf16x8*>(lds + (rbase + i) * KMAJ_LD + kk * 16 + hi * 8);
+  } else {
+    // transposing read: in each 16-lane group, lane q supplies the address of 4 consecutive rows-elements
+    // (k = kb + (q>>2), r = rb + 4*(q&3) .. +3) and receives (k = kb + 0..3, r = rb + q).
+    const int g = lane >> 4, q = lane & 15;
+    constexpr int LD = R + 32;
+    const int kb = kk * 16 + (g >> 1) * 8;
+    const int rb = rbase + (g & 1) * 16;
+    const bf16_t* p0 = lds + (kb + (q >> 2)) * LD + rb + 4 * (q & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p0));
+    bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p0 + 4 * LD));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+    return r;
+  }
+}
+
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  // bijective "each XCD gets a contiguous chunk" remap (blocks are dispatched round-robin over the 8 XCDs)
+  const int q = n >> 3, r = n & 7, xcd = id & 7, local = id >> 3;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + local;
+}
+
+// epilogue on 4 consecutive columns n..n+3 of row m
+template <bool OUT_F32>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int m, int n, float v0, float v1, float v2,
+                                               float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  if (g.flags & OFA_GEMM_BIAS_COL) {
+    const uint2 b = *reinterpret_cast<const uint2*>((const bf16_t*)g.bias + n);
+    v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
+    v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
+  }
+  if (g.flags & OFA_GEMM_BIAS_ROW) {
+    const float b = bf2f(((const bf16_t*)g.bias)[m]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += b;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= g.alpha;
+  if (OUT_F32) {
+    float* p = (float*)Cb + (int64_t)m * g.ldc + n;
+    if (g.flags & OFA_GEMM_ACCUM) {
+      const float4 o = *reinterpret_cast<const float4*>(p);
+      v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    bf16_t* p = (bf16_t*)Cb + (int64_t)m * g.ldc + n;
+    if (g.flags & OFA_GEMM_ACCUM) {
+      const uint2 o = *reinterpret_cast<const uint2*>(p);
+      v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
+      v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+    }
+    uint2 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+}
+
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
+                                                               float* __restrict__ ws) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+  typedef TileGeom<BM, A_KMAJ> GA;
+  typedef TileGeom<BN, B_KMAJ> GB;
+  constexpr int NVA = GA::NVEC / NT, NVB = GB::NVEC / NT;
+  static_assert(GA::NVEC % NT == 0 && GB::NVEC % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sA[2];
+  bf16_t* sB[2];
+  sA[0] = reinterpret_cast<bf16_t*>(smem_raw);
+  sA[1] = sA[0] + GA::ELEMS;
+  sB[0] = sA[1] + GA::ELEMS;
+  sB[1] = sB[0] + GB::ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = tiles_m * tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int tm = t / tiles_n, tn = t % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z, ks = blockIdx.y;
+  const bf16_t* A = (const bf16_t*)g.A + (int64_t)bz * g.strideA;
+  const bf16_t* B = (const bf16_t*)g.B + (int64_t)bz * g.strideB;
+  const int kbeg = ks * ksplit;
+  const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[NVA], rb[NVB];
+  if (nk > 0) {
+    stage_load<BM, A_KMAJ, NT, NVA>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
+    stage_load<BN, B_KMAJ, NT, NVB>(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+    stage_store<BM, A_KMAJ, NT, NVA>(ra, sA[0], tid);
+    stage_store<BN, B_KMAJ, NT, NVB>(rb, sB[0], tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      stage_load<BM, A_KMAJ, NT, NVA>(ra, A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
+      stage_load<BN, B_KMAJ, NT, NVB>(rb, B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
+    }
+    const bf16_t* a_s = sA[cur];
+    const bf16_t* b_s = sB[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fx[2], fw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fx[i] = load_frag<BM, A_KMAJ>(a_s, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fw[j] = load_frag<BN, B_KMAJ>(b_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+    if (more) {
+      stage_store<BM, A_KMAJ, NT, NVA>(ra, sA[cur ^ 1], tid);
+      stage_store<BN, B_KMAJ, NT, NVB>(rb, sB[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns output row m = .. + (lane&31); register r holds column (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int hi = lane >> 5;
+  const bool split = gridDim.y > 1;
+  void* Cb = OUT_F32 ? (void*)((float*)g.C + (int64_t)bz * g.strideC) : (void*)((bf16_t*)g.C + (int64_t)bz * g.strideC);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+        if (n >= g.N) continue;   // N % 4 == 0 is a launch precondition
+        const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2],
+                    v3 = acc[i][j][4 * q + 3];
+        if (split) {
+          float* p = ws + (((int64_t)bz * gridDim.y + ks) * g.M + m) * g.N + n;
+          *reinterpret_cast<float4*>(p) = make_float4(v0, v1, v2, v3);
+        } else {
+          epilogue_store<OUT_F32>(g, Cb, m, n, v0, v1, v2, v3);
+        }
+      }
+    }
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const float* __restrict__ ws, int splits) {
+  const int64_t quads = (int64_t)g.M * (g.N / 4);
+  const int bz = blockIdx.y;
+  void* Cb = OUT_F32 ? (void*)((float*)g.C + (int64_t)bz * g.strideC) : (void*)((bf16_t*)g.C + (int64_t)bz * g.strideC);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / (g.N / 4)), n = (int)(i % (g.N / 4)) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 p = *reinterpret_cast<const float4*>(ws + (((int64_t)bz * splits + k) * g.M + m) * g.N + n);
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    epilogue_store<OUT_F32>(g, Cb, m, n, s.x, s.y, s.z, s.w);
+  }
+}
+
+bool gemm_mfma_supported(const GemmArgs& g) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+  if ((g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || (g.N & 3)) return false;
+  if ((g.strideA & 7) || (g.strideB & 7) || (g.strideC & 3)) return false;
+  if (!g.transA && (g.K & 7)) return false;  // k-major A: vectors along k
+  if (g.transB && (g.K & 7)) return false;   // k-major B
+  if (g.transA && (g.M & 7)) return false;   // m-major A: vectors along m
+  if (!g.transB && (g.N & 7)) return false;  // m-major B: vectors along n
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.C & 15)) return false;
+  if ((g.flags & OFA_GEMM_BIAS_COL) && ((uintptr_t)g.bias & 7)) return false;
+  return true;
+}
+
+template <int WM, int WN, bool AK, bool BKM, bool OF>
+static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+  const size_t lds = 2 * (size_t)(TileGeom<BM, AK>::ELEMS + TileGeom<BN, BKM>::ELEMS) * sizeof(bf16_t);
+  auto kern = gemm_mfma_kernel<WM, WN, AK, BKM, OF>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(tiles_m * tiles_n, splits, batch), block(WM * WN * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
+}
+
+template <bool AK, bool BKM, bool OF>
+static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int splits, int ksplit, float* ws,
+                         hipStream_t st) {
+  if (wm == 2 && wn == 2) launch_cfg<2, 2, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+  else if (wm == 1 && wn == 2) launch_cfg<1, 2, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+  else launch_cfg<1, 1, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+}
+
+int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+  // tile choice: biggest tile that still gives >= ~2 workgroups per CU; otherwise shrink, then split K.
+  const int64_t t22 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
+  const int64_t t12 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 128) * batch;
+  const int64_t t11 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) * batch;
+  int wm, wn;
+  int64_t tiles;
+  if (t22 >= 384) { wm = 2; wn = 2; tiles = t22; }
+  else if (t12 >= 384 || t11 < 256) { wm = 1; wn = 2; tiles = t12; }
+  else { wm = 1; wn = 1; tiles = t11; }
+  if (g.N < 128 && wn == 2) { wm = 1; wn = 1; tiles = t11; }
+  int splits = 1;
+  if (ws && tiles < 256 && g.K >= 1024) {
+    splits = (int)((512 + tiles - 1) / tiles);
+    const int maxs = g.K / 512;
+    if (splits > maxs) splits = maxs;
+    if (splits > 32) splits = 32;
+    while (splits > 1 && (int64_t)splits * batch * g.M * g.N * 4 > ws_bytes) --splits;
+    if (splits < 1) splits = 1;
+  }
+  int ksplit = g.K;
+  if (splits > 1) {
+    ksplit = cdiv(cdiv(g.K, splits), BK) * BK;
+    splits = cdiv(g.K, ksplit);
+  }
+  const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
+#define GEMM_DISPATCH(AK, BKM, OF) launch_shape<AK, BKM, OF>(g, batch, wm, wn, splits, ksplit, (float*)ws, st)
+  if (ak && bk) { if (of) GEMM_DISPATCH(true, true, true); else GEMM_DISPATCH(true, true, false); }
+  else if (ak && !bk) { if (of) GEMM_DISPATCH(true, false, true); else GEMM_DISPATCH(true, false, false); }
+  else if (!ak && !bk) { if (of) GEMM_DISPATCH(false, false, true); else GEMM_DISPATCH(false, false, false); }
+  else { if (of) GEMM_DISPATCH(false, true, true); else GEMM_DISPATCH(false, true, false); }
+#undef GEMM_DISPATCH
+  int rc = check_launch("gemm_mfma");
+  if (rc) return rc;
+  if (splits > 1) {
+    const int64_t quads = (int64_t)g.M * (g.N / 4);
+    dim3 grid((unsigned)((quads + 255) / 256 > 2048 ? 2048 : (quads + 255) / 256), batch), block(256);
+    if (of) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, block, 0, st, g, (const float*)ws, splits);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, block, 0, st, g, (const float*)ws, splits);
+    rc = check_launch("gemm_splitk_reduce");
+  }
+  return rc;
+}
+
+}  // namespace ofa
+
+using namespace ofa;
+
+extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA,
+                        int transB, int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB,
+                        int64_t strideC, float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "gemm: bad dtype %d", dtype);
+  OFA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, OFA_ERR_INVALID, "gemm: negative size");
+  if (M == 0 || N == 0 || batch == 0) return 0;
+  OFA_REQUIRE(A && B && C, OFA_ERR_INVALID, "gemm: null pointer");
+  OFA_REQUIRE(!(flags & (OFA_GEMM_BIAS_COL | OFA_GEMM_BIAS_ROW)) || bias, OFA_ERR_INVALID, "gemm: bias flag without bias");
+  OFA_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, OFA_ERR_INVALID,
+              "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb,
+              (long long)ldc);
+  OFA_REQUIRE(!(dtype == OFA_F32 && (flags & OFA_GEMM_OUT_F32)), OFA_ERR_INVALID, "gemm: OUT_F32 is for bf16 inputs");
+  GemmArgs g{A, B, C, bias, M, N, K, transA, transB, lda, ldb, ldc, strideA, strideB, strideC, alpha, flags};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_BF16 && !(flags & OFA_GEMM_FORCE_SIMPLE) && K > 0 && gemm_mfma_supported(g))
+    return gemm_mfma_launch(g, batch, ws, ws_bytes, st);
+  return gemm_simple_launch(g, batch, dtype, st);
+}

@@ -1,0 +1,303 @@
+// LayerNorm forward/backward for gfx950: one 64-lane wavefront per row, the row lives in registers
+// (16-byte vector loads, two-pass mean/variance in fp32), optional fused exact-erf GELU in front of it.
+//
+// Reference arithmetic: torch.nn.LayerNorm(eps=1e-5, affine)  (module/layer_norm.py:27-32); the GELU+LN pair is
+// transformer_layer.py:194-197 / :480-483 (activation_fn(fc1(x)) -> ffn_layernorm), GELU per module/gelu.py:18-19.
+// HBM-bound: algorithmic bytes = 2 * rows * cols * sizeof(T) forward (read x, write y).
+#include "common.h"
+
+namespace ofa {
+
+template <typename T, int NV, bool GELU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int cols, float eps) {
+  constexpr int N = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float v[NV][N];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * N;
+    if (c < cols) {
+      load_vec<T>(xr + c, v[i]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (GELU) v[i][j] = gelu_f(v[i][j]);
+        s += v[i][j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * N;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float d = v[i][j] - mu;
+        q += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)cols;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  T* yr = y + row * cols;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * N;
+    if (c < cols) {
+      float g[N], b[N], o[N];
+      load_vec<T>(gamma + c, g);
+      load_vec<T>(beta + c, b);
+#pragma unroll
+      for (int j = 0; j < N; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+      store_vec<T>(yr + c, o);
+    }
+  }
+}
+
+// Backward.  Each wave walks rows with a grid stride; its running dgamma/dbeta live in a private LDS slice
+// (lane-contiguous read-modify-write, no atomics), so register pressure stays at x, dy, gamma.  Partials go to
+// ws[wave][cols] and a second kernel folds them (deterministic: fixed row->wave assignment and summation order).
+template <typename T, int NV, bool GELU>
+__global__ __launch_bounds__(128) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ ws, int64_t rows, int cols, int nwaves) {
+  constexpr int N = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 2 + wib;
+  float* accg = smem + (size_t)wib * 2 * cols;
+  float* accb = accg + cols;
+  float g[NV][N];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * N;
+    if (c < cols) {
+      load_vec<T>(gamma + c, g[i]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) accg[c + j] = accb[c + j] = 0.f;
+    }
+  }
+  for (int64_t row = wave; row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    const T* xr = x + row * cols;
+    const T* dyr = dy + row * cols;
+    float hv[NV][N], d[NV][N];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * N;
+      if (c < cols) {
+        load_vec<T>(xr + c, hv[i]);
+        load_vec<T>(dyr + c, d[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * N;
+      if (c < cols) {
+        float4 ag[N / 4], ab[N / 4];
+#pragma unroll
+        for (int j = 0; j < N / 4; ++j) {
+          ag[j] = *reinterpret_cast<float4*>(accg + c + 4 * j);
+          ab[j] = *reinterpret_cast<float4*>(accb + c + 4 * j);
+        }
+        float* pag = reinterpret_cast<float*>(ag);
+        float* pab = reinterpret_cast<float*>(ab);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float xv = GELU ? gelu_f(hv[i][j]) : hv[i][j];
+          const float xh = (xv - mu) * rs;
+          const float gy = d[i][j] * g[i][j];
+          s1 += gy;
+          s2 += gy * xh;
+          pag[j] += d[i][j] * xh;
+          pab[j] += d[i][j];
+        }
+#pragma unroll
+        for (int j = 0; j < N / 4; ++j) {
+          *reinterpret_cast<float4*>(accg + c + 4 * j) = ag[j];
+          *reinterpret_cast<float4*>(accb + c + 4 * j) = ab[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+    T* dxr = dx + row * cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * N;
+      if (c < cols) {
+        float o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float xv = GELU ? gelu_f(hv[i][j]) : hv[i][j];
+          const float xh = (xv - mu) * rs;
+          float t = rs * (d[i][j] * g[i][j] - s1 - xh * s2);
+          if (GELU) t *= gelu_grad_f(hv[i][j]);
+          o[j] = t;
+        }
+        store_vec<T>(dxr + c, o);
+      }
+    }
+  }
+  float* wg = ws + (int64_t)wave * cols;
+  float* wb = ws + (int64_t)nwaves * cols + (int64_t)wave * cols;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * N;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        wg[c + j] = accg[c + j];
+        wb[c + j] = accb[c + j];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int cols, int nwaves) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float a = 0.f, b = 0.f;
+  if (c < cols) {
+    for (int w = ry; w < nwaves; w += 4) {
+      a += ws[(int64_t)w * cols + c];
+      b += ws[(int64_t)nwaves * cols + (int64_t)w * cols + c];
+    }
+  }
+  sg[ry][cx] = a;
+  sb[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    dgamma[c] = sg[0][cx] + sg[1][cx] + sg[2][cx] + sg[3][cx];
+    dbeta[c] = sb[0][cx] + sb[1][cx] + sb[2][cx] + sb[3][cx];
+  }
+}
+
+constexpr int LN_BWD_WAVES = 1024;
+
+template <typename T, bool GELU>
+static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y, float* mean, float* rstd, int64_t rows,
+                           int cols, float eps, hipStream_t st) {
+  constexpr int N = Vec<T>::N;
+  const int nv = cdiv(cols, 64 * N);
+  dim3 grid(cdiv(rows, 4)), block(256);
+#define LN_CASE(NV)                                                                                                \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, NV, GELU>), grid, block, 0, st, (const T*)x, (const T*)g, (const T*)b, (T*)y, \
+                     mean, rstd, rows, cols, eps)
+  if (nv <= 1) LN_CASE(1);
+  else if (nv <= 2) LN_CASE(2);
+  else if (nv <= 4) LN_CASE(4);
+  else if (nv <= 8) LN_CASE(8);
+  else if (nv <= 16) LN_CASE(16);
+  else LN_CASE(32);
+#undef LN_CASE
+  return check_launch("layernorm_fwd");
+}
+
+template <typename T, bool GELU>
+static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
+                           float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, hipStream_t st) {
+  constexpr int N = Vec<T>::N;
+  const int nv = cdiv(cols, 64 * N);
+  const int nwaves = LN_BWD_WAVES;
+  dim3 grid(nwaves / 2), block(128);
+  const size_t lds = (size_t)2 * 2 * cols * sizeof(float);
+#define LN_CASE(NV)                                                                                                  \
+  do {                                                                                                               \
+    if (lds > 48 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, NV, GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                           \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NV, GELU>), grid, block, lds, st, (const T*)dy, (const T*)x, (const T*)g,   \
+                       mean, rstd, (T*)dx, ws, rows, cols, nwaves);                                                  \
+  } while (0)
+  if (nv <= 1) LN_CASE(1);
+  else if (nv <= 2) LN_CASE(2);
+  else if (nv <= 4) LN_CASE(4);
+  else if (nv <= 8) LN_CASE(8);
+  else LN_CASE(16);
+#undef LN_CASE
+  int rc = check_launch("layernorm_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, ws, dgamma, dbeta, cols, nwaves);
+  return check_launch("layernorm_bwd_reduce");
+}
+
+static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
+  OFA_REQUIRE(rows >= 0 && cols > 0, OFA_ERR_INVALID, "layernorm: bad shape rows=%lld cols=%d", (long long)rows, cols);
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "layernorm: bad dtype %d", dtype);
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(cols % n == 0, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d must be a multiple of %d", cols, n);
+  const int maxc = 64 * n * (bwd ? 16 : 32);
+  OFA_REQUIRE(cols <= maxc, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d exceeds %d", cols, maxc);
+  return 0;
+}
+
+}  // namespace ofa
+
+using namespace ofa;
+
+extern "C" int ofa_layernorm_bwd_ws_rows(void) { return LN_BWD_WAVES; }
+
+extern "C" int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                 int64_t rows, int cols, float eps, int dtype, void* stream) {
+  if (int rc = ln_check(rows, cols, dtype, false)) return rc;
+  OFA_REQUIRE(x && gamma && beta && y, OFA_ERR_INVALID, "layernorm_fwd: null pointer");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == OFA_F32 ? ln_fwd_dispatch<float, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+                          : ln_fwd_dispatch<bf16_t, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+}
+
+extern "C" int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean,
+                                      float* rstd, int64_t rows, int cols, float eps, int dtype, void* stream) {
+  if (int rc = ln_check(rows, cols, dtype, false)) return rc;
+  OFA_REQUIRE(h && gamma && beta && y, OFA_ERR_INVALID, "gelu_layernorm_fwd: null pointer");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == OFA_F32 ? ln_fwd_dispatch<float, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+                          : ln_fwd_dispatch<bf16_t, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+}
+
+extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                                 void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
+                                 void* stream) {
+  if (int rc = ln_check(rows, cols, dtype, true)) return rc;
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, OFA_ERR_INVALID,
+              "layernorm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == OFA_F32
+             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, st)
+             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, st);
+}
+
+extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean,
+                                      const float* rstd, void* dh, float* dgamma, float* dbeta, float* ws, int64_t rows,
+                                      int cols, int dtype, void* stream) {
+  if (int rc = ln_check(rows, cols, dtype, true)) return rc;
+  OFA_REQUIRE(dy && h && gamma && mean && rstd && dh && dgamma && dbeta && ws, OFA_ERR_INVALID,
+              "gelu_layernorm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == OFA_F32
+             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, st)
+             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, st);
+}

@@ -1,0 +1,203 @@
+// Criterion + train-step glue for gfx950 (HBM-bound, fp32 math):
+//   cross entropy   engine/criterion/cross_entropy.py:27-67 (log_softmax in fp32, NLL sum, ignore_index = pad)
+//   sum of squares  module/utils.py:342-384 (total grad norm for clip_grad_norm_)
+//   Adam            engine/optim/adam.py:144-218 on the fp32 master copy of engine/optim/fp16_optimizer.py:32-71,
+//                   fused with the grad multiply (engine/trainer.py:857-860) and the model-dtype copy-back.
+#include "common.h"
+
+namespace ofa {
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+  const float mm = fmaxf(m, m2);
+  if (mm == -INFINITY) { m = mm; s = 0.f; return; }
+  s = s * expf(m - mm) + s2 * expf(m2 - mm);
+  m = mm;
+}
+
+// one 256-thread block per row
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     float* __restrict__ lse, float* __restrict__ row_loss, int64_t V,
+                                                     int64_t ld, int64_t ignore_index) {
+  constexpr int N = Vec<T>::N;
+  __shared__ float sm[4], ss[4];
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  float m = -INFINITY, s = 0.f;
+  const int64_t nvec = V / N;
+  for (int64_t v = threadIdx.x; v < nvec; v += 256) {
+    float a[N];
+    load_vec<T>(x + v * N, a);
+    float lm = a[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) lm = fmaxf(lm, a[j]);
+    const float mm = fmaxf(m, lm);
+    float acc = s * expf(m - mm);
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc += expf(a[j] - mm);
+    m = mm;
+    s = acc;
+  }
+  for (int64_t e = nvec * N + threadIdx.x; e < V; e += 256) online_merge(m, s, ld1<T>(x + e), 1.f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    online_merge(m, s, m2, s2);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[wave] = m; ss[wave] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float M = sm[0], S = ss[0];
+    for (int w = 1; w < 4; ++w) online_merge(M, S, sm[w], ss[w]);
+    const float l = M + logf(S);
+    lse[row] = l;
+    const int64_t t = target[row];
+    row_loss[row] = (t == ignore_index) ? 0.f : l - ld1<T>(x + t);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                     T* __restrict__ dlogits, int64_t V, int64_t ld, int64_t ignore_index) {
+  constexpr int N = Vec<T>::N;
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  T* dx = dlogits + row * ld;
+  const int64_t t = target[row];
+  const bool ignored = t == ignore_index;
+  const float g = gscale ? gscale[0] : 1.0f;
+  const float l = lse[row];
+  const int64_t nvec = ld / N;   // ld is a multiple of the vector width (launch precondition)
+  for (int64_t v = threadIdx.x; v < nvec; v += 256) {
+    float a[N], o[N];
+    load_vec<T>(x + v * N, a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int64_t c = v * N + j;
+      float d = 0.f;
+      if (!ignored && c < V) d = (expf(a[j] - l) - (c == t ? 1.f : 0.f)) * g;
+      o[j] = d;
+    }
+    store_vec<T>(dx + v * N, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t n) {
+  constexpr int N = Vec<T>::N;
+  __shared__ float sw[4];
+  float s = 0.f;
+  const int64_t nvec = n / N;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float a[N];
+    load_vec<T>(x + v * N, a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) s += a[j] * a[j];
+  }
+  if (blockIdx.x == 0)
+    for (int64_t e = nvec * N + threadIdx.x; e < n; e += 256) { const float a = ld1<T>(x + e); s += a * a; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nb) {
+  __shared__ float sw[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                   const T* __restrict__ grad, T* __restrict__ model,
+                                                   const float* __restrict__ coef, int64_t n, float lr, float beta1,
+                                                   float beta2, float eps, float wd, float step_size) {
+  const float gmul = coef ? coef[0] : 1.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float g = ld1<T>(grad + i) * gmul;
+    float p = master[i];
+    const float mi = m[i] * beta1 + (1.f - beta1) * g;
+    const float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    if (wd != 0.f) p -= wd * lr * p;
+    p -= step_size * mi / (sqrtf(vi) + eps);
+    master[i] = p;
+    st1<T>(model + i, p);
+  }
+}
+
+}  // namespace ofa
+using namespace ofa;
+
+extern "C" int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, int64_t rows,
+                                     int64_t V, int64_t ld, int64_t ignore_index, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "cross_entropy_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && target && lse && row_loss, OFA_ERR_INVALID, "cross_entropy_fwd: bad argument");
+  OFA_REQUIRE(ld % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_INVALID, "cross_entropy_fwd: ld=%lld must be a multiple of the 16-byte vector width", (long long)ld);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((ce_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_loss, V, ld, ignore_index);
+  else
+    hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_loss, V, ld, ignore_index);
+  return check_launch("cross_entropy_fwd");
+}
+
+extern "C" int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,
+                                     void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,
+                                     void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "cross_entropy_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && target && lse && dlogits, OFA_ERR_INVALID, "cross_entropy_bwd: bad argument");
+  OFA_REQUIRE(ld % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_INVALID, "cross_entropy_bwd: ld must be a multiple of the 16-byte vector width");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, grad_scale, (float*)dlogits, V, ld, ignore_index);
+  else
+    hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index);
+  return check_launch("cross_entropy_bwd");
+}
+
+extern "C" int ofa_sumsq_ws_floats(void) { return 1024; }
+
+extern "C" int ofa_sumsq(const void* x, float* out, float* ws, int64_t n, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "sumsq: bad dtype %d", dtype);
+  OFA_REQUIRE(n >= 0 && out && ws && (n == 0 || x), OFA_ERR_INVALID, "sumsq: bad argument");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int vecw = dtype == OFA_F32 ? 4 : 8;
+  int64_t nbl = (n / vecw + 255) / 256;
+  const int nb = (int)(nbl < 1 ? 1 : (nbl > 1024 ? 1024 : nbl));
+  if (dtype == OFA_F32) hipLaunchKernelGGL((sumsq_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, ws, n);
+  else hipLaunchKernelGGL((sumsq_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, ws, n);
+  int rc = check_launch("sumsq");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, nb);
+  return check_launch("sumsq_final");
+}
+
+extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
+                             const float* coef, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "adam_step: bad dtype %d", dtype);
+  OFA_REQUIRE(n >= 0 && step >= 1 && master && exp_avg && exp_avg_sq && grad && model_param, OFA_ERR_INVALID, "adam_step: bad argument");
+  if (n == 0) return 0;
+  // adam.py:205-207
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)(lr * sqrt(bc2) / bc1);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nbl = (n + 255) / 256;
+  const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((adam_kernel<float>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const float*)grad, (float*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size);
+  else
+    hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size);
+  return check_launch("adam_step");
+}

@@ -1,0 +1,338 @@
+"""Thin functional wrappers over the C ABI (no autograd here -- see ofasys_amd/ops.py).
+
+Each wrapper allocates outputs with torch (plumbing: device memory + streams), checks layout, and enqueues the HIP
+kernel on torch's current stream.  Everything here requires GPU tensors; nothing falls back to torch math.
+"""
+import torch
+
+from .lib import (BF16, F32, GEMM_ACCUM, GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_FORCE_SIMPLE, GEMM_OUT_F32, OfaError,
+                  dtype_code, lib, ptr, stream)
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """A per-device grow-only scratch buffer (fp32 words)."""
+    key = (tag, device)
+    buf = _ws_cache.get(key)
+    n = (nbytes + 3) // 4
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _rows_cols(x):
+    cols = x.shape[-1]
+    return x.numel() // cols, cols
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps=1e-5, fuse_gelu=False):
+    x = x.contiguous()
+    rows, cols = _rows_cols(x)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib().call("ofa_gelu_layernorm_fwd" if fuse_gelu else "ofa_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y),
+               ptr(mean), ptr(rstd), rows, cols, eps, dtype_code(x), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False):
+    dy = dy.contiguous()
+    x = x.contiguous()
+    rows, cols = _rows_cols(x)
+    dx = torch.empty_like(x)
+    dg = torch.empty(cols, dtype=torch.float32, device=x.device)
+    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    wsr = lib().cdll.ofa_layernorm_bwd_ws_rows()
+    ws = workspace(2 * wsr * cols * 4, x.device, "ln")
+    lib().call("ofa_gelu_layernorm_bwd" if fuse_gelu else "ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean),
+               ptr(rstd), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, cols, dtype_code(x), stream())
+    return dx, dg.to(gamma.dtype), db.to(gamma.dtype)
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.0, out=None, accumulate=False,
+         out_f32=False, force_simple=False):
+    """C = alpha * (op(a) @ op(b) + bias) [+ C].  a, b: 2-D (or 3-D batched) tensors whose last dim is contiguous."""
+    assert a.dim() == b.dim() and a.dim() in (2, 3)
+    batched = a.dim() == 3
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    batch = a.shape[0] if batched else 1
+    ar, ac = a.shape[-2], a.shape[-1]
+    br, bc = b.shape[-2], b.shape[-1]
+    M, K = (ac, ar) if trans_a else (ar, ac)
+    N, Kb = (br, bc) if trans_b else (bc, br)
+    if K != Kb:
+        raise OfaError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    dt = dtype_code(a)
+    if b.dtype != a.dtype:
+        raise OfaError("gemm: operand dtypes differ")
+    if out is None:
+        odt = torch.float32 if (out_f32 or a.dtype == torch.float32) else a.dtype
+        out = torch.empty((batch, M, N) if batched else (M, N), dtype=odt, device=a.device)
+    flags = 0
+    if bias is not None:
+        flags |= GEMM_BIAS_ROW if bias_row else GEMM_BIAS_COL
+    if accumulate:
+        flags |= GEMM_ACCUM
+    if force_simple:
+        flags |= GEMM_FORCE_SIMPLE
+    if dt == BF16 and out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    lda, ldb, ldc = a.stride(-2), b.stride(-2), out.stride(-2)
+    sa = a.stride(0) if batched else 0
+    sb = b.stride(0) if batched else 0
+    sc = out.stride(0) if batched else 0
+    ws = workspace(256 << 20, a.device, "gemm")
+    lib().call("ofa_gemm", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, batch,
+               sa, sb, sc, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
+    return out
+
+
+# ------------------------------------------------------------------ softmax family
+def scaled_softmax(x, scale):
+    x = x.contiguous()
+    b, np_, sq, sk = x.shape
+    y = torch.empty_like(x)
+    lib().call("ofa_scaled_softmax_fwd", ptr(x), ptr(y), float(scale), b, np_, sq, sk, dtype_code(x), stream())
+    return y
+
+
+def scaled_softmax_bwd(dy, y, scale, inplace=False):
+    dy = dy.contiguous()
+    y = y.contiguous()
+    rows = y.numel() // y.shape[-1]
+    dx = dy if inplace else torch.empty_like(dy)
+    lib().call("ofa_scaled_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), 1, 1, rows, y.shape[-1], dtype_code(y),
+               stream())
+    return dx
+
+
+def scaled_masked_softmax(x, mask, scale):
+    x = x.contiguous()
+    mask = mask.to(torch.uint8).contiguous()
+    b, np_, sq, sk = x.shape
+    y = torch.empty_like(x)
+    lib().call("ofa_scaled_masked_softmax_fwd", ptr(x), ptr(mask), ptr(y), float(scale), b, np_, sq, sk, mask.shape[0],
+               dtype_code(x), stream())
+    return y
+
+
+def scaled_upper_triang_masked_softmax(x, scale):
+    x = x.contiguous()
+    ab, sq, sk = x.shape
+    assert sq == sk
+    y = torch.empty_like(x)
+    lib().call("ofa_scaled_upper_triang_masked_softmax_fwd", ptr(x), ptr(y), float(scale), ab, sq, dtype_code(x), stream())
+    return y
+
+
+def get_batch_per_block(sq, sk, b, np_):
+    return lib().cdll.ofa_get_batch_per_block(sq, sk, b, np_)
+
+
+def attn_softmax(x, bias, kpm, scale, heads, causal):
+    x = x.contiguous()
+    BA, T, S = x.shape
+    if bias is not None:
+        bias = bias.contiguous()
+    if kpm is not None:
+        kpm = kpm.to(torch.uint8).contiguous()
+    p = torch.empty_like(x)
+    lib().call("ofa_attn_softmax_fwd", ptr(x), ptr(bias), ptr(kpm), ptr(p), float(scale), BA, heads, T, S, int(causal),
+               dtype_code(x), stream())
+    return p
+
+
+# ------------------------------------------------------------------ fused attention (bf16)
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def transpose_heads(x, T_pad):
+    """x: [B, T, C] (last dim contiguous) -> [B, C, T_pad], zero for t >= T."""
+    B, T, C = x.shape
+    if x.stride(-1) != 1 or x.stride(0) != T * x.stride(1):
+        x = x.contiguous()
+    xt = torch.empty(B, C, T_pad, dtype=x.dtype, device=x.device)
+    lib().call("ofa_transpose_heads", ptr(x), ptr(xt), B, T, C, T_pad, x.stride(1), dtype_code(x), stream())
+    return xt
+
+
+def _rows3(x):
+    """[B, T, D] view with contiguous last dim and dense batch stride; returns (tensor, ld)."""
+    if x.stride(-1) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        x = x.contiguous()
+    return x, x.stride(1)
+
+
+def attn_fwd(q, k, vt, heads, scale, bias=None, kpm=None, c_attn=None, causal=False):
+    """q [B,T,D], k [B,S,D], vt [B,D,Spad] -> out [B,T,D], lse [B*heads, Tpad]."""
+    q, ldq = _rows3(q)
+    k, ldk = _rows3(k)
+    B, T, D = q.shape
+    S = k.shape[1]
+    Spad = vt.shape[2]
+    Tpad = pad32(T)
+    out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    if kpm is not None:
+        kpm = kpm.to(torch.uint8).contiguous()
+    lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(vt), ptr(bias), ptr(kpm), ptr(c_attn), ptr(out), ptr(lse), B, heads, T,
+               S, Tpad, Spad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False):
+    q, ldq = _rows3(q)
+    k, ldk = _rows3(k)
+    v, ldv = _rows3(v)
+    if ldv != ldk:
+        v = v.contiguous()
+        k = k.contiguous()
+        ldk = ldv = k.stride(1)
+    dout, ldo = _rows3(dout)
+    out, ldo2 = _rows3(out)
+    if ldo != ldo2:
+        dout, out = dout.contiguous(), out.contiguous()
+        ldo = dout.stride(1)
+    B, T, D = q.shape
+    S = k.shape[1]
+    Tpad, Spad = pad32(T), pad32(S)
+    delta = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
+    lib().call("ofa_attn_bwd_prep", ptr(dout), ptr(out), ptr(delta), B, heads, T, Tpad, ldo, dtype_code(q), stream())
+    qt = transpose_heads(q, Tpad)
+    kt = transpose_heads(k, Spad)
+    dot = transpose_heads(dout, Tpad)
+    dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+    dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+    dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+    dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if need_dbias else None
+    if bias is not None:
+        bias = bias.contiguous()
+    if kpm is not None:
+        kpm = kpm.to(torch.uint8).contiguous()
+    # dq is written with ld = ldq, dk/dv with ld = ldk: give the kernel dense outputs by passing dense strides
+    if ldq != D:
+        q = q.contiguous()
+        ldq = D
+    if ldk != D:
+        k, v = k.contiguous(), v.contiguous()
+        ldk = D
+    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(qt), ptr(kt), ptr(dot), ptr(dout), ptr(bias), ptr(kpm),
+               ptr(c_attn), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, Spad, ldq,
+               ldk, ldo, float(scale), int(causal), dtype_code(q), stream())
+    return dq, dk, dv, dbias, delta
+
+
+# ------------------------------------------------------------------ elementwise / embedding
+def gelu_fwd(x):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib().call("ofa_gelu_fwd", ptr(x), ptr(y), x.numel(), dtype_code(x), stream())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dy, x = dy.contiguous(), x.contiguous()
+    dx = torch.empty_like(x)
+    lib().call("ofa_gelu_bwd", ptr(dy), ptr(x), ptr(dx), x.numel(), dtype_code(x), stream())
+    return dx
+
+
+def dropout_add(x, residual, p, seed, offset):
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    y = torch.empty_like(x)
+    lib().call("ofa_dropout_add_fwd", ptr(x), ptr(residual), ptr(y), x.numel(), float(p), seed, offset, dtype_code(x),
+               stream())
+    return y
+
+
+def dropout_bwd(dy, p, seed, offset):
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    lib().call("ofa_dropout_bwd", ptr(dy), ptr(dx), dy.numel(), float(p), seed, offset, dtype_code(dy), stream())
+    return dx
+
+
+def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+    a = a.contiguous()
+    rows, cols = _rows_cols(a)
+    if b is not None:
+        b = b.contiguous()
+    if rowmask is not None:
+        rowmask = rowmask.to(torch.uint8).contiguous()
+    y = torch.empty_like(a)
+    lib().call("ofa_add_rowvec_mask", ptr(a), ptr(b), ptr(vec), ptr(rowmask), ptr(y), rows, cols, dtype_code(a), stream())
+    return y
+
+
+def embedding_fwd(weight, ids):
+    ids = ids.contiguous()
+    V, D = weight.shape
+    out = torch.empty(*ids.shape, D, dtype=weight.dtype, device=weight.device)
+    lib().call("ofa_embedding_fwd", ptr(weight), ptr(ids), ptr(out), ids.numel(), D, V, dtype_code(weight), stream())
+    return out
+
+
+def embedding_bwd(dout, ids, V, padding_idx=-1, dweight=None):
+    dout = dout.contiguous()
+    ids = ids.contiguous()
+    D = dout.shape[-1]
+    if dweight is None:
+        dweight = torch.zeros(V, D, dtype=dout.dtype, device=dout.device)
+    lib().call("ofa_embedding_bwd", ptr(dout), ptr(ids), ptr(dweight), ids.numel(), D, V,
+               -1 if padding_idx is None else padding_idx, dtype_code(dout), stream())
+    return dweight
+
+
+def im2col_patch(img, p, Kpad):
+    img = img.contiguous()
+    B, C, H, W = img.shape
+    col = torch.empty(B * (H // p) * (W // p), Kpad, dtype=img.dtype, device=img.device)
+    lib().call("ofa_im2col_patch", ptr(img), ptr(col), B, C, H, W, p, Kpad, dtype_code(img), stream())
+    return col
+
+
+# ------------------------------------------------------------------ criterion / optimizer
+def cross_entropy_fwd(logits2d, target, V, ignore_index):
+    """logits2d: [rows, ld] storage (ld >= V, multiple of the vector width); returns lse [rows], row_loss [rows]."""
+    rows, ld = logits2d.shape[0], logits2d.stride(0)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    lib().call("ofa_cross_entropy_fwd", ptr(logits2d), ptr(target), ptr(lse), ptr(row_loss), rows, V, ld, ignore_index,
+               dtype_code(logits2d), stream())
+    return lse, row_loss
+
+
+def cross_entropy_bwd(logits2d, target, lse, grad_scale, V, ignore_index, dlogits=None):
+    rows, ld = logits2d.shape[0], logits2d.stride(0)
+    if dlogits is None:
+        dlogits = torch.empty(rows, ld, dtype=logits2d.dtype, device=logits2d.device)
+    lib().call("ofa_cross_entropy_bwd", ptr(logits2d), ptr(target), ptr(lse), ptr(grad_scale), ptr(dlogits), rows, V, ld,
+               ignore_index, dtype_code(logits2d), stream())
+    return dlogits
+
+
+def sumsq(x, out):
+    """out (fp32[1]) += sum(x*x)."""
+    x = x.contiguous()
+    ws = workspace(lib().cdll.ofa_sumsq_ws_floats() * 4, x.device, "sumsq")
+    lib().call("ofa_sumsq", ptr(x), ptr(out), ptr(ws), x.numel(), dtype_code(x), stream())
+    return out
+
+
+def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, beta2, eps, weight_decay, step):
+    lib().call("ofa_adam_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), ptr(model_param), ptr(coef),
+               master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+               dtype_code(grad), stream())

@@ -1,0 +1,344 @@
+"""GPU parity tests of every C-ABI kernel against a plain PyTorch fp32 reference of the same op (and the oracle's
+restatements where the op is OFASys-specific).  Run with: pytest -m gpu"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ofasys_amd import kernels
+    return kernels
+
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(5, 256), (130, 768), (67, 3072), (9, 1024), (3, 64)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm(K, dtype, rows, cols, gelu):
+    torch.manual_seed(0)
+    x = torch.randn(rows, cols, device=DEV).to(dtype)
+    g = (1 + 0.1 * torch.randn(cols, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(cols, device=DEV)).to(dtype)
+    dy = torch.randn(rows, cols, device=DEV).to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr = g.float().requires_grad_(True)
+    br = b.float().requires_grad_(True)
+    yr = F.layer_norm(F.gelu(xr) if gelu else xr, (cols,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5, fuse_gelu=gelu)
+    dx, dg, db = K.layernorm_bwd(dy, x, g, mean, rstd, fuse_gelu=gelu)
+    t = tol(dtype)
+    assert rel(y, yr) < t
+    assert rel(dx, xr.grad) < 2 * t
+    assert rel(dg, gr.grad) < 2 * t
+    assert rel(db, br.grad) < 2 * t
+
+
+GEMM_SHAPES = [(64, 64, 64), (128, 128, 128), (200, 136, 72), (130, 768, 256), (534, 264, 768), (77, 64, 1032),
+               (256, 3072, 768), (1000, 208, 264)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm(K, dtype, M, N, K_, ta, tb):
+    torch.manual_seed(1)
+    a = torch.randn((K_, M) if ta else (M, K_), device=DEV).to(dtype)
+    b = torch.randn((N, K_) if tb else (K_, N), device=DEV).to(dtype)
+    bias = torch.randn(N, device=DEV).to(dtype)
+    ref = ((a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float()) + bias.float()) * 0.5
+    out = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5)
+    assert out.dtype == dtype
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(out, ref) < t
+    if dtype == torch.bfloat16:
+        # exact-tier kernel on the same bf16 data, fp32 output and accumulate flag
+        out32 = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5, out_f32=True)
+        assert out32.dtype == torch.float32 and rel(out32, ref) < 2e-3
+        outs = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5, force_simple=True)
+        assert rel(outs, ref) < 1e-2
+        acc = out32.clone()
+        K.gemm(a, b, ta, tb, alpha=1.0, out=acc, accumulate=True)
+        ref2 = ref + (a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())
+        assert rel(acc, ref2) < 2e-3
+
+
+def test_gemm_splitk_and_batched(K):
+    torch.manual_seed(2)
+    # wgrad shape: skinny output, long contraction -> split-K path
+    dy = torch.randn(4096, 768, device=DEV).bfloat16()
+    x = torch.randn(4096, 256, device=DEV).bfloat16()
+    dw = K.gemm(dy, x, True, False)
+    assert rel(dw, dy.float().t() @ x.float()) < 1e-2
+    # row-bias + batched (the V^T projection layout): C_b[N,T] = W[N,K] X_b[T,K]^T
+    W = torch.randn(192, 128, device=DEV).bfloat16()
+    X = torch.randn(3, 40, 128, device=DEV).bfloat16()
+    bias = torch.randn(192, device=DEV).bfloat16()
+    out = torch.zeros(3, 192, 64, device=DEV, dtype=torch.bfloat16)
+    K.gemm(W.unsqueeze(0).expand(3, -1, -1), X, False, True, bias=bias, bias_row=True, out=out[:, :, :40])
+    ref = torch.einsum("nk,btk->bnt", W.float(), X.float()) + bias.float()[None, :, None]
+    assert rel(out[:, :, :40], ref) < 1e-2 and float(out[:, :, 40:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sk", [16, 40, 129, 448, 1000])
+def test_softmax_family(K, dtype, sk):
+    from oracle import restate
+    torch.manual_seed(3)
+    x = (2 * torch.randn(2, 3, 8, sk, device=DEV)).to(dtype)
+    t = 1e-6 if dtype == torch.float32 else 1e-2
+    y = K.scaled_softmax(x, 0.37)
+    assert rel(y, restate.scaled_softmax(x.cpu(), 0.37).to(DEV)) < max(t, 1e-6)
+    mask = torch.rand(2, 1, 8, sk, device=DEV) > 0.8
+    ym = K.scaled_masked_softmax(x, mask, 0.37)
+    assert rel(ym, restate.scaled_masked_softmax(x.cpu(), mask.cpu(), 0.37).to(DEV)) < max(t, 1e-6)
+    ym1 = K.scaled_masked_softmax(x, mask[:1], 0.37)
+    assert rel(ym1, restate.scaled_masked_softmax(x.cpu(), mask[:1].cpu(), 0.37).to(DEV)) < max(t, 1e-6)
+    dy = torch.randn_like(x)
+    dx = K.scaled_softmax_bwd(dy, y, 0.37)
+    assert rel(dx, restate.scaled_softmax_bwd(dy.cpu(), y.cpu(), 0.37).to(DEV)) < max(10 * t, 1e-5)
+    dyc = dy.clone()
+    dxi = K.scaled_softmax_bwd(dyc, y, 0.37, inplace=True)
+    assert dxi.data_ptr() == dyc.data_ptr() and torch.equal(dxi, dx)
+    if sk <= 448:
+        xc = x[0, :, :, :8].contiguous() if sk >= 8 else None
+        sq = torch.randn(6, sk, sk, device=DEV).to(dtype)
+        yc = K.scaled_upper_triang_masked_softmax(sq, 0.5)
+        assert rel(yc, restate.scaled_upper_triang_masked_softmax(sq.cpu(), 0.5).to(DEV)) < max(t, 1e-6)
+        assert float(torch.triu(yc.float(), 1).abs().max()) == 0.0
+
+
+def test_fused_softmax_golden(K, golden_dir):
+    import numpy as np
+    g = np.load(golden_dir + "/fused_softmax.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    s = float(g["scale"][0])
+    assert rel(K.scaled_softmax(x, s).cpu(), torch.from_numpy(g["y"])) < 1e-6
+    assert rel(K.scaled_masked_softmax(x, torch.from_numpy(g["mask"]).to(DEV), s).cpu(), torch.from_numpy(g["y_masked"])) < 1e-6
+    from oracle import restate
+    for a in [(128, 128, 2, 4), (64, 448, 2, 4), (4, 16, 1, 1), (8, 4096, 1, 1)]:
+        assert K.get_batch_per_block(*a) == restate.get_batch_per_block(*a)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_softmax(K, dtype):
+    torch.manual_seed(4)
+    B, A, T, S = 2, 3, 9, 21
+    x = torch.randn(B * A, T, S, device=DEV).to(dtype)
+    bias = torch.randn(B * A, T, S, device=DEV).to(dtype)
+    kpm = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+    kpm[1, 15:] = True
+    for causal in (False, True):
+        if causal:
+            xs, bs, kp = x[:, :, :T].contiguous(), bias[:, :, :T].contiguous(), kpm[:, :T].contiguous()
+        else:
+            xs, bs, kp = x, bias, kpm
+        w = xs.float() * 0.3 + bs.float()
+        if causal:
+            w = w + torch.triu(torch.full((T, T), float("-inf"), device=DEV), 1)
+        w = w.view(B, A, T, -1).masked_fill(kp[:, None, None, :], float("-inf")).view(B * A, T, -1)
+        ref = torch.softmax(w, -1)
+        p = K.attn_softmax(xs, bs, kp, 0.3, A, causal)
+        assert rel(p, ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+def _attn_ref(q, k, v, heads, scale, bias, kpm, c_attn, causal):
+    B, T, D = q.shape
+    S = k.shape[1]
+    hd = D // heads
+    qh = q.view(B, T, heads, hd).transpose(1, 2)
+    kh = k.view(B, S, heads, hd).transpose(1, 2)
+    vh = v.view(B, S, heads, hd).transpose(1, 2)
+    w = qh @ kh.transpose(-1, -2) * scale
+    if bias is not None:
+        w = w + bias.view(B, heads, T, S)
+    if causal:
+        w = w + torch.triu(torch.full((T, S), float("-inf"), device=q.device), 1)
+    if kpm is not None:
+        w = w.masked_fill(kpm[:, None, None, :], float("-inf"))
+    p = torch.softmax(w, -1)
+    o = p @ vh
+    if c_attn is not None:
+        o = o * c_attn.view(1, heads, 1, 1)
+    return o.transpose(1, 2).reshape(B, T, D)
+
+
+@pytest.mark.parametrize("B,heads,T,S,causal,use_bias,use_kpm", [
+    (2, 4, 32, 32, False, False, False),
+    (2, 4, 45, 45, True, True, True),
+    (1, 12, 130, 130, False, True, True),
+    (2, 4, 20, 77, False, True, True),     # cross attention
+    (2, 3, 64, 267, False, False, True),
+    (1, 2, 200, 200, True, False, False),
+])
+def test_fused_attention(K, B, heads, T, S, causal, use_bias, use_kpm):
+    torch.manual_seed(5)
+    D = heads * 64
+    q = torch.randn(B, T, D, device=DEV).bfloat16()
+    k = torch.randn(B, S, D, device=DEV).bfloat16()
+    v = torch.randn(B, S, D, device=DEV).bfloat16()
+    bias = torch.randn(B * heads, T, S, device=DEV).bfloat16() if use_bias else None
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        kpm[-1, S - 5:] = True
+    c = (1 + 0.2 * torch.randn(heads, device=DEV)).float()
+    scale = (64 * 2) ** -0.5
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    br = bias.float().requires_grad_(True) if use_bias else None
+    cr = c.clone().requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, heads, scale, br, kpm, cr, causal)
+    dout = torch.randn(B, T, D, device=DEV).bfloat16()
+    ref.backward(dout.float())
+    vt = K.transpose_heads(v, K.pad32(S))
+    assert torch.equal(vt[:, :, :S], v.transpose(1, 2)) and float(vt[:, :, S:].float().abs().max() if vt.shape[2] > S else 0) == 0
+    out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal)
+    assert rel(out, ref) < 2e-2
+    dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c,
+                                           causal=causal, need_dbias=use_bias)
+    assert rel(dq, qr.grad) < 3e-2
+    assert rel(dk, kr.grad) < 3e-2
+    assert rel(dv, vr.grad) < 3e-2
+    if use_bias:
+        assert rel(dbias, br.grad) < 3e-2
+    # dc_attn[h] = sum(delta[:, h, :T]) / c[h]
+    dc = delta.view(B, heads, -1)[:, :, :T].sum((0, 2)) / c
+    assert rel(dc, cr.grad) < 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_elementwise(K, dtype):
+    torch.manual_seed(6)
+    x = torch.randn(1000, 264, device=DEV).to(dtype)
+    dy = torch.randn_like(x)
+    xr = x.float().requires_grad_(True)
+    yr = F.gelu(xr)
+    yr.backward(dy.float())
+    t = tol(dtype)
+    assert rel(K.gelu_fwd(x), yr) < t
+    assert rel(K.gelu_bwd(dy, x), xr.grad) < t
+    # dropout: keep-rate statistics, scaling, determinism in (seed, offset), backward uses the same mask
+    res = torch.randn_like(x)
+    y = K.dropout_add(x, res, 0.1, 1234, 77)
+    y2 = K.dropout_add(x, res, 0.1, 1234, 77)
+    assert torch.equal(y, y2)
+    ones = torch.ones_like(x)
+    kept = K.dropout_add(ones, None, 0.1, 1234, 77).float() > 0       # the mask depends on (seed, offset, index) only
+    rate = kept.float().mean().item()
+    assert abs(rate - 0.9) < 0.01
+    want = torch.where(kept, x.float() / 0.9, torch.zeros_like(x.float())) + res.float()
+    assert rel(y, want) < (1e-6 if dtype == torch.float32 else 2e-2)
+    g = K.dropout_bwd(dy, 0.1, 1234, 77)
+    assert rel(g, torch.where(kept, dy.float() / 0.9, torch.zeros_like(dy.float()))) < (1e-6 if dtype == torch.float32 else 1e-2)
+    y3 = K.dropout_add(x, res, 0.1, 1234, 78)
+    assert not torch.equal(y, y3)
+    # p = 0 is the identity + residual
+    assert rel(K.dropout_add(x, res, 0.0, 1, 0), x.float() + res.float()) < t
+    # add + row vector + row mask
+    vec = torch.randn(264, device=DEV).to(dtype)
+    mask = torch.rand(1000, device=DEV) > 0.7
+    ref = (x.float() + res.float() + vec.float()) * (~mask).float()[:, None]
+    assert rel(K.add_rowvec_mask(x, res, vec, mask), ref) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embedding(K, dtype):
+    torch.manual_seed(7)
+    V, D = 500, 256
+    w = torch.randn(V, D, device=DEV).to(dtype)
+    ids = torch.randint(0, V, (7, 33), device=DEV)
+    ids[0, :10] = 1
+    ids[3, 5:9] = 42
+    out = K.embedding_fwd(w, ids)
+    assert torch.equal(out, w[ids])
+    dout = torch.randn(7, 33, D, device=DEV).to(dtype)
+    dw = K.embedding_bwd(dout, ids, V, padding_idx=1)
+    wr = w.float().requires_grad_(True)
+    F.embedding(ids, wr, padding_idx=1).backward(dout.float())
+    assert rel(dw, wr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+    assert float(dw[1].float().abs().max()) == 0.0
+    dw2 = K.embedding_bwd(dout, ids, V, padding_idx=1)
+    assert torch.equal(dw, dw2)      # deterministic
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_embed_im2col(K, dtype):
+    torch.manual_seed(8)
+    img = torch.randn(2, 3, 28, 42, device=DEV).to(dtype)
+    w = torch.randn(64, 3, 14, 14, device=DEV).to(dtype)
+    Kp = 592
+    col = K.im2col_patch(img, 14, Kp)
+    assert col.shape == (2 * 2 * 3, Kp) and float(col[:, 588:].float().abs().max()) == 0.0
+    wp = torch.zeros(64, Kp, device=DEV, dtype=dtype)
+    wp[:, :588] = w.view(64, -1)
+    out = K.gemm(col, wp, False, True)
+    ref = F.conv2d(img.float(), w.float(), stride=14).flatten(2).transpose(1, 2).reshape(-1, 64)
+    assert rel(out, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [204, 1001, 51265])
+def test_cross_entropy(K, dtype, V):
+    torch.manual_seed(9)
+    rows = 37
+    ld = (V + 7) // 8 * 8
+    store = torch.randn(rows, ld, device=DEV).to(dtype) * 3
+    logits = store[:, :V]
+    target = torch.randint(0, V, (rows,), device=DEV)
+    target[::5] = 1
+    lr = logits.float().requires_grad_(True)
+    loss_ref = F.nll_loss(F.log_softmax(lr, -1), target, ignore_index=1, reduction="sum")
+    loss_ref.backward()
+    lse, row_loss = K.cross_entropy_fwd(store, target, V, 1)
+    assert rel(row_loss.sum(), loss_ref.detach()) < 1e-5
+    gs = torch.tensor([1.0], device=DEV)
+    d = K.cross_entropy_bwd(store, target, lse, gs, V, 1)
+    assert rel(d[:, :V], lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    if ld > V:
+        assert float(d[:, V:].float().abs().max()) == 0.0
+
+
+def test_adam_and_sumsq(K):
+    torch.manual_seed(10)
+    n = 100003
+    p0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV).bfloat16()
+    # restatement of engine/optim/adam.py:192-212 (eps is added to sqrt(v) BEFORE the bias correction, unlike torch.optim.Adam)
+    ref_p, rm, rv = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    master = p0.clone()
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    model = p0.bfloat16()
+    coef = torch.tensor([0.5], device=DEV)
+    for step in (1, 2, 3):
+        gg = g.float() * 0.5
+        rm.mul_(0.9).add_(gg, alpha=0.1)
+        rv.mul_(0.999).addcmul_(gg, gg, value=0.001)
+        step_size = 1e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        ref_p.add_(ref_p, alpha=-0.01 * 1e-3)
+        ref_p.addcdiv_(rm, rv.sqrt().add_(1e-8), value=-step_size)
+        K.adam_step(master, m, v, g, model, coef, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert rel(master, ref_p) < 1e-6
+    assert torch.equal(model, master.bfloat16())
+    out = torch.zeros(1, device=DEV)
+    K.sumsq(g, out)
+    K.sumsq(master, out)
+    assert rel(out, (g.float() ** 2).sum() + (master ** 2).sum()) < 1e-5

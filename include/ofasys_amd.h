@@ -40,7 +40,8 @@ enum {
   OFA_GEMM_BIAS_ROW = 2,   /* C[m][n] += bias[m]  (transposed-output projections)                */
   OFA_GEMM_ACCUM = 4,      /* C = result + C_old  (gradient accumulation)                        */
   OFA_GEMM_FORCE_SIMPLE = 8, /* use the exact-fp32-FMA VALU kernel even for bf16 (tests)         */
-  OFA_GEMM_OUT_F32 = 16    /* bf16 inputs, fp32 output                                           */
+  OFA_GEMM_OUT_F32 = 16,   /* bf16 inputs, fp32 output                                           */
+  OFA_GEMM_A_KPAD_ZERO = 32 /* caller guarantees A[m][K..roundup8(K)) == 0 (padded logits-gradient rows) */
 };
 
 int ofa_version(void);
@@ -66,11 +67,14 @@ int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, con
  * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.
  *   transA == 0: A is [M,K] row-major (lda >= K);  transA == 1: A is stored [K,M] (lda >= M).
  *   transB == 0: B is [K,N] row-major (ldb >= N);  transB == 1: B is stored [N,K] (ldb >= K)  <- nn.Linear weight.
- * batch > 1: strided-batched (strides in elements).  bf16 runs on MFMA (v_mfma_f32_32x32x16_bf16) when every
+ * batch > 1: strided-batched (strides in elements).  Two-level batching for per-(batch, head) products on [B,T,heads*hd]
+ * rows without copies: batch index z addresses operand X at (z / batch_inner)*strideX2 + (z % batch_inner)*strideX
+ * (batch_inner <= 0 or >= batch: single level).  bf16 runs on MFMA (v_mfma_f32_32x32x16_bf16) when every
  * leading dimension is a multiple of 8 elements; fp32 (and OFA_GEMM_FORCE_SIMPLE) run an exact fp32-FMA kernel.
  * `ws`/`ws_bytes`: optional fp32 scratch that enables split-K for skinny outputs (may be NULL). */
 int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA, int transB,
              int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+             int batch_inner, int64_t strideA2, int64_t strideB2, int64_t strideC2,
              float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- the reference's fused softmax extensions, wave64 re-derivations.
@@ -113,6 +117,8 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* qt, co
                  const float* delta, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S,
                  int Tpad, int Spad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype,
                  void* stream);
+/* out[b][i] = mean over heads of p[b][a][i], i < n  (head-averaged attention weights, multihead_attention.py:347-351). */
+int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream);
 /* x: [B, T, C] rows (ld elements) -> xt: [B, C, Tpad] (zero-filled for t >= T). */
 int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, int64_t ld, int dtype, void* stream);
 
@@ -136,6 +142,23 @@ int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed,
 int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y, int64_t rows,
                         int cols, int dtype, void* stream);
 
+/* out[c] (fp32) (+)= alpha * sum_r x[r][c]  -- bias gradients of nn.Linear (autograd of multihead_attention.py:199-217). */
+int ofa_colsum_ws_floats(int cols);
+int ofa_colsum(const void* x, float* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha, int accumulate,
+               int dtype, void* stream);
+
+/* y = a * b, b either [rows,cols] or a [cols] row vector (c_attn head scale, multihead_attention.py:342-345). */
+int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream);
+/* out[0] = sum(x[0..n)) in one deterministic pass (loss = sum of per-row losses). */
+int ofa_reduce_sum_f32(const float* x, float* out, int64_t n, void* stream);
+/* out[h] = sum_b sum_{t<T} x[(b*heads+h)*ld + t]  (gradient of c_attn from the attention row sums). */
+int ofa_head_sum_f32(const float* x, float* out, int B, int heads, int T, int ld, void* stream);
+
+/* ---- attention-bias assembly (adaptor/general.py:265-280): bias [B,A,T,T] (in place) gets values [n,n,A] added on
+ * the diagonal block [start, start+n)^2 of every (b,a); the gradient reduces that block over the batch. */
+int ofa_bias_block_add(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype, void* stream);
+int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
+
 /* ---- patch embedding (adaptor/image_patch_embed.py:59-73): im2col of non-overlapping p x p patches.
  * img [B,C,H,W] -> col [B*(H/p)*(W/p), Kpad] with K = C*p*p in (c,ph,pw) order (= Conv2d weight.view(D,-1)), zero pad. */
 int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype, void* stream);
@@ -148,6 +171,13 @@ int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse,
 int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,
                           void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,
                           void* stream);
+
+/* get_normalized_probs (model/ofa.py:287-299, module/utils.py:451-462): out fp32 [rows, V] = (log-)softmax_fp32(logits);
+ * backward writes dlogits [rows, ld] in `dtype` (columns V..ld-1 zero). */
+int ofa_probs_fwd(const void* logits, float* out, int64_t rows, int64_t V, int64_t ld, int log_probs, int dtype,
+                  void* stream);
+int ofa_probs_bwd(const float* dy, const float* y, void* dlogits, int64_t rows, int64_t V, int64_t ld, int log_probs,
+                  int dtype, void* stream);
 
 /* ---- train-step glue (engine/trainer.py:857-884, optim/adam.py:144-218, optim/fp16_optimizer.py): flat arenas. */
 int ofa_sumsq_ws_floats(void);

@@ -1,0 +1,149 @@
+"""AdaptorOutput / BaseAdaptorConfig / BaseAdaptor -- the plugin base the `@register_config("ofasys.adaptor", ...)`
+adaptors derive from (reference: adaptor/base.py:19-266).  Same constructor signature, hook semantics and state-dict
+keys; the post-forward hook (scale, optional position entangling, type embedding, LayerNorms, dropout, rel-pos bias
+list) runs on the HIP kernels."""
+import math
+from abc import abstractmethod
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Union
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..configure import BaseDataclass
+from ..module import Dropout, Embedding, LayerNorm
+from ..preprocessor import Dictionary, Slot
+
+
+@dataclass
+class AdaptorOutput:
+    """embed [B,T,H], masks bool [B,T], pos_embed [B,T,H], self_attn_bias List[[B,A,T,T]]  (adaptor/base.py:19-53)."""
+    embed: torch.Tensor
+    masks: torch.Tensor
+    pos_embed: torch.Tensor
+    self_attn_bias: List[torch.Tensor]
+    modal_mask: torch.Tensor = None
+
+    def __post_init__(self):
+        assert self.embed is not None
+        batch_size, seq_length, hidden_size = self.embed.shape
+        if self.masks is not None:
+            assert self.masks.shape == (batch_size, seq_length)
+        if self.pos_embed is not None:
+            assert self.pos_embed.shape == (batch_size, seq_length, hidden_size)
+
+    @property
+    def seq_length(self):
+        return self.embed.shape[1]
+
+
+@dataclass
+class BaseAdaptorConfig(BaseDataclass):
+    is_active: bool = field(default=False, metadata={"help": "is active for config_store"})
+    layernorm_embedding: bool = True
+    layernorm_position: bool = True
+    add_type_embedding: bool = True
+    entangle_position_embedding: bool = False
+    no_scale_embedding: bool = True
+    scale_embedding_gradient: float = 1.0
+    dropout: float = None
+    embed_dim: int = None
+    num_attention_heads: int = None
+    encoder_layers: int = None
+    decoder_layers: int = None
+    max_position: int = None
+    use_self_attn_bias: bool = None
+    share_attn_bias: bool = None
+
+    def parse_from_model_cfg(self, model_cfg):
+        """adaptor/base.py:83-101: fill unset fields from the model config (entangle_position_embedding defaults to
+        False, i.e. it is NOT inherited)."""
+        self.dropout = model_cfg.dropout if self.dropout is None else self.dropout
+        self.embed_dim = model_cfg.encoder.embed_dim if self.embed_dim is None else self.embed_dim
+        self.num_attention_heads = (model_cfg.encoder.attention_heads if self.num_attention_heads is None
+                                    else self.num_attention_heads)
+        self.encoder_layers = model_cfg.encoder.layers if self.encoder_layers is None else self.encoder_layers
+        self.decoder_layers = model_cfg.decoder.layers if self.decoder_layers is None else self.decoder_layers
+        self.max_position = model_cfg.max_source_positions if self.max_position is None else self.max_position
+        self.use_self_attn_bias = (model_cfg.use_self_attn_bias if self.use_self_attn_bias is None
+                                   else self.use_self_attn_bias)
+        self.share_attn_bias = model_cfg.share_attn_bias if self.share_attn_bias is None else self.share_attn_bias
+        self.entangle_position_embedding = (model_cfg.entangle_position_embedding
+                                            if self.entangle_position_embedding is None
+                                            else self.entangle_position_embedding)
+
+
+class BaseAdaptor(torch.nn.Module):
+    def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
+                 cfg: BaseAdaptorConfig):
+        super().__init__()
+        # not registered as child modules, exactly like the reference (adaptor/base.py:128-136)
+        self.embed_tokens = lambda x: embed_tokens(x)
+        self.embed_tokens_T = lambda x: ops.linear(x, embed_tokens.weight)
+        self.dictionary = dictionary
+        self.is_src = is_src
+        self._general_adaptor = [general_adaptor]
+        self.cfg = cfg
+        self.num_layers = cfg.encoder_layers if is_src else cfg.decoder_layers
+        self.dropout_module = Dropout(cfg.dropout, module_name=self.__class__.__name__)
+        self.layernorm_embedding = LayerNorm(cfg.embed_dim) if cfg.layernorm_embedding else None
+        self.layernorm_position = LayerNorm(cfg.embed_dim) if cfg.layernorm_position else None
+        self.type_embedding = Embedding(1, cfg.embed_dim) if cfg.add_type_embedding else None
+        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
+        self.register_forward_hook(BaseAdaptor.forward_hook_fn)
+
+    @property
+    def general_adaptor(self):
+        return self._general_adaptor[0]
+
+    def forward_hook_fn(self, inputs, output: AdaptorOutput):
+        """adaptor/base.py:152-191."""
+        slot: Slot = inputs[0]
+        if self.embed_scale != 1.0:
+            raise NotImplementedError("no_scale_embedding=False is not used by OFASys' default configs")
+        if self.cfg.scale_embedding_gradient != 1.0:
+            raise NotImplementedError("scale_embedding_gradient != 1 is not implemented")
+        embed = output.embed
+        pos = output.pos_embed if (self.cfg.entangle_position_embedding and output.pos_embed is not None) else None
+        typ = self.type_embedding.weight.view(-1) if (slot.is_src and self.type_embedding is not None) else None
+        if pos is not None or typ is not None:
+            embed = ops.add_rowvec_mask(embed, pos, typ)                     # :170-173 in one pass
+        if self.layernorm_embedding is not None:
+            embed = self.layernorm_embedding(embed)
+        if self.layernorm_position is not None and output.pos_embed is not None:
+            output.pos_embed = self.layernorm_position(output.pos_embed)
+        output.embed = self.dropout_module(embed)
+        if not output.self_attn_bias and self.cfg.use_self_attn_bias:
+            output.self_attn_bias = []
+            batch_size, seq_length = output.embed.size()[:2]
+            num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
+            for idx in range(num_rel_pos_tables):
+                values = self.get_rel_pos_bias(batch_size, seq_length, idx)
+                output.self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
+        return output
+
+    @abstractmethod
+    def forward(self, inputs: Union[Slot, List[Slot]], **kwargs) -> AdaptorOutput:
+        raise NotImplementedError
+
+    def forward_output(self, x: Tensor, extra: Dict[str, Any], slot: Slot, **kwargs):
+        return x, extra
+
+    @abstractmethod
+    def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
+        raise NotImplementedError
+
+    def expand_rel_pos_bias(self, values: Tensor, batch_size: int):
+        """[T,T,A] -> [B,A,T,T] expand view (adaptor/base.py:242-256)."""
+        values = values.unsqueeze(0).expand(batch_size, -1, -1, -1)
+        return values.permute([0, 3, 1, 2])
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        pass
+
+    def update_sample(self, sample):
+        return sample
+
+    def check_adaptor_slot(self, slot):
+        return self.general_adaptor.get_adaptor(slot) is self

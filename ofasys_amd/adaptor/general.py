@@ -1,0 +1,166 @@
+"""OFAGeneralAdaptor (reference: adaptor/general.py:36-316): dispatches each Slot to its adaptor (in ModalityType
+order, outputs kept in slot order), concatenates along T and assembles the per-layer attention bias
+(absolute-position bias from pos_q/pos_k projections + each slot's relative-position bias on its diagonal block)."""
+from dataclasses import fields
+from typing import Any, Dict, List
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..configure import ConfigStore
+from ..module import Embedding, OfaLinear
+from ..preprocessor import ModalityType, Slot
+from .base import AdaptorOutput, BaseAdaptor
+
+OFAAdaptorConfig = ConfigStore().make_dataclass("ofasys.adaptor", "OFAAdaptorConfig", __name__)
+
+default_adaptor = {   # adaptor/general.py:36-46
+    ModalityType.TEXT: "text",
+    ModalityType.IMAGE: "image_resnet",
+    ModalityType.BOX: "text",
+    ModalityType.AUDIO: "audio_fbank",
+    ModalityType.PHONE: "text",
+    ModalityType.VIDEO: "video_image_sequence",
+    ModalityType.MOTION: "text",
+    ModalityType.STRUCT: "text",
+    ModalityType.CATEGORY: "text",
+}
+
+
+class OFAGeneralAdaptor(torch.nn.Module):
+    _embed_tokens = None
+
+    def __init__(self, cfg, dictionary, is_src):
+        super().__init__()
+        self.embed_tokens = self.build_embedding(cfg, dictionary)
+        self.cfg = cfg
+        self.is_src = is_src
+        self.name2adaptor: Dict[str, BaseAdaptor] = {}
+        for config_field in fields(cfg.adaptor):
+            name = config_field.name
+            if name.startswith("_"):
+                continue
+            if name == "image_vqgan" and is_src:                        # general.py:73-80
+                continue
+            if name in ("image_resnet", "video_image_sequence", "image_vit") and not is_src:
+                continue
+            config = getattr(cfg.adaptor, name)
+            config.parse_from_model_cfg(cfg)
+            if config.is_active is False:
+                continue
+            self.name2adaptor[name] = ConfigStore().get("ofasys.adaptor", name).target(
+                self.embed_tokens, dictionary, is_src, self, config)
+            setattr(self, name, self.name2adaptor[name])
+        embed_dim = cfg.encoder_embed_dim if is_src else cfg.decoder_embed_dim
+        self.num_attention_heads = cfg.encoder_attention_heads if is_src else cfg.decoder_attention_heads
+        self.pos_scaling = float(embed_dim / cfg.encoder_attention_heads * cfg.attn_scale_factor) ** -0.5   # :98
+        if not self.cfg.entangle_position_embedding:
+            self.pos_q_linear = OfaLinear(embed_dim, embed_dim)
+            self.pos_k_linear = OfaLinear(embed_dim, embed_dim)
+
+    # `embed_tokens` is a shared module registered once per general adaptor (encoder and decoder hold the same object)
+    def get_adaptor(self, slot: Slot) -> BaseAdaptor:
+        if slot.get_attr("adaptor"):
+            return self.name2adaptor[slot.get_attr("adaptor")]
+        return self.name2adaptor[default_adaptor[slot.modality]]
+
+    def forward(self, slots: List[Slot], **kwargs):
+        modality_outputs = [None for _ in range(len(slots))]
+        cnt = 0
+        for mod in ModalityType:                                        # general.py:137-149 (RNG/dropout order)
+            for i, slot in enumerate(slots):
+                if slot.modality == mod:
+                    modality_outputs[i] = self.get_adaptor(slot)(slot, **kwargs)
+                    cnt += 1
+            if cnt == len(slots):
+                break
+        assert cnt == len(slots), cnt
+        output = self.concat(modality_outputs)
+        return output.embed, output.masks, output.pos_embed, output.self_attn_bias, None
+
+    def forward_output(self, x: Tensor, extra: Dict[str, Any], slots: List[Slot], **kwargs):
+        output_slot = None
+        for slot in slots:
+            if not slot.is_src:
+                assert output_slot is None, "supports only one target slot"
+                output_slot = slot
+        assert output_slot
+        return self.get_adaptor(output_slot).forward_output(x, extra, slot=output_slot)
+
+    def build_embedding(self, cfg, dictionary):
+        if OFAGeneralAdaptor._embed_tokens is not None:
+            return OFAGeneralAdaptor._embed_tokens
+        assert cfg.share_all_embeddings
+        assert cfg.encoder_embed_dim == cfg.decoder_embed_dim
+        embed_tokens = Embedding(num_embeddings=len(dictionary), embedding_dim=cfg.encoder_embed_dim,
+                                 padding_idx=dictionary.pad())
+        cfg.share_decoder_input_output_embed = True
+        if cfg.freeze_encoder_embedding:
+            embed_tokens.weight.requires_grad = False
+        OFAGeneralAdaptor._embed_tokens = embed_tokens
+        return embed_tokens
+
+    def build_abs_pos_bias(self, pos_embed):
+        """pos_q*pos_scaling @ pos_k^T per head -> [B,A,T,T] (general.py:223-243)."""
+        batch_size, seq_length = pos_embed.size(0), pos_embed.size(1)
+        if not self.cfg.entangle_position_embedding:
+            pos_q = self.pos_q_linear(pos_embed, alpha=self.pos_scaling)
+            pos_k = self.pos_k_linear(pos_embed)
+            return ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
+        return torch.zeros(batch_size, self.num_attention_heads, seq_length, seq_length, dtype=pos_embed.dtype,
+                           device=pos_embed.device)
+
+    def concat(self, modality_outputs: List[AdaptorOutput]) -> AdaptorOutput:
+        """general.py:245-282."""
+        if len(modality_outputs) == 1:
+            o = modality_outputs[0]
+            output = AdaptorOutput(o.embed, o.masks, o.pos_embed, None)
+        else:
+            output = AdaptorOutput(
+                torch.cat(tuple(x.embed for x in modality_outputs), dim=1),
+                torch.cat(tuple(x.masks for x in modality_outputs), dim=1),
+                torch.cat(tuple(x.pos_embed for x in modality_outputs), dim=1),
+                None,
+            )
+        if not self.cfg.use_self_attn_bias:
+            return output
+        output.self_attn_bias = []
+        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed)
+        num_layers = self.cfg.encoder.layers if self.is_src else self.cfg.decoder.layers
+        num_rel_pos_tables = 1 if self.cfg.share_attn_bias else num_layers
+        starts, s = [], 0
+        for mo in modality_outputs:
+            starts.append(s)
+            s += mo.seq_length
+        assert s == output.seq_length
+        for idx in range(num_rel_pos_tables):
+            values = []
+            for mo in modality_outputs:
+                b = mo.self_attn_bias[idx] if mo.self_attn_bias else None
+                # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values; take the values back
+                values.append(_unexpand(b))
+            output.self_attn_bias.append(ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values))
+        return output
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        for adaptor_name in self.name2adaptor:
+            self.name2adaptor[adaptor_name].upgrade_state_dict_named(state_dict, "{}.{}".format(name, adaptor_name))
+        return state_dict
+
+    def update_sample(self, sample):
+        for adaptor_name in self.name2adaptor:
+            self.name2adaptor[adaptor_name].update_sample(sample)
+        return sample
+
+
+def _unexpand(b):
+    """[B,A,T,T] batch-expanded view (stride 0 on batch) of [T,T,A] values -> the [T,T,A] values; a genuinely
+    per-sample bias (no adaptor in scope produces one) is rejected."""
+    if b is None:
+        return None
+    if b.dim() == 4 and b.stride(0) == 0:
+        return b[0].permute(1, 2, 0)
+    if b.dim() == 3:
+        return b
+    raise NotImplementedError("per-sample self_attn_bias from an adaptor is not supported yet")

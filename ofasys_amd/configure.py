@@ -1,0 +1,77 @@
+"""Minimal counterpart of ofasys.configure for the hot path: the `@register_config(group, name, dataclass)` plugin
+registry that adaptors register themselves in (reference: configure/config_store.py:22-72, 207-230).
+
+Only what the path needs is here (no argparse/omegaconf bridge -- out of scope).
+"""
+import copy
+import dataclasses
+from dataclasses import dataclass, field, fields, is_dataclass
+from typing import Any, Dict
+
+
+@dataclass
+class BaseDataclass:
+    _name: Any = None
+
+    @classmethod
+    def from_dict(cls, d):
+        obj = cls()
+        for k, v in (d or {}).items():
+            cur = getattr(obj, k, None)
+            if is_dataclass(cur) and isinstance(v, dict):
+                for kk, vv in v.items():
+                    setattr(cur, kk, vv)
+            else:
+                setattr(obj, k, v)
+        return obj
+
+    def update(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+        return self
+
+
+@dataclass
+class _Node:
+    target: Any
+    config: Any
+
+
+class ConfigStore:
+    """Singleton registry: group -> name -> (class, default config dataclass)."""
+    _inst = None
+
+    def __new__(cls):
+        if cls._inst is None:
+            cls._inst = super().__new__(cls)
+            cls._inst.repo = {}
+        return cls._inst
+
+    def store(self, group, name, target, config_cls):
+        self.repo.setdefault(group, {})[name] = _Node(target, config_cls)
+
+    def get(self, group, name):
+        return self.repo[group][name]
+
+    def names(self, group):
+        return list(self.repo.get(group, {}).keys())
+
+    def make_dataclass(self, group, cls_name, module):
+        """Synthesise a dataclass with one field per registered plugin of `group` (config_store.py:207-230).
+        Unlike the reference, every instance gets FRESH sub-configs (default_factory), so adaptor settings do not
+        leak between models built in one process (SURVEY.md section 5, config gotcha)."""
+        flds = []
+        for name, node in self.repo.get(group, {}).items():
+            flds.append((name, node.config, field(default_factory=node.config)))
+        dc = dataclasses.make_dataclass(cls_name, flds, bases=(BaseDataclass,))
+        dc.__module__ = module
+        return dc
+
+
+def register_config(group, name, dataclass=None):
+    """Class decorator: `@register_config("ofasys.adaptor", "text", TextAdaptorConfig)` (config_store.py:41-72)."""
+    def deco(cls):
+        ConfigStore().store(group, name, cls, dataclass)
+        cls.__config_group__, cls.__config_name__ = group, name
+        return cls
+    return deco

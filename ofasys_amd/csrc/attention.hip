@@ -461,6 +461,32 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   return check_launch("attn_bwd_dkv");
 }
 
+// out[b][i] = mean_a p[b][a][i]  (head-averaged attention weights, multihead_attention.py:347-351)
+namespace ofa {
+template <typename T>
+__global__ __launch_bounds__(256) void mean_heads_kernel(const T* __restrict__ p, T* __restrict__ out, int heads, int64_t n) {
+  const int b = blockIdx.y;
+  const float inv = 1.0f / (float)heads;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int a = 0; a < heads; ++a) s += ld1<T>(p + ((int64_t)b * heads + a) * n + i);
+    st1<T>(out + (int64_t)b * n + i, s * inv);
+  }
+}
+}  // namespace ofa
+
+extern "C" int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream) {
+  OFA_REQUIRE(p && out && B > 0 && heads > 0 && n > 0, OFA_ERR_INVALID, "mean_heads: bad argument");
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "mean_heads: bad dtype %d", dtype);
+  int64_t gx = (n + 255) / 256;
+  dim3 grid((unsigned)(gx > 1024 ? 1024 : gx), B), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((mean_heads_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)p, (float*)out, heads, n);
+  else
+    hipLaunchKernelGGL((mean_heads_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (bf16_t*)out, heads, n);
+  return check_launch("mean_heads");
+}
+
 extern "C" int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, int64_t ld, int dtype,
                                    void* stream) {
   OFA_REQUIRE(x && xt && B > 0 && T > 0 && C > 0 && Tpad >= T && ld >= C, OFA_ERR_INVALID, "transpose_heads: bad argument");

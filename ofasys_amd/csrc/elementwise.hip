@@ -98,6 +98,20 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict_
   }
 }
 
+// narrow tables (rel-pos bias tables are [n_rel, heads], heads = 4..16): element-wise gather
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_scalar_kernel(const T* __restrict__ w, const int64_t* __restrict__ ids,
+                                                                   T* __restrict__ out, int64_t n, int D, int64_t V) {
+  const int64_t total = n * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / D;
+    const int c = (int)(e % D);
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    out[e] = w[id * D + c];
+  }
+}
+
 // dweight[v] += sum_{i : ids[i]==v} dout[i]   -- one wave per vocabulary row; the wave sweeps the id list 64 at a time,
 // ballots the matches and accumulates the matching rows in increasing position order (deterministic, no atomics).
 template <typename T>
@@ -156,6 +170,45 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const T* __restrict__
     }
     st1<T>(col + e, v);
   }
+}
+
+// column sums of a [rows, cols] matrix (bias gradients): 64 column-vectors x 4 row-lanes per block, grid.y row groups,
+// fp32 partials [grid.y][cols] folded by a second pass (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                             int64_t rows, int cols, int64_t ld) {
+  constexpr int N = Vec<T>::N;
+  __shared__ float red[4][64][N];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * N;
+  float acc[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) acc[j] = 0.f;
+  if (c < cols) {
+    for (int64_t r = (int64_t)blockIdx.y * 4 + ry; r < rows; r += (int64_t)gridDim.y * 4) {
+      float v[N];
+      load_vec<T>(x + r * ld + c, v);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) red[ry][cx][j] = acc[j];
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      partial[(int64_t)blockIdx.y * cols + c + j] = red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j];
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int cols, int groups, float alpha, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * cols + c];
+  s *= alpha;
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 static inline int grid_for(int64_t work) {
@@ -238,9 +291,17 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
                                  void* stream) {
   OFA_DT_CHECK("embedding_fwd");
   OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && weight && ids && out, OFA_ERR_INVALID, "embedding_fwd: bad argument");
-  OFA_REQUIRE(D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "embedding_fwd: D=%d not vectorizable", D);
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (D % (dtype == OFA_F32 ? 4 : 8) != 0) {
+    if (dtype == OFA_F32)
+      hipLaunchKernelGGL((embedding_fwd_scalar_kernel<float>), dim3(grid_for(n * D)), dim3(256), 0, st, (const float*)weight,
+                         ids, (float*)out, n, D, V);
+    else
+      hipLaunchKernelGGL((embedding_fwd_scalar_kernel<bf16_t>), dim3(grid_for(n * D)), dim3(256), 0, st,
+                         (const bf16_t*)weight, ids, (bf16_t*)out, n, D, V);
+    return check_launch("embedding_fwd_scalar");
+  }
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((embedding_fwd_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)weight, ids,
                        (float*)out, n, D, V);
@@ -281,4 +342,96 @@ extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H,
     hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img,
                        (bf16_t*)col, B, C, H, W, p, Kpad);
   return check_launch("im2col_patch");
+}
+
+extern "C" int ofa_colsum_ws_floats(int cols) { return 128 * cols; }
+
+extern "C" int ofa_colsum(const void* x, float* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
+                          int accumulate, int dtype, void* stream) {
+  OFA_DT_CHECK("colsum");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && x && out && ws, OFA_ERR_INVALID, "colsum: bad argument");
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(cols % n == 0 && ld % n == 0, OFA_ERR_UNSUPPORTED, "colsum: cols=%d / ld not vectorizable", cols);
+  hipStream_t st = (hipStream_t)stream;
+  int groups = (int)((rows + 63) / 64);
+  groups = groups < 1 ? 1 : (groups > 128 ? 128 : groups);
+  dim3 grid(cdiv(cols / n, 64), groups), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, ws, rows, cols, ld);
+  else
+    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ws, rows, cols, ld);
+  int rc = check_launch("colsum_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, out, cols, groups,
+                     alpha, accumulate);
+  return check_launch("colsum_final");
+}
+
+// ---- y = a * b  (b same shape, or a row vector broadcast over rows)
+namespace ofa {
+template <typename T>
+__global__ __launch_bounds__(256) void mul_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                  int64_t rows, int cols, int b_rowvec) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = cols / N;
+  const int64_t total = rows * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    float x[N], t[N];
+    load_vec<T>(a + r * cols + c, x);
+    load_vec<T>(b_rowvec ? b + c : b + r * cols + c, t);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] *= t[j];
+    store_vec<T>(y + r * cols + c, x);
+  }
+}
+// out[0] = sum(x[0..n))   single block, deterministic
+__global__ __launch_bounds__(256) void reduce_sum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  __shared__ float sw[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+// out[h] = sum_b sum_t x[(b*heads + h)*ld + t], t < T     one block per head
+__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int heads,
+                                                       int T, int ld) {
+  __shared__ float sw[4];
+  const int h = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int t = threadIdx.x; t < T; t += 256) s += x[((int64_t)b * heads + h) * ld + t];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[h] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+}  // namespace ofa
+
+extern "C" int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream) {
+  OFA_DT_CHECK("mul");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && a && b && y, OFA_ERR_INVALID, "mul: bad argument");
+  OFA_REQUIRE(cols % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "mul: cols=%d not vectorizable", cols);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((mul_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, rows, cols, b_rowvec);
+  else
+    hipLaunchKernelGGL((mul_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, cols, b_rowvec);
+  return check_launch("mul");
+}
+
+extern "C" int ofa_reduce_sum_f32(const float* x, float* out, int64_t n, void* stream) {
+  OFA_REQUIRE(n >= 0 && out && (n == 0 || x), OFA_ERR_INVALID, "reduce_sum_f32: bad argument");
+  hipLaunchKernelGGL(reduce_sum_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  return check_launch("reduce_sum_f32");
+}
+
+extern "C" int ofa_head_sum_f32(const float* x, float* out, int B, int heads, int T, int ld, void* stream) {
+  OFA_REQUIRE(x && out && B > 0 && heads > 0 && T > 0 && ld >= T, OFA_ERR_INVALID, "head_sum_f32: bad argument");
+  hipLaunchKernelGGL(head_sum_kernel, dim3(heads), dim3(256), 0, (hipStream_t)stream, x, out, B, heads, T, ld);
+  return check_launch("head_sum_f32");
 }

@@ -8,7 +8,12 @@ struct GemmArgs {
   int M, N, K, transA, transB;
   int64_t lda, ldb, ldc, strideA, strideB, strideC;
   float alpha; int flags;
+  int batch_inner;                       // batch index z -> (z / batch_inner, z % batch_inner)
+  int64_t strideA2, strideB2, strideC2;  // outer strides (elements)
 };
+__host__ __device__ inline int64_t batch_off(int z, int inner, int64_t s_in, int64_t s_out) {
+  return (int64_t)(z / inner) * s_out + (int64_t)(z % inner) * s_in;
+}
 int gemm_simple_launch(const GemmArgs& g, int batch, int dtype, hipStream_t st);
 int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st);
 bool gemm_mfma_supported(const GemmArgs& g);

@@ -56,7 +56,8 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[NV], const bf16_t* __res
     } else {
       constexpr int VPR = R / 8;
       const int k = v / VPR, c = (v % VPR) * 8;
-      if (k0 + k < kend && r0 + c < rmax) val = *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + k) * ld + r0 + c);
+      // a ragged last vector stays inside ld (launch precondition)
+      if (k0 + k < kend && r0 + c < ((rmax + 7) & ~7)) val = *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + k) * ld + r0 + c);
     }
     reg[i] = val;
   }
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int tm = t / tiles_n, tn = t % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int bz = blockIdx.z, ks = blockIdx.y;
-  const bf16_t* A = (const bf16_t*)g.A + (int64_t)bz * g.strideA;
-  const bf16_t* B = (const bf16_t*)g.B + (int64_t)bz * g.strideB;
+  const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
+  const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
   const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   // epilogue: lane owns output row m = .. + (lane&31); register r holds column (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int hi = lane >> 5;
   const bool split = gridDim.y > 1;
-  void* Cb = OUT_F32 ? (void*)((float*)g.C + (int64_t)bz * g.strideC) : (void*)((bf16_t*)g.C + (int64_t)bz * g.strideC);
+  const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
+  void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
-        if (n >= g.N) continue;   // N % 4 == 0 is a launch precondition
+        if (n >= g.N) continue;   // a ragged last quad stays inside ldc (launch precondition)
         const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2],
                     v3 = acc[i][j][4 * q + 3];
         if (split) {
-          float* p = ws + (((int64_t)bz * gridDim.y + ks) * g.M + m) * g.N + n;
+          float* p = ws + (((int64_t)bz * gridDim.y + ks) * g.M + m) * ((g.N + 3) & ~3) + n;
           *reinterpret_cast<float4*>(p) = make_float4(v0, v1, v2, v3);
         } else {
           epilogue_store<OUT_F32>(g, Cb, m, n, v0, v1, v2, v3);
@@ -250,14 +252,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const float* __restrict__ ws, int splits) {
-  const int64_t quads = (int64_t)g.M * (g.N / 4);
+  const int64_t quads = (int64_t)g.M * ((g.N + 3) / 4);
   const int bz = blockIdx.y;
-  void* Cb = OUT_F32 ? (void*)((float*)g.C + (int64_t)bz * g.strideC) : (void*)((bf16_t*)g.C + (int64_t)bz * g.strideC);
+  const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
+  void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / (g.N / 4)), n = (int)(i % (g.N / 4)) * 4;
+    const int m = (int)(i / ((g.N + 3) / 4)), n = (int)(i % ((g.N + 3) / 4)) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < splits; ++k) {
-      const float4 p = *reinterpret_cast<const float4*>(ws + (((int64_t)bz * splits + k) * g.M + m) * g.N + n);
+      const float4 p = *reinterpret_cast<const float4*>(ws + (((int64_t)bz * splits + k) * g.M + m) * ((g.N + 3) & ~3) + n);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
     epilogue_store<OUT_F32>(g, Cb, m, n, s.x, s.y, s.z, s.w);
@@ -266,12 +269,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const fl
 
 bool gemm_mfma_supported(const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
-  if ((g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || (g.N & 3)) return false;
+  // Leading dimensions are 16-byte multiples; logical sizes may be ragged as long as the padded vector/quad stays
+  // inside the row (ld): e.g. logits [rows, V=51265] stored with ld = 51272 (adaptor/text.py:129-142 output).
+  const int64_t M8 = (g.M + 7) & ~7, N8 = (g.N + 7) & ~7, N4 = (g.N + 3) & ~3, K8 = (g.K + 7) & ~7;
+  if ((g.lda & 7) || (g.ldb & 7) || (g.ldc & 3) || N4 > g.ldc) return false;
   if ((g.strideA & 7) || (g.strideB & 7) || (g.strideC & 3)) return false;
-  if (!g.transA && (g.K & 7)) return false;  // k-major A: vectors along k
-  if (g.transB && (g.K & 7)) return false;   // k-major B
-  if (g.transA && (g.M & 7)) return false;   // m-major A: vectors along m
-  if (!g.transB && (g.N & 7)) return false;  // m-major B: vectors along n
+  if ((g.strideA2 & 7) || (g.strideB2 & 7) || (g.strideC2 & 3)) return false;
+  if (!g.transA && (g.K & 7)) {              // k-major A with a ragged K: only against an m-major B (whose k rows are
+    if (g.transB || !(g.flags & OFA_GEMM_A_KPAD_ZERO) || K8 > g.lda) return false;   // exact) and a zero row tail
+  }
+  if (g.transB && (g.K & 7)) return false;   // k-major B: vectors along k must be whole
+  if (g.transA && M8 > g.lda) return false;  // m-major A: vectors along m
+  if (!g.transB && N8 > g.ldb) return false; // m-major B: vectors along n
+  if ((g.flags & OFA_GEMM_BIAS_COL) && (g.N & 3)) return false;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.C & 15)) return false;
   if ((g.flags & OFA_GEMM_BIAS_COL) && ((uintptr_t)g.bias & 7)) return false;
   return true;
@@ -317,7 +327,7 @@ int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, h
     const int maxs = g.K / 512;
     if (splits > maxs) splits = maxs;
     if (splits > 32) splits = 32;
-    while (splits > 1 && (int64_t)splits * batch * g.M * g.N * 4 > ws_bytes) --splits;
+    while (splits > 1 && (int64_t)splits * batch * g.M * ((g.N + 3) & ~3) * 4 > ws_bytes) --splits;
     if (splits < 1) splits = 1;
   }
   int ksplit = g.K;
@@ -335,7 +345,7 @@ int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, h
   int rc = check_launch("gemm_mfma");
   if (rc) return rc;
   if (splits > 1) {
-    const int64_t quads = (int64_t)g.M * (g.N / 4);
+    const int64_t quads = (int64_t)g.M * ((g.N + 3) / 4);
     dim3 grid((unsigned)((quads + 255) / 256 > 2048 ? 2048 : (quads + 255) / 256), batch), block(256);
     if (of) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, block, 0, st, g, (const float*)ws, splits);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, block, 0, st, g, (const float*)ws, splits);
@@ -350,7 +360,8 @@ using namespace ofa;
 
 extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA,
                         int transB, int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB,
-                        int64_t strideC, float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream) {
+                        int64_t strideC, int batch_inner, int64_t strideA2, int64_t strideB2, int64_t strideC2,
+                        float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream) {
   OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "gemm: bad dtype %d", dtype);
   OFA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, OFA_ERR_INVALID, "gemm: negative size");
   if (M == 0 || N == 0 || batch == 0) return 0;
@@ -360,7 +371,9 @@ extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias,
               "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb,
               (long long)ldc);
   OFA_REQUIRE(!(dtype == OFA_F32 && (flags & OFA_GEMM_OUT_F32)), OFA_ERR_INVALID, "gemm: OUT_F32 is for bf16 inputs");
-  GemmArgs g{A, B, C, bias, M, N, K, transA, transB, lda, ldb, ldc, strideA, strideB, strideC, alpha, flags};
+  if (batch_inner <= 0 || batch_inner >= batch) { batch_inner = batch; strideA2 = strideB2 = strideC2 = 0; }
+  GemmArgs g{A, B, C, bias, M, N, K, transA, transB, lda, ldb, ldc, strideA, strideB, strideC, alpha, flags,
+             batch_inner, strideA2, strideB2, strideC2};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_BF16 && !(flags & OFA_GEMM_FORCE_SIMPLE) && K > 0 && gemm_mfma_supported(g))
     return gemm_mfma_launch(g, batch, ws, ws_bytes, st);

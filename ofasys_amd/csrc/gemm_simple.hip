@@ -13,9 +13,9 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(GemmArgs g) {
   __shared__ float sA[BK][BM + 4];
   __shared__ float sB[BK][BN + 4];
   const int bz = blockIdx.z;
-  const T* A = (const T*)g.A + (int64_t)bz * g.strideA;
-  const T* B = (const T*)g.B + (int64_t)bz * g.strideB;
-  TO* C = (TO*)g.C + (int64_t)bz * g.strideC;
+  const T* A = (const T*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
+  const T* B = (const T*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
+  TO* C = (TO*)g.C + batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, each 4 (m) x 4 (n)
   float acc[4][4] = {};

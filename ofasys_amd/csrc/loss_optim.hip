@@ -84,6 +84,54 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   }
 }
 
+// get_normalized_probs (model/ofa.py:287-299): fp32 softmax / log-softmax of the logits, one block per row.
+__device__ __forceinline__ float block_sum(float v, float* sw) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sw[0] + sw[1] + sw[2] + sw[3];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void probs_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int64_t V, int64_t ld,
+                                                        int log_probs) {
+  __shared__ float sw[4];
+  const T* xr = x + (int64_t)blockIdx.x * ld;
+  float* yr = y + (int64_t)blockIdx.x * V;
+  float m = -INFINITY;
+  for (int64_t c = threadIdx.x; c < V; c += 256) m = fmaxf(m, ld1<T>(xr + c));
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sw[0], sw[1]), fmaxf(sw[2], sw[3]));
+  float s = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) s += expf(ld1<T>(xr + c) - m);
+  s = block_sum(s, sw);
+  const float l = m + logf(s);
+  for (int64_t c = threadIdx.x; c < V; c += 256) {
+    const float t = ld1<T>(xr + c) - l;
+    yr[c] = log_probs ? t : expf(t);
+  }
+}
+// log: dx = dy - exp(y)*sum(dy);   prob: dx = y*(dy - sum(dy*y))
+template <typename T>
+__global__ __launch_bounds__(256) void probs_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        T* __restrict__ dx, int64_t V, int64_t ld, int log_probs) {
+  __shared__ float sw[4];
+  const float* dyr = dy + (int64_t)blockIdx.x * V;
+  const float* yr = y + (int64_t)blockIdx.x * V;
+  T* dxr = dx + (int64_t)blockIdx.x * ld;
+  float s = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) s += log_probs ? dyr[c] : dyr[c] * yr[c];
+  s = block_sum(s, sw);
+  for (int64_t c = threadIdx.x; c < ld; c += 256) {
+    float g = 0.f;
+    if (c < V) g = log_probs ? dyr[c] - expf(yr[c]) * s : yr[c] * (dyr[c] - s);
+    st1<T>(dxr + c, g);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t n) {
   constexpr int N = Vec<T>::N;
@@ -163,6 +211,28 @@ extern "C" int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, 
   else
     hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index);
   return check_launch("cross_entropy_bwd");
+}
+
+extern "C" int ofa_probs_fwd(const void* logits, float* out, int64_t rows, int64_t V, int64_t ld, int log_probs, int dtype,
+                             void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "probs_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && out, OFA_ERR_INVALID, "probs_fwd: bad argument");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((probs_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, out, V, ld, log_probs);
+  else hipLaunchKernelGGL((probs_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, out, V, ld, log_probs);
+  return check_launch("probs_fwd");
+}
+
+extern "C" int ofa_probs_bwd(const float* dy, const float* y, void* dlogits, int64_t rows, int64_t V, int64_t ld,
+                             int log_probs, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "probs_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && dy && y && dlogits, OFA_ERR_INVALID, "probs_bwd: bad argument");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((probs_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (float*)dlogits, V, ld, log_probs);
+  else hipLaunchKernelGGL((probs_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (bf16_t*)dlogits, V, ld, log_probs);
+  return check_launch("probs_bwd");
 }
 
 extern "C" int ofa_sumsq_ws_floats(void) { return 1024; }

@@ -55,7 +55,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False):
 
 # ------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.0, out=None, accumulate=False,
-         out_f32=False, force_simple=False):
+         out_f32=False, force_simple=False, a_kpad_zero=False):
     """C = alpha * (op(a) @ op(b) + bias) [+ C].  a, b: 2-D (or 3-D batched) tensors whose last dim is contiguous."""
     assert a.dim() == b.dim() and a.dim() in (2, 3)
     batched = a.dim() == 3
@@ -85,13 +85,29 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
         flags |= GEMM_FORCE_SIMPLE
     if dt == BF16 and out.dtype == torch.float32:
         flags |= GEMM_OUT_F32
+    if a_kpad_zero:
+        flags |= 32   # OFA_GEMM_A_KPAD_ZERO
     lda, ldb, ldc = a.stride(-2), b.stride(-2), out.stride(-2)
     sa = a.stride(0) if batched else 0
     sb = b.stride(0) if batched else 0
     sc = out.stride(0) if batched else 0
     ws = workspace(256 << 20, a.device, "gemm")
     lib().call("ofa_gemm", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, batch,
-               sa, sb, sc, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
+               sa, sb, sc, 0, 0, 0, 0, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
+    return out
+
+
+def gemm_heads(a, b, out, M, N, K, trans_a, trans_b, lda, ldb, ldc, B, heads, sa, sa2, sb, sb2, sc, sc2, alpha=1.0,
+               accumulate=False):
+    """Per-(batch, head) GEMMs straight on [B, T, heads*hd] rows (no permute copies): operand X of product (b, h)
+    starts at X + b*sX2 + h*sX."""
+    dt = dtype_code(a)
+    flags = GEMM_ACCUM if accumulate else 0
+    if dt == BF16 and out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    ws = workspace(256 << 20, a.device, "gemm")
+    lib().call("ofa_gemm", ptr(a), ptr(b), ptr(out), None, M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, B * heads,
+               sa, sb, sc, heads, sa2, sb2, sc2, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
     return out
 
 
@@ -324,6 +340,21 @@ def cross_entropy_bwd(logits2d, target, lse, grad_scale, V, ignore_index, dlogit
     return dlogits
 
 
+def probs_fwd(logits2d, V, ld, log_probs):
+    rows = logits2d.shape[0]
+    y = torch.empty(rows, V, dtype=torch.float32, device=logits2d.device)
+    lib().call("ofa_probs_fwd", ptr(logits2d), ptr(y), rows, V, ld, int(log_probs), dtype_code(logits2d), stream())
+    return y
+
+
+def probs_bwd(dy, y, V, dtype, log_probs):
+    rows = y.shape[0]
+    ld = (V + 7) // 8 * 8
+    d = torch.empty(rows, ld, dtype=dtype, device=y.device)
+    lib().call("ofa_probs_bwd", ptr(dy), ptr(y), ptr(d), rows, V, ld, int(log_probs), dtype_code(d), stream())
+    return d
+
+
 def sumsq(x, out):
     """out (fp32[1]) += sum(x*x)."""
     x = x.contiguous()
@@ -336,3 +367,73 @@ def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, b
     lib().call("ofa_adam_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), ptr(model_param), ptr(coef),
                master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                dtype_code(grad), stream())
+
+
+def colsum(x, alpha=1.0, out=None, accumulate=False):
+    """fp32 column sums of a 2-D tensor (last dim contiguous)."""
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().cdll.ofa_colsum_ws_floats(cols) * 4, x.device, "colsum")
+    lib().call("ofa_colsum", ptr(x), ptr(out), ptr(ws), rows, cols, x.stride(0), float(alpha), int(accumulate),
+               dtype_code(x), stream())
+    return out
+
+
+def mul(a, b):
+    a, b = a.contiguous(), b.contiguous()
+    rows, cols = _rows_cols(a)
+    y = torch.empty_like(a)
+    lib().call("ofa_mul", ptr(a), ptr(b), ptr(y), rows, cols, 0, dtype_code(a), stream())
+    return y
+
+
+def mul_rowvec(a, vec):
+    a, vec = a.contiguous(), vec.contiguous()
+    rows, cols = _rows_cols(a)
+    y = torch.empty_like(a)
+    lib().call("ofa_mul", ptr(a), ptr(vec), ptr(y), rows, cols, 1, dtype_code(a), stream())
+    return y
+
+
+def sum_f32(x):
+    x = x.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    lib().call("ofa_reduce_sum_f32", ptr(x), ptr(out), x.numel(), stream())
+    return out
+
+
+def bias_block_add_(bias, values, start):
+    """In place: bias[B,A,T,T][:, :, s:s+n, s:s+n] += values[n,n,A] (broadcast over batch)."""
+    B, A, T, _ = bias.shape
+    n = values.shape[0]
+    values = values.contiguous()
+    assert bias.is_contiguous() and values.dtype == bias.dtype
+    lib().call("ofa_bias_block_add", ptr(bias), ptr(values), B, A, T, start, n, dtype_code(bias), stream())
+    return bias
+
+
+def bias_block_grad(dbias, start, n):
+    dbias = dbias.contiguous()
+    B, A, T, _ = dbias.shape
+    dvalues = torch.empty(n, n, A, dtype=dbias.dtype, device=dbias.device)
+    lib().call("ofa_bias_block_grad", ptr(dbias), ptr(dvalues), B, A, T, start, n, dtype_code(dbias), stream())
+    return dvalues
+
+
+def mean_heads(p, B, heads):
+    """p: [B*heads, T, S] -> [B, T, S] mean over heads."""
+    p = p.contiguous()
+    T, S = p.shape[1], p.shape[2]
+    out = torch.empty(B, T, S, dtype=p.dtype, device=p.device)
+    lib().call("ofa_mean_heads", ptr(p), ptr(out), B, heads, T * S, dtype_code(p), stream())
+    return out
+
+
+def head_sum(x, B, heads, T):
+    """x: fp32 [B*heads, ld] -> [heads] sums over batch and the first T columns."""
+    out = torch.empty(heads, dtype=torch.float32, device=x.device)
+    lib().call("ofa_head_sum_f32", ptr(x), ptr(out), B, heads, T, x.stride(0), stream())
+    return out

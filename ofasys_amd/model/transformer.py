@@ -1,0 +1,214 @@
+"""TransformerEncoder / TransformerDecoder stacks (reference: model/transformer.py:33-156, 206-539) over the gfx950
+layers.  Activations live batch-major ([B,T,C] storage); the [T,B,C] tensors handed to the layers and returned in
+`encoder_out` are transposed views, so the reference's tensor contract holds without layout copies.
+
+Deliberate differences (same results): no `masks.any()` host sync (transformer.py:110) -- padded rows are zeroed and
+the padding mask is passed unconditionally, which is arithmetically the identity when nothing is padded."""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import kernels as K
+from .. import ops
+from ..adaptor import AdaptorOutput, OFAGeneralAdaptor
+from ..module import LayerNorm, Linear, OfaLinear, TransformerDecoderLayer, TransformerEncoderLayer
+from ..preprocessor import Dictionary, Slot
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, cfg, dictionary: Dictionary):
+        super().__init__()
+        self.cfg = cfg
+        self.dictionary = dictionary
+        self.register_buffer("version", torch.Tensor([3]))
+        OFAGeneralAdaptor._embed_tokens = None          # a fresh shared embedding per model (transformer.py:48)
+        self.adaptor = OFAGeneralAdaptor(cfg, dictionary, True)
+        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations or cfg.encoder_layerdrop > 0:
+            raise NotImplementedError("activation checkpointing / LayerDrop are not implemented in ofasys_amd")
+        self.layers = nn.ModuleList([])
+        dpr = torch.linspace(0, cfg.encode_drop_path_rate, cfg.encoder_layers)
+        self.layers.extend([self.build_encoder_layer(cfg, drop_path_rate=float(dpr[i])) for i in range(cfg.encoder_layers)])
+        self.layer_norm = LayerNorm(cfg.encoder_embed_dim) if cfg.encoder_normalize_before else None
+
+    def build_encoder_layer(self, cfg, drop_path_rate=0.0):
+        return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)
+
+    def forward(self, slots: List[Slot], return_all_hiddens: bool = False, return_all_attention_weights: bool = False):
+        """See model/transformer.py:78-102 for the returned dict."""
+        if len(slots) == 0:
+            return None
+        adaptor_output = AdaptorOutput(*self.adaptor(slots))
+        # zero the padded positions (transformer.py:110-112); unconditional, no host sync
+        adaptor_output.embed = ops.add_rowvec_mask(adaptor_output.embed, None, None, adaptor_output.masks)
+        x = adaptor_output.embed.transpose(0, 1)                     # B x T x C -> T x B x C (view)
+        T = x.size(0)
+        encoder_states = [x] if return_all_hiddens else []
+        encoder_attention_states = []
+        for idx, layer in enumerate(self.layers):
+            if self.cfg.use_self_attn_bias:
+                b = adaptor_output.self_attn_bias[0 if self.cfg.share_attn_bias else idx]
+                self_attn_bias = b.view(-1, T, T)
+            else:
+                self_attn_bias = None
+            x, self_attn_weights = layer(x, encoder_padding_mask=adaptor_output.masks, self_attn_bias=self_attn_bias,
+                                         need_attn=return_all_attention_weights, modal_mask=adaptor_output.modal_mask)
+            if return_all_hiddens:
+                encoder_states.append(x)
+            if return_all_attention_weights:
+                encoder_attention_states.append(self_attn_weights)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return {
+            "encoder_out": [x],                                     # T x B x C
+            "encoder_padding_mask": [adaptor_output.masks],         # B x T
+            "encoder_embedding": [adaptor_output.embed],            # B x T x C
+            "encoder_states": encoder_states,
+            "position_embeddings": [adaptor_output.pos_embed],      # B x T x C
+            "encoder_attention_weights": encoder_attention_states,
+        }
+
+    def reorder_encoder_out(self, encoder_out: Dict[str, List[Tensor]], new_order):
+        def sel(key, dim):
+            return [] if len(encoder_out[key]) == 0 else [encoder_out[key][0].index_select(dim, new_order)]
+        return {
+            "encoder_out": sel("encoder_out", 1), "encoder_padding_mask": sel("encoder_padding_mask", 0),
+            "encoder_embedding": sel("encoder_embedding", 0),
+            "encoder_states": [s.index_select(1, new_order) for s in encoder_out["encoder_states"]],
+            "position_embeddings": sel("position_embeddings", 0),
+        }
+
+    def max_positions(self):
+        return self.cfg.max_source_positions
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, cfg, dictionary, no_encoder_attn=False):
+        super().__init__()
+        self.cfg = cfg
+        self.dictionary = dictionary
+        self.register_buffer("version", torch.Tensor([3]))
+        self._future_mask = torch.empty(0)
+        self.adaptor = OFAGeneralAdaptor(cfg, dictionary, False)
+        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations or cfg.decoder_layerdrop > 0:
+            raise NotImplementedError("activation checkpointing / LayerDrop are not implemented in ofasys_amd")
+        self.share_input_output_embed = cfg.share_decoder_input_output_embed
+        self.num_attention_heads = cfg.decoder_attention_heads
+        embed_dim = cfg.decoder_embed_dim
+        self.embed_dim = embed_dim
+        self.output_embed_dim = int(cfg.decoder_output_dim)
+        if self.cfg.use_self_attn_bias:
+            self.cross_pos_q_linear = OfaLinear(embed_dim, embed_dim)
+            self.cross_pos_k_linear = OfaLinear(embed_dim, embed_dim)
+        self.cross_self_attention = cfg.cross_self_attention
+        self.layers = nn.ModuleList([])
+        # (sic) the reference builds the decoder's drop-path rates from the ENCODER's rate and layer count, :249-252
+        dpr = torch.linspace(0, cfg.encode_drop_path_rate, cfg.encoder_layers)
+        self.layers.extend([self.build_decoder_layer(cfg, no_encoder_attn, drop_path_rate=float(dpr[i]))
+                            for i in range(cfg.decoder_layers)])
+        self.num_layers = len(self.layers)
+        self.layer_norm = LayerNorm(embed_dim) if cfg.decoder_normalize_before else None
+        self.project_out_dim = (Linear(embed_dim, self.output_embed_dim, bias=False)
+                                if embed_dim != self.output_embed_dim and not cfg.tie_adaptive_weights else None)
+        self.adaptive_softmax = None
+
+    def build_decoder_layer(self, cfg, no_encoder_attn=False, drop_path_rate=0.0):
+        return TransformerDecoderLayer(cfg, no_encoder_attn, drop_path_rate=drop_path_rate)
+
+    def get_cross_pos_info(self, embed, tgt_pos_embed, src_pos_embed):
+        """abs position bias for cross attention -> [B,A,Tt,Ts] (model/transformer.py:280-299)."""
+        pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling)
+        pos_k = self.cross_pos_k_linear(src_pos_embed)
+        return ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
+
+    def forward(self, slots: List[Slot], encoder_out: Optional[Dict[str, List[Tensor]]] = None,
+                incremental_state=None, features_only: bool = False, full_context_alignment: bool = False,
+                alignment_layer: Optional[int] = None, alignment_heads: Optional[int] = None,
+                return_all_hiddens: bool = False, return_all_attention_weights: bool = False):
+        x, extra = self.extract_features(slots, encoder_out=encoder_out, incremental_state=incremental_state,
+                                         full_context_alignment=full_context_alignment, alignment_layer=alignment_layer,
+                                         alignment_heads=alignment_heads, return_all_hiddens=return_all_hiddens,
+                                         return_all_attention_weights=return_all_attention_weights)
+        extra["last_hidden_state"] = x
+        if not features_only:
+            return self.adaptor.forward_output(x, extra, slots)
+        return x, extra
+
+    def extract_features(self, slots: List[Slot], encoder_out, incremental_state=None, full_context_alignment: bool = False,
+                         alignment_layer: Optional[int] = None, alignment_heads: Optional[int] = None,
+                         return_all_hiddens: bool = False, return_all_attention_weights: bool = False):
+        if incremental_state is not None:
+            raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
+        adaptor_output = AdaptorOutput(*self.adaptor(slots))
+        bsz, slen = adaptor_output.embed.size()[:2]
+        if alignment_layer is None:
+            alignment_layer = self.num_layers - 1
+        enc = padding_mask = src_pos_embed = None
+        if encoder_out is not None and len(encoder_out["encoder_out"]) > 0:
+            enc = encoder_out["encoder_out"][0]
+            assert enc.size()[1] == bsz, f"Expected enc.shape == (t, {bsz}, c) got {enc.shape}"
+        if encoder_out is not None and len(encoder_out["encoder_padding_mask"]) > 0:
+            padding_mask = encoder_out["encoder_padding_mask"][0]
+        if encoder_out is not None and len(encoder_out["position_embeddings"]) > 0:
+            src_pos_embed = encoder_out["position_embeddings"][0]
+        tgt_embed, tgt_pos_embed = adaptor_output.embed, adaptor_output.pos_embed
+        self_attn_padding_mask = adaptor_output.masks
+        all_self_attn_bias = adaptor_output.self_attn_bias
+        if not self.cfg.entangle_position_embedding:
+            cross_abs_pos_bias = self.get_cross_pos_info(tgt_embed, tgt_pos_embed, src_pos_embed=src_pos_embed)
+            cross_abs_pos_bias = cross_abs_pos_bias.reshape(-1, *cross_abs_pos_bias.size()[-2:])
+        else:
+            cross_abs_pos_bias = None
+        x = tgt_embed.transpose(0, 1)                                 # T x B x C (view)
+        attn = None
+        inner_states: List[Optional[Tensor]] = [x] if return_all_hiddens else []
+        decoder_attentions, cross_attentions = [], []
+        for idx, layer in enumerate(self.layers):
+            self_attn_mask = self.buffered_future_mask(x) if not full_context_alignment else None
+            if self.cfg.use_self_attn_bias:
+                b = all_self_attn_bias[0 if self.cfg.share_attn_bias else idx]
+                self_attn_bias = b.view(-1, *b.size()[-2:])
+            else:
+                self_attn_bias = False                                # forces the slow attention path, :477
+            x, layer_self_attn, layer_cross_attn = layer(
+                x, enc, padding_mask, None, self_attn_mask=self_attn_mask, self_attn_padding_mask=self_attn_padding_mask,
+                need_attn=bool((idx == alignment_layer) or return_all_attention_weights),
+                need_head_weights=bool(idx == alignment_layer), self_attn_bias=self_attn_bias,
+                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask)
+            if return_all_attention_weights:
+                decoder_attentions.append(layer_self_attn)
+                cross_attentions.append(layer_cross_attn)
+            inner_states.append(x)
+            if layer_self_attn is not None and idx == alignment_layer:
+                attn = layer_self_attn                                # [A,B,Tt,Ts]; (sic) this is the CROSS attention, :479
+        if attn is not None:
+            A, B_, Tt, Ts = attn.shape
+            w = attn.detach()
+            if alignment_heads is not None:
+                w = w[:alignment_heads]
+                A = w.shape[0]
+            # mean over heads (:501-506) with the head-mean kernel: [A,B,T,S] view -> [B,A,T,S] storage
+            attn = K.mean_heads(w.transpose(0, 1).reshape(B_ * A, Tt, Ts), B_, A)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        x = x.transpose(0, 1)                                         # T x B x C -> B x T x C
+        if self.project_out_dim is not None:
+            x = self.project_out_dim(x)
+        return x, {"attn": [attn], "inner_states": inner_states, "decoder_attentions": decoder_attentions,
+                   "cross_attentions": cross_attentions}
+
+    def max_positions(self):
+        return self.cfg.max_target_positions
+
+    def buffered_future_mask(self, tensor):
+        """triu(-inf, 1) [T,T] (model/transformer.py:528-539), tagged so MultiheadAttention applies causality inside the
+        kernel instead of reading a T x T mask from HBM."""
+        dim = tensor.size(0)
+        if self._future_mask.size(0) < dim or self._future_mask.device != tensor.device or \
+                self._future_mask.dtype != tensor.dtype:
+            m = torch.triu(torch.full((dim, dim), float("-inf"), dtype=tensor.dtype, device=tensor.device), 1)
+            self._future_mask = m
+        out = self._future_mask[:dim, :dim]
+        out._ofa_causal = True
+        return out

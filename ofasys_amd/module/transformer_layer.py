@@ -1,0 +1,214 @@
+"""TransformerEncoderLayer / TransformerDecoderLayer with the reference's names, signatures and state-dict keys
+(module/transformer_layer.py:18-209, 212-495), on the gfx950 kernels.
+
+Fusions relative to the reference's op-by-op graph (same arithmetic, fewer HBM round trips):
+  * dropout + residual add                      -> one kernel   (transformer_layer.py:181-182, 203-206)
+  * GELU + ffn_layernorm (LayerNorm over 4D)     -> one kernel   (:194-197); the pre-GELU fc1 output is what is saved
+  * q/k/v/out projections, fc1, fc2              -> MFMA GEMM with bias in the epilogue
+Only the configuration space of OFASys' GeneralistModel is implemented: pre- or post-LN, scale_attn / scale_fc /
+scale_heads / scale_resids; modal_ffn (single-device MoE) and cross_self_attention are refused loudly.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from .layers import Dropout, DropPath, LayerNorm, OfaLinear
+from .multihead_attention import MultiheadAttention
+
+
+def _act_name(cfg):
+    return getattr(cfg, "activation_fn", "gelu")
+
+
+class _FFNMixin:
+    def _ffn(self, x):
+        """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494."""
+        residual = x
+        if self.normalize_before:
+            x = self.final_layer_norm(x)
+        h = self.fc1(x)
+        act_p = self.activation_dropout_module.p if self.training else 0.0
+        if self.ffn_layernorm is not None and act_p == 0.0 and self._gelu:
+            x = ops.layer_norm(h, self.ffn_layernorm.weight, self.ffn_layernorm.bias, self.ffn_layernorm.eps, fuse_gelu=True)
+        else:
+            if not self._gelu:
+                raise NotImplementedError("only activation_fn='gelu' (OFASys default) is implemented")
+            x = ops.gelu(h)
+            x = self.activation_dropout_module(x)
+            if self.ffn_layernorm is not None:
+                x = self.ffn_layernorm(x)
+        x = self.fc2(x)
+        if self.w_resid is not None:
+            residual = ops.mul_rowvec(residual, self.w_resid)                   # :204-205
+        x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
+        if not self.normalize_before:
+            x = self.final_layer_norm(x)
+        return x
+
+
+class TransformerEncoderLayer(nn.Module, _FFNMixin):
+    def __init__(self, args, drop_path_rate=0.0):
+        super().__init__()
+        cfg = args
+        self.cfg = cfg
+        if getattr(cfg, "modal_ffn", False):
+            raise NotImplementedError("modal_ffn is not implemented in ofasys_amd")
+        self.embed_dim = cfg.encoder.embed_dim
+        self.self_attn = self.build_self_attention(self.embed_dim, cfg)
+        self.self_attn_layer_norm = LayerNorm(self.embed_dim)
+        self.dropout_module = Dropout(cfg.dropout, module_name=self.__class__.__name__)
+        self._gelu = _act_name(cfg) == "gelu"
+        activation_dropout_p = cfg.activation_dropout
+        if activation_dropout_p == 0:
+            activation_dropout_p = cfg.relu_dropout or 0
+        self.activation_dropout_module = Dropout(float(activation_dropout_p), module_name=self.__class__.__name__)
+        self.normalize_before = cfg.encoder.normalize_before
+        self.fc1 = OfaLinear(self.embed_dim, cfg.encoder.ffn_embed_dim)
+        self.fc2 = OfaLinear(cfg.encoder.ffn_embed_dim, self.embed_dim)
+        self.attn_ln = LayerNorm(self.embed_dim) if cfg.scale_attn else None
+        self.nh = self.self_attn.num_heads
+        self.head_dim = self.self_attn.head_dim
+        self.ffn_layernorm = LayerNorm(cfg.encoder.ffn_embed_dim) if cfg.scale_fc else None
+        self.w_resid = nn.Parameter(torch.ones(self.embed_dim), requires_grad=True) if cfg.scale_resids else None
+        self.final_layer_norm = LayerNorm(self.embed_dim)
+        self.drop_path = DropPath(float(drop_path_rate), batch_axis=1)
+
+    def build_self_attention(self, embed_dim, cfg):
+        return MultiheadAttention(embed_dim, cfg.encoder.attention_heads, dropout=cfg.attention_dropout,
+                                  self_attention=True, scale_factor=cfg.attn_scale_factor, scale_heads=cfg.scale_heads,
+                                  use_fused=cfg.use_fused)
+
+    def residual_connection(self, x, residual):
+        return ops.dropout_add(self.drop_path(x), residual, 0.0, False)
+
+    def forward(self, x, encoder_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor] = None,
+                self_attn_bias: Optional[Tensor] = None, need_attn: bool = False, modal_mask=None):
+        """x: (seq_len, batch, embed_dim); see transformer_layer.py:141-158."""
+        if attn_mask is not None:
+            attn_mask = attn_mask.masked_fill(attn_mask.to(torch.bool), -1e8 if x.dtype == torch.float32 else -1e4)
+        residual = x
+        if self.normalize_before:
+            x = self.self_attn_layer_norm(x)
+        x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=encoder_padding_mask,
+                                              need_weights=need_attn, attn_mask=attn_mask, attn_bias=self_attn_bias)
+        if self.attn_ln is not None:
+            x = self.attn_ln(x)
+        x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)   # :181-182
+        if not self.normalize_before:
+            x = self.self_attn_layer_norm(x)
+        x = self._ffn(x)
+        return x, self_attn_weights
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        layer_norm_map = {"0": "self_attn_layer_norm", "1": "final_layer_norm"}
+        for old, new in layer_norm_map.items():
+            for m in ("weight", "bias"):
+                k = "{}.layer_norms.{}.{}".format(name, old, m)
+                if k in state_dict:
+                    state_dict["{}.{}.{}".format(name, new, m)] = state_dict.pop(k)
+
+
+class TransformerDecoderLayer(nn.Module, _FFNMixin):
+    def __init__(self, args, no_encoder_attn=False, add_bias_kv=False, add_zero_attn=False, drop_path_rate=0.0):
+        super().__init__()
+        cfg = args
+        self.cfg = cfg
+        if getattr(cfg, "modal_ffn", False):
+            raise NotImplementedError("modal_ffn is not implemented in ofasys_amd")
+        if cfg.cross_self_attention:
+            raise NotImplementedError("cross_self_attention is not used by OFASys' GeneralistModel")
+        self.embed_dim = cfg.decoder.embed_dim
+        self.dropout_module = Dropout(cfg.dropout, module_name=self.__class__.__name__)
+        self.cross_self_attention = cfg.cross_self_attention
+        self.self_attn = self.build_self_attention(self.embed_dim, cfg, add_bias_kv=add_bias_kv, add_zero_attn=add_zero_attn)
+        self.self_attn_ln = LayerNorm(self.embed_dim) if cfg.scale_attn else None
+        self.cross_attn_ln = LayerNorm(self.embed_dim) if cfg.scale_attn else None
+        self.nh = self.self_attn.num_heads
+        self.head_dim = self.self_attn.head_dim
+        self._gelu = _act_name(cfg) == "gelu"
+        activation_dropout_p = cfg.activation_dropout
+        if activation_dropout_p == 0:
+            activation_dropout_p = cfg.relu_dropout or 0
+        self.activation_dropout_module = Dropout(float(activation_dropout_p), module_name=self.__class__.__name__)
+        self.normalize_before = cfg.decoder.normalize_before
+        self.self_attn_layer_norm = LayerNorm(self.embed_dim)
+        if no_encoder_attn:
+            self.encoder_attn = None
+            self.encoder_attn_layer_norm = None
+        else:
+            self.encoder_attn = self.build_encoder_attention(self.embed_dim, cfg)
+            self.encoder_attn_layer_norm = LayerNorm(self.embed_dim)
+        self.ffn_layernorm = LayerNorm(cfg.decoder.ffn_embed_dim) if cfg.scale_fc else None
+        self.w_resid = nn.Parameter(torch.ones(self.embed_dim), requires_grad=True) if cfg.scale_resids else None
+        self.fc1 = OfaLinear(self.embed_dim, cfg.decoder.ffn_embed_dim)
+        self.fc2 = OfaLinear(cfg.decoder.ffn_embed_dim, self.embed_dim)
+        self.final_layer_norm = LayerNorm(self.embed_dim)
+        self.need_attn = True
+        self.drop_path = DropPath(float(drop_path_rate), batch_axis=1)
+
+    def build_self_attention(self, embed_dim, cfg, add_bias_kv=False, add_zero_attn=False):
+        return MultiheadAttention(embed_dim, cfg.decoder.attention_heads, dropout=cfg.attention_dropout,
+                                  add_bias_kv=add_bias_kv, add_zero_attn=add_zero_attn,
+                                  self_attention=not cfg.cross_self_attention, scale_factor=cfg.attn_scale_factor,
+                                  scale_heads=cfg.scale_heads, use_fused=cfg.use_fused)
+
+    def build_encoder_attention(self, embed_dim, cfg):
+        return MultiheadAttention(embed_dim, cfg.decoder.attention_heads, kdim=cfg.encoder.embed_dim,
+                                  vdim=cfg.encoder.embed_dim, dropout=cfg.attention_dropout,
+                                  encoder_decoder_attention=True, scale_factor=cfg.attn_scale_factor,
+                                  scale_heads=cfg.scale_heads, use_fused=cfg.use_fused)
+
+    def forward(self, x, encoder_out: Optional[torch.Tensor] = None, encoder_padding_mask: Optional[torch.Tensor] = None,
+                incremental_state: Optional[Dict[str, Dict[str, Optional[Tensor]]]] = None,
+                prev_self_attn_state: Optional[List[torch.Tensor]] = None,
+                prev_attn_state: Optional[List[torch.Tensor]] = None, self_attn_mask: Optional[torch.Tensor] = None,
+                self_attn_padding_mask: Optional[torch.Tensor] = None, need_attn: bool = False,
+                need_head_weights: bool = False, self_attn_bias: Optional[Tensor] = None,
+                cross_attn_bias: Optional[Tensor] = None, modal_mask=None):
+        """x: (seq_len, batch, embed_dim); see transformer_layer.py:367-385."""
+        if need_head_weights:
+            need_attn = True
+        if incremental_state is not None or prev_self_attn_state is not None or prev_attn_state is not None:
+            raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
+        residual = x
+        if self.normalize_before:
+            x = self.self_attn_layer_norm(x)
+        x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask,
+                                              incremental_state=None, need_weights=need_attn, attn_mask=self_attn_mask,
+                                              attn_bias=self_attn_bias)
+        if self.self_attn_ln is not None:
+            x = self.self_attn_ln(x)
+        x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
+        if not self.normalize_before:
+            x = self.self_attn_layer_norm(x)
+        cross_attn_weights = None
+        if self.encoder_attn is not None and encoder_out is not None:
+            residual = x
+            if self.normalize_before:
+                x = self.encoder_attn_layer_norm(x)
+            x, cross_attn_weights = self.encoder_attn(
+                query=x, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
+                incremental_state=None, static_kv=True,
+                need_weights=need_attn or (not self.training and self.need_attn), need_head_weights=need_head_weights,
+                attn_bias=cross_attn_bias)
+            if self.cross_attn_ln is not None:
+                x = self.cross_attn_ln(x)
+            x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
+            if not self.normalize_before:
+                x = self.encoder_attn_layer_norm(x)
+        x = self._ffn(x)
+        return x, cross_attn_weights, self_attn_weights       # (sic) the reference returns them in this order, :495
+
+    def make_generation_fast_(self, need_attn: bool = False, **kwargs):
+        self.need_attn = need_attn
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        layer_norm_map = {"0": "self_attn_layer_norm", "1": "encoder_attn_layer_norm", "2": "final_layer_norm"}
+        for old, new in layer_norm_map.items():
+            for m in ("weight", "bias"):
+                k = "{}.layer_norms.{}.{}".format(name, old, m)
+                if k in state_dict:
+                    state_dict["{}.{}.{}".format(name, new, m)] = state_dict.pop(k)

@@ -1,0 +1,511 @@
+"""torch.autograd.Function wrappers over the HIP kernels (ofasys_amd/kernels.py).
+
+These are the building blocks the mirrored modules (ofasys_amd/module, adaptor, model) call.  Internally every
+activation is a dense [rows, C] matrix in batch-major order ([B,T,C] storage); fairseq's [T,B,C] tensors at the module
+boundary are transposed *views* of that storage, so no layout copies happen between ops.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from .lib import OfaError
+
+
+# ---------------------------------------------------------------------------------------------- layout helpers
+def rows_view(x):
+    """(x2d, restore): x2d is a contiguous [rows, C] view (or copy) of x; restore(y2d) gives y2d the shape/layout of x."""
+    C = x.shape[-1]
+    if x.is_contiguous():
+        lead = x.shape[:-1]
+        return x.view(-1, C), lambda y: y.view(*lead, y.shape[-1])
+    if x.dim() == 3:
+        xt = x.transpose(0, 1)
+        if xt.is_contiguous():          # a [T,B,C] view of [B,T,C] storage
+            b, t = xt.shape[0], xt.shape[1]
+            return xt.view(-1, C), lambda y: y.view(b, t, y.shape[-1]).transpose(0, 1)
+    xc = x.contiguous()
+    lead = xc.shape[:-1]
+    return xc.view(-1, C), lambda y: y.view(*lead, y.shape[-1])
+
+
+def batch_major(x):
+    """[T,B,C] (any strides) -> contiguous [B,T,C] (a view when x is already a transposed batch-major buffer)."""
+    xt = x.transpose(0, 1)
+    return xt if xt.is_contiguous() else xt.contiguous()
+
+
+class _Rng:
+    """Philox (seed, offset) bookkeeping for dropout: one monotonically increasing offset per process."""
+    seed = 0x5EED0FA
+    offset = 0
+
+    @classmethod
+    def manual_seed(cls, seed):
+        cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+
+    @classmethod
+    def reserve(cls, n):
+        o = cls.offset
+        cls.offset += (n + 3) // 4 + 1
+        return cls.seed, o
+
+
+manual_seed = _Rng.manual_seed
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, eps, fuse_gelu):
+        y, mean, rstd = K.layernorm_fwd(x2d, weight, bias, eps, fuse_gelu)
+        ctx.save_for_backward(x2d, weight, mean, rstd)
+        ctx.fuse_gelu = fuse_gelu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, weight, mean, rstd = ctx.saved_tensors
+        dx, dg, db = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
+    """F.layer_norm over the last dim (module/layer_norm.py:27-32); fuse_gelu: LayerNorm(gelu(x))."""
+    x2d, restore = rows_view(x)
+    return restore(LayerNormFn.apply(x2d, weight, bias, eps, fuse_gelu))
+
+
+# ---------------------------------------------------------------------------------------------- Linear
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, alpha):
+        ctx.save_for_backward(x2d, weight)
+        ctx.alpha = alpha
+        ctx.has_bias = bias is not None
+        N = weight.shape[0]
+        out = None
+        ctx.padded = False
+        if N % 8 != 0:
+            # ragged output width (vocabulary logits): pad the row stride to 16 bytes so the MFMA GEMMs, the criterion
+            # and the gradient GEMMs stay vectorised; callers see the exact [rows, N] view.
+            store = torch.empty(x2d.shape[0], (N + 7) // 8 * 8, dtype=x2d.dtype, device=x2d.device)
+            out = store[:, :N]
+            ctx.padded = True
+        return K.gemm(x2d, weight, False, True, bias=bias, alpha=alpha, out=out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, weight = ctx.saved_tensors
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        dx = dw = db = None
+        N = weight.shape[0]
+        # the criterion / probs kernels hand back a zero-padded gradient row (stride a multiple of 8)
+        kpad = ctx.padded and dy.stride(0) >= (N + 7) // 8 * 8 and dy.stride(0) % 8 == 0
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm(dy, weight, False, False, alpha=ctx.alpha, a_kpad_zero=kpad)  # dX = dY W
+        if ctx.needs_input_grad[1]:
+            dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                       # dW = dY^T X
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = K.colsum(dy, alpha=ctx.alpha).to(weight.dtype)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, alpha=1.0):
+    """alpha * F.linear(x, weight, bias)."""
+    x2d, restore = rows_view(x)
+    return restore(LinearFn.apply(x2d, weight, bias, alpha))
+
+
+# ---------------------------------------------------------------------------------------------- GELU / dropout / adds
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.gelu_bwd(dy, x)
+
+
+def gelu(x):
+    x2d, restore = rows_view(x)
+    return restore(GeluFn.apply(x2d))
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """y = residual + dropout_p(x)  (residual may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        seed, off = _Rng.reserve(x.numel())
+        ctx.p, ctx.seed, ctx.off = p, seed, off
+        ctx.has_res = residual is not None
+        return K.dropout_add(x, residual, p, seed, off)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = K.dropout_bwd(dy, ctx.p, ctx.seed, ctx.off)
+        return dx, (dy if ctx.has_res else None), None
+
+
+class AddFn(torch.autograd.Function):
+    """a + b + vec (row broadcast) with rows where rowmask is set forced to zero."""
+
+    @staticmethod
+    def forward(ctx, a, b, vec, rowmask):
+        ctx.save_for_backward(rowmask)
+        ctx.has = (b is not None, vec is not None)
+        ctx.vdtype = vec.dtype if vec is not None else None
+        return K.add_rowvec_mask(a, b, vec, rowmask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rowmask,) = ctx.saved_tensors
+        g = K.add_rowvec_mask(dy, None, None, rowmask) if rowmask is not None else dy
+        dvec = K.colsum(g).to(ctx.vdtype) if ctx.has[1] else None
+        return g, (g if ctx.has[0] else None), dvec, None
+
+
+def dropout_add(x, residual, p, training):
+    """residual + dropout(x) (transformer_layer.py:181-182); plain add when not training / p == 0."""
+    x2d, restore = rows_view(x)
+    r2d = None
+    if residual is not None:
+        r2d, _ = rows_view(residual)
+        if r2d.shape != x2d.shape:
+            raise OfaError("dropout_add: shape mismatch")
+    if training and p > 0:
+        return restore(DropoutAddFn.apply(x2d, r2d, p))
+    if r2d is None:
+        return x
+    return restore(AddFn.apply(x2d, r2d, None, None))
+
+
+def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+    a2d, restore = rows_view(a)
+    b2d = rows_view(b)[0] if b is not None else None
+    m = rowmask.reshape(-1) if rowmask is not None else None
+    return restore(AddFn.apply(a2d, b2d, vec, m))
+
+
+# ---------------------------------------------------------------------------------------------- embedding
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.V, ctx.padding_idx = weight.shape[0], padding_idx
+        return K.embedding_fwd(weight, ids)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dw = K.embedding_bwd(dout, ids, ctx.V, -1 if ctx.padding_idx is None else ctx.padding_idx)
+        return None, dw, None
+
+
+def embedding(ids, weight, padding_idx=None):
+    return EmbeddingFn.apply(ids, weight, padding_idx)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+class FusedAttentionFn(torch.autograd.Function):
+    """bf16 fused attention on [B,T,D] rows (csrc/attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal):
+        vt = K.transpose_heads(v, K.pad32(k.shape[1]))
+        c32 = c_attn.float() if c_attn is not None else None
+        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn)
+        ctx.heads, ctx.scale, ctx.causal = heads, scale, causal
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, bias, kpm, c_attn = ctx.saved_tensors
+        c32 = c_attn.float() if c_attn is not None else None
+        need_dbias = bias is not None and ctx.needs_input_grad[3]
+        dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
+                                              c_attn=c32, causal=ctx.causal, need_dbias=need_dbias)
+        dc = None
+        if c_attn is not None and ctx.needs_input_grad[5]:
+            # d c_attn[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]   (O = c * PV)
+            dsum = K.head_sum(delta, q.shape[0], ctx.heads, q.shape[1])
+            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+        return dq, dk, dv, dbias, None, dc, None, None, None
+
+
+class UnfusedAttentionFn(torch.autograd.Function):
+    """Exact-tier attention (any dtype): scores and probabilities are materialised, every product is a per-(batch, head)
+    GEMM on the [B,T,D] rows.  Used for fp32 parity, need_weights and attention dropout.  Returns (out, probs)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal, dropout_p):
+        B, T, D = q.shape
+        S = k.shape[1]
+        hd = D // heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        scores = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device)
+        K.gemm_heads(q, k, scores, T, S, hd, False, True, D, D, S, B, heads, hd, T * D, hd, S * D, T * S, heads * T * S)
+        p = K.attn_softmax(scores, bias, kpm, scale, heads, causal)
+        pd = p
+        seed = off = 0
+        if dropout_p > 0:
+            seed, off = _Rng.reserve(p.numel())
+            pd = K.dropout_add(p, None, dropout_p, seed, off)
+        o = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+        K.gemm_heads(pd, v, o, T, hd, S, False, False, S, D, D, B, heads, T * S, heads * T * S, hd, S * D, hd, T * D)
+        out = _scale_heads(o, c_attn, heads) if c_attn is not None else o
+        ctx.save_for_backward(q, k, v, p, o, c_attn)
+        ctx.cfg = (heads, scale, dropout_p, seed, off)
+        return out, p
+
+    @staticmethod
+    def backward(ctx, dout, dp_unused):
+        q, k, v, p, o, c_attn = ctx.saved_tensors
+        heads, scale, dropout_p, seed, off = ctx.cfg
+        B, T, D = q.shape
+        S = k.shape[1]
+        hd = D // heads
+        dout = dout.contiguous()
+        dc = None
+        do = dout
+        if c_attn is not None:
+            prod = K.mul(dout, o)                                             # d c[h] = sum_{b,t,d} dout * (PV)
+            dc = K.colsum(K.colsum(prod.view(-1, D)).view(heads, hd).t().contiguous()).to(c_attn.dtype)
+            do = _scale_heads(dout, c_attn, heads)
+        pd = p
+        if dropout_p > 0:
+            pd = K.dropout_add(p, None, dropout_p, seed, off)
+        dv = torch.empty_like(v)
+        K.gemm_heads(pd, do, dv, S, hd, T, True, False, S, D, D, B, heads, T * S, heads * T * S, hd, T * D, hd, S * D)
+        dpd = torch.empty_like(p)
+        K.gemm_heads(do, v, dpd, T, S, hd, False, True, D, D, S, B, heads, hd, T * D, hd, S * D, T * S, heads * T * S)
+        if dropout_p > 0:
+            dpd = K.dropout_bwd(dpd, dropout_p, seed, off)
+        ds = K.scaled_softmax_bwd(dpd, p, 1.0)                                  # dS wrt (scale*qk + bias)
+        dq = torch.empty_like(q)
+        K.gemm_heads(ds, k, dq, T, hd, S, False, False, S, D, D, B, heads, T * S, heads * T * S, hd, S * D, hd, T * D,
+                     alpha=scale)
+        dk = torch.empty_like(k)
+        K.gemm_heads(ds, q, dk, S, hd, T, True, False, S, D, D, B, heads, T * S, heads * T * S, hd, T * D, hd, S * D,
+                     alpha=scale)
+        dbias = ds if ctx.needs_input_grad[3] else None
+        return dq, dk, dv, dbias, None, dc, None, None, None, None
+
+
+def _scale_heads(x, c_attn, heads):
+    """x[b,t,h,:] * c[h]  (multihead_attention.py:342-345) with the row-vector multiply kernel."""
+    B, T, D = x.shape
+    vec = c_attn.to(x.dtype).view(heads, 1).expand(heads, D // heads).reshape(-1)
+    return K.mul_rowvec(x.view(-1, D), vec).view(B, T, D)
+
+
+def attention(q, k, v, heads, scale, bias=None, key_padding_mask=None, c_attn=None, causal=False, dropout_p=0.0,
+              need_weights=False):
+    """Attention core on [B,T,D] rows.  Returns (out [B,T,D], probs [B*heads,T,S] or None)."""
+    fused_ok = (q.dtype == torch.bfloat16 and q.shape[-1] // heads == 64 and dropout_p == 0.0 and not need_weights)
+    if bias is not None and bias.dtype != q.dtype:
+        bias = bias.to(q.dtype)
+    if fused_ok:
+        return FusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal), None
+    out, p = UnfusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal, dropout_p)
+    return out, p
+
+
+# ---------------------------------------------------------------------------------------------- position biases
+class HeadsMatmulNTFn(torch.autograd.Function):
+    """out[b,a] = x_{b,a} y_{b,a}^T for x [B,T,D], y [B,S,D] rows split into `heads` column groups -> [B,A,T,S]
+    (abs-pos bias, adaptor/general.py:223-243; cross abs-pos bias, model/transformer.py:280-299)."""
+
+    @staticmethod
+    def forward(ctx, x, y, heads, alpha):
+        x, y = x.contiguous(), y.contiguous()
+        B, T, D = x.shape
+        S = y.shape[1]
+        hd = D // heads
+        out = torch.empty(B, heads, T, S, dtype=x.dtype, device=x.device)
+        K.gemm_heads(x, y, out, T, S, hd, False, True, D, D, S, B, heads, hd, T * D, hd, S * D, T * S, heads * T * S,
+                     alpha=alpha)
+        ctx.save_for_backward(x, y)
+        ctx.heads, ctx.alpha = heads, alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y = ctx.saved_tensors
+        heads, alpha = ctx.heads, ctx.alpha
+        B, T, D = x.shape
+        S = y.shape[1]
+        hd = D // heads
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(y)
+        K.gemm_heads(dout, y, dx, T, hd, S, False, False, S, D, D, B, heads, T * S, heads * T * S, hd, S * D, hd, T * D,
+                     alpha=alpha)
+        K.gemm_heads(dout, x, dy, S, hd, T, True, False, S, D, D, B, heads, T * S, heads * T * S, hd, T * D, hd, S * D,
+                     alpha=alpha)
+        return dx, dy, None, None
+
+
+def heads_matmul_nt(x, y, heads, alpha=1.0):
+    return HeadsMatmulNTFn.apply(x, y, heads, alpha)
+
+
+class BiasAssembleFn(torch.autograd.Function):
+    """bias_l = abs.clone(); bias_l[:, :, s:e, s:e] += values_k for each slot k (adaptor/general.py:270-280).
+    values_k: [n_k, n_k, A] (the un-expanded rel-pos values) or None."""
+
+    @staticmethod
+    def forward(ctx, abs_bias, starts, *values):
+        out = abs_bias.clone(memory_format=torch.contiguous_format)
+        ctx.blocks = []
+        for s, v in zip(starts, values):
+            if v is not None:
+                K.bias_block_add_(out, v.to(out.dtype), s)
+                ctx.blocks.append((s, v.shape[0], v.dtype))
+            else:
+                ctx.blocks.append(None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = []
+        for blk in ctx.blocks:
+            if blk is None:
+                grads.append(None)
+            else:
+                s, n, dt = blk
+                grads.append(K.bias_block_grad(dout, s, n).to(dt))
+        return (dout, None, *grads)
+
+
+class MulRowvecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, vec):
+        ctx.save_for_backward(a, vec)
+        return K.mul_rowvec(a, vec)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, vec = ctx.saved_tensors
+        return K.mul_rowvec(dy, vec), K.colsum(K.mul(dy, a)).to(vec.dtype)
+
+
+def mul_rowvec(a, vec):
+    a2d, restore = rows_view(a)
+    return restore(MulRowvecFn.apply(a2d, vec))
+
+
+# ---------------------------------------------------------------------------------------------- patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """Conv2d(C, D, kernel=stride=p) as im2col + MFMA GEMM (adaptor/image_patch_embed.py:59-73).  img [B,C,H,W],
+    weight [D,C,p,p], bias [D] -> [B, (H/p)*(W/p), D].  The image itself gets no gradient (it is an input)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, p):
+        B, C, H, W = img.shape
+        D = weight.shape[0]
+        Kc = C * p * p
+        Kpad = (Kc + 7) // 8 * 8
+        col = K.im2col_patch(img.to(weight.dtype), p, Kpad)
+        wp = weight.reshape(D, Kc)
+        if Kpad != Kc:
+            wp2 = torch.zeros(D, Kpad, dtype=weight.dtype, device=weight.device)
+            wp2[:, :Kc].copy_(wp)
+            wp = wp2
+        out = K.gemm(col, wp, False, True, bias=bias)
+        ctx.save_for_backward(col)
+        ctx.meta = (weight.shape, Kc, Kpad, bias is not None)
+        return out.view(B, (H // p) * (W // p), D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (col,) = ctx.saved_tensors
+        wshape, Kc, Kpad, has_bias = ctx.meta
+        d2 = dout.reshape(-1, dout.shape[-1])
+        d2 = d2 if d2.stride(-1) == 1 else d2.contiguous()
+        dw = K.gemm(d2, col, True, False)[:, :Kc].reshape(wshape)
+        db = K.colsum(d2).to(dout.dtype) if has_bias else None
+        return None, dw, db, None
+
+
+def patch_embed(img, weight, bias, p):
+    return PatchEmbedFn.apply(img, weight, bias, p)
+
+
+# ---------------------------------------------------------------------------------------------- criterion
+class CrossEntropyFn(torch.autograd.Function):
+    """sum over rows of NLL(log_softmax_fp32(logits), target), ignore_index rows contribute 0
+    (engine/criterion/cross_entropy.py:27-67).  logits: [..., V] view of storage whose row stride is a multiple of 8."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        V = logits.shape[-1]
+        l2d = logits.reshape(-1, V) if logits.is_contiguous() else logits.view(-1, V)
+        if l2d.stride(1) != 1 or l2d.stride(0) % (4 if l2d.dtype == torch.float32 else 8) != 0:
+            pad = (-V) % 8
+            store = torch.zeros(l2d.shape[0], V + pad, dtype=l2d.dtype, device=l2d.device)
+            store[:, :V].copy_(l2d)
+            l2d = store[:, :V]
+        t = target.reshape(-1).contiguous()
+        lse, row_loss = K.cross_entropy_fwd(l2d, t, V, ignore_index)
+        ctx.save_for_backward(l2d, t, lse)
+        ctx.ignore_index, ctx.shape = ignore_index, logits.shape
+        return K.sum_f32(row_loss)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        l2d, t, lse = ctx.saved_tensors
+        V = l2d.shape[1]
+        gs = dloss.reshape(1).float().contiguous()
+        d = K.cross_entropy_bwd(l2d, t, lse, gs, V, ctx.ignore_index)
+        return d[:, :V].view(ctx.shape), None, None
+
+
+def cross_entropy_sum(logits, target, ignore_index):
+    return CrossEntropyFn.apply(logits, target, ignore_index)
+
+
+def _rows_padded(logits):
+    """[..., V] tensor -> ([rows, V] view with last dim contiguous, ld)."""
+    V = logits.shape[-1]
+    try:
+        l2d = logits.view(-1, V)
+    except RuntimeError:
+        l2d = logits.reshape(-1, V)
+    if l2d.stride(1) != 1:
+        l2d = l2d.contiguous()
+    return l2d, l2d.stride(0)
+
+
+class ProbsFn(torch.autograd.Function):
+    """fp32 softmax / log-softmax over the last dim (get_normalized_probs, model/ofa.py:287-299)."""
+
+    @staticmethod
+    def forward(ctx, logits, log_probs):
+        l2d, ld = _rows_padded(logits)
+        rows, V = l2d.shape
+        y = K.probs_fwd(l2d, V, ld, log_probs)
+        ctx.save_for_backward(y)
+        ctx.meta = (logits.shape, logits.dtype, log_probs)
+        return y.view(*logits.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        shape, dtype, log_probs = ctx.meta
+        V = shape[-1]
+        d = K.probs_bwd(dy.reshape(-1, V).float().contiguous(), y, V, dtype, log_probs)
+        return d[:, :V].view(shape), None
+
+
+def log_softmax_fp32(logits):
+    return ProbsFn.apply(logits, True)
+
+
+def softmax_fp32(logits):
+    return ProbsFn.apply(logits, False)

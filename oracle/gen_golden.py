@@ -126,7 +126,11 @@ def box_vectors():
     g = np.random.Generator(np.random.Philox(key=7))
     coords = g.uniform(0, 512, size=(64, 4)).astype(np.float32)
     max_image_size, num_bins = 512, 1000
-    bins = np.array([[int(round(float(c) / max_image_size * (num_bins - 1))) for c in row] for row in coords], dtype=np.int64)
+    # the reference's own expression (box.py:103-106) on float32 tensors; include exact .5 ties
+    coords[0] = [0.0, 512.0, 256.0, 0.2562562]
+    coords[1] = np.array([k * 512.0 / 999.0 for k in (0.5, 1.5, 2.5, 3.5)], dtype=np.float32)
+    bins = np.array([[int((torch.tensor(c) / max_image_size * (num_bins - 1)).round()) for c in row] for row in coords],
+                    dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "box_bins.npz"), coords=coords, bins=bins,
                         max_image_size=np.array([max_image_size]), num_bins=np.array([num_bins]))
 

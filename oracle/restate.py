@@ -104,8 +104,10 @@ def make_token_bucket_position(bucket_size, max_position):
 
 
 def box_to_bins(coords, max_image_size, num_bins):
-    """preprocessor/default/box.py:101-110 -- int(round(coord / max_image_size * (num_bins-1)))."""
-    return [int(round(float(c) / max_image_size * (num_bins - 1))) for c in coords]
+    """preprocessor/default/box.py:101-110 -- int((coord / max_image_size * (num_bins-1)).round()) evaluated on
+    float32 tensors (round-half-to-even), restated with numpy float32 scalars."""
+    import numpy as np
+    return [int(np.round(np.float32(c) / np.float32(max_image_size) * np.float32(num_bins - 1))) for c in coords]
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""Headline benchmark: multimodal tokens/s for one encoder-decoder TRAINING step (fwd + CE loss + bwd + grad reduce +
+clip + Adam) of the OFASys GeneralistModel on MI355X, BASELINE.json configs[1] ("cfg-2"):
+
+    image_caption: image 224x224 through the image_patch_embed adaptor (257 tokens) + <=191 text tokens (Ts = 448),
+    target <=64 tokens, OFA-base (D=768, 12 heads, 6+6 layers, V=51265), bf16, batch 32 per GPU, synthetic data.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run, one rank per GPU).
+Prints ONE JSON line on rank 0.  `value` is whole-job tokens/s (non-pad encoder + decoder positions, SURVEY.md
+section 8d); `roofline` prices the dominant kernel (the bf16 MFMA GEMM) against the 2.5 PFLOP/s dense bf16 peak;
+`cpu_baseline` times the CPU oracle restatement (oracle/restate.py) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2:1 sparsity excluded)
+V_TEXT = 50260                # 4 specials + 50260 <text>_i + <mask> + 1000 <bin>_i = 51265
+
+
+def fwd_flops_per_sample(D, A, F, Le, Ld, Ts, Tt, V, patch_tokens=256, patch_k=588, bias=False):
+    """Algorithmic forward FLOPs per sample, SURVEY.md section 8d formulas (multiply-add = 2)."""
+    enc = 8 * Ts * D * D + 4 * Ts * Ts * D + 4 * Ts * D * F
+    dec = 8 * Tt * D * D + 4 * Tt * Tt * D + 4 * Tt * D * D + 4 * Ts * D * D + 4 * Tt * Ts * D + 4 * Tt * D * F
+    out = 2 * Tt * D * V
+    adaptor = 2 * patch_tokens * patch_k * D
+    pos = 0
+    if bias:
+        pos = (4 * Ts * D * D + 2 * Ts * Ts * D) + (4 * Tt * D * D + 2 * Tt * Tt * D + 2 * Tt * D * D + 2 * Ts * D * D + 2 * Tt * Ts * D)
+    return Le * enc + Ld * dec + out + adaptor + pos
+
+
+def build(args, device):
+    from ofasys_amd import Dictionary, GeneralistModel
+    d = Dictionary()
+    for i in range(V_TEXT):
+        d.add_symbol(f"<text>_{i}")
+    d.add_symbol("<mask>")
+    d.add_bins(1000)
+    torch.manual_seed(1)
+    m = GeneralistModel()
+    m.cfg.arch = args.arch
+    m.__init__(m.cfg)
+    m.cfg.use_self_attn_bias = False                      # the image_patch_embed adaptor's only working corner,
+    m.cfg.entangle_position_embedding = True
+    for name in ("text", "image_patch_embed"):
+        a = getattr(m.cfg.adaptor, name)
+        a.is_active = True
+        a.entangle_position_embedding = True
+    m.initialize(d)
+    m = m.to(device).to(torch.bfloat16)
+    return m, d
+
+
+def make_batch(d, B, Ts_text, Tt, rank, device):
+    """Synthetic instruction batch [IMAGE,adaptor=image_patch_embed][TEXT] -> [TEXT], seed 1234 + rank."""
+    from ofasys_amd import ModalityType, Slot
+    g = torch.Generator().manual_seed(1234 + rank)
+    V = len(d)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16)
+    src = torch.randint(4, V, (B, Ts_text), generator=g)
+    slen = torch.randint(Ts_text // 2, Ts_text + 1, (B,), generator=g)
+    slen[0] = Ts_text
+    prev = torch.randint(4, V, (B, Tt), generator=g)
+    tlen = torch.randint(Tt // 4, Tt + 1, (B,), generator=g)
+    tlen[0] = Tt
+    prev[:, 0] = d.bos()
+    target = torch.full_like(prev, d.pad())
+    for b in range(B):
+        src[b, slen[b]:] = d.pad()
+        n = int(tlen[b])
+        prev[b, n:] = d.pad()
+        target[b, :n - 1] = prev[b, 1:n]
+        target[b, n - 1] = d.eos()
+    slots = [Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"]),
+             Slot(ModalityType.TEXT, True, src.to(device)),
+             Slot(ModalityType.TEXT, False, prev.to(device))]
+    ntok = B * 257 + int(slen.sum()) + int(tlen.sum())
+    return {"slots": slots, "target": target.to(device)}, ntok
+
+
+def cpu_baseline(args):
+    """The CPU oracle (plain torch fp32 restatement, verified against the reference's golden vectors) timed on this
+    host: same model/config, bounded batch."""
+    from oracle import restate
+    from oracle.restate import OConfig, OSlot
+    torch.manual_seed(0)
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    D, A, F, L = 768, 12, 3072, 6
+    V = 4 + V_TEXT + 1 + 1000
+    B, Ts_text, Tt = args.cpu_batch, 191, 64
+    cfg = OConfig(embed_dim=D, ffn_dim=F, heads=A, enc_layers=L, dec_layers=L, use_self_attn_bias=False,
+                  entangle_position_embedding=True, adaptor_entangle={"text": True, "image_patch_embed": True})
+    st = {}
+
+    def lin(p, o, i):
+        st[p + ".weight"] = (torch.randn(o, i) * 0.02).requires_grad_(True)
+        st[p + ".bias"] = torch.zeros(o, requires_grad=True)
+
+    def ln(p, n):
+        st[p + ".weight"] = torch.ones(n, requires_grad=True)
+        st[p + ".bias"] = torch.zeros(n, requires_grad=True)
+    emb = (torch.randn(V, D) * 0.02).requires_grad_(True)
+    for side in ("encoder", "decoder"):
+        st[f"{side}.adaptor.embed_tokens.weight"] = emb
+        a = f"{side}.adaptor.text"
+        ln(a + ".layernorm_embedding", D); ln(a + ".layernorm_position", D)
+        st[a + ".embed_positions.weight"] = (torch.randn(1026, D) * 0.02).requires_grad_(True)
+        if side == "encoder":
+            st[a + ".type_embedding.weight"] = torch.zeros(1, D, requires_grad=True)
+            p = f"{side}.adaptor.image_patch_embed"
+            ln(p + ".layernorm_embedding", D); ln(p + ".layernorm_position", D)
+            st[p + ".type_embedding.weight"] = torch.zeros(1, D, requires_grad=True)
+            st[p + ".embed_image_positions.weight"] = (torch.randn(257, D) * 0.02).requires_grad_(True)
+            st[p + ".cls_token"] = torch.zeros(1, 1, D, requires_grad=True)
+            st[p + ".proj.weight"] = (torch.randn(D, 3, 14, 14) * 0.02).requires_grad_(True)
+            st[p + ".proj.bias"] = torch.zeros(D, requires_grad=True)
+        for l in range(L):
+            q = f"{side}.layers.{l}"
+            attns = ["self_attn"] + (["encoder_attn"] if side == "decoder" else [])
+            for at in attns:
+                for w in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                    lin(f"{q}.{at}.{w}", D, D)
+                st[f"{q}.{at}.c_attn"] = torch.ones(A, requires_grad=True)
+            ln(q + ".self_attn_layer_norm", D); ln(q + ".final_layer_norm", D); ln(q + ".ffn_layernorm", F)
+            lin(q + ".fc1", F, D); lin(q + ".fc2", D, F)
+            if side == "encoder":
+                ln(q + ".attn_ln", D)
+            else:
+                ln(q + ".self_attn_ln", D); ln(q + ".cross_attn_ln", D); ln(q + ".encoder_attn_layer_norm", D)
+        ln(f"{side}.layer_norm", D)
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(B, 3, 224, 224, generator=g)
+    src = torch.randint(4, V, (B, Ts_text), generator=g)
+    prev = torch.randint(4, V, (B, Tt), generator=g)
+    target = torch.randint(4, V, (B, Tt), generator=g)
+    slots = [OSlot("IMAGE", True, img, ["adaptor=image_patch_embed"]), OSlot("TEXT", True, src), OSlot("TEXT", False, prev)]
+    params = [v for v in st.values() if v.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        logits, _ = restate.model_forward(st, cfg, slots)
+        loss, _ = restate.cross_entropy(logits, target)
+        loss.backward()
+    step()
+    t0 = time.time()
+    n = 0
+    while n < args.cpu_steps:
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    toks = B * (257 + Ts_text + Tt)
+    return {"value": toks / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/restate.py fp32, OFA-base cfg-2, batch {B} (unpadded 448+64 positions), fwd+CE+bwd, "
+                      f"{n} timed steps after 1 warm-up, torch.set_num_threads({cores})", "s_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="base")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--profile-gemm", type=int, default=1, help="instrumented steps after the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+        dist.all_reduce(torch.zeros(1, device=device))            # communicator warm-up (distributed/utils.py:240-241)
+
+    from ofasys_amd import kernels as K
+    from ofasys_amd.trainer import Trainer
+    model, d = build(args, device)
+    if world > 1:                                                  # identical initial weights on every rank
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    trainer = Trainer(model, lr=1e-4, clip_norm=1.0)
+    Ts_text, Tt = 191, 64
+    batch, ntok = make_batch(d, args.batch, Ts_text, Tt, rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step([batch])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step([batch])
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    toks = torch.tensor([float(ntok)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(toks, op=dist.ReduceOp.SUM)
+    dt = float(tmax)
+    total_tokens = float(toks)
+    ms_per_step = dt / args.steps * 1e3
+
+    # dominant kernel: every MFMA GEMM launch of one step bracketed by HIP events on the launch stream
+    prof = None
+    if args.profile_gemm > 0:
+        K.gemm_profile_begin()
+        for _ in range(args.profile_gemm):
+            trainer.train_step([batch])
+        torch.cuda.synchronize()
+        prof = K.gemm_profile_end()
+
+    if rank == 0:
+        cfg = model.cfg
+        fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
+                                   cfg.encoder.layers, cfg.decoder.layers, 257 + Ts_text, Tt, len(d))
+        step_flops = 3 * fwd * args.batch                          # backward = 2x forward
+        step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
+        roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "kernel": "ofa::gemm_mfma_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
+                "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS}
+        if prof and prof["time_ms"] > 0:
+            ach = prof["flops"] / (prof["time_ms"] * 1e-3) / 1e12
+            roof.update({"achieved": ach, "frac": ach / PEAK_BF16_TFLOPS, "launches_per_step": prof["launches"] // args.profile_gemm,
+                         "avg_launch_us": prof["time_ms"] * 1e3 / max(prof["launches"], 1),
+                         "gemm_ms_per_step": prof["time_ms"] / args.profile_gemm,
+                         "gemm_flops_per_step": prof["flops"] / args.profile_gemm,
+                         "how": "HIP events around every MFMA-GEMM launch on the launch stream, instrumented step(s) "
+                                "run right after the timed region"})
+        else:
+            roof.update({"achieved": step_tflops, "frac": step_tflops / PEAK_BF16_TFLOPS})
+        out = {
+            "metric": "multimodal tokens/sec (enc+dec train step)", "value": total_tokens * args.steps / dt,
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "tokens_per_sec_per_gpu": total_tokens * args.steps / dt / world,
+            "config": {"workload": "cfg-2 image_caption: image_patch_embed 224x224 (257 tok) + text<=191 -> text<=64, "
+                                   "OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
+                       "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "padded_positions_per_sample": 257 + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
+                       "vocab": len(d), "parallelism": f"dp{world}", "random_init": True},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

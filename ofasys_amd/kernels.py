@@ -92,9 +92,36 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
     sb = b.stride(0) if batched else 0
     sc = out.stride(0) if batched else 0
     ws = workspace(256 << 20, a.device, "gemm")
+    ev = _prof_start(2.0 * M * N * K * batch) if _prof is not None else None
     lib().call("ofa_gemm", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, batch,
                sa, sb, sc, 0, 0, 0, 0, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
+    if ev is not None:
+        ev.record()
     return out
+
+
+# ---- optional per-launch timing of the GEMM kernel family (bench.py roofline): HIP events on the launch stream
+_prof = None
+
+
+def gemm_profile_begin():
+    global _prof
+    _prof = []
+
+
+def _prof_start(flops):
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _prof.append((flops, e0, e1))
+    return e1
+
+
+def gemm_profile_end():
+    global _prof
+    torch.cuda.synchronize()
+    rec, _prof = _prof, None
+    return {"launches": len(rec), "flops": sum(r[0] for r in rec), "time_ms": sum(r[1].elapsed_time(r[2]) for r in rec)}
 
 
 def gemm_heads(a, b, out, M, N, K, trans_a, trans_b, lda, ldb, ldc, B, heads, sa, sa2, sb, sb2, sc, sc2, alpha=1.0,

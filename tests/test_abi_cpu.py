@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ofasys_amd.h declares; no compute without a GPU."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from ofasys_amd import lib as L
+
+
+def test_header_parses_and_library_exports_every_symbol():
+    protos = L.parse_header()
+    assert len(protos) >= 40
+    for must in ("ofa_gemm", "ofa_attn_fwd", "ofa_attn_bwd", "ofa_layernorm_fwd", "ofa_layernorm_bwd",
+                 "ofa_scaled_softmax_fwd", "ofa_scaled_masked_softmax_fwd", "ofa_scaled_upper_triang_masked_softmax_fwd",
+                 "ofa_get_batch_per_block", "ofa_embedding_bwd", "ofa_cross_entropy_fwd", "ofa_adam_step", "ofa_version",
+                 "ofa_last_error", "ofa_im2col_patch", "ofa_bias_block_add"):
+        assert must in protos
+    assert os.path.exists(L.LIB_PATH), "build with `python __graft_entry__.py` first"
+    cdll = ctypes.CDLL(L.LIB_PATH)
+    for name in protos:
+        getattr(cdll, name)          # AttributeError == declared but not exported
+    h = L.lib()
+    assert h.cdll.ofa_version() >= 100
+
+
+def test_host_only_entry_points():
+    h = L.lib()
+    from oracle import restate
+    for a in [(128, 128, 2, 4), (64, 448, 2, 4), (4, 16, 1, 1), (8, 4096, 1, 1), (16, 100, 3, 3)]:
+        assert h.cdll.ofa_get_batch_per_block(*a) == restate.get_batch_per_block(*a)
+    assert h.cdll.ofa_layernorm_bwd_ws_rows() > 0
+
+
+def test_status_codes_not_asserts():
+    h = L.lib()
+    # argument validation happens before any launch, so it is observable without a GPU
+    with pytest.raises(L.OfaError, match="layernorm"):
+        h.call("ofa_layernorm_fwd", None, None, None, None, None, None, 4, 6, 1e-5, L.BF16, None)   # cols % 8 != 0
+    with pytest.raises(L.OfaError, match="sk"):
+        h.call("ofa_scaled_softmax_fwd", 1, 1, 1.0, 1, 1, 4, 5000, L.F32, None)                       # sk > 4096
+    with pytest.raises(L.OfaError, match="bf16"):
+        h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, 1, None, 1, 1, 32, 32, 32, 32, 64, 64, 64, 1.0, 0, L.F32, None)
+
+
+def test_no_cpu_fallback():
+    x = torch.randn(4, 8)
+    with pytest.raises(L.OfaError, match="no CPU fallback"):
+        L.ptr(x)
+    from ofasys_amd import ops
+    with pytest.raises(L.OfaError):
+        ops.layer_norm(x, torch.ones(8), torch.zeros(8))

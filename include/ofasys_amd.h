@@ -41,7 +41,8 @@ enum {
   OFA_GEMM_ACCUM = 4,      /* C = result + C_old  (gradient accumulation)                        */
   OFA_GEMM_FORCE_SIMPLE = 8, /* use the exact-fp32-FMA VALU kernel even for bf16 (tests)         */
   OFA_GEMM_OUT_F32 = 16,   /* bf16 inputs, fp32 output                                           */
-  OFA_GEMM_A_KPAD_ZERO = 32 /* caller guarantees A[m][K..roundup8(K)) == 0 (padded logits-gradient rows) */
+  OFA_GEMM_A_KPAD_ZERO = 32, /* caller guarantees A[m][K..roundup8(K)) == 0 (padded logits-gradient rows) */
+  OFA_GEMM_NO_LDS_DMA = 64  /* force the register-staged loop (tests / A-B measurements)              */
 };
 
 int ofa_version(void);
@@ -51,17 +52,18 @@ const char* ofa_last_error(void);
  * exactly as the (never built) apex kernel does, fused_kernels/layer_norm_cuda.cpp:136-138. cols <= 8192. */
 int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int cols, float eps, int dtype, void* stream);
-/* dgamma/dbeta are fp32 [cols]; `ws` is fp32 scratch of 2*ofa_layernorm_bwd_ws_rows()*cols floats. */
+/* dgamma/dbeta are [cols] in `dtype` (accumulate != 0: added to their current contents, i.e. straight into a gradient
+ * arena); `ws` is fp32 scratch of 2*ofa_layernorm_bwd_ws_rows()*cols floats. */
 int ofa_layernorm_bwd_ws_rows(void);
 int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                      void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
+                      void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, int dtype,
                       void* stream);
 /* y = LayerNorm(gelu(h)) -- transformer_layer.py:194-197 (fc1 -> GELU (module/gelu.py:18-19, fp32 erf) -> ffn_layernorm). */
 int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                            int64_t rows, int cols, float eps, int dtype, void* stream);
 int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean, const float* rstd,
-                           void* dh, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
-                           void* stream);
+                           void* dh, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate,
+                           int dtype, void* stream);
 
 /* ---- GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+bias) (+C).  Replaces F.linear / torch.bmm / matmul:
  * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.
@@ -142,10 +144,10 @@ int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed,
 int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y, int64_t rows,
                         int cols, int dtype, void* stream);
 
-/* out[c] (fp32) (+)= alpha * sum_r x[r][c]  -- bias gradients of nn.Linear (autograd of multihead_attention.py:199-217). */
+/* out[c] (out_dtype) (+)= alpha * sum_r x[r][c]  -- bias gradients of nn.Linear (autograd of multihead_attention.py:199-217). */
 int ofa_colsum_ws_floats(int cols);
-int ofa_colsum(const void* x, float* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha, int accumulate,
-               int dtype, void* stream);
+int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha, int accumulate,
+               int dtype, int out_dtype, void* stream);
 
 /* y = a * b, b either [rows,cols] or a [cols] row vector (c_attn head scale, multihead_attention.py:342-345). */
 int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream);

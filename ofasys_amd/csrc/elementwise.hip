@@ -201,14 +201,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
       partial[(int64_t)blockIdx.y * cols + c + j] = red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j];
   }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+template <typename TO>
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, TO* __restrict__ out,
                                                            int cols, int groups, float alpha, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
   for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * cols + c];
   s *= alpha;
-  out[c] = accumulate ? out[c] + s : s;
+  if (accumulate) s += ld1<TO>(out + c);
+  st1<TO>(out + c, s);
 }
 
 static inline int grid_for(int64_t work) {
@@ -344,17 +346,18 @@ extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H,
   return check_launch("im2col_patch");
 }
 
-extern "C" int ofa_colsum_ws_floats(int cols) { return 128 * cols; }
+extern "C" int ofa_colsum_ws_floats(int cols) { return 64 * cols; }
 
-extern "C" int ofa_colsum(const void* x, float* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
-                          int accumulate, int dtype, void* stream) {
+extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
+                          int accumulate, int dtype, int out_dtype, void* stream) {
   OFA_DT_CHECK("colsum");
+  OFA_REQUIRE(out_dtype == OFA_F32 || out_dtype == OFA_BF16, OFA_ERR_INVALID, "colsum: bad out dtype %d", out_dtype);
   OFA_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && x && out && ws, OFA_ERR_INVALID, "colsum: bad argument");
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(cols % n == 0 && ld % n == 0, OFA_ERR_UNSUPPORTED, "colsum: cols=%d / ld not vectorizable", cols);
   hipStream_t st = (hipStream_t)stream;
-  int groups = (int)((rows + 63) / 64);
-  groups = groups < 1 ? 1 : (groups > 128 ? 128 : groups);
+  int groups = (int)((rows + 127) / 128);
+  groups = groups < 1 ? 1 : (groups > 64 ? 64 : groups);
   dim3 grid(cdiv(cols / n, 64), groups), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, ws, rows, cols, ld);
@@ -362,8 +365,12 @@ extern "C" int ofa_colsum(const void* x, float* out, float* ws, int64_t rows, in
     hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ws, rows, cols, ld);
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, out, cols, groups,
-                     alpha, accumulate);
+  if (out_dtype == OFA_F32)
+    hipLaunchKernelGGL((colsum_final_kernel<float>), dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, (float*)out,
+                       cols, groups, alpha, accumulate);
+  else
+    hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws,
+                       (bf16_t*)out, cols, groups, alpha, accumulate);
   return check_launch("colsum_final");
 }
 

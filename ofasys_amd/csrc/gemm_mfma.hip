@@ -103,6 +103,89 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* __restrict__ lds, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA staging (global_load_lds_dwordx4): the tile goes HBM/L2 -> LDS without passing through VGPRs or the
+// VGPR->LDS write path (ds_write_b128 sustains only ~79 B/clk/CU, which made the register-staged loop LDS-write
+// bound: PMC showed MFMA busy 21%, 65% of wave cycles stalled on issue).  The DMA writes lane-linear (wave-uniform
+// base + lane*16 B), so the tile is stored unpadded and the bank-conflict fix is an XOR swizzle of the 16-byte chunk
+// index applied to the per-lane SOURCE address and again when reading (cdna_hip_programming.md rule 21):
+//   k-major [R][64]:   chunk c (8 per row) of row r lives at c ^ ((r>>1)&7)   -> 16 rows x one k-slice = 16 distinct slots
+//   m-major [64][R]:   chunk c of k-row k lives at c ^ ((k&3)<<2) (R=128) / c ^ (((k>>1)&1)<<2) (R=64)
+//                      -> the 4 k-rows of a ds_read_b64_tr_b16 group fall in 4 different 64-byte bank quarters.
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int R, bool KMAJ> __device__ __forceinline__ int swz(int row, int c) {
+  if (KMAJ) return c ^ ((row >> 1) & 7);
+  return R == 128 ? (c ^ ((row & 3) << 2)) : (c ^ (((row >> 1) & 1) << 2));
+}
+
+template <int R, bool KMAJ, int NT, int NV>
+__device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ base, int64_t ld, int r0, int rmax, int k0,
+                                           bf16_t* __restrict__ lds, int tid, int wave) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int gidx = tid + i * NT;                       // physical 16-byte granule of the tile
+    const bf16_t* src;
+    if (KMAJ) {
+      const int r = gidx >> 3, c = swz<R, true>(r, gidx & 7);
+      int rr = r0 + r;
+      rr = rr < rmax ? rr : rmax - 1;
+      src = base + (int64_t)rr * ld + k0 + c * 8;
+    } else {
+      constexpr int CPR = R / 8;
+      const int k = gidx / CPR, c = swz<R, false>(k, gidx % CPR);
+      int col = r0 + c * 8;
+      const int last = ((rmax + 7) & ~7) - 8;
+      col = col < last ? col : last;
+      src = base + (int64_t)(k0 + k) * ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + (wave * 64 + i * NT) * 8), 16, 0, 0);
+  }
+}
+
+// Fragment reads of the DMA image are issued as inline asm: hipcc treats an in-flight LDS-DMA as a pending LDS write
+// and would put `s_waitcnt vmcnt(0)` in front of every compiler-visible ds_read, draining the next tile's DMA before
+// the first MFMA (no overlap at all -- seen in the ISA).  The asm reads are invisible to that pass; their own
+// completion is waited for with an explicit lgkmcnt statement that names every destination register ("+v"), which is
+// what orders the consuming MFMAs behind it (cdna_hip_programming.md section 5.7, form (ii)).
+typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+struct FragRegs { bf16x8 v; };
+
+template <int R, bool KMAJ> struct FragAddr {
+  uint32_t base;    // per-lane byte offset inside the tile (without the kk-dependent part for k-major tiles)
+  uint32_t rowsw;   // k-major: ((row>>1)&7); m-major: unused
+  __device__ __forceinline__ void init(int rbase, int lane) {
+    if (KMAJ) {
+      const int row = rbase + (lane & 31);
+      base = (uint32_t)row * 128u;
+      rowsw = (uint32_t)(((row >> 1) & 7) ^ (lane >> 5));     // chunk = (kk*2 + hi) ^ sw = (kk*2) ^ (hi ^ sw): bit0 folded
+    } else {
+      const int g = lane >> 4, q = lane & 15;
+      const int k = (g >> 1) * 8 + (q >> 2);
+      const int col = rbase + (g & 1) * 16 + 4 * (q & 3);
+      base = (uint32_t)(k * R + swz<R, false>(k, col >> 3) * 8 + (col & 7)) * 2u;
+      rowsw = 0;
+    }
+  }
+};
+
+template <int R, bool KMAJ, int KK>
+__device__ __forceinline__ void frag_issue(u64x2& d, const FragAddr<R, KMAJ>& fa, uint32_t tile) {
+  if (KMAJ) {
+    // chunk index (KK*2 + hi) ^ sw, with hi folded into rowsw (hi and KK*2 occupy disjoint bits)
+    const uint32_t addr = tile + fa.base + (((uint32_t)(KK * 2) ^ fa.rowsw) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
+  } else {
+    const uint32_t addr = tile + fa.base;
+    unsigned long long lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(KK * 16 * R * 2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(KK * 16 * R * 2 + 4 * R * 2));
+    d[0] = lo;
+    d[1] = hi;
+  }
+}
+
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   // bijective "each XCD gets a contiguous chunk" remap (blocks are dispatched round-robin over the 8 XCDs)
   const int q = n >> 3, r = n & 7, xcd = id & 7, local = id >> 3;
@@ -148,7 +231,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int 
   }
 }
 
-template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool GLDS>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
   constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
@@ -156,13 +239,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   typedef TileGeom<BN, B_KMAJ> GB;
   constexpr int NVA = GA::NVEC / NT, NVB = GB::NVEC / NT;
   static_assert(GA::NVEC % NT == 0 && GB::NVEC % NT == 0, "tile/threads mismatch");
+  constexpr int EA = GLDS ? BM * BK : GA::ELEMS, EB = GLDS ? BN * BK : GB::ELEMS;   // the DMA image is unpadded
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* sA[2];
   bf16_t* sB[2];
   sA[0] = reinterpret_cast<bf16_t*>(smem_raw);
-  sA[1] = sA[0] + GA::ELEMS;
-  sB[0] = sA[1] + GA::ELEMS;
-  sB[1] = sB[0] + GB::ELEMS;
+  sA[1] = sA[0] + EA;
+  sB[0] = sA[1] + EA;
+  sB[1] = sB[0] + EB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -185,6 +269,58 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  if constexpr (GLDS) {
+    // K (and every split) is a multiple of BK: all tiles are full, rows/columns outside M/N are clamped reads
+    if (nk > 0) {
+      stage_glds<BM, A_KMAJ, NT, NVA>(A, g.lda, m0, g.M, kbeg, sA[0], tid, wave_u);
+      stage_glds<BN, B_KMAJ, NT, NVB>(B, g.ldb, n0, g.N, kbeg, sB[0], tid, wave_u);
+    }
+    __syncthreads();                                     // (the compiler drains vmcnt before the barrier)
+    FragAddr<BM, A_KMAJ> fax[2];
+    FragAddr<BN, B_KMAJ> faw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fax[i].init(wm * 64 + i * 32, lane);
+      faw[i].init(wn * 64 + i * 32, lane);
+    }
+    const uint32_t ldsA0 = (uint32_t)(uintptr_t)sA[0], ldsB0 = (uint32_t)(uintptr_t)sB[0];
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {                                 // DMA of the next tile runs under this tile's MFMAs
+        stage_glds<BM, A_KMAJ, NT, NVA>(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, sA[cur ^ 1], tid, wave_u);
+        stage_glds<BN, B_KMAJ, NT, NVB>(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, sB[cur ^ 1], tid, wave_u);
+      }
+      const uint32_t ta = ldsA0 + (uint32_t)cur * (EA * 2), tb = ldsB0 + (uint32_t)cur * (EB * 2);
+      u64x2 x0[2], w0[2], x1[2], w1[2];
+#define OFA_ISSUE(KK, X, W)                                \
+      frag_issue<BM, A_KMAJ, KK>(X[0], fax[0], ta);        \
+      frag_issue<BM, A_KMAJ, KK>(X[1], fax[1], ta);        \
+      frag_issue<BN, B_KMAJ, KK>(W[0], faw[0], tb);        \
+      frag_issue<BN, B_KMAJ, KK>(W[1], faw[1], tb)
+#define OFA_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
+#define OFA_MMA(X, W)                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
+                                                              __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
+      OFA_ISSUE(0, x0, w0);
+      OFA_WAIT(x0, w0);
+      OFA_ISSUE(1, x1, w1);          // next k-slice's LDS reads fly under this slice's MFMAs
+      OFA_MMA(x0, w0);
+      OFA_WAIT(x1, w1);
+      OFA_ISSUE(2, x0, w0);
+      OFA_MMA(x1, w1);
+      OFA_WAIT(x0, w0);
+      OFA_ISSUE(3, x1, w1);
+      OFA_MMA(x0, w0);
+      OFA_WAIT(x1, w1);
+      OFA_MMA(x1, w1);
+#undef OFA_ISSUE
+#undef OFA_WAIT
+#undef OFA_MMA
+      __syncthreads();               // drains this wave's DMA (vmcnt) and fences the buffer swap
+    }
+  } else {
   uint4 ra[NVA], rb[NVB];
   if (nk > 0) {
     stage_load<BM, A_KMAJ, NT, NVA>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
@@ -220,6 +356,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       stage_store<BN, B_KMAJ, NT, NVB>(rb, sB[cur ^ 1], tid);
     }
     __syncthreads();
+  }
   }
 
   // epilogue: lane owns output row m = .. + (lane&31); register r holds column (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -287,12 +424,13 @@ bool gemm_mfma_supported(const GemmArgs& g) {
   return true;
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF>
-static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+template <int WM, int WN, bool AK, bool BKM, bool OF, bool GL>
+static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  const size_t lds = 2 * (size_t)(TileGeom<BM, AK>::ELEMS + TileGeom<BN, BKM>::ELEMS) * sizeof(bf16_t);
-  auto kern = gemm_mfma_kernel<WM, WN, AK, BKM, OF>;
+  const size_t lds = GL ? 2 * (size_t)(BM + BN) * BK * sizeof(bf16_t)
+                        : 2 * (size_t)(TileGeom<BM, AK>::ELEMS + TileGeom<BN, BKM>::ELEMS) * sizeof(bf16_t);
+  auto kern = gemm_mfma_kernel<WM, WN, AK, BKM, OF, GL>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -300,6 +438,13 @@ static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, flo
   }
   dim3 grid(tiles_m * tiles_n, splits, batch), block(WM * WN * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
+}
+
+template <int WM, int WN, bool AK, bool BKM, bool OF>
+static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+  // LDS-DMA staging needs full K tiles (no zero fill); anything else takes the register-staged loop
+  if ((g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA)) launch_cfg2<WM, WN, AK, BKM, OF, true>(g, batch, splits, ksplit, ws, st);
+  else launch_cfg2<WM, WN, AK, BKM, OF, false>(g, batch, splits, ksplit, ws, st);
 }
 
 template <bool AK, bool BKM, bool OF>
@@ -311,24 +456,24 @@ static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int split
 }
 
 int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
-  // tile choice: biggest tile that still gives >= ~2 workgroups per CU; otherwise shrink, then split K.
+  // tile choice: the biggest tile that, together with split-K (when a workspace is given and K is long), still puts
+  // >= ~1.5 workgroups on every CU; 128x128 tiles halve the LDS traffic per flop of 64-wide ones.
   const int64_t t22 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
   const int64_t t12 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 128) * batch;
   const int64_t t11 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) * batch;
+  int maxs = ws ? g.K / 256 : 1;                 // every split keeps >= 4 K-tiles
+  maxs = maxs < 1 ? 1 : (maxs > 32 ? 32 : maxs);
+  const int64_t want = 384;
   int wm, wn;
   int64_t tiles;
-  if (t22 >= 384) { wm = 2; wn = 2; tiles = t22; }
-  else if (t12 >= 384 || t11 < 256) { wm = 1; wn = 2; tiles = t12; }
+  if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }
+  else if (t12 * maxs >= want && g.N >= 128) { wm = 1; wn = 2; tiles = t12; }
   else { wm = 1; wn = 1; tiles = t11; }
-  if (g.N < 128 && wn == 2) { wm = 1; wn = 1; tiles = t11; }
   int splits = 1;
-  if (ws && tiles < 256 && g.K >= 1024) {
-    splits = (int)((512 + tiles - 1) / tiles);
-    const int maxs = g.K / 512;
+  if (tiles < want && maxs > 1) {
+    splits = (int)((want + tiles - 1) / tiles);
     if (splits > maxs) splits = maxs;
-    if (splits > 32) splits = 32;
     while (splits > 1 && (int64_t)splits * batch * g.M * ((g.N + 3) & ~3) * 4 > ws_bytes) --splits;
-    if (splits < 1) splits = 1;
   }
   int ksplit = g.K;
   if (splits > 1) {

@@ -172,14 +172,17 @@ __global__ __launch_bounds__(128) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int cols, int nwaves) {
-  __shared__ float sg[4][64], sb[4][64];
+// fold the per-wave partials; 64 columns x 16 row-lanes per block; writes the parameter dtype, optionally accumulating
+// into an existing gradient (gradient arena of the train step).
+template <typename T>
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, T* __restrict__ dgamma,
+                                                             T* __restrict__ dbeta, int cols, int nwaves, int accumulate) {
+  __shared__ float sg[16][64], sb[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   float a = 0.f, b = 0.f;
   if (c < cols) {
-    for (int w = ry; w < nwaves; w += 4) {
+    for (int w = ry; w < nwaves; w += 16) {
       a += ws[(int64_t)w * cols + c];
       b += ws[(int64_t)nwaves * cols + (int64_t)w * cols + c];
     }
@@ -188,12 +191,16 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   sb[ry][cx] = b;
   __syncthreads();
   if (ry == 0 && c < cols) {
-    dgamma[c] = sg[0][cx] + sg[1][cx] + sg[2][cx] + sg[3][cx];
-    dbeta[c] = sb[0][cx] + sb[1][cx] + sb[2][cx] + sb[3][cx];
+    float ga = 0.f, be = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ga += sg[r][cx]; be += sb[r][cx]; }
+    if (accumulate) { ga += ld1<T>(dgamma + c); be += ld1<T>(dbeta + c); }
+    st1<T>(dgamma + c, ga);
+    st1<T>(dbeta + c, be);
   }
 }
 
-constexpr int LN_BWD_WAVES = 1024;
+constexpr int LN_BWD_WAVES = 512;   // upper bound on partial rows (workspace sizing)
 
 template <typename T, bool GELU>
 static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y, float* mean, float* rstd, int64_t rows,
@@ -216,10 +223,12 @@ static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y,
 
 template <typename T, bool GELU>
 static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
-                           float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, hipStream_t st) {
+                           void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, hipStream_t st) {
   constexpr int N = Vec<T>::N;
   const int nv = cdiv(cols, 64 * N);
-  const int nwaves = LN_BWD_WAVES;
+  int64_t want = (rows + 3) / 4;                       // >= 4 rows per wave, at most LN_BWD_WAVES partial rows
+  want = want < 2 ? 2 : (want > LN_BWD_WAVES ? LN_BWD_WAVES : want);
+  const int nwaves = (int)((want + 1) & ~1);
   dim3 grid(nwaves / 2), block(128);
   const size_t lds = (size_t)2 * 2 * cols * sizeof(float);
 #define LN_CASE(NV)                                                                                                  \
@@ -238,7 +247,8 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
 #undef LN_CASE
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, st, ws, dgamma, dbeta, cols, nwaves);
+  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (T*)dgamma,
+                     (T*)dbeta, cols, nwaves, accumulate);
   return check_launch("layernorm_bwd_reduce");
 }
 
@@ -279,25 +289,25 @@ extern "C" int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const vo
 }
 
 extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                 void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int cols, int dtype,
-                                 void* stream) {
+                                 void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate,
+                                 int dtype, void* stream) {
   if (int rc = ln_check(rows, cols, dtype, true)) return rc;
   OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, OFA_ERR_INVALID,
               "layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, st)
-             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, st);
+             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, accumulate, st);
 }
 
 extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean,
-                                      const float* rstd, void* dh, float* dgamma, float* dbeta, float* ws, int64_t rows,
-                                      int cols, int dtype, void* stream) {
+                                      const float* rstd, void* dh, void* dgamma, void* dbeta, float* ws, int64_t rows,
+                                      int cols, int accumulate, int dtype, void* stream) {
   if (int rc = ln_check(rows, cols, dtype, true)) return rc;
   OFA_REQUIRE(dy && h && gamma && mean && rstd && dh && dgamma && dbeta && ws, OFA_ERR_INVALID,
               "gelu_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, st)
-             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, st);
+             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, accumulate, st);
 }

@@ -4,11 +4,13 @@ grad overlapped with backward; unused parameters contribute zeros, default_train
 
 MI355X design: gradients already live in ONE flat arena (ofasys_amd/trainer.py), so a "bucket" is just a contiguous
 slice of it -- no gather/scatter copies.  Buckets are cut in reverse parameter order (the order backward produces
-them); a post-accumulate hook counts parameters down and fires `all_reduce(async_op=True)` on the slice as soon as
-its last gradient lands, so RCCL traffic over xGMI overlaps the remaining backward kernels.  Slices that backward
-never touches (unused parameters) are reduced at `finish()`.  Bucket size defaults to 64 MiB: xGMI rings are
-per-link bound (~153 GB/s/link), large messages amortise the per-collective latency, and 288 GB of HBM makes the
-arena free.
+them).  Every gradient contribution -- whether a HIP kernel accumulated it straight into the arena (ops._sink) or
+autograd's AccumulateGrad did -- calls `notify(i)`; once a parameter has received as many contributions as it did in
+the first (learning) step its bucket counts down, and a full bucket fires `all_reduce(async_op=True)` on its slice,
+so RCCL traffic over xGMI overlaps the remaining backward kernels.  Whatever is left (unused parameters, a step whose
+task mix differs from the learned one) is reduced at `finish()`, so the result never depends on the learned counts.
+Bucket size defaults to 64 MiB: xGMI rings are per-link bound (~153 GB/s/link), large messages amortise the
+per-collective latency, and 288 GB of HBM makes the arena free.
 """
 from typing import List
 
@@ -26,8 +28,7 @@ class GradBucketReducer:
         elem = flat_grad.element_size()
         # cut buckets walking the arena from the END (backward order ~ reverse registration order)
         self.buckets = []   # (start, end, [param indices])
-        end = flat_grad.numel()
-        cur_hi, cur_members = end, []
+        cur_hi, cur_members = flat_grad.numel(), []
         for i in reversed(range(len(params))):
             lo = offsets[i]
             cur_members.append(i)
@@ -38,51 +39,69 @@ class GradBucketReducer:
         for b, (_, _, members) in enumerate(self.buckets):
             for i in members:
                 self.param_bucket[i] = b
+        self.expected = None                      # contributions per parameter per step for the current signature
+        self._learned = {}                        # step signature -> learned contribution counts
+        self._sig = None
+        self._count = [0] * len(params)
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
-        self._enabled = True
         self._hooks = []
-        if self.world > 1:
-            for i, p in enumerate(params):
-                if p.requires_grad:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
-        self.reset()
+        for i, p in enumerate(params):
+            if p.requires_grad:
+                p._ofa_grad_ready = self._make_notify(i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self.notify(i)))
+        self._reset()
 
-    def _make_hook(self, i):
-        def hook(param):
-            if not self._enabled:
-                return
+    def _make_notify(self, i):
+        return lambda: self.notify(i)
+
+    def begin_step(self, signature=None):
+        """`signature` identifies the step's structure (which tasks / how many micro-batches); early bucket launches are
+        only armed for a structure whose contribution counts were learned on an earlier, identical step."""
+        self._sig = signature
+        self.expected = self._learned.get(signature)
+        self._reset()
+
+    def notify(self, i):
+        """One gradient contribution for parameter i has been enqueued on the compute stream."""
+        self._count[i] += 1
+        if self.world == 1 or self.expected is None:
+            return
+        if self._count[i] == self.expected[i]:
             b = self.param_bucket[i]
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:
                 self._launch(b)
-        return hook
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self._launched[b] = True
         self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def reset(self):
+    def _reset(self):
+        self._count = [0] * len(self.params)
         for b, (_, _, members) in enumerate(self.buckets):
-            self._pending[b] = sum(1 for i in members if self.params[i].requires_grad)
+            if self.expected is None:
+                self._pending[b] = -1
+            else:
+                self._pending[b] = sum(1 for i in members if self.expected[i] > 0)
+                if self._pending[b] == 0:
+                    self._pending[b] = -1                   # nothing will ever notify: left for finish()
             self._launched[b] = False
         self._handles = []
 
-    def no_sync(self, flag=True):
-        """Skip reduction for this backward (earlier micro-batches / tasks accumulate locally, engine/trainer.py:766-784)."""
-        self._enabled = not flag
-
     def finish(self):
-        """Reduce whatever backward did not trigger (unused parameters), then wait for every bucket."""
+        """Reduce whatever backward did not trigger (unused parameters, learning step), then wait for every bucket."""
         if self.world > 1:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
             for h in self._handles:
                 h.wait()
-        self.reset()
+        if self.expected is None:
+            self._learned[self._sig] = list(self._count)
+        self._reset()
 
 
 def all_reduce_scalars(t: torch.Tensor, group=None):

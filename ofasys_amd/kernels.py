@@ -39,18 +39,22 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, fuse_gelu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None):
+    """dgamma/dbeta given: the parameter gradients are ACCUMULATED into them (gradient arena); else fresh tensors."""
     dy = dy.contiguous()
     x = x.contiguous()
     rows, cols = _rows_cols(x)
     dx = torch.empty_like(x)
-    dg = torch.empty(cols, dtype=torch.float32, device=x.device)
-    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    acc = dgamma is not None
+    if not acc:
+        dgamma = torch.empty(cols, dtype=gamma.dtype, device=x.device)
+        dbeta = torch.empty(cols, dtype=gamma.dtype, device=x.device)
+    assert dgamma.dtype == x.dtype and dbeta.dtype == x.dtype
     wsr = lib().cdll.ofa_layernorm_bwd_ws_rows()
     ws = workspace(2 * wsr * cols * 4, x.device, "ln")
     lib().call("ofa_gelu_layernorm_bwd" if fuse_gelu else "ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean),
-               ptr(rstd), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, cols, dtype_code(x), stream())
-    return dx, dg.to(gamma.dtype), db.to(gamma.dtype)
+               ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
+    return dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------ GEMM
@@ -396,16 +400,16 @@ def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, b
                dtype_code(grad), stream())
 
 
-def colsum(x, alpha=1.0, out=None, accumulate=False):
-    """fp32 column sums of a 2-D tensor (last dim contiguous)."""
+def colsum(x, alpha=1.0, out=None, accumulate=False, out_dtype=torch.float32):
+    """Column sums of a 2-D tensor (last dim contiguous): fresh tensor of `out_dtype`, or (accumulated) into `out`."""
     if x.stride(-1) != 1:
         x = x.contiguous()
     rows, cols = x.shape
     if out is None:
-        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+        out = torch.empty(cols, dtype=out_dtype, device=x.device)
     ws = workspace(lib().cdll.ofa_colsum_ws_floats(cols) * 4, x.device, "colsum")
     lib().call("ofa_colsum", ptr(x), ptr(out), ptr(ws), rows, cols, x.stride(0), float(alpha), int(accumulate),
-               dtype_code(x), stream())
+               dtype_code(x), dtype_code(out), stream())
     return out
 
 

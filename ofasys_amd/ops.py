@@ -54,6 +54,21 @@ class _Rng:
 manual_seed = _Rng.manual_seed
 
 
+# ---------------------------------------------------------------------------------------------- gradient sinks
+# The train step (ofasys_amd/trainer.py) keeps every parameter gradient in one flat arena.  When a parameter carries
+# `_ofa_grad` (its arena view), backward kernels ACCUMULATE straight into it (GEMM epilogue / reduce kernels with the
+# accumulate flag) and return None to autograd: no temporary gradient tensor, no separate `grad += new` pass.
+# `_ofa_grad_ready` (optional) tells the data-parallel reducer that one contribution has landed.
+def _sink(param):
+    return getattr(param, "_ofa_grad", None) if param is not None else None
+
+
+def _sink_done(param):
+    cb = getattr(param, "_ofa_grad_ready", None)
+    if cb is not None:
+        cb()
+
+
 # ---------------------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
@@ -61,11 +76,19 @@ class LayerNormFn(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x2d, weight, bias, eps, fuse_gelu)
         ctx.save_for_backward(x2d, weight, mean, rstd)
         ctx.fuse_gelu = fuse_gelu
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x2d, weight, mean, rstd = ctx.saved_tensors
+        bias = ctx.bias_ref
+        gw, gb = _sink(weight), _sink(bias)
+        if gw is not None and gb is not None:
+            dx, _, _ = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu, dgamma=gw, dbeta=gb)
+            _sink_done(weight)
+            _sink_done(bias)
+            return dx, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu)
         return dx, dg, db, None, None
 
@@ -83,6 +106,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, weight)
         ctx.alpha = alpha
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         N = weight.shape[0]
         out = None
         ctx.padded = False
@@ -105,9 +129,19 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dy, weight, False, False, alpha=ctx.alpha, a_kpad_zero=kpad)  # dX = dY W
         if ctx.needs_input_grad[1]:
-            dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                       # dW = dY^T X
+            gw = _sink(weight)
+            if gw is not None:
+                K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True)   # dW += dY^T X, in the arena
+                _sink_done(weight)
+            else:
+                dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                   # dW = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = K.colsum(dy, alpha=ctx.alpha).to(weight.dtype)
+            gb = _sink(ctx.bias_ref)
+            if gb is not None:
+                K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True)
+                _sink_done(ctx.bias_ref)
+            else:
+                db = K.colsum(dy, alpha=ctx.alpha, out_dtype=weight.dtype)
         return dx, dw, db, None
 
 
@@ -165,7 +199,7 @@ class AddFn(torch.autograd.Function):
     def backward(ctx, dy):
         (rowmask,) = ctx.saved_tensors
         g = K.add_rowvec_mask(dy, None, None, rowmask) if rowmask is not None else dy
-        dvec = K.colsum(g).to(ctx.vdtype) if ctx.has[1] else None
+        dvec = K.colsum(g, out_dtype=ctx.vdtype) if ctx.has[1] else None
         return g, (g if ctx.has[0] else None), dvec, None
 
 
@@ -197,12 +231,19 @@ class EmbeddingFn(torch.autograd.Function):
     def forward(ctx, ids, weight, padding_idx):
         ctx.save_for_backward(ids)
         ctx.V, ctx.padding_idx = weight.shape[0], padding_idx
+        ctx.weight_ref = weight
         return K.embedding_fwd(weight, ids)
 
     @staticmethod
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        dw = K.embedding_bwd(dout, ids, ctx.V, -1 if ctx.padding_idx is None else ctx.padding_idx)
+        pad = -1 if ctx.padding_idx is None else ctx.padding_idx
+        gw = _sink(ctx.weight_ref)
+        if gw is not None:
+            K.embedding_bwd(dout, ids, ctx.V, pad, dweight=gw)       # the kernel accumulates into dweight
+            _sink_done(ctx.weight_ref)
+            return None, None, None
+        dw = K.embedding_bwd(dout, ids, ctx.V, pad)
         return None, dw, None
 
 
@@ -392,7 +433,7 @@ class MulRowvecFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         a, vec = ctx.saved_tensors
-        return K.mul_rowvec(dy, vec), K.colsum(K.mul(dy, a)).to(vec.dtype)
+        return K.mul_rowvec(dy, vec), K.colsum(K.mul(dy, a), out_dtype=vec.dtype)
 
 
 def mul_rowvec(a, vec):
@@ -429,7 +470,7 @@ class PatchEmbedFn(torch.autograd.Function):
         d2 = dout.reshape(-1, dout.shape[-1])
         d2 = d2 if d2.stride(-1) == 1 else d2.contiguous()
         dw = K.gemm(d2, col, True, False)[:, :Kc].reshape(wshape)
-        db = K.colsum(d2).to(dout.dtype) if has_bias else None
+        db = K.colsum(d2, out_dtype=dout.dtype) if has_bias else None
         return None, dw, db, None
 
 

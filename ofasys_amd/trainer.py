@@ -46,12 +46,14 @@ class FlatParams:
                 self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._ofa_grad = p.grad          # backward kernels accumulate straight into the arena (ops._sink)
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point it at the arena
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._ofa_grad = p.grad
 
 
 class Trainer:
@@ -78,8 +80,8 @@ class Trainer:
         model.train()
         self.fp.zero_grad()
         self._stats.zero_()
+        self.reducer.begin_step(tuple(s.get("task", len(s["slots"])) for s in samples))
         for i, s in enumerate(samples):
-            self.reducer.no_sync(i < len(samples) - 1)               # reduce once, after the last backward
             logits = model(s["slots"])[0]
             loss = ops.cross_entropy_sum(logits, s["target"], self.pad)
             loss.backward()

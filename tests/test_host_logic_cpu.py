@@ -86,11 +86,14 @@ def _dp_worker(rank, world, port, q):
     assert len(red.buckets) > 2
     g = torch.Generator().manual_seed(100 + rank)
     xs = [torch.randn(6, 16, generator=g) for _ in range(2)]
-    fp.zero_grad()
-    for i, x in enumerate(xs):                # two micro-batches: reduce only after the last one
-        red.no_sync(i == 0)
-        model[3](model[2](model[1](model[0](x)))).sum().backward()
-    red.finish()
+    for step in range(2):                     # step 0 learns the contribution counts, step 1 overlaps bucket launches
+        fp.zero_grad()
+        red.begin_step("2mb")
+        for x in xs:                          # two micro-batches accumulate; buckets fire on the LAST contribution
+            model[3](model[2](model[1](model[0](x)))).sum().backward()
+        if step == 1:
+            assert any(red._launched)             # buckets fired from inside backward (overlap armed)
+        red.finish()
     n = all_reduce_scalars(torch.tensor([6.0 * 2], dtype=torch.float64))
     q.put((rank, fp.grad.clone(), float(n)))
     dist.destroy_process_group()

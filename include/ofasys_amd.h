@@ -129,7 +129,7 @@ int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, 
 int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
                       void* stream);
 int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
-                      int64_t padding_idx, int dtype, void* stream);
+                      int64_t padding_idx, uint8_t* present_ws /* optional V bytes of scratch */, int dtype, void* stream);
 
 /* ---- elementwise pieces of the layer (transformer_layer.py:167-208): */
 int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);                  /* module/gelu.py:18-19 */

@@ -40,10 +40,10 @@ __device__ __forceinline__ bf16x8 ld_frag8x2(const bf16_t* p) {
 }
 __device__ __forceinline__ bf16x8 pack8(const float* f) {
   union { uint4 u; bf16x8 v; } r;
-  r.u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  r.u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-  r.u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-  r.u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  r.u.x = pack_bf16x2(f[0], f[1]);
+  r.u.y = pack_bf16x2(f[2], f[3]);
+  r.u.z = pack_bf16x2(f[4], f[5]);
+  r.u.w = pack_bf16x2(f[6], f[7]);
   return r.v;
 }
 __device__ __forceinline__ void zero16(f32x16& a) {
@@ -54,8 +54,8 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ void st4bf(bf16_t* p, float a, float b, float c, float d) {
   uint2 o;
-  o.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-  o.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  o.x = pack_bf16x2(a, b);
+  o.y = pack_bf16x2(c, d);
   *reinterpret_cast<uint2*>(p) = o;
 }
 
@@ -69,7 +69,19 @@ struct AttnArgs {
   float scale; int causal;
 };
 
+// 32-bit "dead key" mask of a 32-key block (bit j: key0+j is out of range or padded), wave-uniform, from ONE byte load
+// per lane + a ballot instead of 16 byte loads per lane.
+__device__ __forceinline__ uint32_t key_dead_mask(const uint8_t* kp, int key0, int S, int i) {
+  const int key = key0 + i;
+  bool dead = key >= S;
+  if (kp && !dead) dead = kp[key] != 0;
+  return (uint32_t)__ballot(dead);        // lanes 0..31 and 32..63 carry the same 32 keys; keep the low half
+}
+
 // ------------------------------------------------------------------------------------------------ forward
+// Per 32-key block: S^T = K Q^T (4 MFMAs), online softmax in registers, O^T += V^T P^T (4 MFMAs).  The K rows and V^T
+// rows of block kb+1 are fetched (global -> VGPR, 16 + 16 registers) while block kb is being computed; masks cost
+// nothing on blocks that need none (wave-uniform branch); the O rescale runs only when some row max actually grew.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, hi = lane >> 5;
@@ -97,32 +109,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int lim = (q0 + 31 < a.S - 1 ? q0 + 31 : a.S - 1) / 32 + 1;
     nkb = lim < nkb ? lim : nkb;
   }
+  bf16x8 kf[4], vf[2][2];
+  uint32_t kdead;
+  {
+    const int krow = i < a.S ? i : a.S - 1;
+    const bf16_t* kr = kbase + (int64_t)krow * a.ldk;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) kf[kk] = ld_frag16(kr + kk * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) vf[j][dt] = ld_frag8x2(vtbase + (int64_t)dt * 32 * a.Spad + 16 * j);
+    kdead = key_dead_mask(kp, 0, a.S, i);
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * 32;
-    const int krow = key0 + i < a.S ? key0 + i : a.S - 1;
-    const bf16_t* kr = kbase + (int64_t)krow * a.ldk;
     f32x16 st;
     zero16(st);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag16(kr + kk * 16), qf[kk], st, 0, 0, 0);
+    for (int kk = 0; kk < 4; ++kk) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+    const uint32_t dead_now = kdead;
+    bf16x8 vcur[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) vcur[j][dt] = vf[j][dt];
+    if (kb + 1 < nkb) {                                  // prefetch block kb+1
+      const int nk0 = key0 + 32;
+      const int krow = nk0 + i < a.S ? nk0 + i : a.S - 1;
+      const bf16_t* kr = kbase + (int64_t)krow * a.ldk;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[kk] = ld_frag16(kr + kk * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[j][dt] = ld_frag8x2(vtbase + (int64_t)dt * 32 * a.Spad + nk0 + 16 * j);
+      kdead = key_dead_mask(kp, nk0, a.S, i);
+    }
     float s[16];
     float mx = -INFINITY;
+    const bool diag = a.causal && (key0 + 31 > q0);
+    if (brow || dead_now || diag) {                      // wave-uniform: slow, fully general path
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + crow(r, hi);
-      float t = st[r] * sc;
-      if (brow && key < a.S) t += bf2f(brow[key]) * LOG2E;
-      bool dead = key >= a.S;
-      if (a.causal) dead |= key > qi;
-      if (kp && key < a.S) dead |= kp[key] != 0;
-      t = dead ? -INFINITY : t;
-      s[r] = t;
-      mx = fmaxf(mx, t);
+      for (int r = 0; r < 16; ++r) {
+        const int j = crow(r, hi), key = key0 + j;
+        float t = st[r] * sc;
+        if (brow && key < a.S) t += bf2f(brow[key]) * LOG2E;
+        bool dead = (dead_now >> j) & 1u;
+        if (diag) dead |= key > qi;
+        t = dead ? -INFINITY : t;
+        s[r] = t;
+        mx = fmaxf(mx, t);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = st[r] * sc;
+        mx = fmaxf(mx, s[r]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     float p[16];
     float ps = 0.f;
 #pragma unroll
@@ -131,21 +179,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       ps += p[r];
     }
     ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
+    if (__any(m_new != m_run)) {                         // some row's running max grew: rescale O and l
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      ot[0][r] *= alpha;
-      ot[1][r] *= alpha;
+      for (int r = 0; r < 16; ++r) {
+        ot[0][r] *= alpha;
+        ot[1][r] *= alpha;
+      }
+      m_run = m_new;
     }
+    l_run += ps;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bf16x8 pf = pack8(p + 8 * j);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 vf = ld_frag8x2(vtbase + (int64_t)dt * 32 * a.Spad + key0 + 16 * j);
-        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 2; ++dt) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[j][dt], pf, ot[dt], 0, 0, 0);
     }
   }
   if (qi < a.T) {
@@ -194,6 +243,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
+// lanes <-> queries.  Per 32-key block: S^T = K Q^T, dP^T = V dO^T (8 MFMAs), dS^T = P^T o (dP^T*c - delta), then
+// dQ^T += K^T dS^T (4 MFMAs).  K, V rows and K^T rows of the next block are prefetched under the current one.
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, hi = lane >> 5;
@@ -230,30 +281,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int lim = (q0 + 31 < a.S - 1 ? q0 + 31 : a.S - 1) / 32 + 1;
     nkb = lim < nkb ? lim : nkb;
   }
+  bf16x8 kf[4], vf[4], ktf[2][2];
+  uint32_t kdead;
+  {
+    const int krow = i < a.S ? i : a.S - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = ld_frag16(kbase + (int64_t)krow * a.ldk + kk * 16);
+      vf[kk] = ld_frag16(vbase + (int64_t)krow * a.ldk + kk * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ktf[j][dt] = ld_frag8x2(ktbase + (int64_t)dt * 32 * a.Spad + 16 * j);
+    kdead = key_dead_mask(kp, 0, a.S, i);
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * 32;
-    const int krow = key0 + i < a.S ? key0 + i : a.S - 1;
-    const bf16_t* kr = kbase + (int64_t)krow * a.ldk;
-    const bf16_t* vr = vbase + (int64_t)krow * a.ldk;
     f32x16 st, dp;
     zero16(st);
     zero16(dp);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag16(kr + kk * 16), qf[kk], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag16(vr + kk * 16), dof[kk], dp, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dp, 0, 0, 0);
+    }
+    const uint32_t dead_now = kdead;
+    bf16x8 ktc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ktc[j][dt] = ktf[j][dt];
+    if (kb + 1 < nkb) {
+      const int nk0 = key0 + 32;
+      const int krow = nk0 + i < a.S ? nk0 + i : a.S - 1;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = ld_frag16(kbase + (int64_t)krow * a.ldk + kk * 16);
+        vf[kk] = ld_frag16(vbase + (int64_t)krow * a.ldk + kk * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ktf[j][dt] = ld_frag8x2(ktbase + (int64_t)dt * 32 * a.Spad + nk0 + 16 * j);
+      kdead = key_dead_mask(kp, nk0, a.S, i);
     }
     float ds[16];
+    const bool diag = a.causal && (key0 + 31 > q0);
+    if (brow || dead_now || diag) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + crow(r, hi);
-      float t = st[r] * sc;
-      if (brow && key < a.S) t += bf2f(brow[key]) * LOG2E;
-      bool dead = key >= a.S;
-      if (a.causal) dead |= key > qi;
-      if (kp && key < a.S) dead |= kp[key] != 0;
-      const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - lse_q);
-      ds[r] = p * (dp[r] * c - delta_q);
+      for (int r = 0; r < 16; ++r) {
+        const int j = crow(r, hi), key = key0 + j;
+        float t = st[r] * sc;
+        if (brow && key < a.S) t += bf2f(brow[key]) * LOG2E;
+        bool dead = (dead_now >> j) & 1u;
+        if (diag) dead |= key > qi;
+        const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - lse_q);
+        ds[r] = p * (dp[r] * c - delta_q);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[r] * sc - lse_q);
+        ds[r] = p * (dp[r] * c - delta_q);
+      }
     }
     if (dbrow && qi < a.T) {
 #pragma unroll
@@ -266,10 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int j = 0; j < 2; ++j) {
       const bf16x8 dsf = pack8(ds + 8 * j);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 kf = ld_frag8x2(ktbase + (int64_t)dt * 32 * a.Spad + key0 + 16 * j);
-        dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf, dqt[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 2; ++dt) dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktc[j][dt], dsf, dqt[dt], 0, 0, 0);
     }
   }
   if (dbrow && qi < a.T && nkb < nkb_all) {   // causally skipped blocks: dS == 0
@@ -290,6 +378,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
+// lanes <-> keys.  Per 32-query block: S = Q K^T, dP = dO V^T (8 MFMAs), then dV^T += dO^T P and dK^T += Q^T dS
+// (8 MFMAs).  Q, dO rows, Q^T, dO^T rows and the lse/delta vectors of the next query block are prefetched.
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, hi = lane >> 5;
@@ -307,13 +397,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     vf[kk] = ld_frag16(vp_ + kk * 16);
   }
   const bool key_dead = ki >= a.S || (a.kpm && a.kpm[(int64_t)b * a.S + krow] != 0);
+  const float live = key_dead ? 0.f : 1.f;
   const float c = a.c_attn ? a.c_attn[h] : 1.0f;
   const bf16_t* qbase = a.q + (int64_t)b * a.T * a.ldq + h * HD + hi * 8;
   const bf16_t* dobase = a.dout + (int64_t)b * a.T * a.ldo + h * HD + hi * 8;
   const bf16_t* qtbase = a.qt + ((int64_t)bh * HD + i) * a.Tpad + 4 * hi;
   const bf16_t* dotbase = a.dot + ((int64_t)bh * HD + i) * a.Tpad + 4 * hi;
-  const float* lse_b = a.lse + (int64_t)bh * a.Tpad;
-  const float* delta_b = a.delta + (int64_t)bh * a.Tpad;
+  const float* lse_b = a.lse + (int64_t)bh * a.Tpad + 4 * hi;
+  const float* delta_b = a.delta + (int64_t)bh * a.Tpad + 4 * hi;
   const bf16_t* bcol = a.bias ? a.bias + (int64_t)bh * a.T * a.S + krow : nullptr;
   const float sc = a.scale * LOG2E;
 
@@ -321,37 +412,71 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   zero16(dvt[0]); zero16(dvt[1]); zero16(dkt[0]); zero16(dkt[1]);
   const int nqb = (a.T + 31) / 32;
   const int qb0 = a.causal ? key0 / 32 : 0;
+  bf16x8 qf[4], dof[4], qtf[2][2], dotf[2][2];
+  float4 l4[4], d4[4];
+  auto fetch = [&](int q0) {
+    const int qrow = q0 + i < a.T ? q0 + i : a.T - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = ld_frag16(qbase + (int64_t)qrow * a.ldq + kk * 16);
+      dof[kk] = ld_frag16(dobase + (int64_t)qrow * a.ldo + kk * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        qtf[j][dt] = ld_frag8x2(qtbase + (int64_t)dt * 32 * a.Tpad + q0 + 16 * j);
+        dotf[j][dt] = ld_frag8x2(dotbase + (int64_t)dt * 32 * a.Tpad + q0 + 16 * j);
+      }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      l4[g4] = *reinterpret_cast<const float4*>(lse_b + q0 + 8 * g4);
+      d4[g4] = *reinterpret_cast<const float4*>(delta_b + q0 + 8 * g4);
+    }
+  };
+  if (qb0 < nqb) fetch(qb0 * 32);
   for (int qb = qb0; qb < nqb; ++qb) {
     const int q0 = qb * 32;
-    const int qrow = q0 + i < a.T ? q0 + i : a.T - 1;
-    const bf16_t* qr = qbase + (int64_t)qrow * a.ldq;
-    const bf16_t* dor = dobase + (int64_t)qrow * a.ldo;
     f32x16 st, dp;
     zero16(st);
     zero16(dp);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag16(qr + kk * 16), kf[kk], st, 0, 0, 0);   // S[q][key]
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag16(dor + kk * 16), vf[kk], dp, 0, 0, 0);  // dP[q][key]
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], kf[kk], st, 0, 0, 0);    // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[kk], vf[kk], dp, 0, 0, 0);   // dP[q][key]
     }
-    float p[16], ds[16];
+    bf16x8 qtc[2][2], dotc[2][2];
+    float lv[16], dv16[16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { qtc[j][dt] = qtf[j][dt]; dotc[j][dt] = dotf[j][dt]; }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const float4 l4 = *reinterpret_cast<const float4*>(lse_b + q0 + 8 * g4 + 4 * hi);
-      const float4 d4 = *reinterpret_cast<const float4*>(delta_b + q0 + 8 * g4 + 4 * hi);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-      const float dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+      lv[4 * g4] = l4[g4].x; lv[4 * g4 + 1] = l4[g4].y; lv[4 * g4 + 2] = l4[g4].z; lv[4 * g4 + 3] = l4[g4].w;
+      dv16[4 * g4] = d4[g4].x; dv16[4 * g4 + 1] = d4[g4].y; dv16[4 * g4 + 2] = d4[g4].z; dv16[4 * g4 + 3] = d4[g4].w;
+    }
+    if (qb + 1 < nqb) fetch(q0 + 32);
+    float p[16], ds[16];
+    const bool general = bcol || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
+    if (general) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g4 + e;
-        const int q = q0 + 8 * g4 + 4 * hi + e;
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + crow(r, hi);
         float t = st[r] * sc;
         if (bcol && q < a.T) t += bf2f(bcol[(int64_t)q * a.S]) * LOG2E;
         bool dead = key_dead || q >= a.T;
         if (a.causal) dead |= ki > q;
-        const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[e]);
+        const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[r]);
         p[r] = pv;
-        ds[r] = dead ? 0.f : pv * (dp[r] * c - dv4[e]);
+        ds[r] = dead ? 0.f : pv * (dp[r] * c - dv16[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[r] * sc - lv[r]) * live;
+        p[r] = pv;
+        ds[r] = pv * (dp[r] * c - dv16[r]);
       }
     }
 #pragma unroll
@@ -360,10 +485,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const bf16x8 dsf = pack8(ds + 8 * j);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 dof = ld_frag8x2(dotbase + (int64_t)dt * 32 * a.Tpad + q0 + 16 * j);
-        const bf16x8 qf = ld_frag8x2(qtbase + (int64_t)dt * 32 * a.Tpad + q0 + 16 * j);
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotc[j][dt], pf, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtc[j][dt], dsf, dkt[dt], 0, 0, 0);
       }
     }
   }

@@ -27,11 +27,13 @@ int check_launch(const char* what);
 typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t x = __float_as_uint(f);
-  if ((x & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x >> 16) | 0x40);  // quiet NaN
-  x += 0x7fffu + ((x >> 16) & 1u);
-  return (bf16_t)(x >> 16);
+// fp32 -> bf16 is the hardware conversion (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserved)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Vec;  // 16-byte vector of T
@@ -60,7 +62,7 @@ template <> __device__ __forceinline__ void store_vec<float>(float* p, const flo
 template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float* in) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
   *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 

@@ -112,15 +112,24 @@ __global__ __launch_bounds__(256) void embedding_fwd_scalar_kernel(const T* __re
   }
 }
 
+__global__ __launch_bounds__(256) void embedding_mark_kernel(const int64_t* __restrict__ ids, uint8_t* __restrict__ present,
+                                                             int64_t n, int64_t V) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t id = ids[i];
+    if (id >= 0 && id < V) present[id] = 1;     // benign race: every writer stores the same value
+  }
+}
+
 // dweight[v] += sum_{i : ids[i]==v} dout[i]   -- one wave per vocabulary row; the wave sweeps the id list 64 at a time,
 // ballots the matches and accumulates the matching rows in increasing position order (deterministic, no atomics).
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
                                                             T* __restrict__ dw, int64_t n, int D, int64_t V,
-                                                            int64_t padding_idx) {
+                                                            int64_t padding_idx, const uint8_t* __restrict__ present) {
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (v >= V || v == padding_idx) return;
+  if (present && !present[v]) return;      // most vocabulary rows do not occur in a batch: skip their scan
   constexpr int MAXC = 32;                 // columns per lane held in registers: D <= 2048
   float acc[MAXC];
 #pragma unroll
@@ -172,20 +181,20 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const T* __restrict__
   }
 }
 
-// column sums of a [rows, cols] matrix (bias gradients): 64 column-vectors x 4 row-lanes per block, grid.y row groups,
+// column sums of a [rows, cols] matrix (bias gradients): 32 column-vectors x 8 row-lanes per block, grid.y row groups,
 // fp32 partials [grid.y][cols] folded by a second pass (deterministic).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                              int64_t rows, int cols, int64_t ld) {
   constexpr int N = Vec<T>::N;
-  __shared__ float red[4][64][N];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + cx) * N;
+  __shared__ float red[8][32][N];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cx) * N;
   float acc[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) acc[j] = 0.f;
   if (c < cols) {
-    for (int64_t r = (int64_t)blockIdx.y * 4 + ry; r < rows; r += (int64_t)gridDim.y * 4) {
+    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < rows; r += (int64_t)gridDim.y * 8) {
       float v[N];
       load_vec<T>(x + r * ld + c, v);
 #pragma unroll
@@ -197,20 +206,33 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   __syncthreads();
   if (ry == 0 && c < cols) {
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-      partial[(int64_t)blockIdx.y * cols + c + j] = red[0][cx][j] + red[1][cx][j] + red[2][cx][j] + red[3][cx][j];
+    for (int j = 0; j < N; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[r][cx][j];
+      partial[(int64_t)blockIdx.y * cols + c + j] = t;
+    }
   }
 }
 template <typename TO>
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, TO* __restrict__ out,
-                                                           int cols, int groups, float alpha, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, TO* __restrict__ out,
+                                                            int cols, int groups, float alpha, int accumulate) {
+  __shared__ float sm[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int g = 0; g < groups; ++g) s += partial[(int64_t)g * cols + c];
-  s *= alpha;
-  if (accumulate) s += ld1<TO>(out + c);
-  st1<TO>(out + c, s);
+  if (c < cols)
+    for (int g = ry; g < groups; g += 16) s += partial[(int64_t)g * cols + c];
+  sm[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][cx];
+    t *= alpha;
+    if (accumulate) t += ld1<TO>(out + c);
+    st1<TO>(out + c, t);
+  }
 }
 
 static inline int grid_for(int64_t work) {
@@ -314,19 +336,23 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
 }
 
 extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
-                                 int64_t padding_idx, int dtype, void* stream) {
+                                 int64_t padding_idx, uint8_t* present_ws, int dtype, void* stream) {
   OFA_DT_CHECK("embedding_bwd");
   OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && dout && ids && dweight, OFA_ERR_INVALID, "embedding_bwd: bad argument");
   OFA_REQUIRE(D <= 2048, OFA_ERR_UNSUPPORTED, "embedding_bwd: D=%d exceeds 2048", D);
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (present_ws) {                                   // optional V-byte scratch: mark the rows that occur
+    (void)hipMemsetAsync(present_ws, 0, (size_t)V, st);
+    hipLaunchKernelGGL(embedding_mark_kernel, dim3(grid_for(n)), dim3(256), 0, st, ids, present_ws, n, V);
+  }
   dim3 grid((unsigned)((V + 3) / 4)), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((embedding_bwd_kernel<float>), grid, block, 0, st, (const float*)dout, ids, (float*)dweight, n, D, V,
-                       padding_idx);
+                       padding_idx, (const uint8_t*)present_ws);
   else
     hipLaunchKernelGGL((embedding_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, n, D,
-                       V, padding_idx);
+                       V, padding_idx, (const uint8_t*)present_ws);
   return check_launch("embedding_bwd");
 }
 
@@ -346,7 +372,7 @@ extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H,
   return check_launch("im2col_patch");
 }
 
-extern "C" int ofa_colsum_ws_floats(int cols) { return 64 * cols; }
+extern "C" int ofa_colsum_ws_floats(int cols) { return 128 * cols; }
 
 extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
                           int accumulate, int dtype, int out_dtype, void* stream) {
@@ -356,9 +382,9 @@ extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(cols % n == 0 && ld % n == 0, OFA_ERR_UNSUPPORTED, "colsum: cols=%d / ld not vectorizable", cols);
   hipStream_t st = (hipStream_t)stream;
-  int groups = (int)((rows + 127) / 128);
-  groups = groups < 1 ? 1 : (groups > 64 ? 64 : groups);
-  dim3 grid(cdiv(cols / n, 64), groups), block(256);
+  int groups = (int)((rows + 63) / 64);
+  groups = groups < 1 ? 1 : (groups > 128 ? 128 : groups);
+  dim3 grid(cdiv(cols / n, 32), groups), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, ws, rows, cols, ld);
   else
@@ -366,10 +392,10 @@ extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
   if (out_dtype == OFA_F32)
-    hipLaunchKernelGGL((colsum_final_kernel<float>), dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, (float*)out,
+    hipLaunchKernelGGL((colsum_final_kernel<float>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (float*)out,
                        cols, groups, alpha, accumulate);
   else
-    hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws,
+    hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws,
                        (bf16_t*)out, cols, groups, alpha, accumulate);
   return check_launch("colsum_final");
 }

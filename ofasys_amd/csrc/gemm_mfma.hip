@@ -225,8 +225,8 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int 
       v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
     }
     uint2 o;
-    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = o;
   }
 }

@@ -69,104 +69,117 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
-// Backward.  Each wave walks rows with a grid stride; its running dgamma/dbeta live in a private LDS slice
-// (lane-contiguous read-modify-write, no atomics), so register pressure stays at x, dy, gamma.  Partials go to
-// ws[wave][cols] and a second kernel folds them (deterministic: fixed row->wave assignment and summation order).
-template <typename T, int NV, bool GELU>
-__global__ __launch_bounds__(128) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// Backward.  A 256-thread block walks rows with a grid stride.  A row is split over WPR (1, 2 or 4) of the block's
+// waves -- wide rows (the 4D FFN LayerNorm) spread over four waves so that each lane keeps <= 2 vectors of x, dy, gamma
+// AND its running dgamma/dbeta in registers (no LDS accumulators, no spills, full occupancy); the two row statistics
+// cross the waves through a 2 x 4-float LDS exchange.  With GELU the activation and its derivative share one erf
+// (gelu = x*Phi, gelu' = Phi + x*phi).  Partials go to ws[block_row_slot][cols]; a second kernel folds them
+// (deterministic: fixed row->slot assignment and summation order).
+template <typename T, int NV, int WPR, bool GELU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ ws, int64_t rows, int cols, int nwaves) {
+                                                     float* __restrict__ ws, int64_t rows, int cols, int nslots) {
   constexpr int N = Vec<T>::N;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  const int wave = blockIdx.x * 2 + wib;
-  float* accg = smem + (size_t)wib * 2 * cols;
-  float* accb = accg + cols;
-  float g[NV][N];
+  constexpr int RPB = 4 / WPR;                       // rows per block iteration
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int rib = wib / WPR, part = wib % WPR;       // row-in-block, column part
+  const int cpp = cols / WPR;                        // columns per part (launcher guarantees divisibility by N)
+  const int c0 = part * cpp;
+  const int slot = blockIdx.x * RPB + rib;
+  float g[NV][N], dg[NV][N], db[NV][N];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * N;
-    if (c < cols) {
-      load_vec<T>(gamma + c, g[i]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) accg[c + j] = accb[c + j] = 0.f;
+    for (int j = 0; j < N; ++j) dg[i][j] = db[i][j] = 0.f;
+    if (c < cpp) load_vec<T>(gamma + c0 + c, g[i]);
+  }
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  const int64_t niter = (rows + stride - 1) / stride;
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t row = it * stride + slot;
+    const bool live = row < rows;
+    float xv[NV][N], gp[NV][N], d[NV][N];           // xv: LN input (gelu(h) or x); gp: gelu'(h)
+    float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
+    if (live) {
+      mu = mean[row];
+      rs = rstd[row];
+      const T* xr = x + row * cols + c0;
+      const T* dyr = dy + row * cols + c0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * N;
+        if (c < cpp) {
+          load_vec<T>(xr + c, xv[i]);
+          load_vec<T>(dyr + c, d[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * N;
+        if (c < cpp) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            if (GELU) {
+              const float h = xv[i][j];
+              const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752440f));
+              gp[i][j] = cdf + h * 0.39894228040143267794f * __expf(-0.5f * h * h);
+              xv[i][j] = h * cdf;
+            }
+            const float xh = (xv[i][j] - mu) * rs;
+            const float gy = d[i][j] * g[i][j];
+            s1 += gy;
+            s2 += gy * xh;
+            dg[i][j] += d[i][j] * xh;
+            db[i][j] += d[i][j];
+            xv[i][j] = xh;
+            d[i][j] = gy;
+          }
+        }
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (WPR > 1) {
+      if (lane == 0) { red[0][wib] = s1; red[1][wib] = s2; }
+      __syncthreads();
+      s1 = 0.f; s2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < WPR; ++p) { s1 += red[0][rib * WPR + p]; s2 += red[1][rib * WPR + p]; }
+      __syncthreads();
+    }
+    s1 /= (float)cols;
+    s2 /= (float)cols;
+    if (live) {
+      T* dxr = dx + row * cols + c0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * N;
+        if (c < cpp) {
+          float o[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            float t = rs * (d[i][j] - s1 - xv[i][j] * s2);
+            if (GELU) t *= gp[i][j];
+            o[j] = t;
+          }
+          store_vec<T>(dxr + c, o);
+        }
+      }
     }
   }
-  for (int64_t row = wave; row < rows; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    const T* xr = x + row * cols;
-    const T* dyr = dy + row * cols;
-    float hv[NV][N], d[NV][N];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * N;
-      if (c < cols) {
-        load_vec<T>(xr + c, hv[i]);
-        load_vec<T>(dyr + c, d[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * N;
-      if (c < cols) {
-        float4 ag[N / 4], ab[N / 4];
-#pragma unroll
-        for (int j = 0; j < N / 4; ++j) {
-          ag[j] = *reinterpret_cast<float4*>(accg + c + 4 * j);
-          ab[j] = *reinterpret_cast<float4*>(accb + c + 4 * j);
-        }
-        float* pag = reinterpret_cast<float*>(ag);
-        float* pab = reinterpret_cast<float*>(ab);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          const float xv = GELU ? gelu_f(hv[i][j]) : hv[i][j];
-          const float xh = (xv - mu) * rs;
-          const float gy = d[i][j] * g[i][j];
-          s1 += gy;
-          s2 += gy * xh;
-          pag[j] += d[i][j] * xh;
-          pab[j] += d[i][j];
-        }
-#pragma unroll
-        for (int j = 0; j < N / 4; ++j) {
-          *reinterpret_cast<float4*>(accg + c + 4 * j) = ag[j];
-          *reinterpret_cast<float4*>(accb + c + 4 * j) = ab[j];
-        }
-      }
-    }
-    s1 = wave_sum(s1) / (float)cols;
-    s2 = wave_sum(s2) / (float)cols;
-    T* dxr = dx + row * cols;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * N;
-      if (c < cols) {
-        float o[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          const float xv = GELU ? gelu_f(hv[i][j]) : hv[i][j];
-          const float xh = (xv - mu) * rs;
-          float t = rs * (d[i][j] * g[i][j] - s1 - xh * s2);
-          if (GELU) t *= gelu_grad_f(hv[i][j]);
-          o[j] = t;
-        }
-        store_vec<T>(dxr + c, o);
-      }
-    }
-  }
-  float* wg = ws + (int64_t)wave * cols;
-  float* wb = ws + (int64_t)nwaves * cols + (int64_t)wave * cols;
+  float* wg = ws + (int64_t)slot * cols + c0;
+  float* wb = ws + (int64_t)nslots * cols + (int64_t)slot * cols + c0;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * N;
-    if (c < cols) {
+    if (c < cpp) {
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        wg[c + j] = accg[c + j];
-        wb[c + j] = accb[c + j];
+        wg[c + j] = dg[i][j];
+        wb[c + j] = db[i][j];
       }
     }
   }
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
 }
 
-constexpr int LN_BWD_WAVES = 512;   // upper bound on partial rows (workspace sizing)
+constexpr int LN_BWD_WAVES = 1024;  // upper bound on partial rows (workspace sizing)
 
 template <typename T, bool GELU>
 static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y, float* mean, float* rstd, int64_t rows,
@@ -225,30 +238,36 @@ template <typename T, bool GELU>
 static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
                            void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, hipStream_t st) {
   constexpr int N = Vec<T>::N;
-  const int nv = cdiv(cols, 64 * N);
-  int64_t want = (rows + 3) / 4;                       // >= 4 rows per wave, at most LN_BWD_WAVES partial rows
-  want = want < 2 ? 2 : (want > LN_BWD_WAVES ? LN_BWD_WAVES : want);
-  const int nwaves = (int)((want + 1) & ~1);
-  dim3 grid(nwaves / 2), block(128);
-  const size_t lds = (size_t)2 * 2 * cols * sizeof(float);
-#define LN_CASE(NV)                                                                                                  \
-  do {                                                                                                               \
-    if (lds > 48 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<T, NV, GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                           \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, NV, GELU>), grid, block, lds, st, (const T*)dy, (const T*)x, (const T*)g,   \
-                       mean, rstd, (T*)dx, ws, rows, cols, nwaves);                                                  \
+  // waves per row: keep <= 2 vectors per lane when the row can be split evenly
+  int wpr = 1;
+  while (wpr < 4 && cdiv(cols / wpr, 64 * N) > 2 && (cols % (wpr * 2 * N)) == 0) wpr *= 2;
+  const int nv = cdiv(cols / wpr, 64 * N);
+  const int rpb = 4 / wpr;
+  int64_t nblk = (rows + rpb * 4 - 1) / (rpb * 4);      // >= 4 rows per slot
+  const int64_t maxblk = LN_BWD_WAVES / rpb;
+  nblk = nblk < 1 ? 1 : (nblk > maxblk ? maxblk : nblk);
+  const int nslots = (int)nblk * rpb;
+  dim3 grid((unsigned)nblk), block(256);
+#define LN_LAUNCH(NV, WPR)                                                                                           \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NV, WPR, GELU>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)g,  \
+                     mean, rstd, (T*)dx, ws, rows, cols, nslots)
+#define LN_CASE(WPR)                      \
+  do {                                    \
+    if (nv <= 1) LN_LAUNCH(1, WPR);       \
+    else if (nv <= 2) LN_LAUNCH(2, WPR);  \
+    else if (nv <= 4) LN_LAUNCH(4, WPR);  \
+    else if (nv <= 8) LN_LAUNCH(8, WPR);  \
+    else LN_LAUNCH(16, WPR);              \
   } while (0)
-  if (nv <= 1) LN_CASE(1);
-  else if (nv <= 2) LN_CASE(2);
-  else if (nv <= 4) LN_CASE(4);
-  else if (nv <= 8) LN_CASE(8);
-  else LN_CASE(16);
+  if (wpr == 1) LN_CASE(1);
+  else if (wpr == 2) LN_CASE(2);
+  else LN_CASE(4);
 #undef LN_CASE
+#undef LN_LAUNCH
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (T*)dgamma,
-                     (T*)dbeta, cols, nwaves, accumulate);
+                     (T*)dbeta, cols, nslots, accumulate);
   return check_launch("layernorm_bwd_reduce");
 }
 

@@ -338,8 +338,9 @@ def embedding_bwd(dout, ids, V, padding_idx=-1, dweight=None):
     D = dout.shape[-1]
     if dweight is None:
         dweight = torch.zeros(V, D, dtype=dout.dtype, device=dout.device)
+    present = workspace(V, dout.device, "embed_present") if V > 4096 else None
     lib().call("ofa_embedding_bwd", ptr(dout), ptr(ids), ptr(dweight), ids.numel(), D, V,
-               -1 if padding_idx is None else padding_idx, dtype_code(dout), stream())
+               -1 if padding_idx is None else padding_idx, ptr(present), dtype_code(dout), stream())
     return dweight
 
 

@@ -20,6 +20,8 @@
 //   * skinny outputs (wgrad: M,N ~ 768..3072, K = tokens) use split-K into an fp32 workspace + a reduce/epilogue
 //     kernel (deterministic, no atomics).
 // Roofline: MFMA-bound; algorithmic flops = 2*M*N*K.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace ofa {
@@ -152,37 +154,66 @@ __device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ base, int6
 typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
 struct FragRegs { bf16x8 v; };
 
+// Per-lane LDS byte addresses of one operand's fragments, computed ONCE per kernel: the K loop is unrolled by two so
+// the double-buffer select becomes a compile-time `offset:` immediate and a K-step issues its 16 fragment reads with no
+// address arithmetic at all (PMC: instruction issue used to cost as many cycles per K-step as the MFMAs themselves).
 template <int R, bool KMAJ> struct FragAddr {
-  uint32_t base;    // per-lane byte offset inside the tile (without the kk-dependent part for k-major tiles)
-  uint32_t rowsw;   // k-major: ((row>>1)&7); m-major: unused
-  __device__ __forceinline__ void init(int rbase, int lane) {
+  uint32_t a[KMAJ ? 4 : 1];          // k-major: one address per k-slice (the XOR swizzle depends on kk); m-major: base
+  __device__ __forceinline__ void init(uint32_t tile0, int rbase, int lane) {
     if (KMAJ) {
-      const int row = rbase + (lane & 31);
-      base = (uint32_t)row * 128u;
-      rowsw = (uint32_t)(((row >> 1) & 7) ^ (lane >> 5));     // chunk = (kk*2 + hi) ^ sw = (kk*2) ^ (hi ^ sw): bit0 folded
+      const int row = rbase + (lane & 31), hi = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a[kk] = tile0 + (uint32_t)(row * 64 + swz<R, true>(row, kk * 2 + hi) * 8) * 2u;
     } else {
       const int g = lane >> 4, q = lane & 15;
       const int k = (g >> 1) * 8 + (q >> 2);
       const int col = rbase + (g & 1) * 16 + 4 * (q & 3);
-      base = (uint32_t)(k * R + swz<R, false>(k, col >> 3) * 8 + (col & 7)) * 2u;
-      rowsw = 0;
+      a[0] = tile0 + (uint32_t)(k * R + swz<R, false>(k, col >> 3) * 8 + (col & 7)) * 2u;   // swz(k + 16*kk + 4, .) == swz(k, .)
     }
   }
 };
 
-template <int R, bool KMAJ, int KK>
-__device__ __forceinline__ void frag_issue(u64x2& d, const FragAddr<R, KMAJ>& fa, uint32_t tile) {
-  if (KMAJ) {
-    // chunk index (KK*2 + hi) ^ sw, with hi folded into rowsw (hi and KK*2 occupy disjoint bits)
-    const uint32_t addr = tile + fa.base + (((uint32_t)(KK * 2) ^ fa.rowsw) << 4);
-    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
+template <int R, bool KMAJ, int KK, int BUFOFF>
+__device__ __forceinline__ void frag_issue(u64x2& d, const FragAddr<R, KMAJ>& fa) {
+  if constexpr (KMAJ) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(fa.a[KK]), "i"(BUFOFF));
   } else {
-    const uint32_t addr = tile + fa.base;
     unsigned long long lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(KK * 16 * R * 2));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(KK * 16 * R * 2 + 4 * R * 2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(fa.a[0]), "i"(BUFOFF + KK * 16 * R * 2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(fa.a[0]), "i"(BUFOFF + KK * 16 * R * 2 + 4 * R * 2));
     d[0] = lo;
     d[1] = hi;
+  }
+}
+
+// DMA source pointers of one operand tile, advanced by a constant stride per K-step.
+template <int R, bool KMAJ, int NT, int NV>
+__device__ __forceinline__ void glds_ptrs(const bf16_t* (&ptr)[NV], const bf16_t* __restrict__ base, int64_t ld, int r0,
+                                          int rmax, int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int gidx = tid + i * NT;
+    if (KMAJ) {
+      const int r = gidx >> 3, c = swz<R, true>(r, gidx & 7);
+      int rr = r0 + r;
+      rr = rr < rmax ? rr : rmax - 1;
+      ptr[i] = base + (int64_t)rr * ld + k0 + c * 8;
+    } else {
+      constexpr int CPR = R / 8;
+      const int k = gidx / CPR, c = swz<R, false>(k, gidx % CPR);
+      int col = r0 + c * 8;
+      const int last = ((rmax + 7) & ~7) - 8;
+      col = col < last ? col : last;
+      ptr[i] = base + (int64_t)(k0 + k) * ld + col;
+    }
+  }
+}
+template <int NT, int NV>
+__device__ __forceinline__ void glds_issue(const bf16_t* (&ptr)[NV], int64_t step, bf16_t* __restrict__ lds, int wave) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __builtin_amdgcn_global_load_lds((gvoid_t*)ptr[i], (lvoid_t*)(lds + (wave * 64 + i * NT) * 8), 16, 0, 0);
+    ptr[i] += step;
   }
 }
 
@@ -252,7 +283,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = tiles_m * tiles_n;
   const int t = xcd_remap(blockIdx.x, ntiles);
-  const int tm = t / tiles_n, tn = t % tiles_n;
+  // grouped order inside the XCD's run: consecutive ids walk GM tile-rows before moving to the next tile-column, so the
+  // ~64 workgroups resident on an XCD cover a GM x (64/GM) block of tiles and every A / B panel they pull into the
+  // XCD's 4 MiB L2 is shared by ~8 of them.
+  constexpr int GM = 8;
+  const int gsz = GM * tiles_n;
+  const int gid = t / gsz, first_m = gid * GM;
+  const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
   const int m0 = tm * BM, n0 = tn * BN;
   const int bz = blockIdx.z, ks = blockIdx.y;
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
@@ -272,54 +310,67 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   if constexpr (GLDS) {
     // K (and every split) is a multiple of BK: all tiles are full, rows/columns outside M/N are clamped reads
+    const bf16_t* pa[NVA];
+    const bf16_t* pb[NVB];
+    glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+    glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+    const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
     if (nk > 0) {
-      stage_glds<BM, A_KMAJ, NT, NVA>(A, g.lda, m0, g.M, kbeg, sA[0], tid, wave_u);
-      stage_glds<BN, B_KMAJ, NT, NVB>(B, g.ldb, n0, g.N, kbeg, sB[0], tid, wave_u);
+      glds_issue<NT, NVA>(pa, stepA, sA[0], wave_u);
+      glds_issue<NT, NVB>(pb, stepB, sB[0], wave_u);
     }
     __syncthreads();                                     // (the compiler drains vmcnt before the barrier)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
     FragAddr<BM, A_KMAJ> fax[2];
     FragAddr<BN, B_KMAJ> faw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      fax[i].init(wm * 64 + i * 32, lane);
-      faw[i].init(wn * 64 + i * 32, lane);
+      fax[i].init(lds0, wm * 64 + i * 32, lane);
+      faw[i].init(lds0, wn * 64 + i * 32, lane);
     }
-    const uint32_t ldsA0 = (uint32_t)(uintptr_t)sA[0], ldsB0 = (uint32_t)(uintptr_t)sB[0];
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) {                                 // DMA of the next tile runs under this tile's MFMAs
-        stage_glds<BM, A_KMAJ, NT, NVA>(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, sA[cur ^ 1], tid, wave_u);
-        stage_glds<BN, B_KMAJ, NT, NVB>(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, sB[cur ^ 1], tid, wave_u);
-      }
-      const uint32_t ta = ldsA0 + (uint32_t)cur * (EA * 2), tb = ldsB0 + (uint32_t)cur * (EB * 2);
-      u64x2 x0[2], w0[2], x1[2], w1[2];
-#define OFA_ISSUE(KK, X, W)                                \
-      frag_issue<BM, A_KMAJ, KK>(X[0], fax[0], ta);        \
-      frag_issue<BM, A_KMAJ, KK>(X[1], fax[1], ta);        \
-      frag_issue<BN, B_KMAJ, KK>(W[0], faw[0], tb);        \
-      frag_issue<BN, B_KMAJ, KK>(W[1], faw[1], tb)
+    constexpr int OA0 = 0, OA1 = EA * 2, OB0 = 2 * EA * 2, OB1 = 2 * EA * 2 + EB * 2;   // byte offsets of the 4 buffers
+    static_assert(OB1 + 3 * 16 * (BM > BN ? BM : BN) * 2 + 4 * (BM > BN ? BM : BN) * 2 < 65536, "ds offset field");
+#define OFA_ISSUE(KK, X, W, OA, OB)                          \
+    frag_issue<BM, A_KMAJ, KK, OA>(X[0], fax[0]);            \
+    frag_issue<BM, A_KMAJ, KK, OA>(X[1], fax[1]);            \
+    frag_issue<BN, B_KMAJ, KK, OB>(W[0], faw[0]);            \
+    frag_issue<BN, B_KMAJ, KK, OB>(W[1], faw[1])
 #define OFA_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
-#define OFA_MMA(X, W)                                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
-                                                              __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
-      OFA_ISSUE(0, x0, w0);
-      OFA_WAIT(x0, w0);
-      OFA_ISSUE(1, x1, w1);          // next k-slice's LDS reads fly under this slice's MFMAs
-      OFA_MMA(x0, w0);
-      OFA_WAIT(x1, w1);
-      OFA_ISSUE(2, x0, w0);
-      OFA_MMA(x1, w1);
-      OFA_WAIT(x0, w0);
-      OFA_ISSUE(3, x1, w1);
-      OFA_MMA(x0, w0);
-      OFA_WAIT(x1, w1);
-      OFA_MMA(x1, w1);
+#define OFA_MMA(X, W)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
+                                                            __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
+#define OFA_KSTEP(OA, OB, NEXT_A, NEXT_B, MORE)                                                        \
+    {                                                                                                  \
+      if (MORE) {                      /* DMA of the next tile runs under this tile's MFMAs */          \
+        glds_issue<NT, NVA>(pa, stepA, NEXT_A, wave_u);                                                \
+        glds_issue<NT, NVB>(pb, stepB, NEXT_B, wave_u);                                                \
+      }                                                                                                \
+      u64x2 x0[2], w0[2], x1[2], w1[2];                                                                \
+      OFA_ISSUE(0, x0, w0, OA, OB);                                                                    \
+      OFA_WAIT(x0, w0);                                                                                \
+      OFA_ISSUE(1, x1, w1, OA, OB);    /* next k-slice's LDS reads fly under this slice's MFMAs */      \
+      OFA_MMA(x0, w0);                                                                                 \
+      OFA_WAIT(x1, w1);                                                                                \
+      OFA_ISSUE(2, x0, w0, OA, OB);                                                                    \
+      OFA_MMA(x1, w1);                                                                                 \
+      OFA_WAIT(x0, w0);                                                                                \
+      OFA_ISSUE(3, x1, w1, OA, OB);                                                                    \
+      OFA_MMA(x0, w0);                                                                                 \
+      OFA_WAIT(x1, w1);                                                                                \
+      OFA_MMA(x1, w1);                                                                                 \
+      __syncthreads();                 /* drains this wave's DMA (vmcnt) and fences the buffer swap */ \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      OFA_KSTEP(OA0, OB0, sA[1], sB[1], true);
+      OFA_KSTEP(OA1, OB1, sA[0], sB[0], (kt + 2 < nk));
+    }
+    if (kt < nk) OFA_KSTEP(OA0, OB0, sA[1], sB[1], false);
+#undef OFA_KSTEP
 #undef OFA_ISSUE
 #undef OFA_WAIT
 #undef OFA_MMA
-      __syncthreads();               // drains this wave's DMA (vmcnt) and fences the buffer swap
-    }
   } else {
   uint4 ra[NVA], rb[NVB];
   if (nk > 0) {
@@ -469,6 +520,10 @@ int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, h
   if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }
   else if (t12 * maxs >= want && g.N >= 128) { wm = 1; wn = 2; tiles = t12; }
   else { wm = 1; wn = 1; tiles = t11; }
+  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11
+  if (force_tile == 22) { wm = 2; wn = 2; tiles = t22; }
+  else if (force_tile == 12) { wm = 1; wn = 2; tiles = t12; }
+  else if (force_tile == 11) { wm = 1; wn = 1; tiles = t11; }
   int splits = 1;
   if (tiles < want && maxs > 1) {
     splits = (int)((want + tiles - 1) / tiles);

@@ -189,7 +189,7 @@ __device__ __forceinline__ void frag_issue(u64x2& d, const FragAddr<R, KMAJ>& fa
 // DMA source pointers of one operand tile, advanced by a constant stride per K-step.
 template <int R, bool KMAJ, int NT, int NV>
 __device__ __forceinline__ void glds_ptrs(const bf16_t* (&ptr)[NV], const bf16_t* __restrict__ base, int64_t ld, int r0,
-                                          int rmax, int k0, int tid) {
+                                          int rmax, int k0, int tid, int krows = 0x7fffffff) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int gidx = tid + i * NT;
@@ -204,7 +204,9 @@ __device__ __forceinline__ void glds_ptrs(const bf16_t* (&ptr)[NV], const bf16_t
       int col = r0 + c * 8;
       const int last = ((rmax + 7) & ~7) - 8;
       col = col < last ? col : last;
-      ptr[i] = base + (int64_t)(k0 + k) * ld + col;
+      int kr = k0 + k;
+      kr = kr < krows ? kr : krows - 1;       // rows past the operand's end (zero-padded contraction tail) are clamped
+      ptr[i] = base + (int64_t)kr * ld + col;
     }
   }
 }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     const bf16_t* pa[NVA];
     const bf16_t* pb[NVB];
     glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
-    glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid);
+    glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
     const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
     if (nk > 0) {
       glds_issue<NT, NVA>(pa, stepA, sA[0], wave_u);
@@ -343,8 +345,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 #define OFA_KSTEP(OA, OB, NEXT_A, NEXT_B, MORE)                                                        \
     {                                                                                                  \
       if (MORE) {                      /* DMA of the next tile runs under this tile's MFMAs */          \
+        if (!B_KMAJ && knext + BK > g.b_krows)   /* zero-padded contraction tail: clamp B's k rows */    \
+          glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);                \
         glds_issue<NT, NVA>(pa, stepA, NEXT_A, wave_u);                                                \
         glds_issue<NT, NVB>(pb, stepB, NEXT_B, wave_u);                                                \
+        knext += BK;                                                                                   \
       }                                                                                                \
       u64x2 x0[2], w0[2], x1[2], w1[2];                                                                \
       OFA_ISSUE(0, x0, w0, OA, OB);                                                                    \
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       __syncthreads();                 /* drains this wave's DMA (vmcnt) and fences the buffer swap */ \
     }
     int kt = 0;
+    int knext = kbeg + BK;
     for (; kt + 1 < nk; kt += 2) {
       OFA_KSTEP(OA0, OB0, sA[1], sB[1], true);
       OFA_KSTEP(OA1, OB1, sA[0], sB[0], (kt + 2 < nk));
@@ -506,7 +512,13 @@ static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int split
   else launch_cfg<1, 1, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
 }
 
-int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+  GemmArgs g = g_in;
+  g.b_krows = g.K;
+  // zero-padded contraction (vocabulary-logit gradients, lda padded to a multiple of 64): run the LDS-DMA loop over the
+  // padded K; A's tail columns are zeros, B's rows past K are clamped reads
+  if ((g.flags & OFA_GEMM_A_KPAD_ZERO) && !g.transA && !g.transB && (g.K % BK) != 0 && ((g.K + BK - 1) / BK) * BK <= g.lda)
+    g.K = ((g.K + BK - 1) / BK) * BK;
   // tile choice: the biggest tile that, together with split-K (when a workspace is given and K is long), still puts
   // >= ~1.5 workgroups on every CU; 128x128 tiles halve the LDS traffic per flop of 64-wide ones.
   const int64_t t22 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;

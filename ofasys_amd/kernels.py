@@ -22,6 +22,12 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
+def _u8(mask):
+    """bool/uint8 mask as a contiguous uint8 tensor without a copy when possible."""
+    mask = mask.contiguous()
+    return mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+
+
 def _rows_cols(x):
     cols = x.shape[-1]
     return x.numel() // cols, cols
@@ -190,7 +196,7 @@ def attn_softmax(x, bias, kpm, scale, heads, causal):
     if bias is not None:
         bias = bias.contiguous()
     if kpm is not None:
-        kpm = kpm.to(torch.uint8).contiguous()
+        kpm = _u8(kpm)
     p = torch.empty_like(x)
     lib().call("ofa_attn_softmax_fwd", ptr(x), ptr(bias), ptr(kpm), ptr(p), float(scale), BA, heads, T, S, int(causal),
                dtype_code(x), stream())
@@ -232,13 +238,16 @@ def attn_fwd(q, k, vt, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fa
     if bias is not None:
         bias = bias.contiguous()
     if kpm is not None:
-        kpm = kpm.to(torch.uint8).contiguous()
+        kpm = _u8(kpm)
     lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(vt), ptr(bias), ptr(kpm), ptr(c_attn), ptr(out), ptr(lse), B, heads, T,
                S, Tpad, Spad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
     return out, lse
 
 
-def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False):
+def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False,
+             outs=None):
+    """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
+    packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
     q, ldq = _rows3(q)
     k, ldk = _rows3(k)
     v, ldv = _rows3(v)
@@ -259,21 +268,25 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     qt = transpose_heads(q, Tpad)
     kt = transpose_heads(k, Spad)
     dot = transpose_heads(dout, Tpad)
-    dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
-    dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-    dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
     dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if need_dbias else None
     if bias is not None:
         bias = bias.contiguous()
     if kpm is not None:
-        kpm = kpm.to(torch.uint8).contiguous()
-    # dq is written with ld = ldq, dk/dv with ld = ldk: give the kernel dense outputs by passing dense strides
-    if ldq != D:
-        q = q.contiguous()
-        ldq = D
-    if ldk != D:
-        k, v = k.contiguous(), v.contiguous()
-        ldk = D
+        kpm = _u8(kpm)
+    if outs is not None:
+        dq, dk, dv = outs
+        assert dq.stride(1) == ldq and dk.stride(1) == ldk and dv.stride(1) == ldk
+    else:
+        # dq is written with ld = ldq, dk/dv with ld = ldk: give the kernel dense outputs by passing dense strides
+        if ldq != D:
+            q = q.contiguous()
+            ldq = D
+        if ldk != D:
+            k, v = k.contiguous(), v.contiguous()
+            ldk = D
+        dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+        dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+        dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
     lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(qt), ptr(kt), ptr(dot), ptr(dout), ptr(bias), ptr(kpm),
                ptr(c_attn), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, Spad, ldq,
                ldk, ldo, float(scale), int(causal), dtype_code(q), stream())
@@ -318,7 +331,7 @@ def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
     if b is not None:
         b = b.contiguous()
     if rowmask is not None:
-        rowmask = rowmask.to(torch.uint8).contiguous()
+        rowmask = _u8(rowmask)
     y = torch.empty_like(a)
     lib().call("ofa_add_rowvec_mask", ptr(a), ptr(b), ptr(vec), ptr(rowmask), ptr(y), rows, cols, dtype_code(a), stream())
     return y

@@ -47,6 +47,9 @@ class MultiheadAttention(nn.Module):
         self.bias_k = self.bias_v = None
         self.add_zero_attn = False
         self.use_fused = use_fused      # kept for config compatibility; the HIP path is always "fused"
+        # filled by ofasys_amd.trainer.FlatParams when k|v|q (or k|v) weights sit next to each other in the flat arena:
+        # zero-copy packed projection weights / gradient sinks for the single N = 3D (2D) GEMM
+        self._pack = {}
         self.reset_parameters()
 
     def reset_parameters(self):                                             # :93-111
@@ -80,10 +83,7 @@ class MultiheadAttention(nn.Module):
             xv = ops.batch_major(value)
         else:
             xv = xk
-        q = self.q_proj(xq)
-        k = self.k_proj(xk)
-        v = self.v_proj(xv)
-        src_len = k.shape[1]
+        src_len = xk.shape[1]
         scale = (1.0 / math.sqrt(self.head_dim)) if fast else self.scaling
         c_attn = None if fast else self.c_attn
 
@@ -95,13 +95,31 @@ class MultiheadAttention(nn.Module):
             if getattr(attn_mask, "_ofa_causal", False):
                 causal = True                                                # triu(-inf, 1) from buffered_future_mask
             else:                                                            # arbitrary additive mask: fold into the bias
-                m = attn_mask.to(q.dtype).unsqueeze(0).expand(bsz * self.num_heads, tgt_len, src_len).contiguous()
+                m = attn_mask.to(xq.dtype).unsqueeze(0).expand(bsz * self.num_heads, tgt_len, src_len).contiguous()
                 bias = m if bias is None else ops.add_rowvec_mask(bias.contiguous(), m)
         if key_padding_mask is not None and key_padding_mask.dim() == 0:
             key_padding_mask = None
         p_drop = self.dropout_module.p if (self.training or self.dropout_module.apply_during_inference) else 0.0
-        out, probs = ops.attention(q, k, v, self.num_heads, scale, bias=bias, key_padding_mask=key_padding_mask,
-                                   c_attn=c_attn, causal=causal, dropout_p=p_drop, need_weights=need_weights)
+        fused = (xq.dtype == torch.bfloat16 and self.head_dim == 64 and p_drop == 0.0 and not need_weights
+                 and self.q_proj.bias is not None)
+        if bias is not None and bias.dtype != xq.dtype:
+            bias = bias.to(xq.dtype)
+        probs = None
+        if fused and xk is xq and xv is xq:
+            # one packed k|v|q projection + fused attention (csrc/gemm_mfma.hip, csrc/attention.hip)
+            out = ops.PackedSelfAttentionFn.apply(
+                xq, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
+                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, causal, self._pack)
+        elif fused and xv is xk:
+            out = ops.PackedCrossAttentionFn.apply(
+                xq, xk, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
+                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, self._pack)
+        else:
+            q = self.q_proj(xq)
+            k = self.k_proj(xk)
+            v = self.v_proj(xv)
+            out, probs = ops.attention(q, k, v, self.num_heads, scale, bias=bias, key_padding_mask=key_padding_mask,
+                                       c_attn=c_attn, causal=causal, dropout_p=p_drop, need_weights=need_weights)
         out = self.out_proj(out).transpose(0, 1)                            # back to T x B x C (a view)
         attn_weights = None
         if need_weights:

@@ -111,9 +111,9 @@ class LinearFn(torch.autograd.Function):
         out = None
         ctx.padded = False
         if N % 8 != 0:
-            # ragged output width (vocabulary logits): pad the row stride to 16 bytes so the MFMA GEMMs, the criterion
-            # and the gradient GEMMs stay vectorised; callers see the exact [rows, N] view.
-            store = torch.empty(x2d.shape[0], (N + 7) // 8 * 8, dtype=x2d.dtype, device=x2d.device)
+            # ragged output width (vocabulary logits): pad the row stride to a multiple of 64 elements so the MFMA GEMMs
+            # (LDS-DMA K tiles), the criterion and the gradient GEMMs stay vectorised; callers see the exact [rows, N] view.
+            store = torch.empty(x2d.shape[0], (N + 63) // 64 * 64, dtype=x2d.dtype, device=x2d.device)
             out = store[:, :N]
             ctx.padded = True
         return K.gemm(x2d, weight, False, True, bias=bias, alpha=alpha, out=out)
@@ -125,7 +125,7 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         N = weight.shape[0]
         # the criterion / probs kernels hand back a zero-padded gradient row (stride a multiple of 8)
-        kpad = ctx.padded and dy.stride(0) >= (N + 7) // 8 * 8 and dy.stride(0) % 8 == 0
+        kpad = ctx.padded and dy.stride(0) >= (N + 7) // 8 * 8 and dy.stride(0) % 8 == 0   # zero tail up to the stride
         if ctx.needs_input_grad[0]:
             dx = K.gemm(dy, weight, False, False, alpha=ctx.alpha, a_kpad_zero=kpad)  # dX = dY W
         if ctx.needs_input_grad[1]:
@@ -277,6 +277,130 @@ class FusedAttentionFn(torch.autograd.Function):
             dsum = K.head_sum(delta, q.shape[0], ctx.heads, q.shape[1])
             dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
         return dq, dk, dv, dbias, None, dc, None, None, None
+
+
+def _packed(ws, arena_view):
+    """Packed projection weight [sum(N_i), K] (or bias [sum N_i]): the arena view when the parameters are adjacent in
+    the flat arena (zero copy), else a concatenated copy."""
+    return arena_view if arena_view is not None else torch.cat([w.reshape(w.shape[0], -1) if w.dim() > 1 else w for w in ws])
+
+
+def _packed_grads(ws, gview, grad_packed_fn):
+    """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (and notify the sinks);
+    otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
+    if gview is not None:
+        grad_packed_fn(gview, True)
+        for w in ws:
+            _sink_done(w)
+        return [None] * len(ws)
+    g = grad_packed_fn(None, False)
+    outs, o = [], 0
+    for w in ws:
+        n = w.shape[0]
+        outs.append(g[o:o + n].view(w.shape))
+        o += n
+    return outs
+
+
+class PackedSelfAttentionFn(torch.autograd.Function):
+    """Self-attention core with ONE packed k|v|q projection (N = 3D) in front of the fused attention kernels
+    (multihead_attention.py:199-346 up to, not including, out_proj).  The attention backward writes dk|dv|dq as column
+    slices of one [B,T,3D] buffer, which then feeds one dgrad GEMM (K = 3D), one wgrad GEMM and one bias reduce."""
+
+    @staticmethod
+    def forward(ctx, x, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, causal, pack):
+        B, T, D = x.shape
+        W = _packed((wk, wv, wq), pack.get("w"))
+        Bv = _packed((bk, bv, bq), pack.get("b"))
+        x2d = x.view(B * T, D)
+        kvq = K.gemm(x2d, W, False, True, bias=Bv).view(B, T, 3 * D)
+        k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
+        vt = K.transpose_heads(v, K.pad32(T))
+        c32 = c_attn.float() if c_attn is not None else None
+        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W)
+        ctx.params = (wk, wv, wq, bk, bv, bq)
+        ctx.cfg = (heads, scale, causal, pack)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, kvq, out, lse, bias, kpm, c_attn, W = ctx.saved_tensors
+        heads, scale, causal, pack = ctx.cfg
+        wk, wv, wq, bk, bv, bq = ctx.params
+        B, T, D3 = kvq.shape
+        D = D3 // 3
+        k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
+        dkvq = torch.empty_like(kvq)
+        c32 = c_attn.float() if c_attn is not None else None
+        need_dbias = bias is not None and ctx.needs_input_grad[7]
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c32,
+                                           causal=causal, need_dbias=need_dbias,
+                                           outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
+        d2 = dkvq.view(B * T, D3)
+        dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
+        gws = _packed_grads((wk, wv, wq), pack.get("gw"),
+                            lambda o, acc: K.gemm(d2, x2d, True, False, out=o, accumulate=acc))
+        gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
+                            lambda o, acc: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype))
+        dc = None
+        if c_attn is not None and ctx.needs_input_grad[9]:
+            dsum = K.head_sum(delta, B, heads, T)
+            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+        return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None)
+
+
+class PackedCrossAttentionFn(torch.autograd.Function):
+    """Encoder-decoder attention core: q projection from the decoder stream, ONE packed k|v projection (N = 2D) from the
+    encoder output (multihead_attention.py:203-211)."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, pack):
+        B, T, D = xq.shape
+        S = xkv.shape[1]
+        W = _packed((wk, wv), pack.get("w"))
+        Bv = _packed((bk, bv), pack.get("b"))
+        xq2, xkv2 = xq.view(B * T, D), xkv.view(B * S, D)
+        q = K.gemm(xq2, wq, False, True, bias=bq).view(B, T, D)
+        kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
+        k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
+        vt = K.transpose_heads(v, K.pad32(S))
+        c32 = c_attn.float() if c_attn is not None else None
+        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=False)
+        ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
+        ctx.params = (wk, wv, wq, bk, bv, bq)
+        ctx.cfg = (heads, scale, pack)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W = ctx.saved_tensors
+        heads, scale, pack = ctx.cfg
+        wk, wv, wq, bk, bv, bq = ctx.params
+        B, T, D = q.shape
+        S = kv.shape[1]
+        k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        c32 = c_attn.float() if c_attn is not None else None
+        need_dbias = bias is not None and ctx.needs_input_grad[8]
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c32,
+                                           causal=False, need_dbias=need_dbias,
+                                           outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
+        dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
+        dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
+        dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
+        gq = _packed_grads((wq,), _sink(wq), lambda o, acc: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc))
+        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype))
+        gws = _packed_grads((wk, wv), pack.get("gw"),
+                            lambda o, acc: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc))
+        gbs = _packed_grads((bk, bv), pack.get("gb"),
+                            lambda o, acc: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype))
+        dc = None
+        if c_attn is not None and ctx.needs_input_grad[10]:
+            dsum = K.head_sum(delta, B, heads, T)
+            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+        return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None)
 
 
 class UnfusedAttentionFn(torch.autograd.Function):

@@ -25,11 +25,32 @@ class FlatParams:
     """All trainable parameters as views of one flat buffer (model dtype), with a matching flat gradient arena."""
 
     def __init__(self, model: torch.nn.Module):
+        from .module.multihead_attention import MultiheadAttention
+        # arena order = registration order, except that each attention's k|v|q (self) or k|v (cross) projection weights
+        # and biases are made adjacent so ONE packed GEMM can use them (and their gradients) without any copy
+        mha_of, mhas = {}, []
+        for m in model.modules():
+            if isinstance(m, MultiheadAttention) and m.q_proj.bias is not None:
+                mhas.append(m)
+                for p in (m.k_proj.weight, m.v_proj.weight, m.q_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.bias):
+                    mha_of[id(p)] = m
         seen, params = set(), []
         for p in model.parameters():
-            if p.requires_grad and id(p) not in seen:
-                seen.add(id(p))
-                params.append(p)
+            if not p.requires_grad or id(p) in seen:
+                continue
+            m = mha_of.get(id(p))
+            group = [p]
+            if m is not None:
+                if m.self_attention:
+                    group = [m.k_proj.weight, m.v_proj.weight, m.q_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.bias]
+                else:
+                    group = [m.k_proj.weight, m.v_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.weight, m.q_proj.bias]
+                if not all(g.requires_grad for g in group):
+                    group = [p]
+            for g in group:
+                if id(g) not in seen:
+                    seen.add(id(g))
+                    params.append(g)
         assert params, "no trainable parameters"
         self.params = params
         dtype, device = params[0].dtype, params[0].device
@@ -47,6 +68,21 @@ class FlatParams:
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._ofa_grad = p.grad          # backward kernels accumulate straight into the arena (ops._sink)
+        off_of = {id(p): o for p, o in zip(params, self.offsets)}
+        for m in mhas:
+            n = 3 if m.self_attention else 2
+            kw, kb = m.k_proj.weight, m.k_proj.bias
+            if id(kw) not in off_of or kw.shape[0] != kw.shape[1] and not m.self_attention and m.kdim != m.embed_dim:
+                continue
+            D, Kin = kw.shape
+            ow, ob = off_of[id(kw)], off_of[id(kb)]
+            ws = [m.k_proj.weight, m.v_proj.weight, m.q_proj.weight][:n]
+            bs = [m.k_proj.bias, m.v_proj.bias, m.q_proj.bias][:n]
+            ok = all(off_of.get(id(w)) == ow + i * D * Kin for i, w in enumerate(ws)) and \
+                all(off_of.get(id(b)) == ob + i * D for i, b in enumerate(bs)) and (D * Kin) % 8 == 0 and D % 8 == 0
+            if ok:
+                m._pack = {"w": self.flat[ow:ow + n * D * Kin].view(n * D, Kin), "b": self.flat[ob:ob + n * D],
+                           "gw": self.grad[ow:ow + n * D * Kin].view(n * D, Kin), "gb": self.grad[ob:ob + n * D]}
 
     def zero_grad(self):
         self.grad.zero_()

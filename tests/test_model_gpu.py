@@ -112,3 +112,38 @@ def test_get_normalized_probs_and_train_mode():
     ops.manual_seed(7)
     l1b = ops.cross_entropy_sum(model(slots)[0], target.to(DEV), d.pad())
     assert float(l1b) == float(l1)
+
+
+@pytest.mark.parametrize("name", ["tiny_text", "base_patch"])
+def test_arena_sinks_match_autograd(name):
+    """Train-step mode (flat gradient arena, packed k|v|q weights, backward kernels accumulating straight into the
+    arena) must produce the same gradients as plain autograd accumulation, and two micro-batches must add up."""
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import FlatParams
+    case = CASES[name]
+    vals, target = case_inputs(case)
+    ref_model, d = build_model(case, DEV, torch.bfloat16)
+    ref_model.eval()
+    slots = make_slots(vals, DEV, torch.bfloat16)
+    ops.cross_entropy_sum(ref_model(slots)[0], target.to(DEV), d.pad()).backward()
+    want = {k: p.grad.float().clone() for k, p in ref_model.named_parameters() if p.grad is not None}
+    model, _ = build_model(case, DEV, torch.bfloat16)
+    model.eval()
+    fp = FlatParams(model)
+    packed = [m for m in model.modules() if getattr(m, "_pack", None)]
+    assert len(packed) >= case_layers(case)            # every attention got zero-copy packed weights
+    for rep in range(2):
+        ops.cross_entropy_sum(model(slots)[0], target.to(DEV), d.pad()).backward()
+    scale = max(float(v.abs().max()) for v in want.values())
+    for k, p in model.named_parameters():
+        if k not in want:
+            continue
+        got = p.grad.float() / 2                       # two identical micro-batches accumulated
+        err = float((got - want[k]).abs().max())
+        assert err <= 3e-2 * float(want[k].abs().max()) + 2e-3 * scale, (k, err)
+    fp.zero_grad()
+    assert float(fp.grad.float().abs().sum()) == 0.0
+
+
+def case_layers(case):
+    return {"tiny": 4 + 8, "base": 6 + 12}[case["arch"]]

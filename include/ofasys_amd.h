@@ -100,25 +100,24 @@ int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, vo
                          int T, int S, int causal, int dtype, void* stream);
 
 /* ---- fused attention (bf16, head_dim 64): multihead_attention.py:218-346 without materialising [BA,T,S].
- * q,k: [B, T|S, heads*64] rows (ld = ldq/ldk elements); vt: V transposed [B, heads*64, Spad] (key-contiguous);
+ * q: [B, T, heads*64] rows (ld = ldq elements); k, v: [B, S, heads*64] rows (both with ld = ldk);
  * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional fp32
- * [heads] per-head output scale (:342-345). out: [B, T, heads*64]; lse: fp32 [B*heads, Tpad].  scale multiplies q.k
- * (the reference pre-scales q, :218).  Tpad/Spad: multiples of 32 covering T/S; vt must be zero for keys >= S.
+ * [heads] per-head output scale (:342-345). out: [B, T, heads*64] (ld = ldo); lse: fp32 [B*heads, Tpad].  scale
+ * multiplies q.k (the reference pre-scales q, :218).  Tpad: a multiple of 32 covering T.
  * Attention dropout is not supported here (the reference default is attention_dropout = 0.0). */
-int ofa_attn_fwd(const void* q, const void* k, const void* vt, const void* bias, const uint8_t* kpm,
-                 const float* c_attn, void* out, float* lse, int B, int heads, int T, int S, int Tpad, int Spad,
+int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
+                 const float* c_attn, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
                  int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream);
 /* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
- * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep.  qt/kt/dot: transposed copies
- * [B, heads*64, Tpad|Spad] of q, k and dO (ofa_transpose_heads); v: [B,S,heads*64] rows with the same ld as k.
- * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS. */
+ * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep; dout: [B,T,heads*64] rows (ld = ldo).
+ * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS.
+ * No transposed operand copies are needed: the kernels transpose tiles on the LDS read (ds_read_b64_tr_b16). */
 int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
                       int dtype, void* stream);
-int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* dot,
-                 const void* dout, const void* bias, const uint8_t* kpm, const float* c_attn, const float* lse,
-                 const float* delta, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S,
-                 int Tpad, int Spad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype,
-                 void* stream);
+int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
+                 const float* c_attn, const float* lse, const float* delta, void* dq, void* dk, void* dv, void* dbias,
+                 int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                 int causal, int dtype, void* stream);
 /* out[b][i] = mean over heads of p[b][a][i], i < n  (head-averaged attention weights, multihead_attention.py:347-351). */
 int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream);
 /* x: [B, T, C] rows (ld elements) -> xt: [B, C, Tpad] (zero-filled for t >= T). */

@@ -1,0 +1,108 @@
+// Small attention-side kernels: rowsum(dO*O) for the fused backward, head-mean of attention weights, [B,T,C]->[B,C,Tpad].
+#include "common.h"
+
+namespace ofa {
+constexpr int HD = 64;
+
+// ------------------------------------------------------------------------------------------------ backward: delta
+// delta[bh, q] = sum_d dout[q,h,d] * out[q,h,d]   (row-sum of dO*O; invariant under the c_attn output scale)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                         float* __restrict__ delta, int B, int heads, int T, int Tpad,
+                                                         int64_t ldo) {
+  // 8 lanes per (row, head): each lane 8 elements
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t item = gid >> 3;
+  const int sub = (int)(gid & 7);
+  const int64_t total = (int64_t)B * T * heads;
+  float s = 0.f;
+  int64_t row = 0;
+  int h = 0;
+  if (item < total) {
+    row = item / heads;
+    h = (int)(item % heads);
+    float x[8], y[8];
+    load_vec<bf16_t>(dout + row * ldo + h * HD + sub * 8, x);
+    load_vec<bf16_t>(out + row * ldo + h * HD + sub * 8, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j] * y[j];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (item < total && sub == 0) {
+    const int64_t b = row / T, t = row % T;
+    delta[(b * heads + h) * Tpad + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ [B,T,C] -> [B,C,Tpad]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_heads_kernel(const T* __restrict__ x, T* __restrict__ xt, int Tn, int C,
+                                                             int Tpad, int64_t ld) {
+  __shared__ T tile[64][66];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int t = t0 + r, c = c0 + tx;
+    T v = 0;
+    if (t < Tn && c < C) v = x[((int64_t)b * Tn + t) * ld + c];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, t = t0 + tx;
+    if (c < C && t < Tpad) xt[((int64_t)b * C + c) * Tpad + t] = tile[tx][r];
+  }
+}
+
+}  // namespace ofa
+using namespace ofa;
+
+extern "C" int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad,
+                                 int64_t ldo, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_BF16, OFA_ERR_UNSUPPORTED, "attn_bwd_prep: bf16 only");
+  OFA_REQUIRE(dout && out && delta && (ldo % 8) == 0 && Tpad >= T, OFA_ERR_INVALID, "attn_bwd_prep: bad argument");
+  const int64_t threads = (int64_t)B * T * heads * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)out, delta, B, heads, T, Tpad, ldo);
+  return check_launch("attn_bwd_prep");
+}
+
+// out[b][i] = mean_a p[b][a][i]  (head-averaged attention weights, multihead_attention.py:347-351)
+namespace ofa {
+template <typename T>
+__global__ __launch_bounds__(256) void mean_heads_kernel(const T* __restrict__ p, T* __restrict__ out, int heads, int64_t n) {
+  const int b = blockIdx.y;
+  const float inv = 1.0f / (float)heads;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int a = 0; a < heads; ++a) s += ld1<T>(p + ((int64_t)b * heads + a) * n + i);
+    st1<T>(out + (int64_t)b * n + i, s * inv);
+  }
+}
+}  // namespace ofa
+
+extern "C" int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream) {
+  OFA_REQUIRE(p && out && B > 0 && heads > 0 && n > 0, OFA_ERR_INVALID, "mean_heads: bad argument");
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "mean_heads: bad dtype %d", dtype);
+  int64_t gx = (n + 255) / 256;
+  dim3 grid((unsigned)(gx > 1024 ? 1024 : gx), B), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((mean_heads_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)p, (float*)out, heads, n);
+  else
+    hipLaunchKernelGGL((mean_heads_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (bf16_t*)out, heads, n);
+  return check_launch("mean_heads");
+}
+
+extern "C" int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, int64_t ld, int dtype,
+                                   void* stream) {
+  OFA_REQUIRE(x && xt && B > 0 && T > 0 && C > 0 && Tpad >= T && ld >= C, OFA_ERR_INVALID, "transpose_heads: bad argument");
+  dim3 grid(cdiv(Tpad, 64), cdiv(C, 64), B), block(256);
+  if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((transpose_heads_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)xt,
+                       T, C, Tpad, ld);
+  else
+    hipLaunchKernelGGL((transpose_heads_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)xt, T,
+                       C, Tpad, ld);
+  return check_launch("transpose_heads");
+}

@@ -225,13 +225,21 @@ def _rows3(x):
     return x, x.stride(1)
 
 
-def attn_fwd(q, k, vt, heads, scale, bias=None, kpm=None, c_attn=None, causal=False):
-    """q [B,T,D], k [B,S,D], vt [B,D,Spad] -> out [B,T,D], lse [B*heads, Tpad]."""
-    q, ldq = _rows3(q)
+def _same_ld(k, v):
     k, ldk = _rows3(k)
+    v, ldv = _rows3(v)
+    if ldv != ldk:
+        k, v = k.contiguous(), v.contiguous()
+        ldk = k.stride(1)
+    return k, v, ldk
+
+
+def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False):
+    """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad]."""
+    q, ldq = _rows3(q)
+    k, v, ldk = _same_ld(k, v)
     B, T, D = q.shape
     S = k.shape[1]
-    Spad = vt.shape[2]
     Tpad = pad32(T)
     out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
@@ -239,8 +247,8 @@ def attn_fwd(q, k, vt, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fa
         bias = bias.contiguous()
     if kpm is not None:
         kpm = _u8(kpm)
-    lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(vt), ptr(bias), ptr(kpm), ptr(c_attn), ptr(out), ptr(lse), B, heads, T,
-               S, Tpad, Spad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
+    lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(kpm), ptr(c_attn), ptr(out), ptr(lse), B, heads, T,
+               S, Tpad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
     return out, lse
 
 
@@ -249,12 +257,7 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
     packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
     q, ldq = _rows3(q)
-    k, ldk = _rows3(k)
-    v, ldv = _rows3(v)
-    if ldv != ldk:
-        v = v.contiguous()
-        k = k.contiguous()
-        ldk = ldv = k.stride(1)
+    k, v, ldk = _same_ld(k, v)
     dout, ldo = _rows3(dout)
     out, ldo2 = _rows3(out)
     if ldo != ldo2:
@@ -262,12 +265,9 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         ldo = dout.stride(1)
     B, T, D = q.shape
     S = k.shape[1]
-    Tpad, Spad = pad32(T), pad32(S)
+    Tpad = pad32(T)
     delta = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
     lib().call("ofa_attn_bwd_prep", ptr(dout), ptr(out), ptr(delta), B, heads, T, Tpad, ldo, dtype_code(q), stream())
-    qt = transpose_heads(q, Tpad)
-    kt = transpose_heads(k, Spad)
-    dot = transpose_heads(dout, Tpad)
     dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if need_dbias else None
     if bias is not None:
         bias = bias.contiguous()
@@ -287,9 +287,9 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
         dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
         dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(qt), ptr(kt), ptr(dot), ptr(dout), ptr(bias), ptr(kpm),
-               ptr(c_attn), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, Spad, ldq,
-               ldk, ldo, float(scale), int(causal), dtype_code(q), stream())
+    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), ptr(lse), ptr(delta),
+               ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal),
+               dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
 
 

@@ -257,9 +257,8 @@ class FusedAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal):
-        vt = K.transpose_heads(v, K.pad32(k.shape[1]))
         c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn)
         ctx.heads, ctx.scale, ctx.causal = heads, scale, causal
         return out
@@ -315,9 +314,8 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         x2d = x.view(B * T, D)
         kvq = K.gemm(x2d, W, False, True, bias=Bv).view(B, T, 3 * D)
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
-        vt = K.transpose_heads(v, K.pad32(T))
         c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
         ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W)
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, causal, pack)
@@ -364,9 +362,8 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         q = K.gemm(xq2, wq, False, True, bias=bq).view(B, T, D)
         kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
-        vt = K.transpose_heads(v, K.pad32(S))
         c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, vt, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=False)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=False)
         ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, pack)

@@ -95,7 +95,7 @@ def _dp_worker(rank, world, port, q):
             assert any(red._launched)             # buckets fired from inside backward (overlap armed)
         red.finish()
     n = all_reduce_scalars(torch.tensor([6.0 * 2], dtype=torch.float64))
-    q.put((rank, fp.grad.clone(), float(n)))
+    q.put((rank, fp.grad.clone().numpy(), float(n)))       # by value: a shared-memory tensor can outlive its worker
     dist.destroy_process_group()
 
 
@@ -108,6 +108,7 @@ def test_dp_bucket_reducer_gloo_world2():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(g), n) for r, g, n in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -53,7 +53,8 @@ const char* ofa_last_error(void);
 int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int cols, float eps, int dtype, void* stream);
 /* dgamma/dbeta are [cols] in `dtype` (accumulate != 0: added to their current contents, i.e. straight into a gradient
- * arena); `ws` is fp32 scratch of 2*ofa_layernorm_bwd_ws_rows()*cols floats. */
+ * arena); `ws` is fp32 scratch of ofa_layernorm_bwd_ws_rows()*cols floats.  cols <= 2048 (fp32) / 4096 (bf16) per
+ * row-part: rows up to 4x that are split over four waves. */
 int ofa_layernorm_bwd_ws_rows(void);
 int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                       void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, int dtype,
@@ -61,9 +62,11 @@ int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const fl
 /* y = LayerNorm(gelu(h)) -- transformer_layer.py:194-197 (fc1 -> GELU (module/gelu.py:18-19, fp32 erf) -> ffn_layernorm). */
 int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                            int64_t rows, int cols, float eps, int dtype, void* stream);
+/* dbias (optional, [cols]): column sums of dh = gradient of the bias of the Linear that produced h (fc1), same
+ * accumulate rule as dgamma/dbeta. */
 int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean, const float* rstd,
-                           void* dh, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate,
-                           int dtype, void* stream);
+                           void* dh, void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows, int cols,
+                           int accumulate, int dtype, void* stream);
 
 /* ---- GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+bias) (+C).  Replaces F.linear / torch.bmm / matmul:
  * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.

@@ -69,39 +69,49 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
-// Backward.  A 256-thread block walks rows with a grid stride.  A row is split over WPR (1, 2 or 4) of the block's
-// waves -- wide rows (the 4D FFN LayerNorm) spread over four waves so that each lane keeps <= 2 vectors of x, dy, gamma
-// AND its running dgamma/dbeta in registers (no LDS accumulators, no spills, full occupancy); the two row statistics
-// cross the waves through a 2 x 4-float LDS exchange.  With GELU the activation and its derivative share one erf
-// (gelu = x*Phi, gelu' = Phi + x*phi).  Partials go to ws[block_row_slot][cols]; a second kernel folds them
-// (deterministic: fixed row->slot assignment and summation order).
+// Backward.  One 1024-thread block (16 waves) per CU walks rows with a grid stride -- 4 waves per SIMD keep enough
+// loads in flight to cover HBM latency (the earlier 256-thread / 1024-slot version ran ONE wave per SIMD: 2.9 TB/s).
+// A row is split over WPR (1, 2 or 4) waves -- wide rows (the 4D FFN LayerNorm) spread over four waves so that each
+// lane keeps <= 2 vectors of x, dy, gamma AND its running dgamma/dbeta(/dbias) in registers; the two row statistics
+// cross the waves through a small LDS exchange.  With GELU the activation and its derivative share one erf
+// (gelu = x*Phi, gelu' = Phi + x*phi) and the column sums of dh (= the gradient of the bias of the Linear that
+// produced h, transformer_layer.py:194) come for free.  At the end the block folds its waves' partials through LDS
+// and writes ONE partial row per block to ws[q][block][cols]; a second small kernel folds the <= 256 block rows
+// (deterministic: fixed row->wave assignment and summation order).
+constexpr int LN_WPB = 16;          // waves per block
+constexpr int LN_BWD_BLOCKS = 256;  // one block per CU; also the workspace row count
+
 template <typename T, int NV, int WPR, bool GELU>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                     const T* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ ws, int64_t rows, int cols, int nslots) {
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, T* __restrict__ dx,
+                                                      float* __restrict__ ws, int64_t rows, int cols, int want_dbias) {
   constexpr int N = Vec<T>::N;
-  constexpr int RPB = 4 / WPR;                       // rows per block iteration
-  __shared__ float red[2][4];
+  constexpr int RPB = LN_WPB / WPR;                  // rows per block iteration
+  __shared__ float red[2][LN_WPB];
+  __shared__ float fold[LN_WPB][64 * N];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rib = wib / WPR, part = wib % WPR;       // row-in-block, column part
   const int cpp = cols / WPR;                        // columns per part (launcher guarantees divisibility by N)
   const int c0 = part * cpp;
-  const int slot = blockIdx.x * RPB + rib;
-  float g[NV][N], dg[NV][N], db[NV][N];
+  float g[NV][N], dg[NV][N], db[NV][N], dbi[GELU ? NV : 1][N];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * N;
 #pragma unroll
-    for (int j = 0; j < N; ++j) dg[i][j] = db[i][j] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      dg[i][j] = db[i][j] = 0.f;
+      if (GELU) dbi[i][j] = 0.f;
+      g[i][j] = 0.f;
+    }
     if (c < cpp) load_vec<T>(gamma + c0 + c, g[i]);
   }
   const int64_t stride = (int64_t)gridDim.x * RPB;
   const int64_t niter = (rows + stride - 1) / stride;
   for (int64_t it = 0; it < niter; ++it) {
-    const int64_t row = it * stride + slot;
+    const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
     const bool live = row < rows;
-    float xv[NV][N], gp[NV][N], d[NV][N];           // xv: LN input (gelu(h) or x); gp: gelu'(h)
+    float xv[NV][N], gp[GELU ? NV : 1][N], d[NV][N];  // xv: LN input (gelu(h) or x); gp: gelu'(h)
     float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
     if (live) {
       mu = mean[row];
@@ -162,7 +172,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             float t = rs * (d[i][j] - s1 - xv[i][j] * s2);
-            if (GELU) t *= gp[i][j];
+            if (GELU) {
+              t *= gp[i][j];
+              dbi[i][j] += t;
+            }
             o[j] = t;
           }
           store_vec<T>(dxr + c, o);
@@ -170,50 +183,57 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  float* wg = ws + (int64_t)slot * cols + c0;
-  float* wb = ws + (int64_t)nslots * cols + (int64_t)slot * cols + c0;
+  // fold the block's waves: quantity q of vector i goes through fold[wave][lane*N + j]; the rib == 0 wave of each
+  // column part sums its RPB peers in fixed order and writes the block's partial row
+  const int nq = (GELU && want_dbias) ? 3 : 2;
+  for (int q = 0; q < nq; ++q) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * N;
-    if (c < cpp) {
+    for (int i = 0; i < NV; ++i) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        wg[c + j] = dg[i][j];
-        wb[c + j] = db[i][j];
+      for (int j = 0; j < N; ++j)
+        fold[wib][lane * N + j] = q == 0 ? dg[i][j] : (q == 1 ? db[i][j] : dbi[GELU ? i : 0][j]);
+      __syncthreads();
+      const int c = (i * 64 + lane) * N;
+      if (rib == 0 && c < cpp) {
+        float* w = ws + ((int64_t)q * gridDim.x + blockIdx.x) * cols + c0 + c;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < RPB; ++r) a += fold[r * WPR + part][lane * N + j];
+          w[j] = a;
+        }
       }
+      __syncthreads();
     }
   }
 }
 
-// fold the per-wave partials; 64 columns x 16 row-lanes per block; writes the parameter dtype, optionally accumulating
-// into an existing gradient (gradient arena of the train step).
+// fold the per-block partial rows: 32 columns x 8 row-lanes per block, grid.y = quantity (dgamma, dbeta, dbias); writes
+// the parameter dtype, optionally accumulating into an existing gradient (gradient arena of the train step).
 template <typename T>
-__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, T* __restrict__ dgamma,
-                                                             T* __restrict__ dbeta, int cols, int nwaves, int accumulate) {
-  __shared__ float sg[16][64], sb[16][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  float a = 0.f, b = 0.f;
-  if (c < cols) {
-    for (int w = ry; w < nwaves; w += 16) {
-      a += ws[(int64_t)w * cols + c];
-      b += ws[(int64_t)nwaves * cols + (int64_t)w * cols + c];
-    }
-  }
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, T* __restrict__ o0,
+                                                            T* __restrict__ o1, T* __restrict__ o2, int cols, int nslots,
+                                                            int accumulate) {
+  __shared__ float sg[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const int q = blockIdx.y;
+  T* out = q == 0 ? o0 : (q == 1 ? o1 : o2);
+  const float* w = ws + (int64_t)q * nslots * cols;
+  float a = 0.f;
+  if (c < cols)
+    for (int s = ry; s < nslots; s += 8) a += w[(int64_t)s * cols + c];
   sg[ry][cx] = a;
-  sb[ry][cx] = b;
   __syncthreads();
   if (ry == 0 && c < cols) {
-    float ga = 0.f, be = 0.f;
+    float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ga += sg[r][cx]; be += sb[r][cx]; }
-    if (accumulate) { ga += ld1<T>(dgamma + c); be += ld1<T>(dbeta + c); }
-    st1<T>(dgamma + c, ga);
-    st1<T>(dbeta + c, be);
+    for (int r = 0; r < 8; ++r) t += sg[r][cx];
+    if (accumulate) t += ld1<T>(out + c);
+    st1<T>(out + c, t);
   }
 }
-
-constexpr int LN_BWD_WAVES = 1024;  // upper bound on partial rows (workspace sizing)
 
 template <typename T, bool GELU>
 static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y, float* mean, float* rstd, int64_t rows,
@@ -236,28 +256,27 @@ static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y,
 
 template <typename T, bool GELU>
 static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
-                           void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, hipStream_t st) {
+                           void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows, int cols, int accumulate,
+                           hipStream_t st) {
   constexpr int N = Vec<T>::N;
   // waves per row: keep <= 2 vectors per lane when the row can be split evenly
   int wpr = 1;
   while (wpr < 4 && cdiv(cols / wpr, 64 * N) > 2 && (cols % (wpr * 2 * N)) == 0) wpr *= 2;
   const int nv = cdiv(cols / wpr, 64 * N);
-  const int rpb = 4 / wpr;
-  int64_t nblk = (rows + rpb * 4 - 1) / (rpb * 4);      // >= 4 rows per slot
-  const int64_t maxblk = LN_BWD_WAVES / rpb;
-  nblk = nblk < 1 ? 1 : (nblk > maxblk ? maxblk : nblk);
-  const int nslots = (int)nblk * rpb;
-  dim3 grid((unsigned)nblk), block(256);
+  const int rpb = LN_WPB / wpr;
+  int64_t nblk = (rows + rpb - 1) / rpb;
+  nblk = nblk < 1 ? 1 : (nblk > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nblk);
+  const int want_dbias = dbias != nullptr;
+  dim3 grid((unsigned)nblk), block(64 * LN_WPB);
 #define LN_LAUNCH(NV, WPR)                                                                                           \
   hipLaunchKernelGGL((ln_bwd_kernel<T, NV, WPR, GELU>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)g,  \
-                     mean, rstd, (T*)dx, ws, rows, cols, nslots)
+                     mean, rstd, (T*)dx, ws, rows, cols, want_dbias)
 #define LN_CASE(WPR)                      \
   do {                                    \
     if (nv <= 1) LN_LAUNCH(1, WPR);       \
     else if (nv <= 2) LN_LAUNCH(2, WPR);  \
     else if (nv <= 4) LN_LAUNCH(4, WPR);  \
-    else if (nv <= 8) LN_LAUNCH(8, WPR);  \
-    else LN_LAUNCH(16, WPR);              \
+    else LN_LAUNCH(8, WPR);               \
   } while (0)
   if (wpr == 1) LN_CASE(1);
   else if (wpr == 2) LN_CASE(2);
@@ -266,8 +285,8 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
 #undef LN_LAUNCH
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (T*)dgamma,
-                     (T*)dbeta, cols, nslots, accumulate);
+  hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 32), want_dbias ? 3 : 2), dim3(256), 0, st,
+                     (const float*)ws, (T*)dgamma, (T*)dbeta, (T*)dbias, cols, (int)nblk, accumulate);
   return check_launch("layernorm_bwd_reduce");
 }
 
@@ -276,8 +295,13 @@ static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
   OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "layernorm: bad dtype %d", dtype);
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(cols % n == 0, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d must be a multiple of %d", cols, n);
-  const int maxc = 64 * n * (bwd ? 16 : 32);
-  OFA_REQUIRE(cols <= maxc, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d exceeds %d", cols, maxc);
+  if (bwd) {                                      // the same row split the dispatcher makes; <= 8 vectors per lane
+    int wpr = 1;
+    while (wpr < 4 && cdiv(cols / wpr, 64 * n) > 2 && (cols % (wpr * 2 * n)) == 0) wpr *= 2;
+    OFA_REQUIRE(cdiv(cols / wpr, 64 * n) <= 8, OFA_ERR_UNSUPPORTED, "layernorm_bwd: cols=%d too wide", cols);
+  } else {
+    OFA_REQUIRE(cols <= 64 * n * 32, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d exceeds %d", cols, 64 * n * 32);
+  }
   return 0;
 }
 
@@ -285,7 +309,7 @@ static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
 
 using namespace ofa;
 
-extern "C" int ofa_layernorm_bwd_ws_rows(void) { return LN_BWD_WAVES; }
+extern "C" int ofa_layernorm_bwd_ws_rows(void) { return 3 * LN_BWD_BLOCKS; }
 
 extern "C" int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                  int64_t rows, int cols, float eps, int dtype, void* stream) {
@@ -315,18 +339,18 @@ extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamm
               "layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, rows, cols, accumulate, st);
+             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st);
 }
 
 extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean,
-                                      const float* rstd, void* dh, void* dgamma, void* dbeta, float* ws, int64_t rows,
-                                      int cols, int accumulate, int dtype, void* stream) {
+                                      const float* rstd, void* dh, void* dgamma, void* dbeta, void* dbias, float* ws,
+                                      int64_t rows, int cols, int accumulate, int dtype, void* stream) {
   if (int rc = ln_check(rows, cols, dtype, true)) return rc;
   OFA_REQUIRE(dy && h && gamma && mean && rstd && dh && dgamma && dbeta && ws, OFA_ERR_INVALID,
               "gelu_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, ws, rows, cols, accumulate, st);
+             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st);
 }

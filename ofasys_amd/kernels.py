@@ -45,8 +45,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, fuse_gelu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None):
-    """dgamma/dbeta given: the parameter gradients are ACCUMULATED into them (gradient arena); else fresh tensors."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None, dbias=None, want_dbias=False):
+    """dgamma/dbeta given: the parameter gradients are ACCUMULATED into them (gradient arena); else fresh tensors.
+    fuse_gelu + (dbias or want_dbias): also the column sums of dx (gradient of the bias of the Linear feeding the GELU)."""
     dy = dy.contiguous()
     x = x.contiguous()
     rows, cols = _rows_cols(x)
@@ -55,12 +56,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=
     if not acc:
         dgamma = torch.empty(cols, dtype=gamma.dtype, device=x.device)
         dbeta = torch.empty(cols, dtype=gamma.dtype, device=x.device)
-    assert dgamma.dtype == x.dtype and dbeta.dtype == x.dtype
+        if want_dbias:
+            dbias = torch.empty(cols, dtype=gamma.dtype, device=x.device)
+    assert dgamma.dtype == x.dtype and dbeta.dtype == x.dtype and (dbias is None or dbias.dtype == x.dtype)
     wsr = lib().cdll.ofa_layernorm_bwd_ws_rows()
-    ws = workspace(2 * wsr * cols * 4, x.device, "ln")
-    lib().call("ofa_gelu_layernorm_bwd" if fuse_gelu else "ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean),
-               ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
-    return dx, dgamma, dbeta
+    ws = workspace(wsr * cols * 4, x.device, "ln")
+    if fuse_gelu:
+        lib().call("ofa_gelu_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
+                   ptr(dbeta), ptr(dbias), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
+        return dx, dgamma, dbeta, dbias
+    lib().call("ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+               ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
+    return dx, dgamma, dbeta, None
 
 
 # ------------------------------------------------------------------ GEMM

@@ -29,13 +29,14 @@ class _FFNMixin:
         residual = x
         if self.normalize_before:
             x = self.final_layer_norm(x)
-        h = self.fc1(x)
         act_p = self.activation_dropout_module.p if self.training else 0.0
-        if self.ffn_layernorm is not None and act_p == 0.0 and self._gelu:
-            x = ops.layer_norm(h, self.ffn_layernorm.weight, self.ffn_layernorm.bias, self.ffn_layernorm.eps, fuse_gelu=True)
+        if self.ffn_layernorm is not None and act_p == 0.0 and self._gelu and self.fc1.bias is not None:
+            x = ops.linear_gelu_layer_norm(x, self.fc1.weight, self.fc1.bias, self.ffn_layernorm.weight,
+                                           self.ffn_layernorm.bias, self.ffn_layernorm.eps)
         else:
             if not self._gelu:
                 raise NotImplementedError("only activation_fn='gelu' (OFASys default) is implemented")
+            h = self.fc1(x)
             x = ops.gelu(h)
             x = self.activation_dropout_module(x)
             if self.ffn_layernorm is not None:

@@ -85,11 +85,11 @@ class LayerNormFn(torch.autograd.Function):
         bias = ctx.bias_ref
         gw, gb = _sink(weight), _sink(bias)
         if gw is not None and gb is not None:
-            dx, _, _ = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu, dgamma=gw, dbeta=gb)
+            dx = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu, dgamma=gw, dbeta=gb)[0]
             _sink_done(weight)
             _sink_done(bias)
             return dx, None, None, None, None
-        dx, dg, db = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu)
+        dx, dg, db, _ = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu)
         return dx, dg, db, None, None
 
 
@@ -149,6 +149,47 @@ def linear(x, weight, bias=None, alpha=1.0):
     """alpha * F.linear(x, weight, bias)."""
     x2d, restore = rows_view(x)
     return restore(LinearFn.apply(x2d, weight, bias, alpha))
+
+
+class LinearGeluLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(gelu(x W^T + b)): fc1 -> GELU -> ffn_layernorm (transformer_layer.py:194-197).  Saves only the pre-GELU
+    h; the backward LN kernel also produces the fc1 bias gradient (column sums of dh) from registers."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, ln_w, ln_b, eps):
+        h = K.gemm(x2d, weight, False, True, bias=bias)
+        y, mean, rstd = K.layernorm_fwd(h, ln_w, ln_b, eps, True)
+        ctx.save_for_backward(x2d, weight, h, ln_w, mean, rstd)
+        ctx.refs = (bias, ln_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, weight, h, ln_w, mean, rstd = ctx.saved_tensors
+        bias, ln_b = ctx.refs
+        gg, gb, gbias = _sink(ln_w), _sink(ln_b), _sink(bias)
+        sunk = gg is not None and gb is not None and gbias is not None
+        if sunk:
+            dh = K.layernorm_bwd(dy, h, ln_w, mean, rstd, True, dgamma=gg, dbeta=gb, dbias=gbias)[0]
+            for p in (ln_w, ln_b, bias):
+                _sink_done(p)
+            dg = db = dbias = None
+        else:
+            dh, dg, db, dbias = K.layernorm_bwd(dy, h, ln_w, mean, rstd, True, want_dbias=True)
+        dx = K.gemm(dh, weight, False, False) if ctx.needs_input_grad[0] else None
+        gw = _sink(weight)
+        dw = None
+        if gw is not None:
+            K.gemm(dh, x2d, True, False, out=gw, accumulate=True)
+            _sink_done(weight)
+        else:
+            dw = K.gemm(dh, x2d, True, False)
+        return dx, dw, dbias, dg, db, None
+
+
+def linear_gelu_layer_norm(x, weight, bias, ln_w, ln_b, eps=1e-5):
+    x2d, restore = rows_view(x)
+    return restore(LinearGeluLayerNormFn.apply(x2d, weight, bias, ln_w, ln_b, eps))
 
 
 # ---------------------------------------------------------------------------------------------- GELU / dropout / adds

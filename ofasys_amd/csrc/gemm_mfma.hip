@@ -22,6 +22,8 @@
 // Roofline: MFMA-bound; algorithmic flops = 2*M*N*K.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace ofa {
@@ -112,14 +114,14 @@ __device__ __forceinline__ bf16x8 load_frag(const bf16_t* __restrict__ lds, int 
 // base + lane*16 B), so the tile is stored unpadded and the bank-conflict fix is an XOR swizzle of the 16-byte chunk
 // index applied to the per-lane SOURCE address and again when reading (cdna_hip_programming.md rule 21):
 //   k-major [R][64]:   chunk c (8 per row) of row r lives at c ^ ((r>>1)&7)   -> 16 rows x one k-slice = 16 distinct slots
-//   m-major [64][R]:   chunk c of k-row k lives at c ^ ((k&3)<<2) (R=128) / c ^ (((k>>1)&1)<<2) (R=64)
+//   m-major [64][R]:   chunk c of k-row k lives at c ^ ((k&3)<<2) (R=128, 256) / c ^ (((k>>1)&1)<<2) (R=64)
 //                      -> the 4 k-rows of a ds_read_b64_tr_b16 group fall in 4 different 64-byte bank quarters.
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <int R, bool KMAJ> __device__ __forceinline__ int swz(int row, int c) {
   if (KMAJ) return c ^ ((row >> 1) & 7);
-  return R == 128 ? (c ^ ((row & 3) << 2)) : (c ^ (((row >> 1) & 1) << 2));
+  return R >= 128 ? (c ^ ((row & 3) << 2)) : (c ^ (((row >> 1) & 1) << 2));
 }
 
 template <int R, bool KMAJ, int NT, int NV>
@@ -261,6 +263,109 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int 
     o.x = pack_bf16x2(v[0], v[1]);
     o.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = o;
+  }
+}
+
+// Coalesced epilogue.  The MFMA accumulator layout gives each lane 4 consecutive columns of ONE row per register quad,
+// so storing straight from registers makes every store instruction touch 64 different rows (64 x 8 B): the memory pipe
+// handles that at one row per clock, ~8 us for a 256x256 tile -- as long as the whole K loop at K = 768.  Instead each
+// wave bounces its block through its private slice of the (now idle) LDS stages: quads go in with an XOR swizzle on the
+// 16-byte chunk index, come back out as whole 16-byte row segments, and one store instruction writes 2-8 full rows.
+// Bias / alpha are applied on the way in, C-accumulation on the way out.  RAW: split-K partials (fp32, no bias/alpha).
+template <int TM, int TN, bool F32, bool RAW>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&acc)[TM][TN], unsigned char* __restrict__ wl,
+                                             int region_bytes, void* __restrict__ Cb, int64_t ldc, int m_w, int n_w,
+                                             int lane) {
+  constexpr int E = F32 ? 4 : 2;
+  constexpr int ROWB = TN * 32 * E;                    // bytes per staged row
+  constexpr int CH = ROWB / 16;                        // 16-byte chunks per row
+  constexpr int SH = ROWB < 256 ? 1 : 0;
+  constexpr int LPR = CH;                              // lanes per row when reading back
+  constexpr int RPI = 64 / LPR;                        // rows per store instruction
+  const int hi = lane >> 5, ml = lane & 31;
+  const int ipass = region_bytes / (32 * ROWB) < TM ? region_bytes / (32 * ROWB) : TM;   // 32-row tiles per pass
+  const bool vec16 = F32 || ((ldc & 7) == 0);
+  for (int ip0 = 0; ip0 < TM; ip0 += ipass) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i < ip0 || i >= ip0 + ipass) continue;
+      const int mloc = (i - ip0) * 32 + ml;
+      const int sw = (mloc >> SH) & (CH - 1);
+      float brow = 0.f;
+      if (!RAW && (g.flags & OFA_GEMM_BIAS_ROW)) {
+        const int m = m_w + i * 32 + ml;
+        brow = bf2f(((const bf16_t*)g.bias)[m < g.M ? m : g.M - 1]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nloc = j * 32 + 8 * q + 4 * hi;
+          float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if (!RAW) {
+            if (g.flags & OFA_GEMM_BIAS_COL) {
+              const int n = n_w + nloc;
+              if (n < g.N) {
+                const uint2 b = *reinterpret_cast<const uint2*>((const bf16_t*)g.bias + n);
+                v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
+                v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] + brow) * g.alpha;
+          }
+          if (F32) {
+            *reinterpret_cast<float4*>(wl + mloc * ROWB + (((nloc >> 2) ^ sw) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(wl + mloc * ROWB + (((nloc >> 3) ^ sw) << 4) + ((nloc >> 2) & 1) * 8) = o;
+          }
+        }
+      }
+    }
+    // read back whole 16-byte row segments (same wave: LDS operations complete in order) and store
+    const int c = lane % LPR;
+    const int n = n_w + c * (16 / E);
+    const int rows_here = (TM - ip0 < ipass ? TM - ip0 : ipass) * 32;
+    for (int r0 = 0; r0 < rows_here; r0 += RPI) {
+      const int mloc = r0 + lane / LPR;
+      const int m = m_w + ip0 * 32 + mloc;
+      const uint4 u = *reinterpret_cast<const uint4*>(wl + mloc * ROWB + ((c ^ ((mloc >> SH) & (CH - 1))) << 4));
+      if (m >= g.M || n >= g.N) continue;
+      if (F32) {
+        float* p = (float*)Cb + (int64_t)m * ldc + n;
+        float4 o = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        if (!RAW && (g.flags & OFA_GEMM_ACCUM)) {
+          const float4 old = *reinterpret_cast<const float4*>(p);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(p) = o;
+      } else {
+        bf16_t* p = (bf16_t*)Cb + (int64_t)m * ldc + n;
+        const bool second = n + 4 < g.N;                // the chunk's second quad (inside ldc by the launch precondition)
+        uint4 o = u;
+        if (g.flags & OFA_GEMM_ACCUM) {
+          uint4 old = make_uint4(0, 0, 0, 0);
+          if (vec16 && second) old = *reinterpret_cast<const uint4*>(p);
+          else {
+            const uint2 a = *reinterpret_cast<const uint2*>(p);
+            old.x = a.x; old.y = a.y;
+            if (second) { const uint2 b = *reinterpret_cast<const uint2*>(p + 4); old.z = b.x; old.w = b.y; }
+          }
+          o.x = pack_bf16x2(__uint_as_float(u.x << 16) + __uint_as_float(old.x << 16), __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(old.x & 0xffff0000u));
+          o.y = pack_bf16x2(__uint_as_float(u.y << 16) + __uint_as_float(old.y << 16), __uint_as_float(u.y & 0xffff0000u) + __uint_as_float(old.y & 0xffff0000u));
+          o.z = pack_bf16x2(__uint_as_float(u.z << 16) + __uint_as_float(old.z << 16), __uint_as_float(u.z & 0xffff0000u) + __uint_as_float(old.z & 0xffff0000u));
+          o.w = pack_bf16x2(__uint_as_float(u.w << 16) + __uint_as_float(old.w << 16), __uint_as_float(u.w & 0xffff0000u) + __uint_as_float(old.w & 0xffff0000u));
+        }
+        if (vec16 && second) *reinterpret_cast<uint4*>(p) = o;
+        else {
+          *reinterpret_cast<uint2*>(p) = make_uint2(o.x, o.y);
+          if (second) *reinterpret_cast<uint2*>(p + 4) = make_uint2(o.z, o.w);
+        }
+      }
+    }
   }
 }
 
@@ -416,30 +521,265 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   }
   }
 
-  // epilogue: lane owns output row m = .. + (lane&31); register r holds column (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int hi = lane >> 5;
-  const bool split = gridDim.y > 1;
-  const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
-  void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
+  // epilogue through the wave's slice of the (idle) LDS stages: see epilogue_lds
+  __syncthreads();                                     // every wave is done with the fragment reads / the last DMA
+  {
+    const bool split = gridDim.y > 1;
+    constexpr int REGION = ((GLDS ? 2 * (EA + EB) * 2 : 2 * (GA::ELEMS + GB::ELEMS) * 2) / (WM * WN)) & ~1023;
+    unsigned char* wl = smem_raw + wave * REGION;
+    const int m_w = m0 + wm * 64, n_w = n0 + wn * 64;
+    if (split) {
+      const int64_t n4 = (g.N + 3) & ~3;
+      float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
+      epilogue_lds<2, 2, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+    } else {
+      const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
+      void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
+      epilogue_lds<2, 2, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Big-tile kernel: 4 waves, each owning a (32*TM) x (32*TN) block of accumulators (TM x TN MFMA tiles; 4 x 4 = 256 fp32
+// registers per lane, the unified VGPR/AccVGPR file of CDNA3/4 holds 512).  Why: with 64x64 per wave every K-step moves
+// 16 KiB of fragments per wave out of LDS for 16 MFMAs -- 128 B/clk/CU, exactly the LDS peak, so the 128x128 kernel
+// saturates LDS at ~40% MFMA utilisation.  A 128x128 wave tile needs 8 fragment reads per 16 MFMAs (64 B/clk/CU).
+// One workgroup per CU (128 KiB of LDS: 2 stages x (A 32 KiB + B 32 KiB)), one wave per SIMD, so the overlap is built
+// into the wave's own instruction stream: fragments of k-slice kk+1 are read while slice kk multiplies, the barrier that
+// retires an LDS stage sits in front of the LAST slice's MFMAs, and the DMA of tile t+2 is issued right behind it.
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// per-lane LDS byte addresses (relative to LDS base, buffer 0 of the operand)
+template <int R, bool KMAJ> struct BigAddr {
+  uint32_t a[4];   // k-major: one per k-slice (tile index is an immediate); m-major: one per 32-row tile (k-slice immediate)
+  __device__ __forceinline__ void init(uint32_t op0, int rbase, int lane) {
+    if (KMAJ) {
+      const int row = rbase + (lane & 31), hi = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-    if (m >= g.M) continue;
+      for (int kk = 0; kk < 4; ++kk) a[kk] = op0 + (uint32_t)(row * 64 + swz<R, true>(row, kk * 2 + hi) * 8) * 2u;
+    } else {
+      const int g = lane >> 4, q = lane & 15;
+      const int k = (g >> 1) * 8 + (q >> 2);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
-        if (n >= g.N) continue;   // a ragged last quad stays inside ldc (launch precondition)
-        const float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2],
-                    v3 = acc[i][j][4 * q + 3];
-        if (split) {
-          float* p = ws + (((int64_t)bz * gridDim.y + ks) * g.M + m) * ((g.N + 3) & ~3) + n;
-          *reinterpret_cast<float4*>(p) = make_float4(v0, v1, v2, v3);
-        } else {
-          epilogue_store<OUT_F32>(g, Cb, m, n, v0, v1, v2, v3);
-        }
+      for (int ti = 0; ti < 4; ++ti) {
+        const int col = rbase + ti * 32 + (g & 1) * 16 + 4 * (q & 3);
+        a[ti] = op0 + (uint32_t)(k * R + swz<R, false>(k, col >> 3) * 8 + (col & 7)) * 2u;
       }
+    }
+  }
+};
+
+// issue the reads of fragment `TI` (32 rows) of k-slice KK from the buffer at byte offset BUFOFF
+template <int R, bool KMAJ, int KK, int TI, int BUFOFF>
+__device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
+#ifdef OFA_EXP_NOREAD
+  if (OFA_EXP_NOREAD == 2 || KMAJ == (OFA_EXP_NOREAD == 1)) {      // 2: no reads at all; 1: skip k-major operands; 0: skip m-major
+    asm volatile("; no read" : "=v"(d) : "v"(fa.a[0]));
+    return;
+  }
+#endif
+  if constexpr (KMAJ) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(fa.a[KK]), "i"(BUFOFF + TI * 32 * 128));
+  } else {
+    unsigned long long lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(fa.a[TI]), "i"(BUFOFF + KK * 16 * R * 2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(fa.a[TI]), "i"(BUFOFF + KK * 16 * R * 2 + 4 * R * 2));
+    d[0] = lo;
+    d[1] = hi;
+  }
+}
+
+// which fragment read (0..nr-1, or -1) follows MFMA number t of a slice
+#ifndef OFA_BIG_PAT
+#define OFA_BIG_PAT 1
+#endif
+__host__ __device__ constexpr int big_read_after(int t, int nr) {
+  return OFA_BIG_PAT == 1 ? (t < nr ? t : -1)                      // one read behind each of the first nr MFMAs
+                          : ((t % 2) == 0 && t / 2 < nr ? t / 2 : -1);   // one read per two MFMAs
+}
+
+template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
+                                                       float* __restrict__ ws) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
+  static_assert(A_KMAJ || BM == 256, "m-major tiles are 256 wide (swizzle)");
+  static_assert(B_KMAJ || BN == 256, "m-major tiles are 256 wide (swizzle)");
+  constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
+  constexpr int STAGE = 256 * BK;                           // elements per operand stage (32 KiB, also for BM = 192):
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // a power of two, so "other stage" is addr ^ 32768
+  bf16_t* sA0 = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* sA1 = sA0 + STAGE;
+  bf16_t* sB0 = sA1 + STAGE;
+  bf16_t* sB1 = sB0 + STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = tiles_m * tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  constexpr int GM = 8;
+  const int gsz = GM * tiles_n;
+  const int gid = t / gsz, first_m = gid * GM;
+  const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z, ks = blockIdx.y;
+  const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
+  const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
+  const int kbeg = ks * ksplit;
+  const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
+#ifdef OFA_EXP_NOLOOP
+  const int nk = g.alpha == 12345.f ? 1 : 0;
+#else
+  const int nk = (kend - kbeg) / BK;                        // launcher guarantees whole K tiles
+#endif
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bf16_t* pa[NVA];
+  const bf16_t* pb[NVB];
+  glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
+  const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
+  int knext = kbeg;
+  auto dma = [&](bf16_t* da, bf16_t* db) {
+    if (!B_KMAJ && knext + BK > g.b_krows)                  // zero-padded contraction tail: clamp B's k rows
+      glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
+    glds_issue<NT, NVA>(pa, stepA, da, wave_u);
+    glds_issue<NT, NVB>(pb, stepB, db, wave_u);
+    knext += BK;
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+  BigAddr<BM, A_KMAJ> fax;
+  BigAddr<BN, B_KMAJ> faw;
+  fax.init(lds0, wm * TM * 32, lane);
+  faw.init(lds0 + 2 * STAGE * 2, wn * TN * 32, lane);
+
+  u64x2 xa[2][TM], wb[2][TN];
+#define BIG_ISSUE(KK, SET)                                                                                        \
+  static_for<0, TM>([&](auto ic) { big_frag<BM, A_KMAJ, KK, decltype(ic)::value, 0>(xa[SET][decltype(ic)::value], fax); }); \
+  static_for<0, TN>([&](auto ic) { big_frag<BN, B_KMAJ, KK, decltype(ic)::value, 0>(wb[SET][decltype(ic)::value], faw); })
+#ifdef OFA_EXP_NOWAIT
+#define BIG_WAITCNT "; nowait"
+#else
+#define BIG_WAITCNT "s_waitcnt lgkmcnt(0)"
+#endif
+#define BIG_WAIT(SET)                                                                  \
+  if constexpr (TM == 4)                                                               \
+    asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]), "+v"(xa[SET][3]),   \
+                 "+v"(wb[SET][0]), "+v"(wb[SET][1]), "+v"(wb[SET][2]), "+v"(wb[SET][3]));                           \
+  else                                                                                 \
+    asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]),                     \
+                 "+v"(wb[SET][0]), "+v"(wb[SET][1]), "+v"(wb[SET][2]), "+v"(wb[SET][3]))
+  // One k-slice: TM*TN MFMAs on fragment set SET, with the NEXT slice's fragment reads (k-slice KKN into the other set)
+  // woven in between them.  Issuing the 8 reads in one burst in front of the MFMAs serialises the two: all four waves
+  // run in lockstep behind the stage barrier, their 32 reads queue up in the LDS pipe and the in-order wave cannot reach
+  // its MFMAs until its own reads are accepted (measured: 1272 TF with burst reads vs 1990 TF with no reads at all).
+  // sched_barrier pins the order; without it hipcc hoists the (dependence-free) MFMAs above the asm reads.
+#define BIG_SB __builtin_amdgcn_sched_barrier(0)
+#define BIG_SLICE(SET, KKN)                                                                                         \
+  static_for<0, TM * TN>([&](auto tc) {                                                                             \
+    constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;                                                  \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[SET][j]),                     \
+                                                        __builtin_bit_cast(bf16x8, xa[SET][i]), acc[i][j], 0, 0, 0); \
+    constexpr int r = big_read_after(t, TM + TN);                                                                   \
+    if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, KKN, (r < TM ? r : 0), 0>(xa[1 - (SET)][r < TM ? r : 0], fax); \
+    if constexpr (r >= TM) big_frag<BN, B_KMAJ, KKN, (r >= TM ? r - TM : 0), 0>(wb[1 - (SET)][r >= TM ? r - TM : 0], faw); \
+    BIG_SB;                                                                                                         \
+  })
+  if (nk > 0) {
+    dma(sA0, sB0);
+    __syncthreads();
+    if (nk > 1) dma(sA1, sB1);
+    BIG_ISSUE(0, 0);
+    bf16_t* curA = sA0;                // the stage being multiplied; its buffers are refilled with tile kt+2
+    bf16_t* curB = sB0;
+    // ONE copy of the K-step (the stage toggle is an XOR on the 8 fragment address registers, not an unrolled immediate):
+    // with 256 accumulator registers live, any second copy of the loop body makes hipcc spill at the joins
+    for (int kt = 0; kt < nk; ++kt) {
+      BIG_WAIT(0); BIG_SB; BIG_SLICE(0, 1);
+      BIG_WAIT(1); BIG_SB; BIG_SLICE(1, 2);
+      BIG_WAIT(0); BIG_SB; BIG_SLICE(0, 3);
+      BIG_WAIT(1);
+      if (kt + 1 < nk) __syncthreads();   // tile kt+1 has landed (vmcnt) and every wave is done reading this stage
+#ifndef OFA_EXP_NODMA
+      const bool more2 = kt + 2 < nk;     // refill the retired stage with tile kt+2 ...
+#else
+      const bool more2 = false;
+#endif
+      if (more2 && !B_KMAJ && knext + BK > g.b_krows)          // zero-padded contraction tail: clamp B's k rows
+        glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fax.a[i] ^= (uint32_t)(STAGE * 2);
+        faw.a[i] ^= (uint32_t)(STAGE * 2);
+      }
+      BIG_SB;
+      // ... one LDS-DMA piece per MFMA gap: a piece costs the wave ~60 issue cycles, and 16 of them in one burst in
+      // front of the MFMAs left the matrix pipe idle for ~1000 cycles per K-step (GRBM cycles 1.83M vs 1.31M without DMA).
+      // (after the last K-step the reads below fetch a stale stage; they are waited for and dropped)
+      static_for<0, TM * TN>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[1][j]),
+                                                            __builtin_bit_cast(bf16x8, xa[1][i]), acc[i][j], 0, 0, 0);
+        constexpr int r = big_read_after(t, TM + TN);
+        if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, 0, (r < TM ? r : 0), 0>(xa[0][r < TM ? r : 0], fax);
+        if constexpr (r >= TM) big_frag<BN, B_KMAJ, 0, (r >= TM ? r - TM : 0), 0>(wb[0][r >= TM ? r - TM : 0], faw);
+        if (more2) {
+          constexpr int NP = NVA + NVB, NM = TM * TN;
+          static_for<t * NP / NM, (t + 1) * NP / NM>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value;
+            if constexpr (pi < NVA) {
+              __builtin_amdgcn_global_load_lds((gvoid_t*)pa[pi], (lvoid_t*)(curA + (wave_u * 64 + pi * NT) * 8), 16, 0, 0);
+              pa[pi] += stepA;
+            } else {
+              __builtin_amdgcn_global_load_lds((gvoid_t*)pb[pi - NVA], (lvoid_t*)(curB + (wave_u * 64 + (pi - NVA) * NT) * 8), 16, 0, 0);
+              pb[pi - NVA] += stepB;
+            }
+          });
+        }
+        BIG_SB;
+      });
+      if (more2) knext += BK;
+      curA = (bf16_t*)((uintptr_t)curA ^ (uintptr_t)(STAGE * 2));
+      curB = (bf16_t*)((uintptr_t)curB ^ (uintptr_t)(STAGE * 2));
+    }
+    BIG_WAIT(0);
+  }
+#undef BIG_SLICE
+#undef BIG_SB
+#undef BIG_WAIT
+#undef BIG_ISSUE
+
+  __syncthreads();                                     // every wave is done with the fragment reads
+#ifdef OFA_EXP_NOEPI
+  if (g.alpha == 12345.f)
+#endif
+  {
+    const bool split = gridDim.y > 1;
+    constexpr int REGION = 4 * STAGE * 2 / 4;          // 32 KiB per wave
+    unsigned char* wl = smem_raw + wave * REGION;
+    const int m_w = m0 + wm * TM * 32, n_w = n0 + wn * TN * 32;
+    if (split) {
+      const int64_t n4 = (g.N + 3) & ~3;
+      float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
+      epilogue_lds<TM, TN, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+    } else {
+      const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
+      void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
+      epilogue_lds<TM, TN, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
 }
@@ -512,6 +852,29 @@ static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int split
   else launch_cfg<1, 1, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
 }
 
+template <int TM, int TN, bool AK, bool BKM, bool OF>
+static void launch_big(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+  const size_t lds = 4 * (size_t)256 * BK * sizeof(bf16_t);     // 2 operands x 2 stages x 32 KiB
+  auto kern = gemm_big_kernel<TM, TN, AK, BKM, OF>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(tiles_m * tiles_n, splits, batch), block(256);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
+}
+
+template <bool AK, bool BKM, bool OF>
+static void launch_big_shape(const GemmArgs& g, int batch, int tm, int splits, int ksplit, float* ws, hipStream_t st) {
+  if constexpr (AK) {
+    if (tm == 3) { launch_big<3, 4, AK, BKM, OF>(g, batch, splits, ksplit, ws, st); return; }
+  }
+  launch_big<4, 4, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+}
+
 int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
   GemmArgs g = g_in;
   g.b_krows = g.K;
@@ -532,12 +895,32 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
   if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }
   else if (t12 * maxs >= want && g.N >= 128) { wm = 1; wn = 2; tiles = t12; }
   else { wm = 1; wn = 1; tiles = t11; }
-  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11
+  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11 / 44 / 34
   if (force_tile == 22) { wm = 2; wn = 2; tiles = t22; }
   else if (force_tile == 12) { wm = 1; wn = 2; tiles = t12; }
   else if (force_tile == 11) { wm = 1; wn = 1; tiles = t11; }
+  // big tiles (one 256-thread workgroup per CU, 128x128 or 96x128 per wave): whole K tiles only.  With one workgroup per
+  // CU nothing overlaps a tile's output burst (the C write of a 14336 x 2304 x 768 product is 30% of its time, measured
+  // by removing the epilogue) -- two co-resident 128x128 workgroups hide it -- so the big tile only pays off when the K
+  // loop is long enough to amortise it: K >= 4096 and a grid that fills the 256 CUs.
+  int big_tm = 0;
+  const bool big_ok = (g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA) && g.N >= 256 && g.M >= 192;
+  if (big_ok && force_tile != 22 && force_tile != 12 && force_tile != 11) {
+    auto fill = [&](int bm) {
+      const int64_t t = (int64_t)cdiv(g.M, bm) * cdiv(g.N, 256) * batch;
+      return (double)t / (double)(cdiv(t, 256) * 256) * ((double)g.M / (cdiv(g.M, bm) * bm)) * ((double)g.N / (cdiv(g.N, 256) * 256));
+    };
+    const double f4 = fill(256), f3 = g.transA ? 0.0 : fill(192) * 0.97;
+    if (force_tile == 44) big_tm = 4;
+    else if (force_tile == 34) big_tm = g.transA ? 4 : 3;
+    else if (g.K >= 4096 && (f4 >= 0.8 || f3 >= 0.8)) big_tm = f4 >= f3 ? 4 : 3;
+  }
+  if (big_tm) {
+    wm = wn = 0;
+    tiles = (int64_t)cdiv(g.M, big_tm * 64) * cdiv(g.N, 256) * batch;
+  }
   int splits = 1;
-  if (tiles < want && maxs > 1) {
+  if (!big_tm && tiles < want && maxs > 1) {
     splits = (int)((want + tiles - 1) / tiles);
     if (splits > maxs) splits = maxs;
     while (splits > 1 && (int64_t)splits * batch * g.M * ((g.N + 3) & ~3) * 4 > ws_bytes) --splits;
@@ -548,7 +931,11 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
     splits = cdiv(g.K, ksplit);
   }
   const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
-#define GEMM_DISPATCH(AK, BKM, OF) launch_shape<AK, BKM, OF>(g, batch, wm, wn, splits, ksplit, (float*)ws, st)
+#define GEMM_DISPATCH(AK, BKM, OF)                                                                      \
+  do {                                                                                                  \
+    if (big_tm) launch_big_shape<AK, BKM, OF>(g, batch, big_tm, splits, ksplit, (float*)ws, st);        \
+    else launch_shape<AK, BKM, OF>(g, batch, wm, wn, splits, ksplit, (float*)ws, st);                   \
+  } while (0)
   if (ak && bk) { if (of) GEMM_DISPATCH(true, true, true); else GEMM_DISPATCH(true, true, false); }
   else if (ak && !bk) { if (of) GEMM_DISPATCH(true, false, true); else GEMM_DISPATCH(true, false, false); }
   else if (!ak && !bk) { if (of) GEMM_DISPATCH(false, false, true); else GEMM_DISPATCH(false, false, false); }

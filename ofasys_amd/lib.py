@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: the .so resolves libamdhip6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ofasys_amd.h")
-LIB_PATH = os.path.join(_HERE, "libofasys_amd.so")
+LIB_PATH = os.environ.get("OFASYS_AMD_LIB") or os.path.join(_HERE, "libofasys_amd.so")   # override: kernel experiments
 
 F32, BF16 = 0, 1
 GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_ACCUM, GEMM_FORCE_SIMPLE, GEMM_OUT_F32 = 1, 2, 4, 8, 16

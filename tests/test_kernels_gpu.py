@@ -63,6 +63,23 @@ GEMM_SHAPES = [(64, 64, 64), (128, 128, 128), (200, 136, 72), (130, 768, 256), (
                (256, 3072, 768), (1000, 208, 264)]
 
 
+@pytest.mark.parametrize("M,N,K_", [(3584, 4096, 4096), (3320, 3848, 4160)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_big_tile(K, M, N, K_, ta, tb):
+    """Long-K products that fill the chip take the 256x256 / 192x256 workgroup tiles (csrc/gemm_mfma.hip, gemm_big_kernel)."""
+    torch.manual_seed(11)
+    a = torch.randn((K_, M) if ta else (M, K_), device=DEV).bfloat16()
+    b = torch.randn((N, K_) if tb else (K_, N), device=DEV).bfloat16()
+    bias = torch.randn(N, device=DEV).bfloat16()
+    ref = ((a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float()) + bias.float()) * 0.5
+    out = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5)
+    assert rel(out, ref) < 1e-2
+    acc = torch.ones(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(a, b, ta, tb, out=acc, accumulate=True)
+    assert rel(acc.float() - 1, ref * 2 - bias.float()) < 2e-2
+    assert rel(K.gemm(a, b, ta, tb, bias=bias, alpha=0.5, out_f32=True), ref) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])

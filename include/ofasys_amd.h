@@ -136,11 +136,13 @@ int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64
 /* ---- elementwise pieces of the layer (transformer_layer.py:167-208): */
 int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);                  /* module/gelu.py:18-19 */
 int ofa_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
-/* y = residual + dropout_p(x); mask is regenerated from (seed, offset) with Philox4x32-10, nothing is stored. */
+/* y = residual + dropout_p(x); mask is regenerated from (seed, offset) with Philox4x32-10, nothing is stored.
+ * offset_base (optional, device int64[1]) is added to `offset` on the device: the stream position of a captured
+ * (hipGraph) train step lives there and is advanced by the step itself, so replays draw fresh masks. */
 int ofa_dropout_add_fwd(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed,
-                        uint64_t offset, int dtype, void* stream);
-int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
-                    void* stream);
+                        uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
+int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset,
+                    const int64_t* offset_base, int dtype, void* stream);
 /* y[r][c] = (a[r][c] + (b? b[r][c]:0) + (vec? vec[c]:0)) * (rowmask && rowmask[r] ? 0 : 1)  -- adaptor/base.py:168-173,
  * model/transformer.py:110-112 */
 int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y, int64_t rows,
@@ -188,7 +190,9 @@ int ofa_sumsq_ws_floats(void);
 int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* ws /* ofa_sumsq_ws_floats() floats */,
               int64_t n, int dtype, void* stream);
 /* Adam on fp32 master weights with grads of `dtype`; coef[0] = grad multiplier (world/sample_size and clip folded
- * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p). */
+ * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p).
+ * step >= 1: bias correction from (lr, step) on the host.  step == 0: coef is device fp32[3] = [grad multiplier,
+ * lr*sqrt(1-b2^t)/(1-b1^t), lr] -- the schedule state stays on the device (captured train steps). */
 int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
                   const float* coef, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, int dtype, void* stream);

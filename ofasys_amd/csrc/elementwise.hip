@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ dy, con
 // element e uses Philox counter (offset + e/4), word e%4.
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                                      int64_t n, float p, uint64_t seed, uint64_t offset) {
+                                                      int64_t n, float p, uint64_t seed, uint64_t offset,
+                                                      const int64_t* __restrict__ offset_base) {
+  if (offset_base) offset += (uint64_t)offset_base[0];   // device-resident stream position (hipGraph replays advance it)
   const Philox rng(seed);
   const float keep_scale = 1.0f / (1.0f - p);
   const int64_t nq = (n + 3) / 4;
@@ -274,25 +276,25 @@ extern "C" int ofa_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, 
 }
 
 extern "C" int ofa_dropout_add_fwd(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed,
-                                   uint64_t offset, int dtype, void* stream) {
+                                   uint64_t offset, const int64_t* offset_base, int dtype, void* stream) {
   OFA_DT_CHECK("dropout_add_fwd");
   OFA_REQUIRE(n >= 0 && p >= 0.f && p < 1.f && (n == 0 || (x && y)), OFA_ERR_INVALID, "dropout_add_fwd: bad argument");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(grid_for((n + 3) / 4)), block(256);
   if (dtype == OFA_F32) {
-    if (residual) hipLaunchKernelGGL((dropout_kernel<float, true>), grid, block, 0, st, (const float*)x, (const float*)residual, (float*)y, n, p, seed, offset);
-    else hipLaunchKernelGGL((dropout_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (float*)y, n, p, seed, offset);
+    if (residual) hipLaunchKernelGGL((dropout_kernel<float, true>), grid, block, 0, st, (const float*)x, (const float*)residual, (float*)y, n, p, seed, offset, offset_base);
+    else hipLaunchKernelGGL((dropout_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (float*)y, n, p, seed, offset, offset_base);
   } else {
-    if (residual) hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, p, seed, offset);
-    else hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, p, seed, offset);
+    if (residual) hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, p, seed, offset, offset_base);
+    else hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, p, seed, offset, offset_base);
   }
   return check_launch("dropout_add_fwd");
 }
 
-extern "C" int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype,
-                               void* stream) {
-  return ofa_dropout_add_fwd(dy, nullptr, dx, n, p, seed, offset, dtype, stream);
+extern "C" int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset,
+                               const int64_t* offset_base, int dtype, void* stream) {
+  return ofa_dropout_add_fwd(dy, nullptr, dx, n, p, seed, offset, offset_base, dtype, stream);
 }
 
 extern "C" int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y,

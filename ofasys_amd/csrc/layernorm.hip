@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // Backward.  One 1024-thread block (16 waves) per CU walks rows with a grid stride -- 4 waves per SIMD keep enough
 // loads in flight to cover HBM latency (the earlier 256-thread / 1024-slot version ran ONE wave per SIMD: 2.9 TB/s).
-// A row is split over WPR (1, 2 or 4) waves -- wide rows (the 4D FFN LayerNorm) spread over four waves so that each
+// A row is split over WPR (1, 2, 4 or 8) waves -- wide rows (the 4D FFN LayerNorm) spread over four waves so that each
 // lane keeps <= 2 vectors of x, dy, gamma AND its running dgamma/dbeta(/dbias) in registers; the two row statistics
 // cross the waves through a small LDS exchange.  With GELU the activation and its derivative share one erf
 // (gelu = x*Phi, gelu' = Phi + x*phi) and the column sums of dh (= the gradient of the bias of the Linear that
@@ -259,9 +259,11 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
                            void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows, int cols, int accumulate,
                            hipStream_t st) {
   constexpr int N = Vec<T>::N;
-  // waves per row: keep <= 2 vectors per lane when the row can be split evenly
+  // waves per row: keep <= 2 vectors per lane (1 with GELU, whose extra gelu'/dbias registers would otherwise spill at
+  // the 128-VGPR cap of a 1024-thread block: 169 us instead of ~70 for the 14336 x 3072 FFN LayerNorm) when the row
+  // can be split evenly
   int wpr = 1;
-  while (wpr < 4 && cdiv(cols / wpr, 64 * N) > 2 && (cols % (wpr * 2 * N)) == 0) wpr *= 2;
+  while (wpr < 8 && cdiv(cols / wpr, 64 * N) > (GELU ? 1 : 2) && (cols % (wpr * 2 * N)) == 0) wpr *= 2;
   const int nv = cdiv(cols / wpr, 64 * N);
   const int rpb = LN_WPB / wpr;
   int64_t nblk = (rows + rpb - 1) / rpb;
@@ -280,7 +282,8 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
   } while (0)
   if (wpr == 1) LN_CASE(1);
   else if (wpr == 2) LN_CASE(2);
-  else LN_CASE(4);
+  else if (wpr == 4) LN_CASE(4);
+  else LN_CASE(8);
 #undef LN_CASE
 #undef LN_LAUNCH
   int rc = check_launch("layernorm_bwd");
@@ -297,7 +300,7 @@ static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
   OFA_REQUIRE(cols % n == 0, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d must be a multiple of %d", cols, n);
   if (bwd) {                                      // the same row split the dispatcher makes; <= 8 vectors per lane
     int wpr = 1;
-    while (wpr < 4 && cdiv(cols / wpr, 64 * n) > 2 && (cols % (wpr * 2 * n)) == 0) wpr *= 2;
+    while (wpr < 8 && cdiv(cols / wpr, 64 * n) > 2 && (cols % (wpr * 2 * n)) == 0) wpr *= 2;
     OFA_REQUIRE(cdiv(cols / wpr, 64 * n) <= 8, OFA_ERR_UNSUPPORTED, "layernorm_bwd: cols=%d too wide", cols);
   } else {
     OFA_REQUIRE(cols <= 64 * n * 32, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d exceeds %d", cols, 64 * n * 32);

@@ -165,8 +165,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                    const T* __restrict__ grad, T* __restrict__ model,
                                                    const float* __restrict__ coef, int64_t n, float lr, float beta1,
-                                                   float beta2, float eps, float wd, float step_size) {
+                                                   float beta2, float eps, float wd, float step_size, int dev_sched) {
   const float gmul = coef ? coef[0] : 1.0f;
+  if (dev_sched) {                       // schedule state lives on the device: coef = [grad multiplier, step size, lr]
+    step_size = coef[1];
+    lr = coef[2];
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float g = ld1<T>(grad + i) * gmul;
     float p = master[i];
@@ -257,17 +261,19 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
                              const float* coef, int64_t n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int step, int dtype, void* stream) {
   OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "adam_step: bad dtype %d", dtype);
-  OFA_REQUIRE(n >= 0 && step >= 1 && master && exp_avg && exp_avg_sq && grad && model_param, OFA_ERR_INVALID, "adam_step: bad argument");
+  OFA_REQUIRE(n >= 0 && step >= 0 && master && exp_avg && exp_avg_sq && grad && model_param, OFA_ERR_INVALID, "adam_step: bad argument");
+  OFA_REQUIRE(step >= 1 || coef, OFA_ERR_INVALID, "adam_step: step == 0 takes the step size and lr from coef[1], coef[2]");
   if (n == 0) return 0;
   // adam.py:205-207
+  const int dev_sched = step == 0;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)(lr * sqrt(bc2) / bc1);
+  const float step_size = dev_sched ? 0.f : (float)(lr * sqrt(bc2) / bc1);
   hipStream_t st = (hipStream_t)stream;
   int64_t nbl = (n + 255) / 256;
   const int nb = (int)(nbl > 4096 ? 4096 : nbl);
   if (dtype == OFA_F32)
-    hipLaunchKernelGGL((adam_kernel<float>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const float*)grad, (float*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size);
+    hipLaunchKernelGGL((adam_kernel<float>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const float*)grad, (float*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   else
-    hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size);
+    hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   return check_launch("adam_step");
 }

@@ -39,6 +39,7 @@ class GradBucketReducer:
         for b, (_, _, members) in enumerate(self.buckets):
             for i in members:
                 self.param_bucket[i] = b
+        self.overlap = True                       # False: never launch from inside backward (captured steps)
         self.expected = None                      # contributions per parameter per step for the current signature
         self._learned = {}                        # step signature -> learned contribution counts
         self._sig = None
@@ -60,7 +61,7 @@ class GradBucketReducer:
         """`signature` identifies the step's structure (which tasks / how many micro-batches); early bucket launches are
         only armed for a structure whose contribution counts were learned on an earlier, identical step."""
         self._sig = signature
-        self.expected = self._learned.get(signature)
+        self.expected = self._learned.get(signature) if self.overlap else None
         self._reset()
 
     def notify(self, i):
@@ -77,6 +78,9 @@ class GradBucketReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self._launched[b] = True
+        if self.flat_grad.is_cuda:
+            from . import ops
+            ops.side_join()                        # weight-gradient kernels run on a side stream: order them before the collective
         self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _reset(self):
@@ -99,7 +103,7 @@ class GradBucketReducer:
                     self._launch(b)
             for h in self._handles:
                 h.wait()
-        if self.expected is None:
+        if self.expected is None and self.overlap:
             self._learned[self._sig] = list(self._count)
         self._reset()
 

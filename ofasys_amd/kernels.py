@@ -12,8 +12,8 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="ws"):
-    """A per-device grow-only scratch buffer (fp32 words)."""
-    key = (tag, device)
+    """A grow-only scratch buffer (fp32 words) per (tag, device, HIP stream): kernels on different streams never share one."""
+    key = (tag, device, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
     buf = _ws_cache.get(key)
     n = (nbytes + 3) // 4
     if buf is None or buf.numel() < n:
@@ -315,20 +315,22 @@ def gelu_bwd(dy, x):
     return dx
 
 
-def dropout_add(x, residual, p, seed, offset):
+def dropout_add(x, residual, p, seed, offset, offset_base=None):
+    """offset_base: optional device int64[1] added to `offset` on the device (graph-safe Philox stream position)."""
     x = x.contiguous()
     if residual is not None:
         residual = residual.contiguous()
     y = torch.empty_like(x)
-    lib().call("ofa_dropout_add_fwd", ptr(x), ptr(residual), ptr(y), x.numel(), float(p), seed, offset, dtype_code(x),
-               stream())
+    lib().call("ofa_dropout_add_fwd", ptr(x), ptr(residual), ptr(y), x.numel(), float(p), seed, offset, ptr(offset_base),
+               dtype_code(x), stream())
     return y
 
 
-def dropout_bwd(dy, p, seed, offset):
+def dropout_bwd(dy, p, seed, offset, offset_base=None):
     dy = dy.contiguous()
     dx = torch.empty_like(dy)
-    lib().call("ofa_dropout_bwd", ptr(dy), ptr(dx), dy.numel(), float(p), seed, offset, dtype_code(dy), stream())
+    lib().call("ofa_dropout_bwd", ptr(dy), ptr(dx), dy.numel(), float(p), seed, offset, ptr(offset_base), dtype_code(dy),
+               stream())
     return dx
 
 

@@ -36,22 +36,40 @@ def batch_major(x):
 
 
 class _Rng:
-    """Philox (seed, offset) bookkeeping for dropout: one monotonically increasing offset per process."""
+    """Philox (seed, offset) bookkeeping for dropout.  The stream position is `base` (a device int64, one per device) +
+    `offset` (host, relative): kernels add the two on the device, so a captured (hipGraph) train step -- whose host
+    arguments are frozen at capture time -- still draws fresh masks on every replay once the step ends with
+    `advance()` (a captured device-side `base += offset`)."""
     seed = 0x5EED0FA
     offset = 0
+    base = {}
 
     @classmethod
     def manual_seed(cls, seed):
         cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+        for b in cls.base.values():
+            b.zero_()
 
     @classmethod
-    def reserve(cls, n):
+    def reserve(cls, n, device):
         o = cls.offset
         cls.offset += (n + 3) // 4 + 1
-        return cls.seed, o
+        b = cls.base.get(device)
+        if b is None:
+            b = cls.base[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        return cls.seed, o, b
+
+    @classmethod
+    def advance(cls):
+        """Fold the relative offset consumed so far into the device-side base (call at the end of a train step)."""
+        if cls.offset:
+            for b in cls.base.values():
+                b.add_(cls.offset)
+            cls.offset = 0
 
 
 manual_seed = _Rng.manual_seed
+rng_advance = _Rng.advance
 
 
 # ---------------------------------------------------------------------------------------------- gradient sinks
@@ -67,6 +85,66 @@ def _sink_done(param):
     cb = getattr(param, "_ofa_grad_ready", None)
     if cb is not None:
         cb()
+
+
+# Weight / bias gradients that land in the arena have no consumer until the end of backward (reducer, clip, Adam), so
+# they run on a SIDE HIP stream: the MFMA-bound wgrad GEMMs overlap the HBM-bound LayerNorm / dropout / attention
+# backward kernels and the dgrad chain on the main stream, and each GEMM's output burst hides under the other stream's
+# work.  Ordering: side waits for main at every launch (its inputs were just produced there); main waits for side once,
+# in a callback at the end of the backward pass (`side_join`, also called by the bucket reducer before an all-reduce).
+class _Side:
+    enabled = False                                # measured on cfg-2 (graph replay): 20.8 ms with, 20.4 ms without -> off by default
+    stream = None
+    pending = False
+    queued = False
+    keep = []                                      # inputs of in-flight side kernels, released at the join
+
+    @classmethod
+    def get(cls):
+        if cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+        return cls.stream
+
+
+def side_stream():
+    """The side stream (created on first use; call before a graph capture begins)."""
+    return _Side.get()
+
+
+def side_stream_enabled(flag=None):
+    if flag is not None:
+        _Side.enabled = bool(flag)
+    return _Side.enabled
+
+
+def side_join():
+    """Make the current stream wait for every side-stream gradient kernel queued so far."""
+    _Side.queued = False
+    if _Side.pending:
+        torch.cuda.current_stream().wait_stream(_Side.get())
+        _Side.pending = False
+    _Side.keep.clear()                             # freed blocks return to the main stream, which is now ordered behind side
+
+
+def _on_side(fn, *inputs):
+    """Run fn() (kernel launches that only WRITE arena gradients) on the side stream, after everything already queued on
+    the current stream; `inputs` are the tensors it reads (kept alive until the side stream is done with them)."""
+    if not _Side.enabled:
+        fn()
+        return
+    cur = torch.cuda.current_stream()
+    side = _Side.get()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        fn()
+    _Side.keep.append(inputs)                      # (not record_stream: that is not capturable into a hipGraph)
+    _Side.pending = True
+    if not _Side.queued:
+        try:                                       # only legal while the autograd engine is running a backward pass
+            torch.autograd.Variable._execution_engine.queue_callback(side_join)
+            _Side.queued = True
+        except RuntimeError:
+            side_join()
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
@@ -130,15 +208,15 @@ class LinearFn(torch.autograd.Function):
             dx = K.gemm(dy, weight, False, False, alpha=ctx.alpha, a_kpad_zero=kpad)  # dX = dY W
         if ctx.needs_input_grad[1]:
             gw = _sink(weight)
-            if gw is not None:
-                K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True)   # dW += dY^T X, in the arena
+            if gw is not None:                                                       # dW += dY^T X, in the arena
+                _on_side(lambda: K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True), dy, x2d)
                 _sink_done(weight)
             else:
                 dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                   # dW = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _sink(ctx.bias_ref)
             if gb is not None:
-                K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True)
+                _on_side(lambda: K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True), dy)
                 _sink_done(ctx.bias_ref)
             else:
                 db = K.colsum(dy, alpha=ctx.alpha, out_dtype=weight.dtype)
@@ -180,7 +258,7 @@ class LinearGeluLayerNormFn(torch.autograd.Function):
         gw = _sink(weight)
         dw = None
         if gw is not None:
-            K.gemm(dh, x2d, True, False, out=gw, accumulate=True)
+            _on_side(lambda: K.gemm(dh, x2d, True, False, out=gw, accumulate=True), dh, x2d)
             _sink_done(weight)
         else:
             dw = K.gemm(dh, x2d, True, False)
@@ -215,14 +293,14 @@ class DropoutAddFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, p):
-        seed, off = _Rng.reserve(x.numel())
-        ctx.p, ctx.seed, ctx.off = p, seed, off
+        seed, off, base = _Rng.reserve(x.numel(), x.device)
+        ctx.p, ctx.seed, ctx.off, ctx.base = p, seed, off, base
         ctx.has_res = residual is not None
-        return K.dropout_add(x, residual, p, seed, off)
+        return K.dropout_add(x, residual, p, seed, off, base)
 
     @staticmethod
     def backward(ctx, dy):
-        dx = K.dropout_bwd(dy, ctx.p, ctx.seed, ctx.off)
+        dx = K.dropout_bwd(dy, ctx.p, ctx.seed, ctx.off, ctx.base)
         return dx, (dy if ctx.has_res else None), None
 
 
@@ -325,11 +403,11 @@ def _packed(ws, arena_view):
     return arena_view if arena_view is not None else torch.cat([w.reshape(w.shape[0], -1) if w.dim() > 1 else w for w in ws])
 
 
-def _packed_grads(ws, gview, grad_packed_fn):
-    """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (and notify the sinks);
-    otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
+def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
+    """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (on the side stream; and
+    notify the sinks); otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
     if gview is not None:
-        grad_packed_fn(gview, True)
+        _on_side(lambda: grad_packed_fn(gview, True), *inputs)
         for w in ws:
             _sink_done(w)
         return [None] * len(ws)
@@ -379,9 +457,9 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         gws = _packed_grads((wk, wv, wq), pack.get("gw"),
-                            lambda o, acc: K.gemm(d2, x2d, True, False, out=o, accumulate=acc))
+                            lambda o, acc: K.gemm(d2, x2d, True, False, out=o, accumulate=acc), (d2, x2d))
         gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
-                            lambda o, acc: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype))
+                            lambda o, acc: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype), (d2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[9]:
             dsum = K.head_sum(delta, B, heads, T)
@@ -428,12 +506,13 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
-        gq = _packed_grads((wq,), _sink(wq), lambda o, acc: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc))
-        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype))
+        gq = _packed_grads((wq,), _sink(wq), lambda o, acc: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc), (dq2, xq2))
+        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype),
+                            (dq2,))
         gws = _packed_grads((wk, wv), pack.get("gw"),
-                            lambda o, acc: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc))
+                            lambda o, acc: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc), (dkv2, xkv2))
         gbs = _packed_grads((bk, bv), pack.get("gb"),
-                            lambda o, acc: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype))
+                            lambda o, acc: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype), (dkv2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[10]:
             dsum = K.head_sum(delta, B, heads, T)
@@ -456,20 +535,21 @@ class UnfusedAttentionFn(torch.autograd.Function):
         p = K.attn_softmax(scores, bias, kpm, scale, heads, causal)
         pd = p
         seed = off = 0
+        base = None
         if dropout_p > 0:
-            seed, off = _Rng.reserve(p.numel())
-            pd = K.dropout_add(p, None, dropout_p, seed, off)
+            seed, off, base = _Rng.reserve(p.numel(), p.device)
+            pd = K.dropout_add(p, None, dropout_p, seed, off, base)
         o = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
         K.gemm_heads(pd, v, o, T, hd, S, False, False, S, D, D, B, heads, T * S, heads * T * S, hd, S * D, hd, T * D)
         out = _scale_heads(o, c_attn, heads) if c_attn is not None else o
         ctx.save_for_backward(q, k, v, p, o, c_attn)
-        ctx.cfg = (heads, scale, dropout_p, seed, off)
+        ctx.cfg = (heads, scale, dropout_p, seed, off, base)
         return out, p
 
     @staticmethod
     def backward(ctx, dout, dp_unused):
         q, k, v, p, o, c_attn = ctx.saved_tensors
-        heads, scale, dropout_p, seed, off = ctx.cfg
+        heads, scale, dropout_p, seed, off, base = ctx.cfg
         B, T, D = q.shape
         S = k.shape[1]
         hd = D // heads
@@ -482,13 +562,13 @@ class UnfusedAttentionFn(torch.autograd.Function):
             do = _scale_heads(dout, c_attn, heads)
         pd = p
         if dropout_p > 0:
-            pd = K.dropout_add(p, None, dropout_p, seed, off)
+            pd = K.dropout_add(p, None, dropout_p, seed, off, base)
         dv = torch.empty_like(v)
         K.gemm_heads(pd, do, dv, S, hd, T, True, False, S, D, D, B, heads, T * S, heads * T * S, hd, T * D, hd, S * D)
         dpd = torch.empty_like(p)
         K.gemm_heads(do, v, dpd, T, S, hd, False, True, D, D, S, B, heads, hd, T * D, hd, S * D, T * S, heads * T * S)
         if dropout_p > 0:
-            dpd = K.dropout_bwd(dpd, dropout_p, seed, off)
+            dpd = K.dropout_bwd(dpd, dropout_p, seed, off, base)
         ds = K.scaled_softmax_bwd(dpd, p, 1.0)                                  # dS wrt (scale*qk + bias)
         dq = torch.empty_like(q)
         K.gemm_heads(ds, k, dq, T, hd, S, False, False, S, D, D, B, heads, T * S, heads * T * S, hd, S * D, hd, T * D,

@@ -93,31 +93,62 @@ class FlatParams:
 
 
 class Trainer:
+    """One optimisation step = `train_step(samples)`.
+
+    use_graph: capture the step into a hipGraph (torch.cuda.graphs) and replay it.  The eager step is HOST-bound on an
+    MI355X (~600 kernel launches + autograd bookkeeping take as long as the kernels themselves); a replay costs one
+    launch.  Everything a replay must see fresh lives on the device: the Philox stream position (ops._Rng.base), the
+    Adam step counter / bias corrections / lr (self._sched), the clip coefficient.  Each distinct batch structure
+    (slot and target shapes) gets its own graph after `graph_warmup` eager steps; new batches of a captured structure are
+    copied into the graph's static input tensors.  With world_size > 1 the step is two graphs (forward+backward,
+    clip+Adam) around an eager all-reduce of the gradient arena: collectives are kept out of the captured region."""
+
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
-                 bucket_bytes: int = 64 << 20):
+                 bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2):
         self.model = model
         self.fp = FlatParams(model)
         dev = self.fp.flat.device
         self.master = self.fp.flat.float().clone() if self.fp.flat.dtype != torch.float32 else self.fp.flat
         self.exp_avg = torch.zeros(self.fp.numel, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.fp.numel, dtype=torch.float32, device=dev)
-        self.lr, self.betas, self.eps, self.weight_decay, self.clip_norm = lr, betas, eps, weight_decay, clip_norm
+        self.betas, self.eps, self.weight_decay, self.clip_norm = betas, eps, weight_decay, clip_norm
         self.num_updates = 0
         self.group = process_group
         self.reducer = GradBucketReducer(self.fp.params, self.fp.grad, self.fp.offsets, process_group, bucket_bytes)
+        self.world = self.reducer.world
         self.pad = model.global_dict.pad()
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)      # [sample_size, loss_sum, ntokens]
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # device-resident schedule: _step_t = number of updates done; _lr_t = learning rate; _sched = [grad multiplier,
+        # lr*sqrt(1-b2^t)/(1-b1^t), lr] consumed by ofa_adam_step(step = 0)
+        self._step_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._lr_t = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
+        self._sched = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._lr = float(lr)
+        self.use_graph = bool(use_graph) and dev.type == "cuda"
+        self.graph_warmup = graph_warmup
+        self._graphs = {}                           # batch structure -> dict(graphs, static samples, seen count)
         self.last = {}
 
-    def train_step(self, samples: List[dict]):
-        """samples: one dict per (task, micro-batch): {"slots": [...], "target": LongTensor[B,Tt]}."""
+    # ------------------------------------------------------------------ learning rate (host -> device scalar)
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self._lr_t.fill_(self._lr)                  # outside any captured region: replays read the new value
+
+    # ------------------------------------------------------------------ the three phases of a step
+    def _fwd_bwd(self, samples, overlap_reduce):
         model = self.model
         model.train()
         self.fp.zero_grad()
         self._stats.zero_()
+        self.reducer.overlap = overlap_reduce
         self.reducer.begin_step(tuple(s.get("task", len(s["slots"])) for s in samples))
-        for i, s in enumerate(samples):
+        for s in samples:
             logits = model(s["slots"])[0]
             loss = ops.cross_entropy_sum(logits, s["target"], self.pad)
             loss.backward()
@@ -125,8 +156,14 @@ class Trainer:
             self._stats[0] += n
             self._stats[1] += loss.detach().double()
             self._stats[2] += n
+        ops.side_join()                             # side-stream weight gradients are complete beyond this point
+        ops.rng_advance()
+
+    def _reduce(self):
         self.reducer.finish()
         all_reduce_scalars(self._stats, self.group)
+
+    def _update(self):
         # coef = (1/sample_size) * min(1, clip / (||g/sample_size|| + 1e-6)), all on the device
         self._gsq.zero_()
         K.sumsq(self.fp.grad, self._gsq)
@@ -135,8 +172,95 @@ class Trainer:
         coef = inv_n.reshape(1)
         if self.clip_norm > 0:
             coef = coef * (self.clip_norm / (gnorm + 1e-6)).clamp(max=1.0)
+        self._step_t += 1                           # adam.py:205-207 on the device
+        bc1 = 1.0 - self.betas[0] ** self._step_t
+        bc2 = 1.0 - self.betas[1] ** self._step_t
+        self._sched[0:1] = coef
+        self._sched[1:2] = (self._lr_t * bc2.sqrt() / bc1).float()
+        self._sched[2:3] = self._lr_t.float()
+        K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.fp.grad, self.fp.flat, self._sched, 0.0,
+                    self.betas[0], self.betas[1], self.eps, self.weight_decay, 0)
+        self._gnorm = gnorm
+
+    # ------------------------------------------------------------------ graph plumbing
+    @staticmethod
+    def _tensors_of(samples):
+        out = []
+        for s in samples:
+            for sl in s["slots"]:
+                v = getattr(sl, "value", None)
+                if torch.is_tensor(v):
+                    out.append(v)
+            out.append(s["target"])
+        return out
+
+    def _signature(self, samples):
+        return tuple((s.get("task", len(s["slots"])),) + tuple((tuple(t.shape), t.dtype) for t in self._tensors_of([s]))
+                     for s in samples)
+
+    def _capture(self, samples):
+        ops.side_stream()                           # streams / RNG bases must exist before capture starts
+        pool = torch.cuda.graph_pool_handle()
+        entry = {"static": samples, "graphs": []}
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._fwd_bwd(samples, overlap_reduce=False)
+                self._update()
+            entry["graphs"] = [g]
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=pool):
+                self._fwd_bwd(samples, overlap_reduce=False)
+            with torch.cuda.graph(gb, pool=pool):
+                self._update()
+            entry["graphs"] = [ga, gb]
+        return entry
+
+    def _replay(self, entry, samples):
+        if samples is not entry["static"]:
+            for dst, src in zip(self._tensors_of(entry["static"]), self._tensors_of(samples)):
+                if dst is not src:
+                    dst.copy_(src, non_blocking=True)
+        entry["graphs"][0].replay()
+        if self.world > 1:
+            self.reducer.overlap = False
+            self.reducer.begin_step(None)
+            self._reduce()
+            entry["graphs"][1].replay()
+
+    def train_step(self, samples: List[dict], eager: bool = False):
+        """samples: one dict per (task, micro-batch): {"slots": [...], "target": LongTensor[B,Tt]}."""
+        done = False
+        if self.use_graph and not eager:
+            sig = self._signature(samples)
+            entry = self._graphs.get(sig)
+            if entry is None:
+                entry = self._graphs[sig] = {"seen": 0}
+            if "graphs" in entry:
+                self._replay(entry, samples)
+                done = True
+            elif entry["seen"] >= self.graph_warmup:
+                rng_state = (ops._Rng.offset,)
+                try:
+                    torch.cuda.synchronize()
+                    cap = self._capture(samples)
+                except Exception as e:              # anything uncapturable in a custom adaptor: stay eager, loudly
+                    import warnings
+                    warnings.warn(f"ofasys_amd.Trainer: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+                    self.use_graph = False
+                    ops._Rng.offset = rng_state[0]
+                    ops.side_join()
+                else:
+                    entry.update(cap)
+                    self._replay(entry, samples)
+                    done = True
+            else:
+                entry["seen"] += 1
+        if not done:
+            self._fwd_bwd(samples, overlap_reduce=True)
+            self._reduce()
+            self._update()
         self.num_updates += 1
-        K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.fp.grad, self.fp.flat, coef.contiguous(), self.lr,
-                    self.betas[0], self.betas[1], self.eps, self.weight_decay, self.num_updates)
-        self.last = {"stats": self._stats, "gnorm": gnorm}
+        self.last = {"stats": self._stats, "gnorm": self._gnorm}
         return self.last

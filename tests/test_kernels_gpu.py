@@ -275,6 +275,9 @@ def test_elementwise(K, dtype):
     assert rel(g, torch.where(kept, dy.float() / 0.9, torch.zeros_like(dy.float()))) < (1e-6 if dtype == torch.float32 else 1e-2)
     y3 = K.dropout_add(x, res, 0.1, 1234, 78)
     assert not torch.equal(y, y3)
+    base = torch.tensor([7], dtype=torch.int64, device=DEV)          # device-side stream position: 70 + 7 == 77
+    assert torch.equal(K.dropout_add(x, res, 0.1, 1234, 70, base), y)
+    assert torch.equal(K.dropout_bwd(dy, 0.1, 1234, 70, base), g)
     # p = 0 is the identity + residual
     assert rel(K.dropout_add(x, res, 0.0, 1, 0), x.float() + res.float()) < t
     # add + row vector + row mask

@@ -155,6 +155,13 @@ __device__ __forceinline__ void rdtr(u64x2& d, uint32_t addr_lo, uint32_t addr_h
   d[0] = lo;
   d[1] = hi;
 }
+// stage barrier: this wave's LDS-DMA pieces have landed (explicit vmcnt wait -- hipcc only inserts one in front of LDS reads it
+// can see, and the fragment reads here are inline asm), then everybody else's
+#define ATT_SYNC()                                     \
+  do {                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+    __syncthreads();                                   \
+  } while (0)
 #define ATT_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define ATT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), B, C, 0, 0, 0)
 #define ATT_MFMA2(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   int kflag = dead_flag(kp, 0, a.S, i);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
-  __syncthreads();
+  ATT_SYNC();
   const bool live_wave = q0 < a.T;
   for (int kb = 0; kb < nkb; kb += 2) {
     {
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow, sc);
-      __syncthreads();
+      ATT_SYNC();
     }
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow, sc);
-      __syncthreads();
+      ATT_SYNC();
     }
   }
   if (qi < a.T) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   int kflag = dead_flag(kp, 0, a.S, i);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
-  __syncthreads();
+  ATT_SYNC();
   const bool live_wave = q0 < a.T;
   int my_last = -1;      // last key block this wave actually visited (for zero-filling dbias beyond it)
   for (int kb = 0; kb < nkb; kb += 2) {
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
         dq_block<0>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, brow, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
-      __syncthreads();
+      ATT_SYNC();
     }
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
         dq_block<1>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, brow, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
-      __syncthreads();
+      ATT_SYNC();
     }
   }
   if (dbrow && qi < a.T && my_last + 1 < nkb_all) {       // causally skipped blocks: dS == 0
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   }
-  __syncthreads();
+  ATT_SYNC();
   for (int qb = qb_first; qb < nqb; qb += 2) {
     {
       if (qb + 1 < nqb) {
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) dkv_block<0>(a, ta, trx, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bcol, sc, c, l4, d4);
-      __syncthreads();
+      ATT_SYNC();
     }
     if (qb + 1 < nqb) {
       if (qb + 2 < nqb) {
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) dkv_block<1>(a, ta, trx, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bcol, sc, c, l4n, d4n);
-      __syncthreads();
+      ATT_SYNC();
     }
   }
   if (ki < a.S) {

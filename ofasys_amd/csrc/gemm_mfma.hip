@@ -325,9 +325,26 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
         }
       }
     }
-    // read back whole 16-byte row segments (same wave: LDS operations complete in order) and store
+    // read back whole 16-byte row segments (same wave: LDS operations complete in order) and store.  The memory clobber
+    // keeps hipcc from hoisting the uint4 reads above the uint2 / float4 writes (different types: TBAA says "no alias").
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int c = lane % LPR;
     const int n = n_w + c * (16 / E);
+    if (vec16 && m_w + TM * 32 <= g.M && n_w + TN * 32 <= g.N && (RAW || !(g.flags & OFA_GEMM_ACCUM))) {
+      // interior tile, plain store: straight-line, 8 LDS reads in flight per batch (the guarded loop below pays an LDS
+      // round trip plus ~10 branches per 16-byte store -- ~8 us for a 256x256 tile, measured with the K loop removed)
+      const int rows_full = (TM - ip0 < ipass ? TM - ip0 : ipass) * 32;
+      unsigned char* p = (unsigned char*)Cb + ((int64_t)(m_w + ip0 * 32 + lane / LPR) * ldc + n) * E;
+      const int64_t pstep = (int64_t)RPI * ldc * E;
+#pragma unroll 8
+      for (int r0 = 0; r0 < rows_full; r0 += RPI) {
+        const int mloc = r0 + lane / LPR;
+        const uint4 u = *reinterpret_cast<const uint4*>(wl + mloc * ROWB + ((c ^ ((mloc >> SH) & (CH - 1))) << 4));
+        *reinterpret_cast<uint4*>(p) = u;
+        p += pstep;
+      }
+      continue;
+    }
     const int rows_here = (TM - ip0 < ipass ? TM - ip0 : ipass) * 32;
     for (int r0 = 0; r0 < rows_here; r0 += RPI) {
       const int mloc = r0 + lane / LPR;
@@ -426,7 +443,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       glds_issue<NT, NVA>(pa, stepA, sA[0], wave_u);
       glds_issue<NT, NVB>(pb, stepB, sB[0], wave_u);
     }
-    __syncthreads();                                     // (the compiler drains vmcnt before the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
     FragAddr<BM, A_KMAJ> fax[2];
     FragAddr<BN, B_KMAJ> faw[2];
@@ -469,7 +487,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       OFA_MMA(x0, w0);                                                                                 \
       OFA_WAIT(x1, w1);                                                                                \
       OFA_MMA(x1, w1);                                                                                 \
-      __syncthreads();                 /* drains this wave's DMA (vmcnt) and fences the buffer swap */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's DMA has landed (explicit: never rely on hipcc) */ \
+      __syncthreads();                 /* ... and so has everybody else's; fences the buffer swap */ \
     }
     int kt = 0;
     int knext = kbeg + BK;
@@ -523,6 +542,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 
   // epilogue through the wave's slice of the (idle) LDS stages: see epilogue_lds
   __syncthreads();                                     // every wave is done with the fragment reads / the last DMA
+#ifdef OFA_EXP_NOEPI
+  if (g.alpha == 12345.f)
+#endif
   {
     const bool split = gridDim.y > 1;
     constexpr int REGION = ((GLDS ? 2 * (EA + EB) * 2 : 2 * (GA::ELEMS + GB::ELEMS) * 2) / (WM * WN)) & ~1023;
@@ -701,6 +723,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
   })
   if (nk > 0) {
     dma(sA0, sB0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (nk > 1) dma(sA1, sB1);
     BIG_ISSUE(0, 0);
@@ -713,7 +736,13 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
       BIG_WAIT(1); BIG_SB; BIG_SLICE(1, 2);
       BIG_WAIT(0); BIG_SB; BIG_SLICE(0, 3);
       BIG_WAIT(1);
-      if (kt + 1 < nk) __syncthreads();   // tile kt+1 has landed (vmcnt) and every wave is done reading this stage
+      if (kt + 1 < nk) {
+        // tile kt+1 has landed and every wave is done reading this stage.  The vmcnt wait is explicit: with the DMA
+        // builtins inside conditional blocks hipcc emitted only lgkmcnt(0) in front of this barrier (seen in the ISA;
+        // wrong results under load, when a piece takes longer than one K-step to land)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
 #ifndef OFA_EXP_NODMA
       const bool more2 = kt + 2 < nk;     // refill the retired stage with tile kt+2 ...
 #else
@@ -771,7 +800,11 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
     const bool split = gridDim.y > 1;
     constexpr int REGION = 4 * STAGE * 2 / 4;          // 32 KiB per wave
     unsigned char* wl = smem_raw + wave * REGION;
+#ifdef OFA_EXP_SAMEOUT
+    const int m_w = wm * TM * 32, n_w = wn * TN * 32;
+#else
     const int m_w = m0 + wm * TM * 32, n_w = n0 + wn * TN * 32;
+#endif
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;

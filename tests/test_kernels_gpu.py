@@ -72,8 +72,9 @@ def test_gemm_big_tile(K, M, N, K_, ta, tb):
     b = torch.randn((N, K_) if tb else (K_, N), device=DEV).bfloat16()
     bias = torch.randn(N, device=DEV).bfloat16()
     ref = ((a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float()) + bias.float()) * 0.5
-    out = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5)
-    assert rel(out, ref) < 1e-2
+    for _ in range(3):            # repeat: a missing DMA wait only shows under load (warm caches, all CUs streaming)
+        out = K.gemm(a, b, ta, tb, bias=bias, alpha=0.5)
+        assert rel(out, ref) < 1e-2
     acc = torch.ones(M, N, device=DEV, dtype=torch.bfloat16)
     K.gemm(a, b, ta, tb, out=acc, accumulate=True)
     assert rel(acc.float() - 1, ref * 2 - bias.float()) < 2e-2

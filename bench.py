@@ -164,6 +164,23 @@ def cpu_baseline(args):
                       f"{n} timed steps after 1 warm-up, torch.set_num_threads({cores})", "s_per_step": dt}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the MFMA GEMM kernels from the committed rocprofv3 PMC passes (profiles/, produced by
+    scratch/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on gfx950)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    try:
+        rows = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    n = tot = 0.0
+    for name, r in rows.items():
+        if "gemm_mfma_kernel" in name or "gemm_big_kernel" in name:
+            n += r["launches"]
+            tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
+    return (tot / n, "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA GEMM "
+                     "instantiations of the eager cfg-2 step)") if n else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,7 +257,8 @@ def main():
                                    cfg.encoder.layers, cfg.decoder.layers, 257 + Ts_text, Tt, len(d))
         step_flops = 3 * fwd * args.batch                          # backward = 2x forward
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+        traffic, traffic_src = pmc_traffic()
+        roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "ofa::gemm_mfma_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
                 "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS}
         if prof and prof["time_ms"] > 0:
@@ -249,8 +267,10 @@ def main():
                          "avg_launch_us": prof["time_ms"] * 1e3 / max(prof["launches"], 1),
                          "gemm_ms_per_step": prof["time_ms"] / args.profile_gemm,
                          "gemm_flops_per_step": prof["flops"] / args.profile_gemm,
-                         "how": "HIP events around every MFMA-GEMM launch on the launch stream, instrumented step(s) "
-                                "run right after the timed region"})
+                         "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
+                         "how": f"instrumented eager step(s) right after the timed region: every MFMA-GEMM call of the step "
+                                f"is re-launched {prof['reps']}x back to back between two HIP events on its launch stream "
+                                f"(duration = elapsed/{prof['reps']}; includes the split-K reduce kernel where one is used)"})
         else:
             roof.update({"achieved": step_tflops, "frac": step_tflops / PEAK_BF16_TFLOPS})
         out = {

@@ -285,6 +285,35 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
   const int hi = lane >> 5, ml = lane & 31;
   const int ipass = region_bytes / (32 * ROWB) < TM ? region_bytes / (32 * ROWB) : TM;   // 32-row tiles per pass
   const bool vec16 = F32 || ((ldc & 7) == 0);
+  // column bias of the 4*TN quads this lane owns: loaded ONCE, up front (a load inside the quad loop costs a full
+  // memory round trip per quad -- hipcc waits for each one in place)
+  float bcol[TN][4][4];
+  const bool has_bcol = !RAW && (g.flags & OFA_GEMM_BIAS_COL);
+  if (has_bcol) {
+    uint2 braw[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n_w + j * 32 + 8 * q + 4 * hi;
+        braw[j][q] = n < g.N ? *reinterpret_cast<const uint2*>((const bf16_t*)g.bias + n) : make_uint2(0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bcol[j][q][0] = __uint_as_float(braw[j][q].x << 16); bcol[j][q][1] = __uint_as_float(braw[j][q].x & 0xffff0000u);
+        bcol[j][q][2] = __uint_as_float(braw[j][q].y << 16); bcol[j][q][3] = __uint_as_float(braw[j][q].y & 0xffff0000u);
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bcol[j][q][e] = 0.f;
+  }
+  const float alpha = RAW ? 1.0f : g.alpha;
   for (int ip0 = 0; ip0 < TM; ip0 += ipass) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -301,19 +330,9 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nloc = j * 32 + 8 * q + 4 * hi;
-          float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          if (!RAW) {
-            if (g.flags & OFA_GEMM_BIAS_COL) {
-              const int n = n_w + nloc;
-              if (n < g.N) {
-                const uint2 b = *reinterpret_cast<const uint2*>((const bf16_t*)g.bias + n);
-                v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
-                v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
-              }
-            }
+          float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (v[e] + brow) * g.alpha;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * q + e] + (bcol[j][q][e] + brow)) * alpha;
           if (F32) {
             *reinterpret_cast<float4*>(wl + mloc * ROWB + (((nloc >> 2) ^ sw) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
@@ -630,6 +649,13 @@ template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                        float* __restrict__ ws) {
   constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
+#ifdef OFA_EXP_STAMP
+  unsigned long long stamp[6];
+#define STAMP(i) stamp[i] = __builtin_readcyclecounter()
+#else
+#define STAMP(i)
+#endif
+  STAMP(0);
   static_assert(A_KMAJ || BM == 256, "m-major tiles are 256 wide (swizzle)");
   static_assert(B_KMAJ || BN == 256, "m-major tiles are 256 wide (swizzle)");
   constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
@@ -683,6 +709,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
     glds_issue<NT, NVB>(pb, stepB, db, wave_u);
     knext += BK;
   };
+  STAMP(1);
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
   BigAddr<BM, A_KMAJ> fax;
   BigAddr<BN, B_KMAJ> faw;
@@ -792,7 +819,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
 #undef BIG_WAIT
 #undef BIG_ISSUE
 
+  STAMP(2);
   __syncthreads();                                     // every wave is done with the fragment reads
+  STAMP(3);
 #ifdef OFA_EXP_NOEPI
   if (g.alpha == 12345.f)
 #endif
@@ -815,6 +844,15 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
       epilogue_lds<TM, TN, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
+  STAMP(4);
+#ifdef OFA_EXP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(5);
+  if (tid == 0 && ws) {
+    unsigned long long* o = (unsigned long long*)ws + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+  }
+#endif
 }
 
 template <bool OUT_F32>

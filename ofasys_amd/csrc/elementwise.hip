@@ -122,24 +122,98 @@ __global__ __launch_bounds__(256) void embedding_mark_kernel(const int64_t* __re
   }
 }
 
-// dweight[v] += sum_{i : ids[i]==v} dout[i]   -- one wave per vocabulary row; the wave sweeps the id list 64 at a time,
-// ballots the matches and accumulates the matching rows in increasing position order (deterministic, no atomics).
-template <typename T>
+// dweight[v] += sum_{i : ids[i]==v} dout[i], deterministic, no atomics.  Wave (v, s) sweeps slice s of the id list 64 ids
+// at a time, ballots the matches and adds the matching rows (16-byte loads) in increasing position order.  Big tables
+// (vocabulary: few hits per row) use one slice and add straight into dweight; small tables (positions, token types:
+// thousands of hits per row, which one wave would walk serially) are cut into S slices whose fp32 partial rows are
+// folded in slice order by embedding_fold_kernel.  Rows that do not occur are skipped through a presence byte.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
-                                                            T* __restrict__ dw, int64_t n, int D, int64_t V,
-                                                            int64_t padding_idx, const uint8_t* __restrict__ present) {
+                                                            T* __restrict__ dw, float* __restrict__ part, int64_t n, int D,
+                                                            int64_t V, int64_t padding_idx,
+                                                            const uint8_t* __restrict__ present, int S) {
+  constexpr int N = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sl = blockIdx.y;
   if (v >= V || v == padding_idx) return;
   if (present && !present[v]) return;      // most vocabulary rows do not occur in a batch: skip their scan
+  float acc[NV][N];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[i][j] = 0.f;
+  const int64_t per = ((n + S - 1) / S + 63) / 64 * 64;
+  const int64_t lo = sl * per, hi = lo + per < n ? lo + per : n;
+  bool any = false;
+  for (int64_t base = lo; base < hi; base += 64) {
+    const int64_t idx = base + lane;
+    const bool hit = idx < hi && ids[idx] == v;
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      any = true;
+      const T* row = dout + (base + src) * D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * N;
+        if (c < D) {
+          float x[N];
+          load_vec<T>(row + c, x);
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[i][j] += x[j];
+        }
+      }
+    }
+  }
+  if (S == 1) {
+    if (!any) return;
+    T* wr = dw + v * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * N;
+      if (c < D) {
+        float o[N];
+        load_vec<T>(wr + c, o);
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] += acc[i][j];
+        store_vec<T>(wr + c, o);
+      }
+    }
+  } else {                                 // (zeros too: the fold reads every slice of a present row)
+    float* pr = part + ((int64_t)sl * V + v) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * N;
+      if (c < D)
+#pragma unroll
+        for (int j = 0; j < N; ++j) pr[c + j] = acc[i][j];
+    }
+  }
+}
+
+// narrow / unaligned tables (rel-pos bias tables are [n_rel, heads]): element-wise variant of the same sweep
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_scalar_kernel(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                                   T* __restrict__ dw, float* __restrict__ part, int64_t n,
+                                                                   int D, int64_t V, int64_t padding_idx,
+                                                                   const uint8_t* __restrict__ present, int S) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sl = blockIdx.y;
+  if (v >= V || v == padding_idx) return;
+  if (present && !present[v]) return;
   constexpr int MAXC = 32;                 // columns per lane held in registers: D <= 2048
   float acc[MAXC];
 #pragma unroll
   for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+  const int64_t per = ((n + S - 1) / S + 63) / 64 * 64;
+  const int64_t lo = sl * per, hi = lo + per < n ? lo + per : n;
   bool any = false;
-  for (int64_t base = 0; base < n; base += 64) {
+  for (int64_t base = lo; base < hi; base += 64) {
     const int64_t idx = base + lane;
-    const bool hit = idx < n && ids[idx] == v;
+    const bool hit = idx < hi && ids[idx] == v;
     unsigned long long m = __ballot(hit);
     while (m) {
       const int src = __ffsll((long long)m) - 1;
@@ -153,13 +227,27 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict_
       }
     }
   }
-  if (any) {
-    T* wr = dw + v * D;
+  if (S == 1 && !any) return;
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-      const int c = j * 64 + lane;
-      if (c < D) st1<T>(wr + c, ld1<T>(wr + c) + acc[j]);
+  for (int j = 0; j < MAXC; ++j) {
+    const int c = j * 64 + lane;
+    if (c < D) {
+      if (S == 1) st1<T>(dw + v * D + c, ld1<T>(dw + v * D + c) + acc[j]);
+      else part[((int64_t)sl * V + v) * D + c] = acc[j];
     }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fold_kernel(const float* __restrict__ part, T* __restrict__ dw, int D,
+                                                             int64_t V, int64_t padding_idx,
+                                                             const uint8_t* __restrict__ present, int S) {
+  const int64_t v = blockIdx.x;
+  if (v == padding_idx || (present && !present[v])) return;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[((int64_t)s * V + v) * D + c];
+    st1<T>(dw + v * D + c, ld1<T>(dw + v * D + c) + a);
   }
 }
 
@@ -337,25 +425,58 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
   return check_launch("embedding_fwd");
 }
 
+// slices for a table of V rows: keep S*V partial rows <= 8192 (<= 64 slices)
+extern "C" int ofa_embedding_bwd_slices(int64_t V) {
+  if (V <= 0) return 1;
+  int64_t s = 8192 / V;
+  return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
 extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
-                                 int64_t padding_idx, uint8_t* present_ws, int dtype, void* stream) {
+                                 int64_t padding_idx, uint8_t* present_ws, float* slice_ws, int dtype, void* stream) {
   OFA_DT_CHECK("embedding_bwd");
   OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && dout && ids && dweight, OFA_ERR_INVALID, "embedding_bwd: bad argument");
+  const int vecn = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(D <= 2048, OFA_ERR_UNSUPPORTED, "embedding_bwd: D=%d exceeds 2048", D);
+  const bool vec_ok = D % vecn == 0 && D <= 64 * vecn * 4 && (((uintptr_t)dout | (uintptr_t)dweight) & 15) == 0;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (present_ws) {                                   // optional V-byte scratch: mark the rows that occur
     (void)hipMemsetAsync(present_ws, 0, (size_t)V, st);
     hipLaunchKernelGGL(embedding_mark_kernel, dim3(grid_for(n)), dim3(256), 0, st, ids, present_ws, n, V);
   }
-  dim3 grid((unsigned)((V + 3) / 4)), block(256);
+  const int S = slice_ws ? ofa_embedding_bwd_slices(V) : 1;
+  const int nv = cdiv(D, 64 * vecn);
+  dim3 grid((unsigned)((V + 3) / 4), S), block(256);
+#define EMB_LAUNCH(T, NV)                                                                                               \
+  hipLaunchKernelGGL((embedding_bwd_kernel<T, NV>), grid, block, 0, st, (const T*)dout, ids, (T*)dweight, slice_ws, n, D, V, \
+                     padding_idx, (const uint8_t*)present_ws, S)
+#define EMB_CASE(T)                  \
+  do {                               \
+    if (nv <= 1) EMB_LAUNCH(T, 1);   \
+    else if (nv <= 2) EMB_LAUNCH(T, 2); \
+    else EMB_LAUNCH(T, 4);           \
+  } while (0)
+  if (!vec_ok) {
+    if (dtype == OFA_F32)
+      hipLaunchKernelGGL((embedding_bwd_scalar_kernel<float>), grid, block, 0, st, (const float*)dout, ids, (float*)dweight,
+                         slice_ws, n, D, V, padding_idx, (const uint8_t*)present_ws, S);
+    else
+      hipLaunchKernelGGL((embedding_bwd_scalar_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids,
+                         (bf16_t*)dweight, slice_ws, n, D, V, padding_idx, (const uint8_t*)present_ws, S);
+  } else if (dtype == OFA_F32) EMB_CASE(float);
+  else EMB_CASE(bf16_t);
+#undef EMB_CASE
+#undef EMB_LAUNCH
+  int rc = check_launch("embedding_bwd");
+  if (rc || S == 1) return rc;
   if (dtype == OFA_F32)
-    hipLaunchKernelGGL((embedding_bwd_kernel<float>), grid, block, 0, st, (const float*)dout, ids, (float*)dweight, n, D, V,
-                       padding_idx, (const uint8_t*)present_ws);
+    hipLaunchKernelGGL((embedding_fold_kernel<float>), dim3((unsigned)V), dim3(256), 0, st, slice_ws, (float*)dweight, D, V,
+                       padding_idx, (const uint8_t*)present_ws, S);
   else
-    hipLaunchKernelGGL((embedding_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids, (bf16_t*)dweight, n, D,
-                       V, padding_idx, (const uint8_t*)present_ws);
-  return check_launch("embedding_bwd");
+    hipLaunchKernelGGL((embedding_fold_kernel<bf16_t>), dim3((unsigned)V), dim3(256), 0, st, slice_ws, (bf16_t*)dweight, D, V,
+                       padding_idx, (const uint8_t*)present_ws, S);
+  return check_launch("embedding_fold");
 }
 
 extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype,

@@ -308,6 +308,20 @@ def test_embedding(K, dtype):
     assert torch.equal(dw, dw2)      # deterministic
 
 
+@pytest.mark.parametrize("V,n,D", [(2, 5000, 768), (1026, 6112, 768), (51265, 6112, 768), (9000, 300, 264), (511, 40000, 12), (70, 900, 4)])
+def test_embedding_bwd_tables(K, V, n, D):
+    """Vocabulary-sized tables (few hits per row, presence flags) and tiny ones (token types / positions: thousands of
+    hits per row, reduced in slices); accumulates into an existing gradient."""
+    torch.manual_seed(17)
+    ids = torch.randint(0, V, (n,), device=DEV)
+    dout = torch.randn(n, D, device=DEV).bfloat16()
+    base = torch.randn(V, D, device=DEV).bfloat16()
+    dw = K.embedding_bwd(dout, ids, V, padding_idx=None, dweight=base.clone())
+    ref = base.float().index_add(0, ids, dout.float())
+    assert rel(dw, ref) < 2e-2
+    assert torch.equal(dw, K.embedding_bwd(dout, ids, V, padding_idx=None, dweight=base.clone()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_patch_embed_im2col(K, dtype):
     torch.manual_seed(8)

@@ -42,7 +42,8 @@ enum {
   OFA_GEMM_FORCE_SIMPLE = 8, /* use the exact-fp32-FMA VALU kernel even for bf16 (tests)         */
   OFA_GEMM_OUT_F32 = 16,   /* bf16 inputs, fp32 output                                           */
   OFA_GEMM_A_KPAD_ZERO = 32, /* caller guarantees A[m][K..roundup8(K)) == 0 (padded logits-gradient rows) */
-  OFA_GEMM_NO_LDS_DMA = 64  /* force the register-staged loop (tests / A-B measurements)              */
+  OFA_GEMM_NO_LDS_DMA = 64, /* force the register-staged loop (tests / A-B measurements)              */
+  OFA_GEMM_DEFER_REDUCE = 128 /* split-K: leave the fp32 partials in ws, the caller folds them (ofa_fold_batched) */
 };
 
 int ofa_version(void);
@@ -199,6 +200,29 @@ int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* 
 int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
                   const float* coef, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, int dtype, void* stream);
+
+/* ---- batched fold of fp32 partial rows: out[c] (+)= alpha * sum_{s < nslots} part[s*stride + c], c < cols, for up to
+ * any number of jobs in as few launches as possible (56 jobs per launch).  Producers that were asked to leave their
+ * partials in place (ofa_layernorm_bwd / ofa_gelu_layernorm_bwd / ofa_colsum with accumulate == OFA_DEFER_FOLD,
+ * ofa_gemm with OFA_GEMM_DEFER_REDUCE) are finished by this call; slot order is fixed, results are identical to the
+ * immediate reduce.  `jobs` is a HOST array. */
+typedef struct ofa_fold_job {
+  const float* part;   /* device fp32 partial rows */
+  void* out;           /* device output, fp32 or bf16 */
+  int64_t cols;
+  int64_t stride;      /* elements between consecutive partial rows (>= cols) */
+  int32_t nslots;
+  int32_t accumulate;  /* != 0: added to the current contents of out */
+  float alpha;
+  int32_t out_dtype;   /* OFA_F32 / OFA_BF16 */
+} ofa_fold_job;
+int ofa_fold_batched(const ofa_fold_job* jobs, int njobs, void* stream);
+#define OFA_DEFER_FOLD 2
+/* partial-row count (`nslots`) the corresponding call writes; ws layouts: LayerNorm [q][nslots][cols] with q = dgamma,
+ * dbeta(, dbias); colsum [nslots][cols]; split-K GEMM [splits][M][(N+3)&~3] (ofa_gemm_splits == 1: no partials). */
+int ofa_layernorm_bwd_slots(int64_t rows, int cols, int dtype, int gelu);
+int ofa_colsum_slots(int64_t rows);
+int ofa_gemm_splits(int M, int N, int K, int transA, int transB, int batch, int flags, int dtype, int64_t ws_bytes);
 
 #ifdef __cplusplus
 }

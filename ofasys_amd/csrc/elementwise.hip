@@ -497,23 +497,28 @@ extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H,
 
 extern "C" int ofa_colsum_ws_floats(int cols) { return 128 * cols; }
 
+extern "C" int ofa_colsum_slots(int64_t rows) {
+  int64_t groups = (rows + 63) / 64;
+  return (int)(groups < 1 ? 1 : (groups > 128 ? 128 : groups));
+}
+
 extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
                           int accumulate, int dtype, int out_dtype, void* stream) {
   OFA_DT_CHECK("colsum");
   OFA_REQUIRE(out_dtype == OFA_F32 || out_dtype == OFA_BF16, OFA_ERR_INVALID, "colsum: bad out dtype %d", out_dtype);
-  OFA_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && x && out && ws, OFA_ERR_INVALID, "colsum: bad argument");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && x && (out || accumulate == OFA_DEFER_FOLD) && ws, OFA_ERR_INVALID,
+              "colsum: bad argument");
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(cols % n == 0 && ld % n == 0, OFA_ERR_UNSUPPORTED, "colsum: cols=%d / ld not vectorizable", cols);
   hipStream_t st = (hipStream_t)stream;
-  int groups = (int)((rows + 63) / 64);
-  groups = groups < 1 ? 1 : (groups > 128 ? 128 : groups);
+  const int groups = ofa_colsum_slots(rows);
   dim3 grid(cdiv(cols / n, 32), groups), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, ws, rows, cols, ld);
   else
     hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ws, rows, cols, ld);
   int rc = check_launch("colsum_partial");
-  if (rc) return rc;
+  if (rc || accumulate == OFA_DEFER_FOLD) return rc;          // deferred: the caller folds ws (ofa_fold_batched)
   if (out_dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_final_kernel<float>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (float*)out,
                        cols, groups, alpha, accumulate);

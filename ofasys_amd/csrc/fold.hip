@@ -1,0 +1,154 @@
+// Batched "fold the fp32 partial rows" pass.
+//
+// LayerNorm backward (dgamma / dbeta / fused bias column sums), bias-gradient column sums and split-K weight-gradient
+// GEMMs all end with the same tiny step: out[c] (+)= alpha * sum_s part[s*stride + c].  Each used to be its own launch
+// -- ~320 launches of 5-9 us per train step (2.1 ms of an 18 ms step), every one of them at the launch-latency floor.
+// Their results are gradients that nobody reads before the end of backward, so the producers can leave their partials
+// in place and ONE launch folds up to 56 of them (job descriptors travel by value in the kernel arguments; block ->
+// (job, 128-column chunk) through a prefix table).  Summation order is fixed (slot order), so results are bit-identical
+// to the per-call reduce kernels.  HBM-bound; algorithmic bytes = sum over jobs of nslots*cols*4.
+#include "common.h"
+
+namespace ofa {
+
+constexpr int FOLD_MAX_JOBS = 56;
+
+struct FoldJobs {
+  const float* part[FOLD_MAX_JOBS];
+  void* out[FOLD_MAX_JOBS];
+  int64_t cols[FOLD_MAX_JOBS];
+  int64_t stride[FOLD_MAX_JOBS];
+  float alpha[FOLD_MAX_JOBS];
+  int nslots[FOLD_MAX_JOBS];
+  unsigned block0[FOLD_MAX_JOBS + 1];   // first block of each job
+  unsigned char flags[FOLD_MAX_JOBS];   // bit 0: accumulate, bit 1: out is fp32 (else bf16)
+  int njobs;
+};
+
+__device__ __forceinline__ void fold_store(const FoldJobs& J, int j, int64_t c, int64_t cols, const float (&t)[4]) {
+  const float alpha = J.alpha[j];
+  const bool acc = J.flags[j] & 1, f32 = J.flags[j] & 2;
+  if (c + 4 <= cols && (cols & 3) == 0) {                       // whole quad, aligned (out + c is 8 / 16-byte aligned)
+    if (f32) {
+      float4* o = reinterpret_cast<float4*>((float*)J.out[j] + c);
+      float4 v = make_float4(t[0] * alpha, t[1] * alpha, t[2] * alpha, t[3] * alpha);
+      if (acc) { const float4 u = *o; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+      *o = v;
+    } else {
+      uint2* o = reinterpret_cast<uint2*>((bf16_t*)J.out[j] + c);
+      float v[4] = {t[0] * alpha, t[1] * alpha, t[2] * alpha, t[3] * alpha};
+      if (acc) {
+        const uint2 u = *o;
+        v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+        v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+      }
+      uint2 w;
+      w.x = pack_bf16x2(v[0], v[1]);
+      w.y = pack_bf16x2(v[2], v[3]);
+      *o = w;
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (c + e >= cols) break;
+    const float v = t[e] * alpha;
+    if (f32) {
+      float* o = (float*)J.out[j] + c + e;
+      *o = acc ? *o + v : v;
+    } else {
+      bf16_t* o = (bf16_t*)J.out[j] + c + e;
+      *o = f2bf(acc ? bf2f(*o) + v : v);
+    }
+  }
+}
+
+// Two shapes of job: TALL (many partial rows, few columns: LayerNorm 256 x 768, column sums 128 x 768) -- a block is
+// 32 column-quads x 8 slot-lanes over 128 columns; WIDE (split-K slabs: 3..16 rows of 10^5..10^6 columns) -- a block is
+// 256 column-quads over 1024 columns, each thread walking the slots itself.  flags bit 2 selects WIDE.
+__global__ __launch_bounds__(256) void fold_batched_kernel(FoldJobs J) {
+  __shared__ float4 red[8][32];
+  int j = 0;
+  while (j + 1 < J.njobs && blockIdx.x >= J.block0[j + 1]) ++j;       // uniform scan over <= 56 entries
+  const int64_t chunk = blockIdx.x - J.block0[j];
+  const int64_t cols = J.cols[j], stride = J.stride[j];
+  const float* __restrict__ p = J.part[j];
+  const int ns = J.nslots[j];
+  const bool vec = (cols & 3) == 0 && (stride & 3) == 0;
+  if (J.flags[j] & 4) {
+    const int64_t c = chunk * 1024 + threadIdx.x * 4;
+    if (c >= cols) return;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      for (int s = 0; s < ns; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * stride + c);
+        t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
+      }
+    } else {
+      for (int s = 0; s < ns; ++s)
+        for (int e = 0; e < 4 && c + e < cols; ++e) t[e] += p[(int64_t)s * stride + c + e];
+    }
+    fold_store(J, j, c, cols, t);
+    return;
+  }
+  const int q = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t c = chunk * 128 + q * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    if (vec) {
+      for (int s = sl; s < ns; s += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * stride + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    } else {
+      for (int s = sl; s < ns; s += 8) {
+        const float* r = p + (int64_t)s * stride + c;
+        a.x += r[0];
+        if (c + 1 < cols) a.y += r[1];
+        if (c + 2 < cols) a.z += r[2];
+        if (c + 3 < cols) a.w += r[3];
+      }
+    }
+  }
+  red[sl][q] = a;
+  __syncthreads();
+  if (sl == 0 && c < cols) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {            // fixed order: lane r holds slots r, r+8, ...
+      t[0] += red[r][q].x; t[1] += red[r][q].y; t[2] += red[r][q].z; t[3] += red[r][q].w;
+    }
+    fold_store(J, j, c, cols, t);
+  }
+}
+
+}  // namespace ofa
+using namespace ofa;
+
+extern "C" int ofa_fold_batched(const ofa_fold_job* jobs, int njobs, void* stream) {
+  OFA_REQUIRE(njobs >= 0 && (njobs == 0 || jobs), OFA_ERR_INVALID, "fold_batched: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < njobs; base += FOLD_MAX_JOBS) {
+    FoldJobs J;
+    const int n = njobs - base < FOLD_MAX_JOBS ? njobs - base : FOLD_MAX_JOBS;
+    J.njobs = n;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      const ofa_fold_job& b = jobs[base + i];
+      OFA_REQUIRE(b.part && b.out && b.cols > 0 && b.nslots > 0 && b.stride >= b.cols, OFA_ERR_INVALID, "fold_batched: bad job %d", base + i);
+      OFA_REQUIRE(b.out_dtype == OFA_F32 || b.out_dtype == OFA_BF16, OFA_ERR_INVALID, "fold_batched: bad out dtype %d", b.out_dtype);
+      J.part[i] = b.part; J.out[i] = b.out; J.cols[i] = b.cols; J.stride[i] = b.stride; J.alpha[i] = b.alpha;
+      J.nslots[i] = b.nslots;
+      const bool wide = b.nslots <= 16;
+      J.flags[i] = (unsigned char)((b.accumulate ? 1 : 0) | (b.out_dtype == OFA_F32 ? 2 : 0) | (wide ? 4 : 0));
+      J.block0[i] = blocks;
+      blocks += (unsigned)(wide ? (b.cols + 1023) / 1024 : (b.cols + 127) / 128);
+    }
+    J.block0[n] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(fold_batched_kernel, dim3(blocks), dim3(256), 0, st, J);
+    int rc = check_launch("fold_batched");
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -946,9 +946,11 @@ static void launch_big_shape(const GemmArgs& g, int batch, int tm, int splits, i
   launch_big<4, 4, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
 }
 
-int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
-  GemmArgs g = g_in;
-  g.b_krows = g.K;
+struct GemmPlan { int wm, wn, big_tm, splits, ksplit, K; };
+
+// tile / split-K plan of one product (shared by the launcher and ofa_gemm_splits, which tells a caller that defers the
+// split-K reduce how many partial slabs the launch will write)
+static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) {
   // zero-padded contraction (vocabulary-logit gradients, lda padded to a multiple of 64): run the LDS-DMA loop over the
   // padded K; A's tail columns are zeros, B's rows past K are clamped reads
   if ((g.flags & OFA_GEMM_A_KPAD_ZERO) && !g.transA && !g.transB && (g.K % BK) != 0 && ((g.K + BK - 1) / BK) * BK <= g.lda)
@@ -958,7 +960,7 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
   const int64_t t22 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
   const int64_t t12 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 128) * batch;
   const int64_t t11 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) * batch;
-  int maxs = ws ? g.K / 256 : 1;                 // every split keeps >= 4 K-tiles
+  int maxs = has_ws ? g.K / 256 : 1;                 // every split keeps >= 4 K-tiles
   maxs = maxs < 1 ? 1 : (maxs > 32 ? 32 : maxs);
   const int64_t want = 384;
   int wm, wn;
@@ -1001,6 +1003,17 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
     ksplit = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = cdiv(g.K, ksplit);
   }
+  return GemmPlan{wm, wn, big_tm, splits, ksplit, g.K};
+}
+
+int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes) { return gemm_plan(g, batch, ws_bytes > 0, ws_bytes).splits; }
+
+int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+  GemmArgs g = g_in;
+  g.b_krows = g.K;
+  const GemmPlan pl = gemm_plan(g, batch, ws != nullptr, ws_bytes);
+  g.K = pl.K;
+  const int wm = pl.wm, wn = pl.wn, big_tm = pl.big_tm, splits = pl.splits, ksplit = pl.ksplit;
   const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
 #define GEMM_DISPATCH(AK, BKM, OF)                                                                      \
   do {                                                                                                  \
@@ -1014,7 +1027,7 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
 #undef GEMM_DISPATCH
   int rc = check_launch("gemm_mfma");
   if (rc) return rc;
-  if (splits > 1) {
+  if (splits > 1 && !(g.flags & OFA_GEMM_DEFER_REDUCE)) {
     const int64_t quads = (int64_t)g.M * ((g.N + 3) / 4);
     dim3 grid((unsigned)((quads + 255) / 256 > 2048 ? 2048 : (quads + 255) / 256), batch), block(256);
     if (of) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, block, 0, st, g, (const float*)ws, splits);
@@ -1027,6 +1040,14 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
 }  // namespace ofa
 
 using namespace ofa;
+
+extern "C" int ofa_gemm_splits(int M, int N, int K, int transA, int transB, int batch, int flags, int dtype, int64_t ws_bytes) {
+  if (dtype != OFA_BF16 || (flags & OFA_GEMM_FORCE_SIMPLE) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 1;
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.transA = transA; g.transB = transB; g.flags = flags;
+  g.lda = transA ? M : K; g.ldb = transB ? K : N; g.ldc = N;
+  return gemm_mfma_splits(g, batch, ws_bytes);
+}
 
 extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA,
                         int transB, int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB,

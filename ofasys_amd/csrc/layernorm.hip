@@ -254,6 +254,12 @@ static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y,
   return check_launch("layernorm_fwd");
 }
 
+static int ln_bwd_wpr(int cols, int n, bool gelu) {
+  int wpr = 1;
+  while (wpr < 8 && cdiv(cols / wpr, 64 * n) > (gelu ? 1 : 2) && (cols % (wpr * 2 * n)) == 0) wpr *= 2;
+  return wpr;
+}
+
 template <typename T, bool GELU>
 static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
                            void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows, int cols, int accumulate,
@@ -262,8 +268,7 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
   // waves per row: keep <= 2 vectors per lane (1 with GELU, whose extra gelu'/dbias registers would otherwise spill at
   // the 128-VGPR cap of a 1024-thread block: 169 us instead of ~70 for the 14336 x 3072 FFN LayerNorm) when the row
   // can be split evenly
-  int wpr = 1;
-  while (wpr < 8 && cdiv(cols / wpr, 64 * N) > (GELU ? 1 : 2) && (cols % (wpr * 2 * N)) == 0) wpr *= 2;
+  const int wpr = ln_bwd_wpr(cols, N, GELU);
   const int nv = cdiv(cols / wpr, 64 * N);
   const int rpb = LN_WPB / wpr;
   int64_t nblk = (rows + rpb - 1) / rpb;
@@ -287,7 +292,7 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
 #undef LN_CASE
 #undef LN_LAUNCH
   int rc = check_launch("layernorm_bwd");
-  if (rc) return rc;
+  if (rc || accumulate == OFA_DEFER_FOLD) return rc;          // deferred: the caller folds ws (ofa_fold_batched)
   hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 32), want_dbias ? 3 : 2), dim3(256), 0, st,
                      (const float*)ws, (T*)dgamma, (T*)dbeta, (T*)dbias, cols, (int)nblk, accumulate);
   return check_launch("layernorm_bwd_reduce");
@@ -313,6 +318,12 @@ static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
 using namespace ofa;
 
 extern "C" int ofa_layernorm_bwd_ws_rows(void) { return 3 * LN_BWD_BLOCKS; }
+
+extern "C" int ofa_layernorm_bwd_slots(int64_t rows, int cols, int dtype, int gelu) {
+  const int rpb = LN_WPB / ln_bwd_wpr(cols, dtype == OFA_F32 ? 4 : 8, gelu != 0);
+  int64_t nblk = (rows + rpb - 1) / rpb;
+  return (int)(nblk < 1 ? 1 : (nblk > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nblk));
+}
 
 extern "C" int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                                  int64_t rows, int cols, float eps, int dtype, void* stream) {

@@ -3,6 +3,8 @@
 Each wrapper allocates outputs with torch (plumbing: device memory + streams), checks layout, and enqueues the HIP
 kernel on torch's current stream.  Everything here requires GPU tensors; nothing falls back to torch math.
 """
+import ctypes
+
 import torch
 
 from .lib import (BF16, F32, GEMM_ACCUM, GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_FORCE_SIMPLE, GEMM_OUT_F32, OfaError,
@@ -20,6 +22,49 @@ def workspace(nbytes, device, tag="ws"):
         buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+class _FoldJob(ctypes.Structure):
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("cols", ctypes.c_int64), ("stride", ctypes.c_int64),
+                ("nslots", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("alpha", ctypes.c_float),
+                ("out_dtype", ctypes.c_int32)]
+
+
+DEFER_FOLD = 2            # OFA_DEFER_FOLD
+GEMM_DEFER_REDUCE = 128   # OFA_GEMM_DEFER_REDUCE
+
+
+class FoldQueue:
+    """Deferred `out (+)= alpha * sum_s part[s]` reductions (LayerNorm dgamma/dbeta/dbias, bias column sums, split-K weight
+    gradients): producers leave their fp32 partial rows in a private buffer and register a job; `flush()` folds up to 56
+    jobs per launch (csrc/fold.hip) instead of one 5-9 us launch each."""
+
+    # partial rows are folded while they still sit in the 256 MiB Infinity Cache: deferring a whole backward pass worth
+    # of split-K slabs (3.6 GB on cfg-2) sends them to HBM and back and costs more than the saved launches
+    MAX_PENDING_BYTES = 96 << 20
+
+    def __init__(self):
+        self.jobs, self.keep, self.bytes = [], [], 0
+
+    def add(self, part, part_off, out, cols, stride, nslots, alpha=1.0, accumulate=True, flush_ok=True):
+        assert part.dtype == torch.float32 and out.is_contiguous()
+        self.jobs.append(_FoldJob(part.data_ptr() + part_off * 4, out.data_ptr(), cols, stride, nslots, int(accumulate),
+                                  float(alpha), dtype_code(out)))
+        self.keep.append((part, out))
+        self.bytes += nslots * stride * 4
+        self.want_flush = self.bytes > self.MAX_PENDING_BYTES
+
+    def flush_if_large(self):
+        """Called by a producer AFTER it has launched the kernel that writes the partial rows it just registered."""
+        if getattr(self, "want_flush", False):
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        arr = (_FoldJob * len(self.jobs))(*self.jobs)
+        lib().call("ofa_fold_batched", ctypes.addressof(arr), len(self.jobs), stream())
+        self.jobs, self.keep, self.bytes, self.want_flush = [], [], 0, False   # (same stream: buffers may be reused)
 
 
 def _u8(mask):
@@ -45,7 +90,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, fuse_gelu=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None, dbias=None, want_dbias=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None, dbias=None, want_dbias=False,
+                  fold=None):
     """dgamma/dbeta given: the parameter gradients are ACCUMULATED into them (gradient arena); else fresh tensors.
     fuse_gelu + (dbias or want_dbias): also the column sums of dx (gradient of the bias of the Linear feeding the GELU)."""
     dy = dy.contiguous()
@@ -60,19 +106,30 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=
             dbias = torch.empty(cols, dtype=gamma.dtype, device=x.device)
     assert dgamma.dtype == x.dtype and dbeta.dtype == x.dtype and (dbias is None or dbias.dtype == x.dtype)
     wsr = lib().cdll.ofa_layernorm_bwd_ws_rows()
-    ws = workspace(wsr * cols * 4, x.device, "ln")
+    if fold is not None and acc:
+        # deferred: keep this call's partial rows [q][nslots][cols] in a private buffer; FoldQueue.flush() reduces them
+        ns = lib().cdll.ofa_layernorm_bwd_slots(rows, cols, dtype_code(x), int(fuse_gelu))
+        nq = 3 if (fuse_gelu and dbias is not None) else 2
+        ws = torch.empty(nq * ns * cols, dtype=torch.float32, device=x.device)
+        for q, o in enumerate((dgamma, dbeta, dbias)[:nq]):
+            fold.add(ws, q * ns * cols, o, cols, cols, ns)
+        acc = DEFER_FOLD
+    else:
+        ws = workspace(wsr * cols * 4, x.device, "ln")
     if fuse_gelu:
         lib().call("ofa_gelu_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
                    ptr(dbeta), ptr(dbias), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
-        return dx, dgamma, dbeta, dbias
-    lib().call("ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-               ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
-    return dx, dgamma, dbeta, None
+    else:
+        lib().call("ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                   ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
+    if acc == DEFER_FOLD:
+        fold.flush_if_large()
+    return dx, dgamma, dbeta, (dbias if fuse_gelu else None)
 
 
 # ------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.0, out=None, accumulate=False,
-         out_f32=False, force_simple=False, a_kpad_zero=False):
+         out_f32=False, force_simple=False, a_kpad_zero=False, fold=None):
     """C = alpha * (op(a) @ op(b) + bias) [+ C].  a, b: 2-D (or 3-D batched) tensors whose last dim is contiguous."""
     assert a.dim() == b.dim() and a.dim() in (2, 3)
     batched = a.dim() == 3
@@ -108,10 +165,24 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
     sa = a.stride(0) if batched else 0
     sb = b.stride(0) if batched else 0
     sc = out.stride(0) if batched else 0
-    ws = workspace(256 << 20, a.device, "gemm")
+    ws = None
+    if fold is not None and bias is None and not batched and ldc == N and N % 4 == 0 and _prof is None:
+        # split-K product whose result nobody reads yet (a weight gradient): leave the fp32 slabs [splits][M][N] in a
+        # private buffer and let the FoldQueue reduce them (+ alpha / accumulate) in its batched launch
+        nsp = lib().cdll.ofa_gemm_splits(M, N, K, int(trans_a), int(trans_b), 1, flags, dt, 256 << 20)
+        if nsp > 1:
+            ws = torch.empty(nsp * M * N, dtype=torch.float32, device=a.device)
+            fold.add(ws, 0, out, M * N, M * N, nsp, alpha, accumulate)
+            flags |= GEMM_DEFER_REDUCE
+            ws_bytes = 256 << 20            # (the planner saw this budget; the slabs themselves fit by construction)
+    if ws is None:
+        ws = workspace(256 << 20, a.device, "gemm")
+        ws_bytes = ws.numel() * 4
     args = ("ofa_gemm", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, batch,
-            sa, sb, sc, 0, 0, 0, 0, float(alpha), flags, dt, ptr(ws), ws.numel() * 4, stream())
+            sa, sb, sc, 0, 0, 0, 0, float(alpha), flags, dt, ptr(ws), ws_bytes, stream())
     lib().call(*args)
+    if flags & GEMM_DEFER_REDUCE:
+        fold.flush_if_large()
     if _prof is not None:
         # roofline timing: the same launch again, _PROF_REPS times back to back between two HIP events (back-to-back so
         # the host dispatch gap of an eager launch is not billed to the kernel); an accumulating call is replayed into a
@@ -430,13 +501,23 @@ def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, b
                dtype_code(grad), stream())
 
 
-def colsum(x, alpha=1.0, out=None, accumulate=False, out_dtype=torch.float32):
-    """Column sums of a 2-D tensor (last dim contiguous): fresh tensor of `out_dtype`, or (accumulated) into `out`."""
+def colsum(x, alpha=1.0, out=None, accumulate=False, out_dtype=torch.float32, fold=None):
+    """Column sums of a 2-D tensor (last dim contiguous): fresh tensor of `out_dtype`, or (accumulated) into `out`.
+    fold (with out): only the row-group partials are computed now, the FoldQueue finishes the sum at its flush."""
     if x.stride(-1) != 1:
         x = x.contiguous()
     rows, cols = x.shape
     if out is None:
         out = torch.empty(cols, dtype=out_dtype, device=x.device)
+        fold = None
+    if fold is not None and out.is_contiguous():
+        ns = lib().cdll.ofa_colsum_slots(rows)
+        ws = torch.empty(ns * cols, dtype=torch.float32, device=x.device)
+        fold.add(ws, 0, out, cols, cols, ns, alpha, accumulate)
+        lib().call("ofa_colsum", ptr(x), ptr(out), ptr(ws), rows, cols, x.stride(0), float(alpha), DEFER_FOLD,
+                   dtype_code(x), dtype_code(out), stream())
+        fold.flush_if_large()
+        return out
     ws = workspace(lib().cdll.ofa_colsum_ws_floats(cols) * 4, x.device, "colsum")
     lib().call("ofa_colsum", ptr(x), ptr(out), ptr(ws), rows, cols, x.stride(0), float(alpha), int(accumulate),
                dtype_code(x), dtype_code(out), stream())

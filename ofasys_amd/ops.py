@@ -87,6 +87,40 @@ def _sink_done(param):
         cb()
 
 
+# Deferred folds (kernels.FoldQueue): when enabled, arena-gradient producers leave their fp32 partial rows in place and the
+# queue reduces them in a handful of batched launches at the end of the backward pass.  Only legal when nothing consumes
+# the gradients earlier -- i.e. not together with bucket all-reduces launched from inside backward.
+class _Fold:
+    queue = None
+    queued = False
+
+
+def defer_reductions(flag):
+    if flag and _Fold.queue is None:
+        _Fold.queue = K.FoldQueue()
+    elif not flag and _Fold.queue is not None:
+        flush_folds()
+        _Fold.queue = None
+
+
+def flush_folds():
+    _Fold.queued = False
+    if _Fold.queue is not None:
+        _Fold.queue.flush()
+
+
+def _fold():
+    """The active FoldQueue (or None); makes sure a flush runs when the current backward pass ends."""
+    q = _Fold.queue
+    if q is not None and not _Fold.queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_folds)
+            _Fold.queued = True
+        except RuntimeError:
+            return None                             # not inside a backward pass: reduce immediately
+    return q
+
+
 # Weight / bias gradients that land in the arena have no consumer until the end of backward (reducer, clip, Adam), so
 # they run on a SIDE HIP stream: the MFMA-bound wgrad GEMMs overlap the HBM-bound LayerNorm / dropout / attention
 # backward kernels and the dgrad chain on the main stream, and each GEMM's output burst hides under the other stream's
@@ -163,7 +197,7 @@ class LayerNormFn(torch.autograd.Function):
         bias = ctx.bias_ref
         gw, gb = _sink(weight), _sink(bias)
         if gw is not None and gb is not None:
-            dx = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu, dgamma=gw, dbeta=gb)[0]
+            dx = K.layernorm_bwd(dy, x2d, weight, mean, rstd, ctx.fuse_gelu, dgamma=gw, dbeta=gb, fold=_fold())[0]
             _sink_done(weight)
             _sink_done(bias)
             return dx, None, None, None, None
@@ -209,14 +243,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _sink(weight)
             if gw is not None:                                                       # dW += dY^T X, in the arena
-                _on_side(lambda: K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True), dy, x2d)
+                _on_side(lambda: K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True, fold=_fold()), dy, x2d)
                 _sink_done(weight)
             else:
                 dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                   # dW = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _sink(ctx.bias_ref)
             if gb is not None:
-                _on_side(lambda: K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True), dy)
+                _on_side(lambda: K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True, fold=_fold()), dy)
                 _sink_done(ctx.bias_ref)
             else:
                 db = K.colsum(dy, alpha=ctx.alpha, out_dtype=weight.dtype)
@@ -248,7 +282,7 @@ class LinearGeluLayerNormFn(torch.autograd.Function):
         gg, gb, gbias = _sink(ln_w), _sink(ln_b), _sink(bias)
         sunk = gg is not None and gb is not None and gbias is not None
         if sunk:
-            dh = K.layernorm_bwd(dy, h, ln_w, mean, rstd, True, dgamma=gg, dbeta=gb, dbias=gbias)[0]
+            dh = K.layernorm_bwd(dy, h, ln_w, mean, rstd, True, dgamma=gg, dbeta=gb, dbias=gbias, fold=_fold())[0]
             for p in (ln_w, ln_b, bias):
                 _sink_done(p)
             dg = db = dbias = None
@@ -258,7 +292,7 @@ class LinearGeluLayerNormFn(torch.autograd.Function):
         gw = _sink(weight)
         dw = None
         if gw is not None:
-            _on_side(lambda: K.gemm(dh, x2d, True, False, out=gw, accumulate=True), dh, x2d)
+            _on_side(lambda: K.gemm(dh, x2d, True, False, out=gw, accumulate=True, fold=_fold()), dh, x2d)
             _sink_done(weight)
         else:
             dw = K.gemm(dh, x2d, True, False)
@@ -407,11 +441,11 @@ def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
     """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (on the side stream; and
     notify the sinks); otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
     if gview is not None:
-        _on_side(lambda: grad_packed_fn(gview, True), *inputs)
+        _on_side(lambda: grad_packed_fn(gview, True, _fold()), *inputs)
         for w in ws:
             _sink_done(w)
         return [None] * len(ws)
-    g = grad_packed_fn(None, False)
+    g = grad_packed_fn(None, False, None)
     outs, o = [], 0
     for w in ws:
         n = w.shape[0]
@@ -457,9 +491,9 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         gws = _packed_grads((wk, wv, wq), pack.get("gw"),
-                            lambda o, acc: K.gemm(d2, x2d, True, False, out=o, accumulate=acc), (d2, x2d))
+                            lambda o, acc, f: K.gemm(d2, x2d, True, False, out=o, accumulate=acc, fold=f), (d2, x2d))
         gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
-                            lambda o, acc: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype), (d2,))
+                            lambda o, acc, f: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype, fold=f), (d2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[9]:
             dsum = K.head_sum(delta, B, heads, T)
@@ -506,13 +540,13 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
-        gq = _packed_grads((wq,), _sink(wq), lambda o, acc: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc), (dq2, xq2))
-        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype),
+        gq = _packed_grads((wq,), _sink(wq), lambda o, acc, f: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc, fold=f), (dq2, xq2))
+        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc, f: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype, fold=f),
                             (dq2,))
         gws = _packed_grads((wk, wv), pack.get("gw"),
-                            lambda o, acc: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc), (dkv2, xkv2))
+                            lambda o, acc, f: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc, fold=f), (dkv2, xkv2))
         gbs = _packed_grads((bk, bv), pack.get("gb"),
-                            lambda o, acc: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype), (dkv2,))
+                            lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[10]:
             dsum = K.head_sum(delta, B, heads, T)

@@ -147,6 +147,8 @@ class Trainer:
         self.fp.zero_grad()
         self._stats.zero_()
         self.reducer.overlap = overlap_reduce
+        # gradients are only read after backward unless buckets are all-reduced from inside it: fold lazily, in batches
+        ops.defer_reductions(self.world == 1 or not overlap_reduce)
         self.reducer.begin_step(tuple(s.get("task", len(s["slots"])) for s in samples))
         for s in samples:
             logits = model(s["slots"])[0]
@@ -156,6 +158,7 @@ class Trainer:
             self._stats[0] += n
             self._stats[1] += loss.detach().double()
             self._stats[2] += n
+        ops.flush_folds()
         ops.side_join()                             # side-stream weight gradients are complete beyond this point
         ops.rng_advance()
 

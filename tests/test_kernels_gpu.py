@@ -385,3 +385,39 @@ def test_adam_and_sumsq(K):
     K.sumsq(g, out)
     K.sumsq(master, out)
     assert rel(out, (g.float() ** 2).sum() + (master ** 2).sum()) < 1e-5
+
+
+def test_deferred_folds_match_immediate_reductions(K):
+    """FoldQueue (csrc/fold.hip): LayerNorm dgamma/dbeta/dbias, bias column sums and split-K weight gradients left as fp32
+    partial rows and reduced in ONE batched launch must equal the per-call reductions."""
+    torch.manual_seed(21)
+    dt = torch.bfloat16
+    rows, cols = 5000, 768
+    x = torch.randn(rows, cols, device=DEV).to(dt)
+    dy = torch.randn(rows, cols, device=DEV).to(dt)
+    g = (1 + 0.1 * torch.randn(cols, device=DEV)).to(dt)
+    b = torch.zeros(cols, device=DEV, dtype=dt)
+    _, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5, fuse_gelu=True)
+    a = torch.randn(4096, 768, device=DEV).to(dt)          # wgrad: dW[768, 520] += a^T @ c   (K = 4096 -> split-K)
+    c = torch.randn(4096, 520, device=DEV).to(dt)
+
+    def run(fold):
+        outs = [torch.full((cols,), 0.5, device=DEV, dtype=dt) for _ in range(4)]
+        gw = torch.full((768, 520), 0.25, device=DEV, dtype=dt)
+        dx = K.layernorm_bwd(dy, x, g, mean, rstd, fuse_gelu=True, dgamma=outs[0], dbeta=outs[1], dbias=outs[2], fold=fold)[0]
+        K.colsum(dy, alpha=0.5, out=outs[3], accumulate=True, fold=fold)
+        K.gemm(a, c, True, False, alpha=2.0, out=gw, accumulate=True, fold=fold)
+        if fold is not None:
+            assert len(fold.jobs) == 5                      # 3 LayerNorm quantities + bias + one split-K product
+            assert float((gw.float() - 0.25).abs().max()) == 0.0      # nothing folded yet
+            fold.flush()
+            assert not fold.jobs
+        return [dx] + outs + [gw]
+
+    want = run(None)
+    got = run(K.FoldQueue())
+    assert torch.equal(want[0], got[0])
+    for w, o in zip(want[1:], got[1:]):
+        assert rel(o, w.float()) < 1e-2
+    ref = 0.25 + 2.0 * (a.float().t() @ c.float())
+    assert rel(got[-1], ref) < 1e-2

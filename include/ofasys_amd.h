@@ -57,9 +57,11 @@ int ofa_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* 
  * arena); `ws` is fp32 scratch of ofa_layernorm_bwd_ws_rows()*cols floats.  cols <= 2048 (fp32) / 4096 (bf16) per
  * row-part: rows up to 4x that are split over four waves. */
 int ofa_layernorm_bwd_ws_rows(void);
+/* dres (optional, same shape as x): added to dx -- the gradient that reaches x through a residual branch taken before
+ * the LayerNorm (pre-LN layers: `residual = x; x = LN(x)`, transformer_layer.py:159-161), saving the separate add. */
 int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                      void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate, int dtype,
-                      void* stream);
+                      const void* dres, void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols,
+                      int accumulate, int dtype, void* stream);
 /* y = LayerNorm(gelu(h)) -- transformer_layer.py:194-197 (fc1 -> GELU (module/gelu.py:18-19, fp32 erf) -> ffn_layernorm). */
 int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
                            int64_t rows, int cols, float eps, int dtype, void* stream);

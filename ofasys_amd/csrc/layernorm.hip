@@ -84,8 +84,9 @@ constexpr int LN_BWD_BLOCKS = 256;  // one block per CU; also the workspace row 
 template <typename T, int NV, int WPR, bool GELU>
 __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const T* __restrict__ gamma, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                      float* __restrict__ ws, int64_t rows, int cols, int want_dbias) {
+                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                      T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols,
+                                                      int want_dbias) {
   constexpr int N = Vec<T>::N;
   constexpr int RPB = LN_WPB / WPR;                  // rows per block iteration
   __shared__ float red[2][LN_WPB];
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * N;
         if (c < cpp) {
-          float o[N];
+          float o[N], rsd[N];
+          if (dres) load_vec<T>(dres + row * cols + c0 + c, rsd);   // gradient arriving through the residual branch
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             float t = rs * (d[i][j] - s1 - xv[i][j] * s2);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
               t *= gp[i][j];
               dbi[i][j] += t;
             }
-            o[j] = t;
+            o[j] = dres ? t + rsd[j] : t;
           }
           store_vec<T>(dxr + c, o);
         }
@@ -261,9 +263,9 @@ static int ln_bwd_wpr(int cols, int n, bool gelu) {
 }
 
 template <typename T, bool GELU>
-static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd, void* dx,
-                           void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows, int cols, int accumulate,
-                           hipStream_t st) {
+static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const float* mean, const float* rstd,
+                           const void* dres, void* dx, void* dgamma, void* dbeta, void* dbias, float* ws, int64_t rows,
+                           int cols, int accumulate, hipStream_t st) {
   constexpr int N = Vec<T>::N;
   // waves per row: keep <= 2 vectors per lane (1 with GELU, whose extra gelu'/dbias registers would otherwise spill at
   // the 128-VGPR cap of a 1024-thread block: 169 us instead of ~70 for the 14336 x 3072 FFN LayerNorm) when the row
@@ -277,7 +279,7 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
   dim3 grid((unsigned)nblk), block(64 * LN_WPB);
 #define LN_LAUNCH(NV, WPR)                                                                                           \
   hipLaunchKernelGGL((ln_bwd_kernel<T, NV, WPR, GELU>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)g,  \
-                     mean, rstd, (T*)dx, ws, rows, cols, want_dbias)
+                     mean, rstd, (const T*)dres, (T*)dx, ws, rows, cols, want_dbias)
 #define LN_CASE(WPR)                      \
   do {                                    \
     if (nv <= 1) LN_LAUNCH(1, WPR);       \
@@ -346,15 +348,15 @@ extern "C" int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const vo
 }
 
 extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                 void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols, int accumulate,
-                                 int dtype, void* stream) {
+                                 const void* dres, void* dx, void* dgamma, void* dbeta, float* ws, int64_t rows, int cols,
+                                 int accumulate, int dtype, void* stream) {
   if (int rc = ln_check(rows, cols, dtype, true)) return rc;
   OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, OFA_ERR_INVALID,
               "layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st);
+             ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st);
 }
 
 extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean,
@@ -365,6 +367,6 @@ extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void*
               "gelu_layernorm_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
-             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st);
+             ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st);
 }

@@ -91,7 +91,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, fuse_gelu=False):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=None, dbias=None, want_dbias=False,
-                  fold=None):
+                  fold=None, dres=None):
     """dgamma/dbeta given: the parameter gradients are ACCUMULATED into them (gradient arena); else fresh tensors.
     fuse_gelu + (dbias or want_dbias): also the column sums of dx (gradient of the bias of the Linear feeding the GELU)."""
     dy = dy.contiguous()
@@ -120,8 +120,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, fuse_gelu=False, dgamma=None, dbeta=
         lib().call("ofa_gelu_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
                    ptr(dbeta), ptr(dbias), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
     else:
-        lib().call("ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
-                   ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
+        if dres is not None:
+            dres = dres.contiguous()
+            assert dres.shape == x.shape and dres.dtype == x.dtype
+        lib().call("ofa_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
+                   ptr(dbeta), ptr(ws), rows, cols, int(acc), dtype_code(x), stream())
     if acc == DEFER_FOLD:
         fold.flush_if_large()
     return dx, dgamma, dbeta, (dbias if fuse_gelu else None)

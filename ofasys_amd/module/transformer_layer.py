@@ -26,9 +26,10 @@ def _act_name(cfg):
 class _FFNMixin:
     def _ffn(self, x):
         """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494."""
-        residual = x
         if self.normalize_before:
-            x = self.final_layer_norm(x)
+            residual, x = self.final_layer_norm.fork(x)
+        else:
+            residual = x
         act_p = self.activation_dropout_module.p if self.training else 0.0
         if self.ffn_layernorm is not None and act_p == 0.0 and self._gelu and self.fc1.bias is not None:
             x = ops.linear_gelu_layer_norm(x, self.fc1.weight, self.fc1.bias, self.ffn_layernorm.weight,
@@ -90,9 +91,10 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         """x: (seq_len, batch, embed_dim); see transformer_layer.py:141-158."""
         if attn_mask is not None:
             attn_mask = attn_mask.masked_fill(attn_mask.to(torch.bool), -1e8 if x.dtype == torch.float32 else -1e4)
-        residual = x
         if self.normalize_before:
-            x = self.self_attn_layer_norm(x)
+            residual, x = self.self_attn_layer_norm.fork(x)
+        else:
+            residual = x
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=encoder_padding_mask,
                                               need_weights=need_attn, attn_mask=attn_mask, attn_bias=self_attn_bias)
         if self.attn_ln is not None:
@@ -174,9 +176,10 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
             need_attn = True
         if incremental_state is not None or prev_self_attn_state is not None or prev_attn_state is not None:
             raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
-        residual = x
         if self.normalize_before:
-            x = self.self_attn_layer_norm(x)
+            residual, x = self.self_attn_layer_norm.fork(x)
+        else:
+            residual = x
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask,
                                               incremental_state=None, need_weights=need_attn, attn_mask=self_attn_mask,
                                               attn_bias=self_attn_bias)
@@ -187,9 +190,10 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
             x = self.self_attn_layer_norm(x)
         cross_attn_weights = None
         if self.encoder_attn is not None and encoder_out is not None:
-            residual = x
             if self.normalize_before:
-                x = self.encoder_attn_layer_norm(x)
+                residual, x = self.encoder_attn_layer_norm.fork(x)
+            else:
+                residual = x
             x, cross_attn_weights = self.encoder_attn(
                 query=x, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
                 incremental_state=None, static_kv=True,

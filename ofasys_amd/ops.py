@@ -205,6 +205,41 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class LayerNormForkFn(torch.autograd.Function):
+    """(x, LayerNorm(x)): the pre-LN fork `residual = x; x = LN(x)` (transformer_layer.py:159-161, 186-188) as one node, so
+    the gradient coming back through the residual branch is added inside the LayerNorm backward kernel instead of by a
+    separate elementwise add."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, eps):
+        y, mean, rstd = K.layernorm_fwd(x2d, weight, bias, eps, False)
+        ctx.save_for_backward(x2d, weight, mean, rstd)
+        ctx.bias_ref = bias
+        return x2d.view_as(x2d), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x2d, weight, mean, rstd = ctx.saved_tensors
+        bias = ctx.bias_ref
+        if dy is None:
+            return dres, None, None, None
+        gw, gb = _sink(weight), _sink(bias)
+        if gw is not None and gb is not None:
+            dx = K.layernorm_bwd(dy, x2d, weight, mean, rstd, False, dgamma=gw, dbeta=gb, fold=_fold(), dres=dres)[0]
+            _sink_done(weight)
+            _sink_done(bias)
+            return dx, None, None, None
+        dx, dg, db, _ = K.layernorm_bwd(dy, x2d, weight, mean, rstd, False, dres=dres)
+        return dx, dg, db, None
+
+
+def layer_norm_fork(x, weight, bias, eps=1e-5):
+    """Returns (x, LayerNorm(x)) -- use the first as the residual."""
+    x2d, restore = rows_view(x)
+    r, y = LayerNormForkFn.apply(x2d, weight, bias, eps)
+    return restore(r), restore(y)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
     """F.layer_norm over the last dim (module/layer_norm.py:27-32); fuse_gelu: LayerNorm(gelu(x))."""
     x2d, restore = rows_view(x)

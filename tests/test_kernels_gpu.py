@@ -51,6 +51,10 @@ def test_layernorm(K, dtype, rows, cols, gelu):
     assert rel(dx, xr.grad) < 2 * t
     assert rel(dg, gr.grad) < 2 * t * big
     assert rel(db, br.grad) < 2 * t * big
+    if not gelu:                                      # residual-branch gradient added inside the kernel
+        dres = torch.randn_like(dy)
+        dx2 = K.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)[0]
+        assert rel(dx2, xr.grad + dres.float()) < 2 * t
     if gelu:
         assert rel(dbias, xr.grad.sum(0)) < 2 * t * big
         # accumulate mode adds onto existing gradients (the train step's arena)

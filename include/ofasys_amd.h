@@ -203,6 +203,34 @@ int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* 
                   const float* coef, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, int dtype, void* stream);
 
+/* ---- convolution stack of the image_resnet / video / audio adaptors (module/resnet.py:22-261, module/subsample.py:11-63).
+ * Activations are NHWC rows [B*H*W, C]; a convolution is ofa_im2col (taps ordered (kh, kw, c), row length Kpad >=
+ * kh*kw*C, zero padded) + ofa_gemm against the weight viewed as [Cout, kh*kw*C]; its input gradient is ofa_gemm +
+ * ofa_col2im (gather formulation, deterministic).  x_nchw: the source is the [B,C,H,W] image itself. */
+int ofa_conv_out_size(int in, int k, int stride, int pad);
+int ofa_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+               int x_nchw, int dtype, void* stream);
+int ofa_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+               int dtype, void* stream);
+/* torch.nn.BatchNorm2d over the rows of [rows, C] (module/resnet.py:105-128): y = [relu]((x-mean)*rstd*gamma + beta
+ * [+ residual]).  use_running == 0: batch statistics (biased variance), running buffers (fp32, optional) updated with
+ * `momentum` and the unbiased variance; use_running != 0: eval mode.  mean/rstd: fp32 [C] outputs kept for backward.
+ * ws: ofa_batchnorm_ws_floats(C) floats.  Backward: g = dy*[y>0] when relu; dres (optional) receives g. */
+int ofa_batchnorm_ws_floats(int C);
+int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
+                      float* rstd, float* running_mean, float* running_var, float* ws, int64_t rows, int C, float eps,
+                      float momentum, int use_running, int relu, int dtype, void* stream);
+int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                      void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int batch_stats,
+                      int relu, int accumulate, int dtype, void* stream);
+/* MaxPool2d(K, stride, pad) on NHWC; arg: one byte per output element (arg-max tap), consumed by the backward. */
+int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, int dtype,
+                    void* stream);
+int ofa_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                    int dtype, void* stream);
+/* y = relu(x) (gate == NULL), or y = x*[gate > 0] (its backward with gate = the forward output). */
+int ofa_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
+
 /* ---- batched fold of fp32 partial rows: out[c] (+)= alpha * sum_{s < nslots} part[s*stride + c], c < cols, for up to
  * any number of jobs in as few launches as possible (56 jobs per launch).  Producers that were asked to leave their
  * partials in place (ofa_layernorm_bwd / ofa_gelu_layernorm_bwd / ofa_colsum with accumulate == OFA_DEFER_FOLD,

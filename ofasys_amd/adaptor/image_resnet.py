@@ -1,0 +1,108 @@
+"""ImageResnetAdaptor (reference: adaptor/image_resnet.py:25-202) -- the default IMAGE adaptor: ResNet-{50,101,152}
+stride-16 features -> Linear(1024, D); 2-D position ids `w + h*bucket + 1`; 2-D relative-position bias by a double gather
+into the integer table `image_rp_bucket` and one Embedding table per layer."""
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..configure import ChoiceEnum, register_config
+from ..module import Embedding, Linear
+from ..module.resnet import resnet50_backbone, resnet101_backbone, resnet152_backbone
+from ..preprocessor import Dictionary, ModalityType, Slot
+from .base import AdaptorOutput, BaseAdaptor, BaseAdaptorConfig
+
+
+def make_image_bucket_position(bucket_size, num_relative_distance):
+    """Integer table, bit-exact with adaptor/image_resnet.py:25-40 (built once on the host)."""
+    coords_h = torch.arange(bucket_size)
+    coords_w = torch.arange(bucket_size)
+    coords = torch.stack(torch.meshgrid([coords_h, coords_w], indexing="ij"))
+    coords_flatten = torch.flatten(coords, 1)
+    relative_coords = coords_flatten[:, :, None] - coords_flatten[:, None, :]
+    relative_coords = relative_coords.permute(1, 2, 0).contiguous()
+    relative_coords[:, :, 0] += bucket_size - 1
+    relative_coords[:, :, 1] += bucket_size - 1
+    relative_coords[:, :, 0] *= 2 * bucket_size - 1
+    relative_position_index = torch.zeros(size=(bucket_size * bucket_size + 1,) * 2, dtype=relative_coords.dtype)
+    relative_position_index[1:, 1:] = relative_coords.sum(-1)
+    relative_position_index[0, 0:] = num_relative_distance - 3
+    relative_position_index[0:, 0] = num_relative_distance - 2
+    relative_position_index[0, 0] = num_relative_distance - 1
+    return relative_position_index
+
+
+@dataclass
+class ImageResnetAdaptorConfig(BaseAdaptorConfig):
+    resnet_type: ChoiceEnum(["resnet50", "resnet101", "resnet152"]) = field(default="resnet152", metadata={"help": "resnet type"})
+    resnet_drop_path_rate: float = field(default=0.0, metadata={"help": "resnet drop path rate"})
+    sync_bn: bool = field(default=False, metadata={"help": "sync batchnorm"})
+    freeze_resnet: bool = field(default=False, metadata={"help": "freeze resnet"})
+    image_bucket_size: int = field(default=42, metadata={"help": "image bucket size"})
+    pretrained_ckpt_path: str = field(default="", metadata={"help": "path of pretrained ckpt"})
+
+
+@register_config("ofasys.adaptor", "image_resnet", ImageResnetAdaptorConfig)
+class ImageResnetAdaptor(BaseAdaptor):
+    def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
+                 cfg: ImageResnetAdaptorConfig):
+        super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
+        if cfg.sync_bn:
+            raise NotImplementedError("sync_bn is not implemented (BatchNorm statistics stay per rank, the reference default)")
+        if cfg.pretrained_ckpt_path:
+            raise NotImplementedError("pretrained_ckpt_path: load the state dict through model.load_state_dict instead")
+        self.embed_image_positions = Embedding(cfg.image_bucket_size ** 2 + 1, cfg.embed_dim)
+        backbone = {"resnet50": resnet50_backbone, "resnet101": resnet101_backbone, "resnet152": resnet152_backbone}[cfg.resnet_type]
+        self.embed_images = backbone(norm_layer=None, drop_path_rate=cfg.resnet_drop_path_rate)
+        self.image_proj = Linear(1024, cfg.embed_dim)
+        image_num_rel_dis = (2 * cfg.image_bucket_size - 1) * (2 * cfg.image_bucket_size - 1) + 3
+        image_rp_bucket = make_image_bucket_position(cfg.image_bucket_size, image_num_rel_dis)
+        num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
+        self.image_rel_pos_table_list = nn.ModuleList(
+            [Embedding(image_num_rel_dis, cfg.num_attention_heads, zero_init=True) for _ in range(num_rel_pos_tables)])
+        self.register_buffer("image_rp_bucket", image_rp_bucket)
+
+    def train(self, mode=True):                                               # image_resnet.py:107-114
+        super().train(mode)
+        if self.cfg.freeze_resnet:
+            for m in self.embed_images.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+                    m.weight.requires_grad = False
+                    m.bias.requires_grad = False
+        return self
+
+    def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
+        """[T,T,A] values = table_idx[ bucket[ids][:, ids] ]  (image_resnet.py:116-128).  The reference gathers per batch
+        row and returns [B,A,T,T]; every row of `image_position_ids` is the same arange-derived vector, so the values are
+        computed once and handed to the bias assembly as the usual batch-expanded view."""
+        ids = kwargs["image_position_ids"]
+        rp_bucket = self.image_rp_bucket[ids][:, ids].contiguous()             # integer double gather, bit-exact
+        return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight)
+
+    def get_patch_images_info(self, patch_images):
+        """image_resnet.py:130-164 -> (embed rows [B, h*w, 1024], n, mask, position ids [T], pos_embed [B, T, D])."""
+        device = patch_images.device
+        B = patch_images.size(0)
+        rows, h, w = self.embed_images(patch_images)
+        n = h * w
+        image_embed = rows.view(B, n, rows.shape[-1])
+        image_padding_mask = torch.zeros((B, n), dtype=torch.bool, device=device)
+        idx = (torch.arange(w, device=device).unsqueeze(0).expand(h, w)
+               + torch.arange(h, device=device).unsqueeze(1) * self.cfg.image_bucket_size + 1).view(-1)
+        image_pos_embed = self.embed_image_positions(idx[None, :].expand(B, n))
+        return image_embed, n, image_padding_mask, idx, image_pos_embed
+
+    def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
+        assert slot.modality == ModalityType.IMAGE
+        image_embed, n, mask, position_ids, pos_embed = self.get_patch_images_info(slot.value)
+        image_embed = self.image_proj(image_embed)
+        batch_size, seq_length = image_embed.size()[:2]
+        self_attn_bias = []
+        if self.cfg.use_self_attn_bias:
+            num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
+            for idx in range(num_rel_pos_tables):
+                values = self.get_rel_pos_bias(batch_size, seq_length, idx, image_position_ids=position_ids)
+                self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
+        return AdaptorOutput(image_embed, mask, pos_embed, self_attn_bias)

@@ -9,6 +9,21 @@ from dataclasses import dataclass, field, fields, is_dataclass
 from typing import Any, Dict
 
 
+def ChoiceEnum(choices):
+    """Enum class enforcing a list of string choices (reference: configure/constants.py:12-33); members compare equal to
+    their string value."""
+    import enum
+
+    class _StrEnum(str, enum.Enum):
+        def __str__(self):
+            return self.value
+
+        def __hash__(self):
+            return hash(self.value)
+
+    return _StrEnum("Choices", {k: k for k in choices})
+
+
 @dataclass
 class BaseDataclass:
     _name: Any = None

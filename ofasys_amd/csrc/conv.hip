@@ -1,0 +1,483 @@
+// Convolution-stack pieces of the image_resnet / video / audio adaptors (reference: module/resnet.py:22-261,
+// module/subsample.py:11-63): activations live as NHWC rows [B*H*W, C], so
+//   * a 1x1 stride-1 convolution IS a GEMM on the rows; every other convolution is an im2col gather (taps ordered
+//     (kh, kw, c): one contiguous C-vector per tap) + the MFMA GEMM (gemm_mfma.hip), its input gradient the matching
+//     gather-formulated col2im (deterministic, no atomics);
+//   * BatchNorm2d is a per-column statistic over the rows: one pass of column sums (x, x^2), a finalize kernel (mean,
+//     rstd, running statistics with torch's momentum / unbiased-variance rule), and one fused normalise (+ residual)
+//     (+ ReLU) pass; backward mirrors it (column sums of g and g*xhat, then dx [+ d_residual]);
+//   * MaxPool2d(3, 2, 1) keeps the arg-max tap in a byte per output element.
+// All HBM-bound; algorithmic bytes: im2col (1 + kh*kw) * rows*C*sizeof, BN forward 3 passes, backward 5.
+#include "common.h"
+
+namespace ofa {
+
+static inline int grid_1d(int64_t work) {
+  int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// col[(b, oh, ow)][(kh*KW + kw)*C + c] = x[b, oh*s - p + kh, ow*s - p + kw, c]  (0 outside), columns K..Kpad-1 zero.
+// NCHW: x is [B, C, H, W] (the image itself, first convolution); else [B, H, W, C].
+template <typename T, bool NCHW>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C,
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+  constexpr int N = Vec<T>::N;
+  const int K = KH * KW * C;
+  if (!NCHW && (C % N) == 0 && (Kpad % N) == 0) {
+    const int vpr = Kpad / N;
+    const int64_t total = (int64_t)B * Ho * Wo * vpr;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+      const int k = (int)(v % vpr) * N;
+      const int64_t r = v / vpr;
+      float o[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) o[j] = 0.f;
+      if (k < K) {
+        const int tap = k / C, c = k % C;
+        const int kh = tap / KW, kw = tap % KW;
+        const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho);
+        const int64_t b = r / ((int64_t)Wo * Ho);
+        const int h = oh * stride - pad + kh, w = ow * stride - pad + kw;
+        if (h >= 0 && h < H && w >= 0 && w < W) load_vec<T>(x + ((b * H + h) * W + w) * C + c, o);
+      }
+      store_vec<T>(col + r * Kpad + k, o);
+    }
+    return;
+  }
+  const int64_t total = (int64_t)B * Ho * Wo * Kpad;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % Kpad);
+    const int64_t r = e / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int tap = k / C, c = k % C;
+      const int kh = tap / KW, kw = tap % KW;
+      const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho);
+      const int64_t b = r / ((int64_t)Wo * Ho);
+      const int h = oh * stride - pad + kh, w = ow * stride - pad + kw;
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = NCHW ? ld1<T>(x + ((b * C + c) * H + h) * W + w) : ld1<T>(x + ((b * H + h) * W + w) * C + c);
+    }
+    st1<T>(col + e, v);
+  }
+}
+
+// dx[b, h, w, c] = sum over taps (kh, kw) with oh = (h + p - kh)/s, ow = (w + p - kw)/s integral and in range of
+//                  dcol[(b, oh, ow)][(kh*KW + kw)*C + c]                (NHWC only; C % vector width == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W,
+                                                     int C, int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+  constexpr int N = Vec<T>::N;
+  const int vpc = C / N;
+  const int64_t total = (int64_t)B * H * W * vpc;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int c = (int)(v % vpc) * N;
+    const int64_t p = v / vpc;
+    const int w = (int)(p % W), h = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hh = h + pad - kh;
+      if (hh < 0 || hh % stride) continue;
+      const int oh = hh / stride;
+      if (oh >= Ho) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ww = w + pad - kw;
+        if (ww < 0 || ww % stride) continue;
+        const int ow = ww / stride;
+        if (ow >= Wo) continue;
+        float t[N];
+        load_vec<T>(dcol + ((b * Ho + oh) * Wo + ow) * Kpad + (kh * KW + kw) * C + c, t);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += t[j];
+      }
+    }
+    store_vec<T>(dx + p * C + c, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- column statistics
+// partial[g][0][c] = sum_r a[r][c],  partial[g][1][c] = sum_r a[r][c]*b[r][c]   over the rows of group g, where
+//   MODE 0 (forward):  a = x,              b = x                      -> sum x, sum x^2
+//   MODE 1 (backward): a = g = dy*[y>0],   b = xhat = (x-mean)*rstd   -> sum g, sum g*xhat
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, double* __restrict__ partial,
+                                                         int64_t rows, int C, int relu) {
+  constexpr int N = Vec<T>::N;
+  __shared__ double red[2][8][32][N];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cx) * N;
+  // double accumulators: BatchNorm over few values per channel (B*h*w = 32 on a 64x64 image) makes the backward chain
+  // ill-conditioned; fp64 VALU is full rate on this part and the kernel is HBM-bound anyway
+  double s0[N], s1[N];
+  float mu[N], rs[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { s0[j] = s1[j] = 0.0; mu[j] = 0.f; rs[j] = 1.f; }
+  if (c < C) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
+    }
+    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < rows; r += (int64_t)gridDim.y * 8) {
+      float a[N], b[N];
+      load_vec<T>(x + r * C + c, b);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) { s0[j] += (double)b[j]; s1[j] += (double)b[j] * (double)b[j]; }
+      } else {
+        load_vec<T>(dy + r * C + c, a);
+        if (relu) {
+          float yy[N];
+          load_vec<T>(y + r * C + c, yy);
+#pragma unroll
+          for (int j = 0; j < N; ++j) a[j] = yy[j] > 0.f ? a[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) { s0[j] += (double)a[j]; s1[j] += (double)a[j] * (double)((b[j] - mu[j]) * rs[j]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) { red[0][ry][cx][j] = s0[j]; red[1][ry][cx][j] = s1[j]; }
+  __syncthreads();
+  if (ry < 2 && c < C) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[ry][r][cx][j];
+      partial[((int64_t)blockIdx.y * 2 + ry) * C + c + j] = t;
+    }
+  }
+}
+
+// forward finalize: mean / rstd of the batch + running statistics (torch: running = (1-m)*running + m*stat, unbiased var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int groups, int C, int64_t rows,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    s += partial[((int64_t)g * 2) * C + c];
+    q += partial[((int64_t)g * 2 + 1) * C + c];
+  }
+  const double m = s / (double)rows;
+  double var = q / (double)rows - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// eval mode: statistics come from the running buffers
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restrict__ running_mean,
+                                                            const float* __restrict__ running_var, float eps, int C,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// backward finalize: sums[0][c] = sum g, sums[1][c] = sum g*xhat; parameter gradients in the parameter dtype
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int groups, int C,
+                                                              float* __restrict__ sums, T* __restrict__ dgamma,
+                                                              T* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    s += partial[((int64_t)g * 2) * C + c];
+    q += partial[((int64_t)g * 2 + 1) * C + c];
+  }
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+  if (dgamma) {
+    st1<T>(dgamma + c, (accumulate ? ld1<T>(dgamma + c) : 0.f) + (float)q);
+    st1<T>(dbeta + c, (accumulate ? ld1<T>(dbeta + c) : 0.f) + (float)s);
+  }
+}
+
+// y = [relu]( (x - mean)*rstd*gamma + beta [+ residual] )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                       const T* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const T* __restrict__ residual,
+                                                       T* __restrict__ y, int64_t rows, int C, int relu) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = C / N;
+  const int64_t total = rows * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int c = (int)(v % vpr) * N;
+    float a[N], g[N], b[N], r[N];
+    load_vec<T>(x + v * N, a);
+    load_vec<T>(gamma + c, g);
+    load_vec<T>(beta + c, b);
+    if (residual) load_vec<T>(residual + v * N, r);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float t = (a[j] - mean[c + j]) * rstd[c + j] * g[j] + b[j];
+      if (residual) t += r[j];
+      a[j] = relu ? fmaxf(t, 0.f) : t;
+    }
+    store_vec<T>(y + v * N, a);
+  }
+}
+
+// g = dy*[y>0];  dx = gamma*rstd*(g - [batch_stats] (sum_g + xhat*sum_gx)/rows);  dres = g (optional)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                        const T* __restrict__ x, const T* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ sums, T* __restrict__ dx,
+                                                        T* __restrict__ dres, int64_t rows, int C, int relu,
+                                                        int batch_stats) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = C / N;
+  const int64_t total = rows * vpr;
+  const float inv = 1.0f / (float)rows;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int c = (int)(v % vpr) * N;
+    float g[N], xx[N], gm[N], o[N];
+    load_vec<T>(dy + v * N, g);
+    load_vec<T>(x + v * N, xx);
+    load_vec<T>(gamma + c, gm);
+    if (relu) {
+      float yy[N];
+      load_vec<T>(y + v * N, yy);
+#pragma unroll
+      for (int j = 0; j < N; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float xh = (xx[j] - mean[c + j]) * rstd[c + j];
+      float t = g[j];
+      if (batch_stats) t -= (sums[c + j] + xh * sums[C + c + j]) * inv;
+      o[j] = gm[j] * rstd[c + j] * t;
+    }
+    store_vec<T>(dx + v * N, o);
+    if (dres) store_vec<T>(dres + v * N, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- MaxPool2d(k, s, p), NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
+                                                          int B, int H, int W, int C, int K, int stride, int pad, int Ho,
+                                                          int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t r = e / C;
+    const int ow = (int)(r % Wo), oh = (int)((r / Wo) % Ho);
+    const int64_t b = r / ((int64_t)Wo * Ho);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int kh = 0; kh < K; ++kh) {
+      const int h = oh * stride - pad + kh;
+      if (h < 0 || h >= H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int w = ow * stride - pad + kw;
+        if (w < 0 || w >= W) continue;
+        const float v = ld1<T>(x + ((b * H + h) * W + w) * C + c);
+        if (v > best || (v != v)) { best = v; bi = kh * K + kw; }      // first maximum wins (torch), NaN propagates
+      }
+    }
+    st1<T>(y + e, best);
+    arg[e] = (uint8_t)bi;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                          T* __restrict__ dx, int B, int H, int W, int C, int K, int stride,
+                                                          int pad, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t p = e / C;
+    const int w = (int)(p % W), h = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    float acc = 0.f;
+    for (int kh = 0; kh < K; ++kh) {
+      const int hh = h + pad - kh;
+      if (hh < 0 || hh % stride) continue;
+      const int oh = hh / stride;
+      if (oh >= Ho) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int ww = w + pad - kw;
+        if (ww < 0 || ww % stride) continue;
+        const int ow = ww / stride;
+        if (ow >= Wo) continue;
+        const int64_t o = ((b * Ho + oh) * Wo + ow) * C + c;
+        if (arg[o] == kh * K + kw) acc += ld1<T>(dy + o);
+      }
+    }
+    st1<T>(dx + e, acc);
+  }
+}
+
+// y = max(x, 0) [* mask of y for backward]
+template <typename T>
+__global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, const T* __restrict__ gate, T* __restrict__ y,
+                                                   int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = ld1<T>(x + i);
+    st1<T>(y + i, gate ? (ld1<T>(gate + i) > 0.f ? v : 0.f) : fmaxf(v, 0.f));
+  }
+}
+
+}  // namespace ofa
+using namespace ofa;
+
+#define OFA_DT(name) OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, name ": bad dtype %d", dtype)
+extern "C" int ofa_conv_out_size(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+extern "C" int ofa_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+                          int x_nchw, int dtype, void* stream) {
+  OFA_DT("im2col");
+  OFA_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && Kpad >= KH * KW * C,
+              OFA_ERR_INVALID, "im2col: bad argument");
+  const int Ho = ofa_conv_out_size(H, KH, stride, pad), Wo = ofa_conv_out_size(W, KW, stride, pad);
+  OFA_REQUIRE(Ho > 0 && Wo > 0, OFA_ERR_INVALID, "im2col: empty output (H=%d W=%d k=%dx%d s=%d p=%d)", H, W, KH, KW, stride, pad);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)B * Ho * Wo * Kpad;
+  dim3 grid(grid_1d(total / 4)), block(256);
+  if (dtype == OFA_F32) {
+    if (x_nchw) hipLaunchKernelGGL((im2col_kernel<float, true>), grid, block, 0, st, (const float*)x, (float*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+    else hipLaunchKernelGGL((im2col_kernel<float, false>), grid, block, 0, st, (const float*)x, (float*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  } else {
+    if (x_nchw) hipLaunchKernelGGL((im2col_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+    else hipLaunchKernelGGL((im2col_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  }
+  return check_launch("im2col");
+}
+
+extern "C" int ofa_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
+                          int dtype, void* stream) {
+  OFA_DT("col2im");
+  OFA_REQUIRE(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && Kpad >= KH * KW * C, OFA_ERR_INVALID, "col2im: bad argument");
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(C % n == 0 && Kpad % n == 0, OFA_ERR_UNSUPPORTED, "col2im: C=%d / Kpad=%d must be multiples of %d", C, Kpad, n);
+  const int Ho = ofa_conv_out_size(H, KH, stride, pad), Wo = ofa_conv_out_size(W, KW, stride, pad);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(grid_1d((int64_t)B * H * W * (C / n))), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((col2im_kernel<float>), grid, block, 0, st, (const float*)dcol, (float*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  else
+    hipLaunchKernelGGL((col2im_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  return check_launch("col2im");
+}
+
+static int bn_groups(int64_t rows) {
+  int64_t g = (rows + 127) / 128;
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+extern "C" int ofa_batchnorm_ws_floats(int C) { return 4 * 256 * C + 2 * C; }   // fp64 partials [256][2][C] + fp32 sums [2][C]
+
+// training: batch statistics (+ running update when running_mean != NULL); eval (use_running != 0): running statistics.
+extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
+                                 float* rstd, float* running_mean, float* running_var, float* ws, int64_t rows, int C,
+                                 float eps, float momentum, int use_running, int relu, int dtype, void* stream) {
+  OFA_DT("batchnorm_fwd");
+  OFA_REQUIRE(x && gamma && beta && y && mean && rstd && ws && rows > 0 && C > 0, OFA_ERR_INVALID, "batchnorm_fwd: bad argument");
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
+  OFA_REQUIRE(!use_running || (running_mean && running_var), OFA_ERR_INVALID, "batchnorm_fwd: eval mode needs running statistics");
+  hipStream_t st = (hipStream_t)stream;
+  if (use_running) {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, eps, C, mean, rstd);
+  } else {
+    const int groups = bn_groups(rows);
+    dim3 grid(cdiv(C / n, 32), groups), block(256);
+    if (dtype == OFA_F32)
+      hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+    else
+      hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
+  }
+  int rc = check_launch("batchnorm_stats");
+  if (rc) return rc;
+  dim3 grid(grid_1d(rows * (C / n))), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (const float*)residual, (float*)y, rows, C, relu);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)mean, (const float*)rstd, (const bf16_t*)residual, (bf16_t*)y, rows, C, relu);
+  return check_launch("batchnorm_apply");
+}
+
+// dgamma/dbeta: [C] in `dtype` (accumulate != 0: added); dres (optional): gradient of the residual input (= gated dy).
+extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
+                                 const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows,
+                                 int C, int batch_stats, int relu, int accumulate, int dtype, void* stream) {
+  OFA_DT("batchnorm_bwd");
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && (!relu || y), OFA_ERR_INVALID, "batchnorm_bwd: bad argument");
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = bn_groups(rows);
+  float* sums = ws + (int64_t)4 * 256 * C;
+  dim3 grid(cdiv(C / n, 32), groups), block(256);
+  if (dtype == OFA_F32) {
+    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
+  } else {
+    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
+  }
+  int rc = check_launch("batchnorm_bwd_stats");
+  if (rc) return rc;
+  dim3 g2(grid_1d(rows * (C / n)));
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats);
+  else
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats);
+  return check_launch("batchnorm_bwd_dx");
+}
+
+extern "C" int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad,
+                               int dtype, void* stream) {
+  OFA_DT("maxpool_fwd");
+  OFA_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && K * K <= 255 && stride > 0 && pad >= 0, OFA_ERR_INVALID, "maxpool_fwd: bad argument");
+  const int Ho = ofa_conv_out_size(H, K, stride, pad), Wo = ofa_conv_out_size(W, K, stride, pad);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(grid_1d((int64_t)B * Ho * Wo * C)), block(256);
+  if (dtype == OFA_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int ofa_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                               int dtype, void* stream) {
+  OFA_DT("maxpool_bwd");
+  OFA_REQUIRE(dy && dx && arg && B > 0 && H > 0 && W > 0 && C > 0 && K > 0, OFA_ERR_INVALID, "maxpool_bwd: bad argument");
+  const int Ho = ofa_conv_out_size(H, K, stride, pad), Wo = ofa_conv_out_size(W, K, stride, pad);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(grid_1d((int64_t)B * H * W * C)), block(256);
+  if (dtype == OFA_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), grid, block, 0, st, (const float*)dy, arg, (float*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, arg, (bf16_t*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
+  return check_launch("maxpool_bwd");
+}
+
+// y = relu(x) (gate == NULL)   or   y = x * [gate > 0]  (backward: x = dy, gate = the forward output)
+extern "C" int ofa_relu(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream) {
+  OFA_DT("relu");
+  OFA_REQUIRE(n >= 0 && (n == 0 || (x && y)), OFA_ERR_INVALID, "relu: bad argument");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((relu_kernel<float>), dim3(grid_1d(n)), dim3(256), 0, st, (const float*)x, (const float*)gate, (float*)y, n);
+  else hipLaunchKernelGGL((relu_kernel<bf16_t>), dim3(grid_1d(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)gate, (bf16_t*)y, n);
+  return check_launch("relu");
+}

@@ -582,3 +582,80 @@ def head_sum(x, B, heads, T):
     out = torch.empty(heads, dtype=torch.float32, device=x.device)
     lib().call("ofa_head_sum_f32", ptr(x), ptr(out), B, heads, T, x.stride(0), stream())
     return out
+
+
+# ------------------------------------------------------------------ convolution stack (NHWC rows), csrc/conv.hip
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col(x, B, H, W, C, kh, kw, stride, pad, nchw=False):
+    """x: NHWC rows [B*H*W, C] (or the [B,C,H,W] image when nchw) -> col [B*Ho*Wo, Kpad], taps ordered (kh, kw, c)."""
+    x = x.contiguous()
+    Ho, Wo = conv_out_size(H, kh, stride, pad), conv_out_size(W, kw, stride, pad)
+    K = kh * kw * C
+    Kpad = (K + 7) // 8 * 8
+    col = torch.empty(B * Ho * Wo, Kpad, dtype=x.dtype, device=x.device)
+    lib().call("ofa_im2col", ptr(x), ptr(col), B, H, W, C, kh, kw, stride, pad, Kpad, int(nchw), dtype_code(x), stream())
+    return col, Ho, Wo
+
+
+def col2im(dcol, B, H, W, C, kh, kw, stride, pad):
+    dcol = dcol.contiguous()
+    dx = torch.empty(B * H * W, C, dtype=dcol.dtype, device=dcol.device)
+    lib().call("ofa_col2im", ptr(dcol), ptr(dx), B, H, W, C, kh, kw, stride, pad, dcol.shape[1], dtype_code(dcol), stream())
+    return dx
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu=False, residual=None):
+    """x: [rows, C].  Returns y, mean, rstd (fp32 [C]); updates the running buffers in training mode."""
+    x = x.contiguous()
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().cdll.ofa_batchnorm_ws_floats(C) * 4, x.device, "bn")
+    if residual is not None:
+        residual = residual.contiguous()
+    lib().call("ofa_batchnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(rstd),
+               ptr(running_mean), ptr(running_var), ptr(ws), rows, C, float(eps), float(momentum), int(not training),
+               int(relu), dtype_code(x), stream())
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy, y, x, gamma, mean, rstd, batch_stats, relu, want_dres=False, dgamma=None, dbeta=None):
+    dy = dy.contiguous()
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    acc = dgamma is not None
+    if not acc:
+        dgamma = torch.empty(C, dtype=gamma.dtype, device=x.device)
+        dbeta = torch.empty(C, dtype=gamma.dtype, device=x.device)
+    ws = workspace(lib().cdll.ofa_batchnorm_ws_floats(C) * 4, x.device, "bn")
+    lib().call("ofa_batchnorm_bwd", ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dres), ptr(dgamma),
+               ptr(dbeta), ptr(ws), rows, C, int(batch_stats), int(relu), int(acc), dtype_code(x), stream())
+    return dx, dres, dgamma, dbeta
+
+
+def maxpool_fwd(x, B, H, W, C, k, stride, pad):
+    x = x.contiguous()
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty(B * Ho * Wo, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(B * Ho * Wo, C, dtype=torch.uint8, device=x.device)
+    lib().call("ofa_maxpool_fwd", ptr(x), ptr(y), ptr(arg), B, H, W, C, k, stride, pad, dtype_code(x), stream())
+    return y, arg, Ho, Wo
+
+
+def maxpool_bwd(dy, arg, B, H, W, C, k, stride, pad):
+    dy = dy.contiguous()
+    dx = torch.empty(B * H * W, C, dtype=dy.dtype, device=dy.device)
+    lib().call("ofa_maxpool_bwd", ptr(dy), ptr(arg), ptr(dx), B, H, W, C, k, stride, pad, dtype_code(dy), stream())
+    return dx
+
+
+def relu(x, gate=None):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib().call("ofa_relu", ptr(x), ptr(gate), ptr(y), x.numel(), dtype_code(x), stream())
+    return y

@@ -861,3 +861,138 @@ def log_softmax_fp32(logits):
 
 def softmax_fp32(logits):
     return ProbsFn.apply(logits, False)
+
+
+# ---------------------------------------------------------------------------------------------- convolution stack
+# Feature maps travel as (rows [B*H*W, C], (B, H, W)) pairs: NHWC rows, so 1x1 convolutions are plain GEMMs.
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d(bias optional) on NHWC rows (or on the [B,C,H,W] image itself when `nchw`): im2col + MFMA GEMM
+    (module/resnet.py:22-38, module/subsample.py:29-35).  weight keeps torch's [Cout, Cin, kh, kw] layout (state dict)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom):
+        B, H, W, stride, pad, nchw = geom
+        Cout, Cin, kh, kw = weight.shape
+        direct = kh == 1 and kw == 1 and stride == 1 and pad == 0 and not nchw
+        if direct:
+            col, Ho, Wo = x, H, W
+            w2 = weight.view(Cout, Cin)
+        else:
+            col, Ho, Wo = K.im2col(x, B, H, W, Cin, kh, kw, stride, pad, nchw)
+            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin)        # taps (kh, kw, c), like the columns
+            if col.shape[1] != w2.shape[1]:
+                w2 = torch.nn.functional.pad(w2, (0, col.shape[1] - w2.shape[1]))
+            w2 = w2.contiguous()
+        y = K.gemm(col, w2, False, True, bias=bias)
+        ctx.save_for_backward(col, w2)
+        ctx.geom = (B, H, W, Cin, kh, kw, stride, pad, nchw, direct)
+        ctx.refs = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, w2 = ctx.saved_tensors
+        B, H, W, Cin, kh, kw, stride, pad, nchw, direct = ctx.geom
+        weight, bias = ctx.refs
+        Cout = weight.shape[0]
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0] and not nchw:
+            dcol = K.gemm(dy, w2, False, False)
+            dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
+        dw2 = K.gemm(dy, col, True, False)                                        # [Cout, Kpad]
+        if direct:
+            dw = dw2.view(weight.shape)
+        else:
+            dw = dw2[:, :kh * kw * Cin].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+        db = K.colsum(dy, out_dtype=weight.dtype) if bias is not None else None
+        return dx, dw, db, None
+
+
+def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, nchw=False):
+    """-> (rows [B*Ho*Wo, Cout], Ho, Wo)."""
+    kh, kw = weight.shape[2], weight.shape[3]
+    y = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw))
+    return y, K.conv_out_size(H, kh, stride, pad), K.conv_out_size(W, kw, stride, pad)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d (+ optional residual add and ReLU fused, module/resnet.py:105-128) on NHWC rows."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        y, mean, rstd = K.batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual)
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.cfg = (training, relu, residual is not None)
+        ctx.bias_ref = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        gw, gb = _sink(weight), _sink(ctx.bias_ref)
+        if gw is not None and gb is not None and weight.requires_grad:
+            dx, dres, _, _ = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res, dgamma=gw, dbeta=gb)
+            _sink_done(weight)
+            _sink_done(ctx.bias_ref)
+            dg = db = None
+        else:
+            dx, dres, dg, db = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res)
+        return dx, dres, dg, db, None, None, None, None, None, None
+
+
+def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None):
+    """bn holds torch's parameters / buffers (state-dict parity); statistics follow bn.training like nn.BatchNorm2d."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm, rv = bn.running_mean, bn.running_var
+    cast = rm is not None and rm.dtype != torch.float32       # model.bfloat16() casts the buffers too: keep the update in fp32
+    if cast:
+        rm, rv = rm.float(), rv.float()
+    y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+    if cast and training:
+        bn.running_mean.copy_(rm)
+        bn.running_var.copy_(rv)
+    return y
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, geom):
+        B, H, W, k, stride, pad = geom
+        y, arg, Ho, Wo = K.maxpool_fwd(x, B, H, W, x.shape[1], k, stride, pad)
+        ctx.save_for_backward(arg)
+        ctx.geom = geom + (x.shape[1],)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, H, W, k, stride, pad, C = ctx.geom
+        return K.maxpool_bwd(dy, arg, B, H, W, C, k, stride, pad), None
+
+
+def max_pool(x, B, H, W, k, stride, pad):
+    y = MaxPoolFn.apply(x, (B, H, W, k, stride, pad))
+    return y, K.conv_out_size(H, k, stride, pad), K.conv_out_size(W, k, stride, pad)
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = K.relu(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.relu(dy, y)
+
+
+def relu(x):
+    x2d, restore = rows_view(x)
+    return restore(ReluFn.apply(x2d))

@@ -44,6 +44,27 @@ CASES = {
                     "encoder.layers.5.attn_ln.weight", "decoder.layers.0.self_attn.c_attn",
                     "decoder.layers.5.encoder_attn.out_proj.bias", "encoder.adaptor.text.type_embedding.weight"],
     ),
+    # cfg-2b family: default IMAGE adaptor (ResNet backbone, BatchNorm in TRAIN mode, 2-D rel-pos bias) + text -> text.
+    # dropout = 0 so that train mode is deterministic; resnet50 and a 64x64 image keep the CPU reference run short
+    "tiny_resnet": dict(
+        arch="tiny", active={"text", "image_resnet"}, overrides={"dropout": 0.0},
+        adaptor_overrides={"image_resnet": {"resnet_type": "resnet50"}}, train=True,
+        slots=[("IMAGE", True, ("img", "image", (2, 3, 64, 64)), None),
+               ("TEXT", True, ("tok", "src", (2, 9), [9, 6]), None),
+               ("TEXT", False, ("tok", "prev", (2, 7), [7, 4]), None)],
+        full_grads=["encoder.adaptor.image_resnet.embed_images.conv1.weight",
+                    "encoder.adaptor.image_resnet.embed_images.layer1.0.downsample.0.weight",
+                    "encoder.adaptor.image_resnet.embed_images.layer2.1.conv2.weight",
+                    "encoder.adaptor.image_resnet.embed_images.layer3.5.bn3.weight",
+                    "encoder.adaptor.image_resnet.embed_images.bn1.bias",
+                    "encoder.adaptor.image_resnet.image_proj.weight",
+                    "encoder.adaptor.image_resnet.image_rel_pos_table_list.2.weight",
+                    "encoder.adaptor.image_resnet.embed_image_positions.weight"],
+        buffers=["encoder.adaptor.image_resnet.embed_images.bn1.running_mean",
+                 "encoder.adaptor.image_resnet.embed_images.layer3.5.bn3.running_var",
+                 "encoder.adaptor.image_resnet.embed_images.layer2.0.downsample.1.running_mean",
+                 "encoder.adaptor.image_resnet.embed_images.layer1.2.bn2.num_batches_tracked"],
+    ),
 }
 
 

@@ -34,6 +34,8 @@ def run_case(name, case):
     model, d = build_reference_model(case["arch"], VOCAB_EXTRA, case["active"], case["overrides"], case["adaptor_overrides"])
     recipe.fill_state(model.state_dict())
     model.eval()
+    if case.get("train"):          # dropout is 0 in such cases: train mode only switches BatchNorm to batch statistics
+        model.train()
     V = len(d)
     slots, prev = [], None
     for mod, is_src, spec, attrs in case["slots"]:
@@ -90,8 +92,12 @@ def run_case(name, case):
     params = dict(model.named_parameters())
     for k in case["full_grads"]:
         out["grad." + k] = params[k].grad.detach()
+    for k in case.get("buffers", []):
+        out["buffer." + k] = model.state_dict()[k].detach().clone()
     out["state_keys"] = np.array([f"{k}|{tuple(v.shape)}|{str(v.dtype)}" for k, v in model.state_dict().items()])
     # integer buffers are part of the bit-exact contract
+    if "encoder.adaptor.image_resnet.image_rp_bucket" in model.state_dict():
+        out["image_rp_bucket_crc"] = np.array([zlib_crc(model.state_dict()["encoder.adaptor.image_resnet.image_rp_bucket"])])
     out["token_rp_bucket_crc"] = np.array([zlib_crc(model.state_dict()["encoder.adaptor.text.token_rp_bucket"])])
     out["token_rp_bucket_corner"] = model.state_dict()["encoder.adaptor.text.token_rp_bucket"][:300:7, :300:7].clone()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})

@@ -13,7 +13,7 @@ import zlib
 import numpy as np
 import torch
 
-_SKIP = ("version", "token_rp_bucket")
+_SKIP = ("version", "token_rp_bucket", "image_rp_bucket", "num_batches_tracked")
 
 
 def _gen(key, shape, scale, shift=0.0):
@@ -26,6 +26,10 @@ def value_for(key, shape, pad_idx=1):
     last = key.split(".")[-1]
     if key.endswith("c_attn"):
         return _gen(key, shape, 0.1, 1.0)
+    if last == "running_mean":                        # BatchNorm buffers (image_resnet backbone)
+        return _gen(key, shape, 0.1)
+    if last == "running_var":
+        return _gen(key, shape, 0.1).abs() + 0.8
     if "rel_pos_table" in key:
         return _gen(key, shape, 0.1)
     if key.endswith("cls_token"):

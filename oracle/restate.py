@@ -69,6 +69,9 @@ class OConfig:
     # per-adaptor flags (adaptor/base.py:56-81); NOT inherited from the model cfg (base.py:97-101)
     adaptor_entangle: Dict[str, bool] = field(default_factory=dict)
     patch: int = 14                         # adaptor/image_patch_embed.py:24-29
+    resnet_layers: tuple = (3, 8, 36)       # adaptor/image_resnet.py:44-47 (default resnet152), module/resnet.py:249-261
+    image_bucket_size: int = 42             # adaptor/image_resnet.py:62-65
+    training: bool = False                  # BatchNorm batch statistics (dropout must be 0 for a deterministic oracle)
 
 
 # --------------------------------------------------------------------------------------------
@@ -101,6 +104,22 @@ def make_token_bucket_position(bucket_size, max_position):
     log_pos = log_pos.int()
     bucket = torch.where(abs_pos.le(mid), rel, log_pos * sign).long()
     return bucket + bucket_size - 1
+
+
+def make_image_bucket_position(bucket_size, num_relative_distance):
+    """2-D relative-position bucket table, integer, bit-exact (adaptor/image_resnet.py:25-40)."""
+    coords = torch.stack(torch.meshgrid([torch.arange(bucket_size), torch.arange(bucket_size)], indexing="ij"))
+    flat = torch.flatten(coords, 1)
+    rel = (flat[:, :, None] - flat[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += bucket_size - 1
+    rel[:, :, 1] += bucket_size - 1
+    rel[:, :, 0] *= 2 * bucket_size - 1
+    idx = torch.zeros(size=(bucket_size * bucket_size + 1,) * 2, dtype=rel.dtype)
+    idx[1:, 1:] = rel.sum(-1)
+    idx[0, 0:] = num_relative_distance - 3
+    idx[0:, 0] = num_relative_distance - 2
+    idx[0, 0] = num_relative_distance - 1
+    return idx
 
 
 def box_to_bins(coords, max_image_size, num_bins):
@@ -168,7 +187,64 @@ def image_patch_embed_adaptor(state, cfg, side, slot):
     return embed, masks, pos_embed, None
 
 
-_ADAPTORS = {"text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor}
+def _bn(state, p, x, cfg):
+    """nn.BatchNorm2d (module/resnet.py:105-128): batch statistics + running update when training, else running."""
+    if cfg.training and (p + ".num_batches_tracked") in state:             # torch/nn/modules/batchnorm.py: _BatchNorm.forward
+        state[p + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, state[p + ".running_mean"], state[p + ".running_var"], state[p + ".weight"], state[p + ".bias"],
+                        training=cfg.training, momentum=0.1, eps=1e-5)
+
+
+def _bottleneck(state, p, x, cfg, stride, has_down):
+    """module/resnet.py:112-137 (drop_path rate 0)."""
+    out = F.relu(_bn(state, p + ".bn1", F.conv2d(x, state[p + ".conv1.weight"]), cfg))
+    out = F.relu(_bn(state, p + ".bn2", F.conv2d(out, state[p + ".conv2.weight"], stride=stride, padding=1), cfg))
+    out = _bn(state, p + ".bn3", F.conv2d(out, state[p + ".conv3.weight"]), cfg)
+    identity = x
+    if has_down:
+        identity = _bn(state, p + ".downsample.1", F.conv2d(x, state[p + ".downsample.0.weight"], stride=stride), cfg)
+    return F.relu(identity + out)
+
+
+def resnet_backbone(state, p, x, cfg):
+    """module/resnet.py:232-246: conv1-bn-relu-maxpool-layer1..3 (no layer4)."""
+    x = F.relu(_bn(state, p + ".bn1", F.conv2d(x, state[p + ".conv1.weight"], stride=2, padding=3), cfg))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, (blocks, stride) in enumerate(zip(cfg.resnet_layers, (1, 2, 2)), start=1):
+        for b in range(blocks):
+            x = _bottleneck(state, f"{p}.layer{li}.{b}", x, cfg, stride if b == 0 else 1, b == 0)
+    return x
+
+
+def image_resnet_adaptor(state, cfg, side, slot):
+    """adaptor/image_resnet.py:130-202: backbone -> flatten -> Linear(1024, D); position ids w + h*bucket + 1; rel-pos bias
+    by the double gather into image_rp_bucket (:116-128)."""
+    p = f"{side}.adaptor.image_resnet"
+    img = slot.value
+    B = img.shape[0]
+    feat = resnet_backbone(state, p + ".embed_images", img, cfg)
+    h, w = feat.shape[-2:]
+    n = h * w
+    masks = torch.zeros(B, n, dtype=torch.bool)
+    idx = (torch.arange(w).unsqueeze(0).expand(h, w) + torch.arange(h).unsqueeze(1) * cfg.image_bucket_size + 1).view(-1)
+    ids = idx[None, :].expand(B, n)
+    embed = feat.flatten(2).transpose(1, 2)
+    pos_embed = F.embedding(ids, state[p + ".embed_image_positions.weight"])
+    embed = linear(state, p + ".image_proj", embed)
+    rel = None
+    if cfg.use_self_attn_bias:
+        L = cfg.enc_layers if side == "encoder" else cfg.dec_layers
+        bucket = state[p + ".image_rp_bucket"]
+        S = bucket.size(1)
+        rp = (bucket.unsqueeze(0).expand(B, S, S).gather(1, ids[:, :, None].expand(B, n, S))
+              .gather(2, ids[:, None, :].expand(B, n, n)))
+        rel = [F.embedding(rp, state[p + f".image_rel_pos_table_list.{l}.weight"]).permute(0, 3, 1, 2)
+               for l in range(1 if cfg.share_attn_bias else L)]
+    embed, pos_embed = _post_hook(state, cfg, side, "image_resnet", slot, embed, pos_embed)
+    return embed, masks, pos_embed, rel
+
+
+_ADAPTORS = {"text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor, "image_resnet": image_resnet_adaptor}
 
 
 def general_adaptor(state, cfg, side, slots):

@@ -34,6 +34,11 @@ def state_from_golden(g, dtype=torch.float32):
             if bucket is None:
                 bucket = make_token_bucket_position(256, 1024)
             state[key] = bucket
+        elif key.endswith("image_rp_bucket"):
+            from oracle.restate import make_image_bucket_position
+            state[key] = make_image_bucket_position(42, (2 * 42 - 1) ** 2 + 3)
+        elif key.endswith("num_batches_tracked"):
+            state[key] = torch.zeros((), dtype=torch.long)
         else:
             state[key] = recipe.value_for(key, shape).to(dtype)
     return state
@@ -42,8 +47,11 @@ def state_from_golden(g, dtype=torch.float32):
 def oracle_cfg(case):
     ov = case["overrides"]
     ent = {k: v.get("entangle_position_embedding", False) for k, v in case["adaptor_overrides"].items()}
+    layers = {"resnet50": (3, 4, 6), "resnet101": (3, 4, 23), "resnet152": (3, 8, 36)}[
+        case["adaptor_overrides"].get("image_resnet", {}).get("resnet_type", "resnet152")]
     return OConfig(**ARCH[case["arch"]], use_self_attn_bias=ov.get("use_self_attn_bias", True),
-                   entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent)
+                   entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent,
+                   resnet_layers=layers, training=bool(case.get("train", False)))
 
 
 def case_inputs(case):

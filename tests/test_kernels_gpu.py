@@ -425,3 +425,112 @@ def test_deferred_folds_match_immediate_reductions(K):
         assert rel(o, w.float()) < 1e-2
     ref = 0.25 + 2.0 * (a.float().t() @ c.float())
     assert rel(got[-1], ref) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------- convolution stack
+def _nhwc_rows(t):          # [B,C,H,W] -> [B*H*W, C]
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,W,nchw", [
+    (3, 64, 7, 2, 3, 30, 26, True),       # the stem convolution reads the NCHW image directly
+    (64, 64, 1, 1, 0, 9, 7, False),       # 1x1: plain GEMM on the rows
+    (64, 128, 3, 1, 1, 9, 7, False),
+    (128, 128, 3, 2, 1, 10, 8, False),
+    (256, 512, 1, 2, 0, 8, 8, False),     # strided 1x1 (downsample branch)
+    (8, 16, 3, 2, 0, 11, 9, False),       # no padding (audio subsampling convs)
+])
+def test_conv2d(K, dtype, Cin, Cout, k, stride, pad, H, W, nchw):
+    from ofasys_amd import ops
+    torch.manual_seed(31)
+    B = 2
+    x = torch.randn(B, Cin, H, W, device=DEV).to(dtype)
+    w = (0.1 * torch.randn(Cout, Cin, k, k, device=DEV)).to(dtype)
+    b = torch.randn(Cout, device=DEV).to(dtype) if not nchw else None
+    xr, wr = x.float().clone().requires_grad_(True), w.float().clone().requires_grad_(True)
+    br = b.float().clone().requires_grad_(True) if b is not None else None
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    xin = (x if nchw else _nhwc_rows(x)).detach().clone().requires_grad_(not nchw)
+    wp = w.clone().requires_grad_(True)
+    bp = b.clone().requires_grad_(True) if b is not None else None
+    y, Ho, Wo = ops.conv2d(xin, wp, bp, B, H, W, stride, pad, nchw)
+    assert (Ho, Wo) == tuple(ref.shape[-2:])
+    t = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(y, _nhwc_rows(ref)) < t
+    y.backward(_nhwc_rows(dy).to(dtype))
+    assert rel(wp.grad, wr.grad) < t
+    if not nchw:
+        assert rel(xin.grad, _nhwc_rows(xr.grad)) < t
+    if b is not None:
+        assert rel(bp.grad, br.grad) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training,relu,with_res", [(True, True, True), (True, False, False), (False, True, False), (True, True, False)])
+def test_batchnorm(K, dtype, training, relu, with_res):
+    from ofasys_amd import ops
+    torch.manual_seed(32)
+    B, C, H, W = 3, 64, 7, 5
+    x = (1.5 * torch.randn(B, C, H, W, device=DEV) + 0.3).to(dtype)
+    res = torch.randn(B, C, H, W, device=DEV).to(dtype) if with_res else None
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * torch.randn(C)); bn.bias.copy_(0.1 * torch.randn(C))
+        bn.running_mean.copy_(0.1 * torch.randn(C)); bn.running_var.copy_(1 + 0.1 * torch.rand(C))
+    import copy
+    bnr = copy.deepcopy(bn).float()
+    bn = bn.to(dtype)
+    with torch.no_grad():                          # same (rounded) parameters on both sides: a 0.4% gain difference would
+        for pr, p in zip(bnr.parameters(), bn.parameters()):     # flip ReLU gates of near-zero outputs
+            pr.copy_(p.float())
+        for br_, b_ in zip(bnr.buffers(), bn.buffers()):
+            br_.copy_(b_.to(br_.dtype))
+    bn.train(training); bnr.train(training)
+    xr = x.float().clone().requires_grad_(True)
+    rr = res.float().clone().requires_grad_(True) if with_res else None
+    yr = bnr(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xin = _nhwc_rows(x).requires_grad_(True)
+    rin = _nhwc_rows(res).requires_grad_(True) if with_res else None
+    y = ops.batch_norm(xin, bn, relu=relu, residual=rin)
+    t = 2e-5 if dtype == torch.float32 else 3e-2
+    assert rel(y, _nhwc_rows(yr)) < t
+    y.backward(_nhwc_rows(dy).to(dtype))
+    assert rel(xin.grad, _nhwc_rows(xr.grad)) < 2 * t
+    assert rel(bn.weight.grad, bnr.weight.grad) < 2 * t
+    assert rel(bn.bias.grad, bnr.bias.grad) < 2 * t
+    if with_res:
+        assert rel(rin.grad, _nhwc_rows(rr.grad)) < 2 * t
+    assert rel(bn.running_mean, bnr.running_mean) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel(bn.running_var, bnr.running_var) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert int(bn.num_batches_tracked) == int(bnr.num_batches_tracked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_relu(K, dtype):
+    from ofasys_amd import ops
+    torch.manual_seed(33)
+    B, C, H, W = 2, 16, 13, 10
+    x = torch.randn(B, C, H, W, device=DEV).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    xin = _nhwc_rows(x).requires_grad_(True)
+    y, Ho, Wo = ops.max_pool(xin, B, H, W, 3, 2, 1)
+    assert (Ho, Wo) == tuple(ref.shape[-2:]) and torch.equal(y.float(), _nhwc_rows(ref))
+    y.backward(_nhwc_rows(dy).to(dtype))
+    assert rel(xin.grad, _nhwc_rows(xr.grad)) < (1e-6 if dtype == torch.float32 else 1e-2)
+    z = x.clone().requires_grad_(True)
+    r = ops.relu(z)
+    assert torch.equal(r, F.relu(x))
+    r.backward(torch.ones_like(r))
+    assert torch.equal(z.grad, (x > 0).to(dtype))

@@ -65,6 +65,20 @@ CASES = {
                  "encoder.adaptor.image_resnet.embed_images.layer2.0.downsample.1.running_mean",
                  "encoder.adaptor.image_resnet.embed_images.layer1.2.bn2.num_batches_tracked"],
     ),
+    # cfg-4 family: video clip (3 frames of 64x64, the middle frame of row 1 all-zero = padding) + text -> text
+    "tiny_video": dict(
+        arch="tiny", active={"text", "video_image_sequence"}, overrides={"dropout": 0.0},
+        adaptor_overrides={"image_resnet": {"resnet_type": "resnet50"}}, train=True,
+        slots=[("VIDEO", True, ("vid", "video", (2, 3, 3, 64, 64), [(1, 1)]), None),
+               ("TEXT", True, ("tok", "src", (2, 5), [5, 3]), None),
+               ("TEXT", False, ("tok", "prev", (2, 6), [6, 4]), None)],
+        full_grads=["encoder.adaptor.video_image_sequence.embed_frame_positions.weight",
+                    "encoder.adaptor.video_image_sequence.video_rel_pos_table_list.1.weight",
+                    "encoder.adaptor.image_resnet.image_rel_pos_table_list.0.weight",
+                    "encoder.adaptor.image_resnet.image_proj.bias",
+                    "encoder.adaptor.video_image_sequence.type_embedding.weight"],
+        buffers=["encoder.adaptor.image_resnet.embed_images.layer3.0.bn1.running_mean"],
+    ),
 }
 
 
@@ -74,6 +88,12 @@ def make_value(spec, vocab):
     if spec[0] == "tok":
         _, key, shape, lengths = spec
         return recipe.tokens("input." + key, shape, vocab, lengths, bos=0 if key == "prev" else None)
+    if spec[0] == "vid":                         # ("vid", key, [B,3,F,H,W], [(row, frame) set to exactly zero])
+        _, key, shape, zero_frames = spec
+        v = recipe.floats("input." + key, shape)
+        for r, f in zero_frames:
+            v[r, :, f] = 0.0
+        return v
     _, key, shape = spec
     return recipe.floats("input." + key, shape)
 

@@ -244,7 +244,47 @@ def image_resnet_adaptor(state, cfg, side, slot):
     return embed, masks, pos_embed, rel
 
 
-_ADAPTORS = {"text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor, "image_resnet": image_resnet_adaptor}
+def video_image_sequence_adaptor(state, cfg, side, slot):
+    """adaptor/video_image_sequence.py:111-208: frames through the image_resnet backbone + projection, image + frame
+    positions, zero-frame padding rule, bias = frame rel-pos (+) image rel-pos broadcast to [B,A,F*P,F*P]."""
+    p = f"{side}.adaptor.video_image_sequence"
+    pi = f"{side}.adaptor.image_resnet"
+    clips = slot.value.transpose(1, 2)                                                   # [B,F,3,H,W]
+    B, Fr = clips.shape[:2]
+    feat = resnet_backbone(state, pi + ".embed_images", clips.reshape(-1, *clips.shape[2:]), cfg)
+    h, w = feat.shape[-2:]
+    P = h * w
+    T = P * Fr
+    embed = feat.view(feat.size(0), feat.size(1), -1).transpose(1, 2).reshape(B, T, feat.size(1))
+    masks = (clips.reshape(B, Fr, -1).abs().mean(dim=-1) == 0.0).unsqueeze(-1).expand(B, Fr, P).reshape(B, T)
+    idx = (torch.arange(w).unsqueeze(0).expand(h, w) + torch.arange(h).unsqueeze(1) * cfg.image_bucket_size + 1).view(-1)
+    ids = idx[None, :].expand(B, P)
+    fids = (torch.arange(Fr) + 1)[None, :].expand(B, Fr)
+    image_pos = F.embedding(ids, state[pi + ".embed_image_positions.weight"])
+    frame_pos = F.embedding(fids, state[p + ".embed_frame_positions.weight"])
+    pos_embed = (image_pos.unsqueeze(1) + frame_pos.unsqueeze(2)).reshape(B, T, -1)
+    embed = linear(state, pi + ".image_proj", embed)
+    rel = None
+    if cfg.use_self_attn_bias:
+        L = cfg.enc_layers if side == "encoder" else cfg.dec_layers
+        bucket = state[pi + ".image_rp_bucket"]
+        S = bucket.size(1)
+        rp = (bucket.unsqueeze(0).expand(B, S, S).gather(1, ids[:, :, None].expand(B, P, S))
+              .gather(2, ids[:, None, :].expand(B, P, P)))
+        rel = []
+        for l in range(L):
+            vi = F.embedding(rp, state[pi + f".image_rel_pos_table_list.{l}.weight"]).permute(0, 3, 1, 2)   # [B,A,P,P]
+            vf = F.embedding(state[p + ".video_rp_bucket"][:Fr, :Fr], state[p + f".video_rel_pos_table_list.{l}.weight"])
+            vf = vf.transpose(1, 2).transpose(0, 1).contiguous()                                             # [A,F,F]
+            vi = vi.view(vi.size(0), vi.size(1), 1, vi.size(2), 1, vi.size(3))
+            vf = vf.view(vf.size(0), vf.size(1), 1, vf.size(1), 1)
+            v = vf + vi
+            rel.append(v.view(v.size(0), v.size(1), v.size(2) * v.size(3), v.size(4) * v.size(5)))
+    embed, pos_embed = _post_hook(state, cfg, side, "video_image_sequence", slot, embed, pos_embed)
+    return embed, masks, pos_embed, rel
+
+
+_ADAPTORS = {"video_image_sequence": video_image_sequence_adaptor, "text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor, "image_resnet": image_resnet_adaptor}
 
 
 def general_adaptor(state, cfg, side, slots):

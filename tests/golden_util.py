@@ -30,6 +30,8 @@ def state_from_golden(g, dtype=torch.float32):
         shape = tuple(int(x) for x in shape.strip("()").split(",") if x.strip())
         if key.endswith("version"):
             state[key] = torch.tensor([3.0])
+        elif key.endswith("video_rp_bucket"):
+            state[key] = make_token_bucket_position(256, 1024)
         elif key.endswith("token_rp_bucket"):
             if bucket is None:
                 bucket = make_token_bucket_position(256, 1024)

@@ -79,6 +79,17 @@ CASES = {
                     "encoder.adaptor.video_image_sequence.type_embedding.weight"],
         buffers=["encoder.adaptor.image_resnet.embed_images.layer3.0.bn1.running_mean"],
     ),
+    # cfg-5 family: audio fbank [B,T,80] with ragged lengths (row 1 ends up with one padded frame) + mask_emb rows
+    "tiny_audio": dict(
+        arch="tiny", active={"text", "audio_fbank"}, overrides={"dropout": 0.0}, adaptor_overrides={}, train=False,
+        slots=[("AUDIO", True, ("fbank", "audio", (2, 50, 80), [50, 37], [(0, 2), (0, 3), (1, 5)]), ["use_mask"]),
+               ("TEXT", True, ("tok", "src", (2, 4), [4, 3]), None),
+               ("TEXT", False, ("tok", "prev", (2, 6), [6, 5]), None)],
+        full_grads=["encoder.adaptor.audio_fbank.subsample.conv.0.weight", "encoder.adaptor.audio_fbank.subsample.conv.2.bias",
+                    "encoder.adaptor.audio_fbank.subsample.out.0.bias", "encoder.adaptor.audio_fbank.mask_emb",
+                    "encoder.adaptor.audio_fbank.audio_rel_pos_table_list.1.weight",
+                    "encoder.adaptor.audio_fbank.embed_audio_positions.weight"],
+    ),
 }
 
 
@@ -88,6 +99,16 @@ def make_value(spec, vocab):
     if spec[0] == "tok":
         _, key, shape, lengths = spec
         return recipe.tokens("input." + key, shape, vocab, lengths, bos=0 if key == "prev" else None)
+    if spec[0] == "fbank":                       # ("fbank", key, [B,T,80], lengths, [(row, subsampled frame) masked])
+        _, key, shape, lengths, masked = spec
+        v = recipe.floats("input." + key, shape)
+        for r, n in enumerate(lengths):
+            v[r, n:] = 0.0
+        t2 = ((shape[1] - 3) // 2 + 1 - 3) // 2 + 1
+        mi = torch.zeros(shape[0], t2, dtype=torch.bool)
+        for r, t in masked:
+            mi[r, t] = True
+        return {"fbank": v, "fbank_lengths": torch.tensor(lengths, dtype=torch.long), "mask_indices": mi}
     if spec[0] == "vid":                         # ("vid", key, [B,3,F,H,W], [(row, frame) set to exactly zero])
         _, key, shape, zero_frames = spec
         v = recipe.floats("input." + key, shape)

@@ -13,7 +13,7 @@ import zlib
 import numpy as np
 import torch
 
-_SKIP = ("version", "token_rp_bucket", "image_rp_bucket", "video_rp_bucket", "num_batches_tracked")
+_SKIP = ("version", "token_rp_bucket", "image_rp_bucket", "video_rp_bucket", "audio_rp_bucket", "num_batches_tracked")
 
 
 def _gen(key, shape, scale, shift=0.0):
@@ -42,7 +42,7 @@ def value_for(key, shape, pad_idx=1):
         w = _gen("shared.embed_tokens.weight", shape, 0.1)   # encoder/decoder/output projection share one matrix
         w[pad_idx].zero_()
         return w
-    if "embed_positions" in key or "embed_image_positions" in key or "embed_frame_positions" in key or "type_embedding" in key:
+    if "embed_positions" in key or "embed_image_positions" in key or "embed_frame_positions" in key or "embed_audio_positions" in key or "type_embedding" in key:
         return _gen(key, shape, 0.5)
     if "proj.weight" in key and len(shape) == 4:      # patch conv
         return _gen(key, shape, 0.05)

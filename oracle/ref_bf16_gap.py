@@ -20,7 +20,8 @@ def run(dtype):
     slots = []
     for mod, is_src, spec, attrs in case["slots"]:
         v = make_value(spec, len(d))
-        if v.is_floating_point(): v = v.to(dtype)
+        if isinstance(v, dict): v = {k: (t.to(dtype) if t.is_floating_point() else t) for k, t in v.items()}
+        elif v.is_floating_point(): v = v.to(dtype)
         slots.append(Slot(ModalityType[mod], is_src, v, attributes=attrs))
     with torch.no_grad():
         return model(slots)[0].float()

@@ -49,6 +49,8 @@ class OSlot:
         for a in self.attributes or []:
             if a.startswith(key + "="):
                 return a[len(key) + 1:]
+            if a == key:
+                return ""
         return None
 
 
@@ -284,7 +286,39 @@ def video_image_sequence_adaptor(state, cfg, side, slot):
     return embed, masks, pos_embed, rel
 
 
-_ADAPTORS = {"video_image_sequence": video_image_sequence_adaptor, "text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor, "image_resnet": image_resnet_adaptor}
+def audio_fbank_adaptor(state, cfg, side, slot):
+    """adaptor/audio.py:295-325 (source branch) + module/subsample.py:44-63: two Conv2d(3, stride 2)+ReLU, channel-major
+    flatten, Linear; lengths ((l-1)/2+1).floor() twice; padding = positions past the subsampled length."""
+    p = f"{side}.adaptor.audio_fbank"
+    fbank, lengths = slot.value["fbank"], slot.value["fbank_lengths"]
+    x = fbank.unsqueeze(1)
+    x = F.relu(F.conv2d(x, state[p + ".subsample.conv.0.weight"], state[p + ".subsample.conv.0.bias"], stride=2))
+    x = F.relu(F.conv2d(x, state[p + ".subsample.conv.2.weight"], state[p + ".subsample.conv.2.bias"], stride=2))
+    b, c, t, f = x.size()
+    x = linear(state, p + ".subsample.out.0", x.transpose(1, 2).contiguous().view(b, t, c * f))
+    out_len = lengths.clone()
+    for _ in range(2):
+        out_len = ((out_len.float() - 1) / 2 + 1).floor().long()
+    masks = torch.zeros(b, t, dtype=torch.bool)
+    for i, l in enumerate(out_len):                                                       # audio.py:307-310
+        diff = int(l) - t
+        if diff < 0:
+            masks[i, diff:] = True
+    pos_embed = F.embedding(torch.arange(t).unsqueeze(0).expand(b, t), state[p + ".embed_audio_positions.weight"])
+    mi = slot.value.get("mask_indices")
+    if mi is not None and slot.get_attr("use_mask") is not None:                          # apply_mask, mask_prob > 0
+        x = torch.where(mi.unsqueeze(-1), state[p + ".mask_emb"].view(1, 1, -1), x)
+    embed, pos_embed = _post_hook(state, cfg, side, "audio_fbank", slot, x, pos_embed)
+    rel = None
+    if cfg.use_self_attn_bias:
+        L = cfg.enc_layers if side == "encoder" else cfg.dec_layers
+        bucket = state[p + ".audio_rp_bucket"][:t, :t]
+        rel = [F.embedding(bucket, state[p + f".audio_rel_pos_table_list.{l}.weight"]).unsqueeze(0).expand(b, -1, -1, -1)
+               .permute(0, 3, 1, 2) for l in range(1 if cfg.share_attn_bias else L)]
+    return embed, masks, pos_embed, rel
+
+
+_ADAPTORS = {"audio_fbank": audio_fbank_adaptor, "video_image_sequence": video_image_sequence_adaptor, "text": text_adaptor, "image_patch_embed": image_patch_embed_adaptor, "image_resnet": image_resnet_adaptor}
 
 
 def general_adaptor(state, cfg, side, slots):

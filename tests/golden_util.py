@@ -24,12 +24,16 @@ def state_from_golden(g, dtype=torch.float32):
     """Rebuild the full state dict (reference key schema) from the recipe; integer buffers are recomputed."""
     from oracle.restate import make_token_bucket_position
     state = {}
-    bucket = None
+    bucket = audio_bucket = None
     for item in g["state_keys"]:
         key, shape, _ = str(item).split("|")
         shape = tuple(int(x) for x in shape.strip("()").split(",") if x.strip())
         if key.endswith("version"):
             state[key] = torch.tensor([3.0])
+        elif key.endswith("audio_rp_bucket"):
+            if audio_bucket is None:
+                audio_bucket = make_token_bucket_position(1024, 4096)      # adaptor/audio.py:50-60, bucket = max_position
+            state[key] = audio_bucket
         elif key.endswith("video_rp_bucket"):
             state[key] = make_token_bucket_position(256, 1024)
         elif key.endswith("token_rp_bucket"):

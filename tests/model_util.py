@@ -33,6 +33,10 @@ def make_slots(vals, device, float_dtype=torch.float32):
     from ofasys_amd import ModalityType, Slot
     out = []
     for mod, is_src, v, attrs in vals:
+        if isinstance(v, dict):                      # audio: {"fbank", "fbank_lengths", "mask_indices"}
+            v = {k: (t.to(device).to(float_dtype) if t.is_floating_point() else t.to(device)) for k, t in v.items()}
+            out.append(Slot(ModalityType[mod], is_src, v, attributes=attrs))
+            continue
         v = v.to(device)
         if v.is_floating_point():
             v = v.to(float_dtype)

@@ -13,7 +13,7 @@ from tests.golden_util import load_golden
 from tests.model_util import build_model
 
 
-@pytest.mark.parametrize("name", ["tiny_text", "base_patch", "tiny_resnet", "tiny_video"])
+@pytest.mark.parametrize("name", ["tiny_text", "base_patch", "tiny_resnet", "tiny_video", "tiny_audio"])
 def test_state_dict_schema_matches_reference(name):
     g = load_golden(name)
     model, _ = build_model(CASES[name])

@@ -48,18 +48,24 @@ def build(args, device):
     m = GeneralistModel()
     m.cfg.arch = args.arch
     m.__init__(m.cfg)
-    m.cfg.use_self_attn_bias = False                      # the image_patch_embed adaptor's only working corner,
-    m.cfg.entangle_position_embedding = True
-    for name in ("text", "image_patch_embed"):
-        a = getattr(m.cfg.adaptor, name)
-        a.is_active = True
-        a.entangle_position_embedding = True
+    if getattr(args, "workload", "cfg2") == "cfg2b":
+        # cfg-2b: the default IMAGE adaptor (ResNet backbone) with the default biased attention
+        for name in ("text", "image_resnet"):
+            getattr(m.cfg.adaptor, name).is_active = True
+        m.cfg.adaptor.image_resnet.resnet_type = "resnet101"
+    else:
+        m.cfg.use_self_attn_bias = False                  # the image_patch_embed adaptor's only working corner,
+        m.cfg.entangle_position_embedding = True
+        for name in ("text", "image_patch_embed"):
+            a = getattr(m.cfg.adaptor, name)
+            a.is_active = True
+            a.entangle_position_embedding = True
     m.initialize(d)
     m = m.to(device).to(torch.bfloat16)
     return m, d
 
 
-def make_batch(d, B, Ts_text, Tt, rank, device):
+def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2"):
     """Synthetic instruction batch [IMAGE,adaptor=image_patch_embed][TEXT] -> [TEXT], seed 1234 + rank."""
     from ofasys_amd import ModalityType, Slot
     g = torch.Generator().manual_seed(1234 + rank)
@@ -79,10 +85,11 @@ def make_batch(d, B, Ts_text, Tt, rank, device):
         prev[b, n:] = d.pad()
         target[b, :n - 1] = prev[b, 1:n]
         target[b, n - 1] = d.eos()
-    slots = [Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"]),
+    patch = workload != "cfg2b"
+    slots = [Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"] if patch else None),
              Slot(ModalityType.TEXT, True, src.to(device)),
              Slot(ModalityType.TEXT, False, prev.to(device))]
-    ntok = B * 257 + int(slen.sum()) + int(tlen.sum())
+    ntok = B * (257 if patch else 196) + int(slen.sum()) + int(tlen.sum())
     return {"slots": slots, "target": target.to(device)}, ntok
 
 
@@ -192,6 +199,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--profile-gemm", type=int, default=1, help="instrumented steps after the timed region")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg2b"],
+                    help="cfg2 (headline: image_patch_embed, bias-free) or cfg2b (image_resnet101 + biased attention, 196+252 -> 64)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -214,8 +223,8 @@ def main():
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     trainer = Trainer(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph)
-    Ts_text, Tt = 191, 64
-    batch, ntok = make_batch(d, args.batch, Ts_text, Tt, rank, device)
+    Ts_text, Tt = (191, 64) if args.workload == "cfg2" else (252, 64)
+    batch, ntok = make_batch(d, args.batch, Ts_text, Tt, rank, device, args.workload)
 
     def barrier():
         if world > 1:
@@ -253,8 +262,13 @@ def main():
 
     if rank == 0:
         cfg = model.cfg
-        fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
-                                   cfg.encoder.layers, cfg.decoder.layers, 257 + Ts_text, Tt, len(d))
+        if args.workload == "cfg2b":       # ResNet-101 stride-16 trunk ~ 6.9 GMAC/img + Linear(1024, D), biased attention
+            fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
+                                       cfg.encoder.layers, cfg.decoder.layers, 196 + Ts_text, Tt, len(d), patch_tokens=0,
+                                       bias=True) + 2 * 6.9e9 + 2 * 196 * 1024 * cfg.encoder.embed_dim
+        else:
+            fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
+                                       cfg.encoder.layers, cfg.decoder.layers, 257 + Ts_text, Tt, len(d))
         step_flops = 3 * fwd * args.batch                          # backward = 2x forward
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
@@ -278,10 +292,13 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "tokens_per_sec_per_gpu": total_tokens * args.steps / dt / world,
-            "config": {"workload": "cfg-2 image_caption: image_patch_embed 224x224 (257 tok) + text<=191 -> text<=64, "
+            "config": {"workload": ("cfg-2 image_caption: image_patch_embed 224x224 (257 tok) + text<=191 -> text<=64, "
+                                    if args.workload == "cfg2" else
+                                    "cfg-2b image_caption: image_resnet101 224x224 (196 tok, rel-pos biased attention) + "
+                                    "text<=252 -> text<=64, ") +
                                    "OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "padded_positions_per_sample": 257 + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
+                       "padded_positions_per_sample": (257 if args.workload == "cfg2" else 196) + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
                        "vocab": len(d), "parallelism": f"dp{world}", "random_init": True},
             "roofline": roof,
         }

@@ -132,10 +132,10 @@ int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, 
 /* ---- embeddings: F.embedding gather (adaptor/text.py:119-127) and its dense-gradient scatter-add, deterministic
  * (a wave per (vocabulary row, id-list slice) scans the ids with ballots; no atomics). ids: int64.
  * present_ws: optional V bytes of scratch (rows that do not occur are skipped); slice_ws: optional fp32 scratch of
- * ofa_embedding_bwd_slices(V) * V * D floats -- small tables with thousands of hits per row are then reduced in slices. */
+ * ofa_embedding_bwd_slices(V, D) * V * D floats -- small tables with thousands of hits per row are then reduced in slices. */
 int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
                       void* stream);
-int ofa_embedding_bwd_slices(int64_t V);
+int ofa_embedding_bwd_slices(int64_t V, int D);
 int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
                       int64_t padding_idx, uint8_t* present_ws, float* slice_ws, int dtype, void* stream);
 

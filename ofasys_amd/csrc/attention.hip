@@ -83,6 +83,53 @@ __device__ __forceinline__ int dead_flag(const uint8_t* kp, int key0, int S, int
 }
 __device__ __forceinline__ uint32_t dead_ballot(int flag) { return (uint32_t)__ballot(flag != 0); }
 
+// The additive bias is fetched ONE BLOCK AHEAD (raw, in front of that block's LDS-DMA) and decoded when the block is
+// consumed: loads issued inside the block would sit behind the in-flight DMA in the vmcnt queue and drain it (the biased
+// kernels ran 2-4.5x slower than the bias-free ones that way).  Row form (forward / dQ: 16 keys of one query row, 4 x 8-byte
+// loads when S % 4 == 0 and the block is whole) and column form (dK/dV: one key, 16 query rows, 16 x 2-byte loads).
+struct BiasRow {
+  uint2 raw[4];
+  bool vec;
+  __device__ __forceinline__ void issue(const bf16_t* brow, int key0, int S, int hi) {
+    vec = brow && (S & 3) == 0 && key0 + 32 <= S;
+    if (vec) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) raw[g4] = *reinterpret_cast<const uint2*>(brow + key0 + 8 * g4 + 4 * hi);
+    }
+  }
+};
+__device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]);
+__device__ __forceinline__ void bias_row_take(const BiasRow& p, const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
+  if (!brow) return;
+  if (p.vec) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      b[4 * g4] = __uint_as_float(p.raw[g4].x << 16) * LOG2E;
+      b[4 * g4 + 1] = __uint_as_float(p.raw[g4].x & 0xffff0000u) * LOG2E;
+      b[4 * g4 + 2] = __uint_as_float(p.raw[g4].y << 16) * LOG2E;
+      b[4 * g4 + 3] = __uint_as_float(p.raw[g4].y & 0xffff0000u) * LOG2E;
+    }
+  } else {
+    bias16(brow, key0, S, hi, b);          // ragged tail block / unaligned rows: in place
+  }
+}
+struct BiasCol {
+  unsigned short raw[16];
+  __device__ __forceinline__ void issue(const bf16_t* bcol, int q0, int T, int64_t S, int hi) {
+    if (!bcol) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + crowl(r, hi);
+      raw[r] = q < T ? bcol[(int64_t)q * S] : (unsigned short)0;
+    }
+  }
+  __device__ __forceinline__ void take(const bf16_t* bcol, float (&b)[16]) const {
+    if (!bcol) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r] = __uint_as_float((uint32_t)raw[r] << 16) * LOG2E;
+  }
+};
+
 // additive bias of the 16 scores a lane holds for a 32-key block (keys key0 + crowl(r, hi)), pre-multiplied by log2(e)
 __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
   if ((S & 3) == 0 && key0 + 32 <= S) {
@@ -170,7 +217,7 @@ __device__ __forceinline__ void rdtr(u64x2& d, uint32_t addr_lo, uint32_t addr_h
 template <int BUF>   // BUF selects the double-buffer half at compile time (immediates)
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                           f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
-                                          uint32_t dead_now, const bf16_t* brow, float sc) {
+                                          uint32_t dead_now, bool has_bias, const float (&bz)[16], float sc) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
   u64x2 kf[4];
   rd128<KOFF>(kf[0], ta.km[0]);
@@ -190,14 +237,12 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   float s[16];
   float mx = -INFINITY;
   const bool diag = a.causal && (key0 + 31 > q0);
-  if (brow || dead_now || diag) {
-    float bz[16];
-    if (brow) bias16(brow, key0, a.S, hi, bz);
+  if (has_bias || dead_now || diag) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = crowl(r, hi), key = key0 + j;
       float t = st[r] * sc;
-      if (brow) t += bz[r];
+      if (has_bias) t += bz[r];
       bool dead = (dead_now >> j) & 1u;
       if (diag) dead |= key > qi;
       t = dead ? -INFINITY : t;
@@ -277,31 +322,44 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
     nkb = lim < nkb ? lim : nkb;
   }
   int kflag = dead_flag(kp, 0, a.S, i);
+  BiasRow bpre;
+  bpre.issue(brow, 0, a.S, hi);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
   const bool live_wave = q0 < a.T;
+  float bz[16];
   for (int kb = 0; kb < nkb; kb += 2) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
+      const BiasRow bcur = bpre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
+        bpre.issue(brow, (kb + 1) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
-      if (need) fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow, sc);
+      if (need) {
+        bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
+        fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc);
+      }
       ATT_SYNC();
     }
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
+      const BiasRow bcur = bpre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
+        bpre.issue(brow, (kb + 2) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
-      if (need) fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow, sc);
+      if (need) {
+        bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc);
+      }
       ATT_SYNC();
     }
   }
@@ -323,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
 template <int BUF>
 __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                          const bf16x8 (&dof)[4], f32x16 (&dqt)[2], int key0, int q0, int qi, int hi,
-                                         uint32_t dead_now, const bf16_t* brow, bf16_t* dbrow, float sc, float lse_q,
+                                         uint32_t dead_now, bool has_bias, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
                                          float delta_q, float c) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
   u64x2 kf[4], vf[4];
@@ -346,14 +404,12 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
   }
   float ds[16];
   const bool diag = a.causal && (key0 + 31 > q0);
-  if (brow || dead_now || diag) {
-    float bz[16];
-    if (brow) bias16(brow, key0, a.S, hi, bz);
+  if (has_bias || dead_now || diag) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = crowl(r, hi), key = key0 + j;
       float t = st[r] * sc;
-      if (brow) t += bz[r];
+      if (has_bias) t += bz[r];
       bool dead = (dead_now >> j) & 1u;
       if (diag) dead |= key > qi;
       const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - lse_q);
@@ -367,10 +423,16 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
     }
   }
   if (dbrow && qi < a.T) {
+    if ((a.S & 3) == 0 && key0 + 32 <= a.S) {             // 4 consecutive keys per register quad: 8-byte stores
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + crowl(r, hi);
-      if (key < a.S) dbrow[key] = f2bf(ds[r]);
+      for (int g4 = 0; g4 < 4; ++g4)
+        st4(dbrow + key0 + 8 * g4 + 4 * hi, ds[4 * g4], ds[4 * g4 + 1], ds[4 * g4 + 2], ds[4 * g4 + 3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + crowl(r, hi);
+        if (key < a.S) dbrow[key] = f2bf(ds[r]);
+      }
     }
   }
   ATT_WAIT4(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
@@ -425,36 +487,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
     nkb = lim < nkb ? lim : nkb;
   }
   int kflag = dead_flag(kp, 0, a.S, i);
+  BiasRow bpre;
+  bpre.issue(brow, 0, a.S, hi);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
   const bool live_wave = q0 < a.T;
+  float bz[16];
   int my_last = -1;      // last key block this wave actually visited (for zero-filling dbias beyond it)
   for (int kb = 0; kb < nkb; kb += 2) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
+      const BiasRow bcur = bpre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
+        bpre.issue(brow, (kb + 1) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        dq_block<0>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, brow, dbrow, sc, lse_q, delta_q, c);
+        bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
+        dq_block<0>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
       ATT_SYNC();
     }
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
+      const BiasRow bcur = bpre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
+        bpre.issue(brow, (kb + 2) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        dq_block<1>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, brow, dbrow, sc, lse_q, delta_q, c);
+        bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        dq_block<1>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
       ATT_SYNC();
@@ -481,7 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
 template <int BUF>
 __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&kf)[4],
                                           const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0, int key0,
-                                          int ki, int hi, bool key_dead, float live, const bf16_t* bcol, float sc, float c,
+                                          int ki, int hi, bool key_dead, float live, bool has_bias, const float (&bz)[16], float sc, float c,
                                           const float4 (&l4)[4], const float4 (&d4)[4]) {
   constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES;
   u64x2 qf[4], dof[4];
@@ -513,13 +584,13 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     dv16[4 * g4] = d4[g4].x; dv16[4 * g4 + 1] = d4[g4].y; dv16[4 * g4 + 2] = d4[g4].z; dv16[4 * g4 + 3] = d4[g4].w;
   }
   float p[16], ds[16];
-  const bool general = bcol || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
+  const bool general = has_bias || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
   if (general) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = q0 + crowl(r, hi);
       float t = st[r] * sc;
-      if (bcol && q < a.T) t += bf2f(bcol[(int64_t)q * a.S]) * LOG2E;
+      if (has_bias) t += bz[r];
       bool dead = key_dead || q >= a.T;
       if (a.causal) dead |= ki > q;
       const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[r]);
@@ -592,8 +663,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
       Dd[g4] = *reinterpret_cast<const float4*>(delta_b + q0 + 8 * g4);
     }
   };
+  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight
+  float bz[16];
   if (qb_first < nqb) {
     load_stats(qb_first * 32, l4, d4);
+    bA.issue(bcol, qb_first * 32, a.T, a.S, hi);
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   }
@@ -602,21 +676,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
     {
       if (qb + 1 < nqb) {
         load_stats((qb + 1) * 32, l4n, d4n);            // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
+        bB.issue(bcol, (qb + 1) * 32, a.T, a.S, hi);
         tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
-      if (need) dkv_block<0>(a, ta, trx, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bcol, sc, c, l4, d4);
+      if (need) {
+        bA.take(bcol, bz);
+        dkv_block<0>(a, ta, trx, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bcol != nullptr, bz, sc, c, l4, d4);
+      }
       ATT_SYNC();
     }
     if (qb + 1 < nqb) {
       if (qb + 2 < nqb) {
         load_stats((qb + 2) * 32, l4, d4);
+        bA.issue(bcol, (qb + 2) * 32, a.T, a.S, hi);
         tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
-      if (need) dkv_block<1>(a, ta, trx, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bcol, sc, c, l4n, d4n);
+      if (need) {
+        bB.take(bcol, bz);
+        dkv_block<1>(a, ta, trx, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bcol != nullptr, bz, sc, c, l4n, d4n);
+      }
       ATT_SYNC();
     }
   }

@@ -156,18 +156,33 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
   }
 }
 
+// fold the per-group fp64 partials of one quantity pair: 32 columns x 8 group-lanes per 256-thread block
+__device__ __forceinline__ void bn_fold_groups(const double* __restrict__ partial, int groups, int C, int c, int gl, double& s,
+                                               double& q) {
+  __shared__ double red[2][8][32];
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int g = gl; g < groups; g += 8) {
+      a += partial[((int64_t)g * 2) * C + c];
+      b += partial[((int64_t)g * 2 + 1) * C + c];
+    }
+  red[0][gl][threadIdx.x & 31] = a;
+  red[1][gl][threadIdx.x & 31] = b;
+  __syncthreads();
+  s = q = 0.0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
+}
+
 // forward finalize: mean / rstd of the batch + running statistics (torch: running = (1-m)*running + m*stat, unbiased var)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int groups, int C, int64_t rows,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    s += partial[((int64_t)g * 2) * C + c];
-    q += partial[((int64_t)g * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), gl = threadIdx.x >> 5;
+  double s, q;
+  bn_fold_groups(partial, groups, C, c, gl, s, q);
+  if (gl != 0 || c >= C) return;
   const double m = s / (double)rows;
   double var = q / (double)rows - m * m;
   var = var < 0.0 ? 0.0 : var;
@@ -195,13 +210,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int groups, int C,
                                                               float* __restrict__ sums, T* __restrict__ dgamma,
                                                               T* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    s += partial[((int64_t)g * 2) * C + c];
-    q += partial[((int64_t)g * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), gl = threadIdx.x >> 5;
+  double s, q;
+  bn_fold_groups(partial, groups, C, c, gl, s, q);
+  if (gl != 0 || c >= C) return;
   sums[c] = (float)s;
   sums[C + c] = (float)q;
   if (dgamma) {
@@ -406,7 +418,7 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
       hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
     else
       hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
   if (rc) return rc;
@@ -432,10 +444,10 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   dim3 grid(cdiv(C / n, 32), groups), block(256);
   if (dtype == OFA_F32) {
     hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else {
     hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");
   if (rc) return rc;

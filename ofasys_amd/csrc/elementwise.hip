@@ -425,10 +425,12 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
   return check_launch("embedding_fwd");
 }
 
-// slices for a table of V rows: keep S*V partial rows <= 8192 (<= 64 slices)
-extern "C" int ofa_embedding_bwd_slices(int64_t V) {
-  if (V <= 0) return 1;
-  int64_t s = 8192 / V;
+// slices for a table of V rows of D columns (<= 64 slices)
+extern "C" int ofa_embedding_bwd_slices(int64_t V, int D) {
+  if (V <= 0 || D <= 0) return 1;
+  const int64_t by_rows = 8192 / V;                 // wide tables: <= 8192 partial rows
+  const int64_t by_bytes = ((int64_t)1 << 21) / (V * D);   // narrow ones (rel-pos tables [~7000, heads]): <= 8 MB of partials
+  int64_t s = by_rows > by_bytes ? by_rows : by_bytes;
   return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
@@ -445,7 +447,7 @@ extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dwe
     (void)hipMemsetAsync(present_ws, 0, (size_t)V, st);
     hipLaunchKernelGGL(embedding_mark_kernel, dim3(grid_for(n)), dim3(256), 0, st, ids, present_ws, n, V);
   }
-  const int S = slice_ws ? ofa_embedding_bwd_slices(V) : 1;
+  const int S = slice_ws ? ofa_embedding_bwd_slices(V, D) : 1;
   const int nv = cdiv(D, 64 * vecn);
   dim3 grid((unsigned)((V + 3) / 4), S), block(256);
 #define EMB_LAUNCH(T, NV)                                                                                               \

@@ -440,7 +440,7 @@ def embedding_bwd(dout, ids, V, padding_idx=-1, dweight=None):
     if dweight is None:
         dweight = torch.zeros(V, D, dtype=dout.dtype, device=dout.device)
     present = workspace(V, dout.device, "embed_present") if V > 4096 else None
-    S = lib().cdll.ofa_embedding_bwd_slices(V)
+    S = lib().cdll.ofa_embedding_bwd_slices(V, D)
     slices = workspace(S * V * D * 4, dout.device, "embed_slices") if S > 1 else None
     lib().call("ofa_embedding_bwd", ptr(dout), ptr(ids), ptr(dweight), ids.numel(), D, V,
                -1 if padding_idx is None else padding_idx, ptr(present), ptr(slices), dtype_code(dout), stream())

@@ -109,6 +109,18 @@ class ResNet(nn.Module):
                                 norm_layer=norm_layer, drop_path_rate=dpr[i]))
         return nn.Sequential(*layers)
 
+    def _apply(self, fn, *args, **kwargs):
+        """model.bfloat16() / .half() must not round the BatchNorm running statistics: they are fp32 accumulators updated
+        with momentum 0.1 every step (the reference lets .to(bf16) cast them; loading either dtype works)."""
+        keep = [(m, m.running_mean, m.running_var) for m in self.modules()
+                if isinstance(m, nn.BatchNorm2d) and m.running_mean is not None]
+        super()._apply(fn, *args, **kwargs)
+        for m, rm, rv in keep:
+            if m.running_mean.dtype != torch.float32:
+                m.running_mean = rm.float().to(m.running_mean.device)
+                m.running_var = rv.float().to(m.running_var.device)
+        return self
+
     def forward(self, x):
         """x: [B, 3, H, W] image -> (rows [B*h*w, 1024] in (b, h, w) order, h, w); the reference returns [B,1024,h,w] and
         its caller immediately flattens to [B, h*w, 1024] (adaptor/image_resnet.py:159) -- the same rows."""

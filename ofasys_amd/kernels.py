@@ -44,10 +44,15 @@ class FoldQueue:
     MAX_PENDING_BYTES = 96 << 20
 
     def __init__(self):
-        self.jobs, self.keep, self.bytes = [], [], 0
+        self.jobs, self.keep, self.bytes, self.outs = [], [], 0, set()
 
     def add(self, part, part_off, out, cols, stride, nslots, alpha=1.0, accumulate=True, flush_ok=True):
         assert part.dtype == torch.float32 and out.is_contiguous()
+        if out.data_ptr() in self.outs:
+            # a second contribution to the same gradient (a module applied to several slots): jobs of one launch run
+            # concurrently, so two read-modify-writes of one output must not share a launch
+            self.flush()
+        self.outs.add(out.data_ptr())
         self.jobs.append(_FoldJob(part.data_ptr() + part_off * 4, out.data_ptr(), cols, stride, nslots, int(accumulate),
                                   float(alpha), dtype_code(out)))
         self.keep.append((part, out))
@@ -65,6 +70,7 @@ class FoldQueue:
         arr = (_FoldJob * len(self.jobs))(*self.jobs)
         lib().call("ofa_fold_batched", ctypes.addressof(arr), len(self.jobs), stream())
         self.jobs, self.keep, self.bytes, self.want_flush = [], [], 0, False   # (same stream: buffers may be reused)
+        self.outs = set()
 
 
 def _u8(mask):

@@ -196,3 +196,78 @@ def test_graph_replay_matches_eager_steps():
     assert len(set(l1)) == len(l1)                                                    # every replay drew new masks / moved
     assert l0 == l1
     assert torch.equal(m0, m1)
+
+
+def test_train_step_arithmetic_two_tasks():
+    """engine/trainer.py:747-884 + optim/adam.py:192-212 on a 2-task step: gradients of both micro-batches accumulate,
+    are multiplied by 1/sum(sample_size), clipped to norm 1 (module/utils.py:342-384), then one Adam update.  The same
+    arithmetic is restated on the CPU with the ORACLE model (fp32) and compared with Trainer.train_step (HIP, fp32)."""
+    from oracle import restate
+    from ofasys_amd.trainer import Trainer
+    from tests.golden_util import oracle_cfg, oracle_slots, state_from_golden
+    case_a, case_b = CASES["tiny_text"], CASES["tiny_multislot"]
+    lr, b1, b2, eps, clip = 1e-2, 0.9, 0.999, 1e-8, 1.0
+    # --- oracle side (CPU)
+    state = state_from_golden(load_golden("tiny_text"))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    params = {k: v.requires_grad_(True) for k, v in state.items()
+              if v.is_floating_point() and not k.endswith("version") and not k.startswith("decoder.adaptor.embed_tokens")}
+    n_total, loss_total = 0, 0.0
+    for case in (case_a, case_b):
+        vals, target = case_inputs(case)
+        logits, _ = restate.model_forward(state, oracle_cfg(case), oracle_slots(vals))
+        loss, n = restate.cross_entropy(logits, target)
+        loss.backward()
+        n_total += n
+        loss_total += float(loss)
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) / n_total for k, p in params.items()}
+    gnorm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+    coef = min(1.0, clip / (float(gnorm) + 1e-6))
+    want = {}
+    for k, p in params.items():                      # first Adam step: m = (1-b1) g, v = (1-b2) g^2
+        g = grads[k] * coef
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        step_size = lr * (1 - b2) ** 0.5 / (1 - b1)
+        want[k] = p.detach() - step_size * m / (v.sqrt() + eps)
+    # --- HIP side
+    model, d = build_model(case_a, DEV, torch.float32)
+    tr = Trainer(model, lr=lr, betas=(b1, b2), eps=eps, clip_norm=clip)
+    samples = []
+    for case in (case_a, case_b):
+        vals, target = case_inputs(case)
+        samples.append({"slots": make_slots(vals, DEV), "target": target.to(DEV), "task": case["slots"][0][0]})
+    model.eval()                                     # dropout off (Trainer switches to train mode: force p = 0 instead)
+    for m_ in model.modules():
+        if hasattr(m_, "p") and m_.__class__.__name__ == "Dropout":
+            m_.p = 0.0
+    out = tr.train_step(samples)
+    torch.cuda.synchronize()
+    assert int(out["stats"][0]) == n_total
+    assert abs(float(out["stats"][1]) - loss_total) <= 1e-3 * loss_total
+    assert abs(float(out["gnorm"]) - float(gnorm)) <= 2e-3 * float(gnorm)
+    got = dict(model.named_parameters())
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    # (1) the Adam moments are linear / quadratic in the scaled, clipped gradient: well conditioned
+    offs = {id(p_): (o, p_.numel()) for p_, o in zip(tr.fp.params, tr.fp.offsets)}
+    for k, p_ in got.items():
+        if k not in grads or id(p_) not in offs:
+            continue
+        o, n = offs[id(p_)]
+        g = (grads[k] * coef).reshape(-1)
+        m_got, v_got = tr.exp_avg[o:o + n].cpu(), tr.exp_avg_sq[o:o + n].cpu()
+        assert float((m_got - (1 - b1) * g).abs().max()) <= (1 - b1) * (2e-3 * float(g.abs().max()) + 1e-6 * gmax * coef), k
+        assert float((v_got - (1 - b2) * g * g).abs().max()) <= (1 - b2) * (4e-3 * float((g * g).max()) + 1e-9 * (gmax * coef) ** 2), k
+    # (2) the parameter update itself where it is well determined (first-step Adam is ~ lr*sign(g): elements whose gradient is
+    #     fp32 noise -- e.g. the mathematically zero k_proj.bias gradients -- may legitimately flip sign)
+    checked = 0
+    for k, w in want.items():
+        if k not in got:
+            continue
+        sel = (grads[k].abs() > 1e-3 * gmax)
+        if not bool(sel.any()):
+            continue
+        upd_w = (w - params[k].detach())[sel]
+        upd_g = (got[k].detach().cpu() - params[k].detach())[sel]
+        assert float((upd_w - upd_g).abs().max()) <= 2e-2 * lr, k
+        checked += int(sel.sum())
+    assert checked > 1000

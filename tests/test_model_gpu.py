@@ -271,3 +271,28 @@ def test_train_step_arithmetic_two_tasks():
         assert float((upd_w - upd_g).abs().max()) <= 2e-2 * lr, k
         checked += int(sel.sum())
     assert checked > 1000
+
+
+def test_two_graph_replay_path_of_data_parallel_steps():
+    """With world_size > 1 the captured step is TWO graphs (forward+backward, clip+Adam) around an eager all-reduce.  There
+    is one GPU here, so the path is driven with the world size forced to 2 (the reducer itself stays single-rank): the
+    trajectory must equal the eager one."""
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import Trainer
+    case = CASES["tiny_multislot"]
+    vals, target = case_inputs(case)
+    runs = []
+    for two_graphs in (False, True):
+        model, d = build_model(case, DEV, torch.bfloat16)
+        tr = Trainer(model, lr=1e-3, clip_norm=1.0, use_graph=two_graphs, graph_warmup=1)
+        if two_graphs:
+            tr.world = 2
+        batch = {"slots": make_slots(vals, DEV, torch.bfloat16), "target": target.to(DEV)}
+        ops.manual_seed(5)
+        losses = [float(tr.train_step([batch])["stats"][1]) for _ in range(5)]
+        torch.cuda.synchronize()
+        runs.append((losses, tr.master.clone(), tr))
+    (l0, m0, _), (l1, m1, tr1) = runs
+    entry = [e for e in tr1._graphs.values() if "graphs" in e]
+    assert entry and len(entry[0]["graphs"]) == 2
+    assert l0 == l1 and torch.equal(m0, m1)

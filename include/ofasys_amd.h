@@ -184,6 +184,18 @@ int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float
                           void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,
                           void* stream);
 
+/* label-smoothed cross entropy fused with the log-softmax (engine/criterion/label_smoothed_cross_entropy.py:62-191):
+ * row_loss = (1-eps-eps_i)*nll + eps_i*smooth over the allowed vocabulary: all of it (cstart < 0), or [0,4) U
+ * [cstart,cend) (constraint_range), intersected with the optional per-row byte mask cmask [rows, V].  row_cnt receives
+ * the allowed count (needed by the backward); ignored rows give 0.  Backward: per-row weights row_w (optional; 0 drops a
+ * row -- drop_worst) and the scalar grad_scale multiply the gradient. */
+int ofa_ls_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, float* row_nll,
+                             float* row_cnt, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, float eps,
+                             int64_t cstart, int64_t cend, const uint8_t* cmask, int dtype, void* stream);
+int ofa_ls_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* row_cnt,
+                             const float* row_w, const float* grad_scale, void* dlogits, int64_t rows, int64_t V, int64_t ld,
+                             int64_t ignore_index, float eps, int64_t cstart, int64_t cend, const uint8_t* cmask, int dtype,
+                             void* stream);
 /* get_normalized_probs (model/ofa.py:287-299, module/utils.py:451-462): out fp32 [rows, V] = (log-)softmax_fp32(logits);
  * backward writes dlogits [rows, ld] in `dtype` (columns V..ld-1 zero). */
 int ofa_probs_fwd(const void* logits, float* out, int64_t rows, int64_t V, int64_t ld, int log_probs, int dtype,

@@ -84,6 +84,94 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   }
 }
 
+// ---- label-smoothed cross entropy (engine/criterion/label_smoothed_cross_entropy.py:62-191), fused with the
+// log-softmax: per non-ignored row
+//     nll = lse - x[t];   smooth = sum_{v allowed} (lse - x[v]);   eps_i = eps / (Vc - 1 [+1e-6 with constraints])
+//     loss = (1 - eps - eps_i) * nll + eps_i * smooth
+// where the allowed set is the whole vocabulary, or [0,4) U [cstart, cend) (constraint_range; logits outside are -inf in
+// the reference, :140-151) intersected with an optional per-row byte mask (sample["constraint_masks"]).
+struct LsCfg { float eps; int64_t cstart, cend; const uint8_t* cmask; };
+__device__ __forceinline__ bool ls_allowed(const LsCfg& c, int64_t row, int64_t v, int64_t V) {
+  bool ok = c.cstart < 0 || v < 4 || (v >= c.cstart && v < c.cend);
+  if (ok && c.cmask) ok = c.cmask[row * V + v] != 0;
+  return ok;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lsce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       float* __restrict__ lse, float* __restrict__ row_loss,
+                                                       float* __restrict__ row_nll, float* __restrict__ row_cnt, int64_t V,
+                                                       int64_t ld, int64_t ignore_index, LsCfg cfg) {
+  __shared__ float sm[4], ss[4], sx[4], sc[4];
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  float m = -INFINITY, s = 0.f, sumx = 0.f, cnt = 0.f;
+  for (int64_t v = threadIdx.x; v < V; v += 256) {
+    if (!ls_allowed(cfg, row, v, V)) continue;
+    const float a = ld1<T>(x + v);
+    online_merge(m, s, a, 1.f);
+    sumx += a;
+    cnt += 1.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    online_merge(m, s, m2, s2);
+  }
+  sumx = wave_sum(sumx);
+  cnt = wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[wave] = m; ss[wave] = s; sx[wave] = sumx; sc[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float M = sm[0], S = ss[0];
+    for (int w = 1; w < 4; ++w) online_merge(M, S, sm[w], ss[w]);
+    const float l = M + logf(S);
+    const float X = sx[0] + sx[1] + sx[2] + sx[3], C = sc[0] + sc[1] + sc[2] + sc[3];
+    lse[row] = l;
+    row_cnt[row] = C;
+    const int64_t t = target[row];
+    if (t == ignore_index) {
+      row_loss[row] = 0.f;
+      row_nll[row] = 0.f;
+    } else {
+      const float nll = l - ld1<T>(x + t);
+      const float smooth = C * l - X;
+      const float eps_i = cfg.eps / (cfg.cstart < 0 && !cfg.cmask ? (C - 1.f) : (C - 1.f + 1e-6f));
+      row_nll[row] = nll;
+      row_loss[row] = (1.f - cfg.eps - eps_i) * nll + eps_i * smooth;
+    }
+  }
+}
+
+// d loss_row / d x[v] = (1 - eps - eps_i)(p_v - [v == t]) + eps_i (C p_v - 1)   for allowed v, 0 elsewhere; times
+// row_w[row] (drop_worst / ignored rows: 0) and the scalar grad_scale.
+template <typename T>
+__global__ __launch_bounds__(256) void lsce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       const float* __restrict__ lse, const float* __restrict__ row_cnt,
+                                                       const float* __restrict__ row_w, const float* __restrict__ gscale,
+                                                       T* __restrict__ dlogits, int64_t V, int64_t ld, int64_t ignore_index,
+                                                       LsCfg cfg) {
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  T* dx = dlogits + row * ld;
+  const int64_t t = target[row];
+  float g = gscale ? gscale[0] : 1.0f;
+  if (row_w) g *= row_w[row];
+  if (t == ignore_index) g = 0.f;
+  const float l = lse[row], C = row_cnt[row];
+  const float eps_i = cfg.eps / (cfg.cstart < 0 && !cfg.cmask ? (C - 1.f) : (C - 1.f + 1e-6f));
+  const float w_nll = 1.f - cfg.eps - eps_i;
+  for (int64_t v = threadIdx.x; v < ld; v += 256) {
+    float d = 0.f;
+    if (g != 0.f && v < V && ls_allowed(cfg, row, v, V)) {
+      const float p = expf(ld1<T>(x + v) - l);
+      d = (w_nll * (p - (v == t ? 1.f : 0.f)) + eps_i * (C * p - 1.f)) * g;
+    }
+    st1<T>(dx + v, d);
+  }
+}
+
 // get_normalized_probs (model/ofa.py:287-299): fp32 softmax / log-softmax of the logits, one block per row.
 __device__ __forceinline__ float block_sum(float v, float* sw) {
   v = wave_sum(v);
@@ -215,6 +303,41 @@ extern "C" int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, 
   else
     hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index);
   return check_launch("cross_entropy_bwd");
+}
+
+extern "C" int ofa_ls_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, float* row_nll,
+                                        float* row_cnt, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, float eps,
+                                        int64_t cstart, int64_t cend, const uint8_t* cmask, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "ls_cross_entropy_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 1 && ld >= V && logits && target && lse && row_loss && row_nll && row_cnt, OFA_ERR_INVALID,
+              "ls_cross_entropy_fwd: bad argument");
+  OFA_REQUIRE(eps >= 0.f && eps < 1.f && (cstart < 0 || (cstart >= 4 && cend > cstart && cend <= V)), OFA_ERR_INVALID,
+              "ls_cross_entropy_fwd: bad eps / constraint range [%lld, %lld)", (long long)cstart, (long long)cend);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const LsCfg cfg{eps, cstart, cend, cmask};
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((lsce_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_loss, row_nll, row_cnt, V, ld, ignore_index, cfg);
+  else
+    hipLaunchKernelGGL((lsce_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_loss, row_nll, row_cnt, V, ld, ignore_index, cfg);
+  return check_launch("ls_cross_entropy_fwd");
+}
+
+extern "C" int ofa_ls_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* row_cnt,
+                                        const float* row_w, const float* grad_scale, void* dlogits, int64_t rows, int64_t V,
+                                        int64_t ld, int64_t ignore_index, float eps, int64_t cstart, int64_t cend,
+                                        const uint8_t* cmask, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "ls_cross_entropy_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(rows >= 0 && V > 1 && ld >= V && logits && target && lse && row_cnt && dlogits, OFA_ERR_INVALID,
+              "ls_cross_entropy_bwd: bad argument");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const LsCfg cfg{eps, cstart, cend, cmask};
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((lsce_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_cnt, row_w, grad_scale, (float*)dlogits, V, ld, ignore_index, cfg);
+  else
+    hipLaunchKernelGGL((lsce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_cnt, row_w, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index, cfg);
+  return check_launch("ls_cross_entropy_bwd");
 }
 
 extern "C" int ofa_probs_fwd(const void* logits, float* out, int64_t rows, int64_t V, int64_t ld, int log_probs, int dtype,

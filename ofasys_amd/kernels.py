@@ -481,6 +481,29 @@ def cross_entropy_bwd(logits2d, target, lse, grad_scale, V, ignore_index, dlogit
     return dlogits
 
 
+def ls_cross_entropy_fwd(logits2d, target, V, ignore_index, eps, cstart=-1, cend=-1, cmask=None):
+    """label-smoothed CE rows: returns lse, row_loss, row_nll, row_cnt (fp32 [rows])."""
+    rows, ld = logits2d.shape[0], logits2d.stride(0)
+    out = [torch.empty(rows, dtype=torch.float32, device=logits2d.device) for _ in range(4)]
+    if cmask is not None:
+        cmask = _u8(cmask)
+    lib().call("ofa_ls_cross_entropy_fwd", ptr(logits2d), ptr(target), *[ptr(o) for o in out], rows, V, ld, ignore_index,
+               float(eps), int(cstart), int(cend), ptr(cmask), dtype_code(logits2d), stream())
+    return out
+
+
+def ls_cross_entropy_bwd(logits2d, target, lse, row_cnt, row_w, grad_scale, V, ignore_index, eps, cstart=-1, cend=-1,
+                         cmask=None):
+    rows, ld = logits2d.shape[0], logits2d.stride(0)
+    dlogits = torch.empty(rows, ld, dtype=logits2d.dtype, device=logits2d.device)
+    if cmask is not None:
+        cmask = _u8(cmask)
+    lib().call("ofa_ls_cross_entropy_bwd", ptr(logits2d), ptr(target), ptr(lse), ptr(row_cnt), ptr(row_w), ptr(grad_scale),
+               ptr(dlogits), rows, V, ld, ignore_index, float(eps), int(cstart), int(cend), ptr(cmask),
+               dtype_code(logits2d), stream())
+    return dlogits
+
+
 def probs_fwd(logits2d, V, ld, log_probs):
     rows = logits2d.shape[0]
     y = torch.empty(rows, V, dtype=torch.float32, device=logits2d.device)

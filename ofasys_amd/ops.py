@@ -822,6 +822,67 @@ def cross_entropy_sum(logits, target, ignore_index):
     return CrossEntropyFn.apply(logits, target, ignore_index)
 
 
+def _ce_rows(logits):
+    """[..., V] logits -> [rows, V] view whose row stride is a multiple of the 16-byte vector width (copy only if needed)."""
+    V = logits.shape[-1]
+    l2d = logits.reshape(-1, V) if logits.is_contiguous() else logits.view(-1, V)
+    if l2d.stride(1) != 1 or l2d.stride(0) % (4 if l2d.dtype == torch.float32 else 8) != 0:
+        pad = (-V) % 8
+        store = torch.zeros(l2d.shape[0], V + pad, dtype=l2d.dtype, device=l2d.device)
+        store[:, :V].copy_(l2d)
+        l2d = store[:, :V]
+    return l2d
+
+
+class LabelSmoothedCrossEntropyFn(torch.autograd.Function):
+    """label_smoothed_nll_loss fused with the fp32 log-softmax (engine/criterion/label_smoothed_cross_entropy.py:62-191):
+    returns (loss_sum, nll_sum, ntokens).  constraint_range = (start, end): only [0,4) U [start,end) of the vocabulary takes
+    part (:140-151); constraint_masks: optional bool [rows, V] from the sample; drop_worst_ratio: the worst rows are dropped
+    (:83-86) -- selected with a device-side sort, no host sync (the reference's boolean indexing + topk both sync)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, eps, constraint_range, constraint_masks, drop_worst_ratio):
+        V = logits.shape[-1]
+        l2d = _ce_rows(logits)
+        t = target.reshape(-1).contiguous()
+        cs, ce = constraint_range if constraint_range is not None else (-1, -1)
+        cm = constraint_masks.reshape(-1, V).contiguous() if constraint_masks is not None else None
+        lse, row_loss, row_nll, row_cnt = K.ls_cross_entropy_fwd(l2d, t, V, ignore_index, eps, cs, ce, cm)
+        valid = t.ne(ignore_index)
+        row_w = None
+        if drop_worst_ratio > 0:
+            n = valid.sum()
+            k = (n.double() * (1 - drop_worst_ratio)).floor().long()                # int(n * (1 - ratio)), on the device
+            key = torch.where(valid, row_loss, torch.full_like(row_loss, float("inf")))
+            order = torch.argsort(key, stable=True)
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(order.numel(), device=order.device)
+            row_w = (rank < k).float()
+            row_loss, row_nll = row_loss * row_w, row_nll * row_w
+            ntok = k
+        else:
+            ntok = valid.sum()
+        ctx.save_for_backward(l2d, t, lse, row_cnt, row_w, cm)
+        ctx.cfg = (ignore_index, eps, cs, ce, logits.shape)
+        ctx.mark_non_differentiable(ntok)
+        return K.sum_f32(row_loss), K.sum_f32(row_nll).detach(), ntok
+
+    @staticmethod
+    def backward(ctx, dloss, dnll, dntok):
+        l2d, t, lse, row_cnt, row_w, cm = ctx.saved_tensors
+        ignore_index, eps, cs, ce, shape = ctx.cfg
+        V = l2d.shape[1]
+        gs = dloss.reshape(1).float().contiguous()
+        d = K.ls_cross_entropy_bwd(l2d, t, lse, row_cnt, row_w, gs, V, ignore_index, eps, cs, ce, cm)
+        return d[:, :V].view(shape), None, None, None, None, None, None
+
+
+def label_smoothed_cross_entropy(logits, target, ignore_index, eps, constraint_range=None, constraint_masks=None,
+                                 drop_worst_ratio=0.0):
+    return LabelSmoothedCrossEntropyFn.apply(logits, target, ignore_index, eps, constraint_range, constraint_masks,
+                                             drop_worst_ratio)
+
+
 def _rows_padded(logits):
     """[..., V] tensor -> ([rows, V] view with last dim contiguous, ld)."""
     V = logits.shape[-1]

@@ -104,7 +104,8 @@ class Trainer:
     clip+Adam) around an eager all-reduce of the gradient arena: collectives are kept out of the captured region."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
-                 bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2):
+                 bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2,
+                 label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0):
         self.model = model
         self.fp = FlatParams(model)
         dev = self.fp.flat.device
@@ -117,6 +118,9 @@ class Trainer:
         self.reducer = GradBucketReducer(self.fp.params, self.fp.grad, self.fp.offsets, process_group, bucket_bytes)
         self.world = self.reducer.world
         self.pad = model.global_dict.pad()
+        # criterion: plain cross entropy (engine/criterion/cross_entropy.py) or, with any of these set, the label-smoothed
+        # one (label_smoothed_cross_entropy.py); a sample may carry its own "constraint_masks" [B, Tt, V]
+        self.label_smoothing, self.constraint_range, self.drop_worst_ratio = label_smoothing, constraint_range, drop_worst_ratio
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)      # [sample_size, loss_sum, ntokens]
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
         # device-resident schedule: _step_t = number of updates done; _lr_t = learning rate; _sched = [grad multiplier,
@@ -152,9 +156,14 @@ class Trainer:
         self.reducer.begin_step(tuple(s.get("task", len(s["slots"])) for s in samples))
         for s in samples:
             logits = model(s["slots"])[0]
-            loss = ops.cross_entropy_sum(logits, s["target"], self.pad)
+            cm = s.get("constraint_masks")
+            if self.label_smoothing > 0 or self.constraint_range is not None or self.drop_worst_ratio > 0 or cm is not None:
+                loss, _, n = ops.label_smoothed_cross_entropy(logits, s["target"], self.pad, self.label_smoothing,
+                                                              self.constraint_range, cm, self.drop_worst_ratio)
+            else:
+                loss = ops.cross_entropy_sum(logits, s["target"], self.pad)
+                n = s["target"].ne(self.pad).sum()
             loss.backward()
-            n = s["target"].ne(self.pad).sum()
             self._stats[0] += n
             self._stats[1] += loss.detach().double()
             self._stats[2] += n

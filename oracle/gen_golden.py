@@ -126,6 +126,50 @@ def softmax_vectors():
     print("fused_softmax ok")
 
 
+def ls_ce_vectors():
+    """Golden vectors of the label-smoothed criterion: the reference's own label_smoothed_nll_loss
+    (engine/criterion/label_smoothed_cross_entropy.py:62-94) on log-probs prepared exactly as get_constraint_masks /
+    get_lprobs_and_target / compute_loss do (:140-189; those are methods of a criterion that needs a task object)."""
+    install()
+    import math
+    from ofasys.engine.criterion.label_smoothed_cross_entropy import label_smoothed_nll_loss
+    rows, V, pad = 14, 44, 1
+    logits = recipe.floats("lsce.logits", (rows, V), 2.0)
+    target = recipe.tokens("lsce.target", (rows,), V)
+    target[3] = pad
+    target[9] = pad
+    smask = recipe.floats("lsce.cmask", (rows, V)) > -0.8
+    out = {"logits": logits.numpy(), "target": target.numpy(), "sample_mask": smask.numpy().astype(np.uint8)}
+    for name, eps, crange, use_smask, dw in [("plain", 0.1, None, False, 0.0), ("range", 0.1, (10, 30), False, 0.0),
+                                              ("range_mask", 0.2, (8, 40), True, 0.0), ("drop", 0.1, None, False, 0.25)]:
+        x = logits.clone().requires_grad_(True)
+        tg = target.clone()
+        if crange is not None:                       # keep targets inside the allowed set, as real constrained tasks do
+            tg = torch.where(tg == pad, tg, crange[0] + (tg % (crange[1] - crange[0])))
+        cm = None
+        if crange is not None:
+            cm = torch.ones(x.shape, dtype=torch.bool)
+            cm[..., 4:crange[0]] = 0
+            cm[..., crange[1]:] = 0
+            if use_smask:
+                sm = smask.clone()
+                sm[torch.arange(rows), tg] = True    # the target itself is always allowed
+                cm = torch.logical_and(sm, cm)
+                out[name + ".sample_mask"] = sm.numpy().astype(np.uint8)
+        xin = x if cm is None else x.masked_fill(~cm, -math.inf)
+        lprobs = torch.log_softmax(xin.float(), dim=-1)
+        keep = tg != pad
+        loss, nll, ntok = label_smoothed_nll_loss(lprobs[keep], tg[keep], eps, update_num=10, drop_worst_ratio=dw,
+                                                  drop_worst_after=0, constraint_masks=None if cm is None else cm[keep])
+        loss.backward()
+        out.update({name + ".target": tg.numpy(), name + ".loss": loss.detach().numpy().reshape(1),
+                    name + ".nll": nll.detach().numpy().reshape(1), name + ".ntokens": np.array([ntok]),
+                    name + ".dlogits": x.grad.numpy(), name + ".cfg": np.array([eps, -1 if crange is None else crange[0],
+                                                                                -1 if crange is None else crange[1], dw])})
+    np.savez_compressed(os.path.join(OUT, "ls_cross_entropy.npz"), **out)
+    print("ls_cross_entropy ok")
+
+
 def box_vectors():
     """Integer <bin> indices (bit-exact contract) via the reference's arithmetic
     preprocessor/default/box.py:101-110."""
@@ -153,6 +197,7 @@ if __name__ == "__main__":
     for name in CASES:
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
     softmax_vectors()
+    ls_ce_vectors()
     box_vectors()
     manifest = {
         "generator": "oracle/gen_golden.py",

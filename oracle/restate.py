@@ -545,6 +545,42 @@ def cross_entropy(logits, target, pad_idx=1):
 # --------------------------------------------------------------------------------------------
 # the reference's fused-softmax extensions restated
 # --------------------------------------------------------------------------------------------
+def label_smoothed_cross_entropy(logits, target, eps, pad_idx=1, constraint_range=None, constraint_masks=None,
+                                 drop_worst_ratio=0.0):
+    """engine/criterion/label_smoothed_cross_entropy.py: get_constraint_masks :140-151, get_lprobs_and_target :153-169
+    (masked logits -> -inf, fp32 log-softmax), compute_loss :171-189 (pad rows removed), label_smoothed_nll_loss :62-94.
+    Returns (loss_sum, nll_sum, ntokens)."""
+    V = logits.shape[-1]
+    cm = None
+    if constraint_range is not None:
+        cm = torch.ones(logits.shape, dtype=torch.bool)
+        cm[..., 4:constraint_range[0]] = 0
+        cm[..., constraint_range[1]:] = 0
+        if constraint_masks is not None:
+            cm = torch.logical_and(constraint_masks, cm)
+    elif constraint_masks is not None:
+        cm = constraint_masks
+    x = logits if cm is None else logits.masked_fill(~cm, -math.inf)
+    lprobs = F.log_softmax(x.float(), dim=-1).view(-1, V)
+    target = target.reshape(-1)
+    keep = target != pad_idx
+    if cm is not None:
+        cm = cm.reshape(-1, V)[keep]
+    lprobs, target = lprobs[keep], target[keep]
+    nll = -lprobs.gather(dim=-1, index=target.unsqueeze(-1)).squeeze(-1)
+    if cm is not None:
+        smooth = -lprobs.masked_fill(~cm, 0).sum(dim=-1)
+        eps_i = eps / (cm.sum(1) - 1 + 1e-6)
+    else:
+        smooth = -lprobs.sum(dim=-1)
+        eps_i = eps / (V - 1)
+    loss = (1.0 - eps - eps_i) * nll + eps_i * smooth
+    if drop_worst_ratio > 0:
+        loss, idx = torch.topk(loss, k=int(loss.shape[0] * (1 - drop_worst_ratio)), largest=False)
+        nll = nll[idx]
+    return loss.sum(), nll.sum(), loss.numel()
+
+
 def scaled_softmax(x, scale):
     """fused_kernels/scaled_masked_softmax.h:98-201: y = softmax(scale*x) over the last dim, fp32 accumulate."""
     return F.softmax(x.float() * scale, dim=-1).type_as(x)

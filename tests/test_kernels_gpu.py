@@ -534,3 +534,25 @@ def test_maxpool_relu(K, dtype):
     assert torch.equal(r, F.relu(x))
     r.backward(torch.ones_like(r))
     assert torch.equal(z.grad, (x > 0).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["plain", "range", "range_mask", "drop"])
+def test_label_smoothed_cross_entropy(K, dtype, name):
+    """ops.label_smoothed_cross_entropy (fused log-softmax + smoothing + constraint masks + drop_worst) against golden
+    vectors produced by the reference's label_smoothed_nll_loss (tests/golden/ls_cross_entropy.npz)."""
+    from ofasys_amd import ops
+    from tests.golden_util import load_golden
+    g = load_golden("ls_cross_entropy")
+    eps, cs, ce, dw = [float(v) for v in g[name + ".cfg"]]
+    x = torch.from_numpy(g["logits"]).to(DEV).to(dtype).requires_grad_(True)
+    tg = torch.from_numpy(g[name + ".target"]).to(DEV)
+    crange = None if cs < 0 else (int(cs), int(ce))
+    sm = torch.from_numpy(g[name + ".sample_mask"]).bool().to(DEV) if (name + ".sample_mask") in g else None
+    loss, nll, ntok = ops.label_smoothed_cross_entropy(x, tg, 1, eps, crange, sm, dw)
+    loss.backward()
+    t = 1e-5 if dtype == torch.float32 else 2e-2
+    assert int(ntok) == int(g[name + ".ntokens"][0])
+    assert abs(float(loss) - float(g[name + ".loss"][0])) <= t * abs(float(g[name + ".loss"][0]))
+    assert abs(float(nll) - float(g[name + ".nll"][0])) <= t * abs(float(g[name + ".nll"][0]))
+    assert rel(x.grad, torch.from_numpy(g[name + ".dlogits"]).to(DEV)) < (1e-5 if dtype == torch.float32 else 3e-2)

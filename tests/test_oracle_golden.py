@@ -89,3 +89,18 @@ def test_fused_softmax_semantics():
     c = restate.scaled_upper_triang_masked_softmax(x[0, :, :8, :8].contiguous(), s)
     assert torch.all(torch.triu(c, 1) == 0) and torch.allclose(c.sum(-1), torch.ones(3, 8), atol=1e-6)
     assert restate.get_batch_per_block(128, 128, 2, 4) == 8 and restate.get_batch_per_block(64, 448, 2, 4) == 4
+
+
+@pytest.mark.parametrize("name", ["plain", "range", "range_mask", "drop"])
+def test_label_smoothed_cross_entropy_matches_reference(name):
+    g = load_golden("ls_cross_entropy")
+    eps, cs, ce, dw = [float(v) for v in g[name + ".cfg"]]
+    x = torch.from_numpy(g["logits"]).clone().requires_grad_(True)
+    tg = torch.from_numpy(g[name + ".target"])
+    crange = None if cs < 0 else (int(cs), int(ce))
+    sm = torch.from_numpy(g[name + ".sample_mask"]).bool() if (name + ".sample_mask") in g else None
+    loss, nll, ntok = restate.label_smoothed_cross_entropy(x, tg, eps, 1, crange, sm, dw)
+    loss.backward()
+    assert ntok == int(g[name + ".ntokens"][0])
+    assert rel_err(loss.detach(), g[name + ".loss"][0]) < 1e-6 and rel_err(nll.detach(), g[name + ".nll"][0]) < 1e-6
+    assert rel_err(x.grad, g[name + ".dlogits"]) < 1e-5

@@ -169,8 +169,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * N;
         if (c < cpp) {
-          float o[N], rsd[N];
-          if (dres) load_vec<T>(dres + row * cols + c0 + c, rsd);   // gradient arriving through the residual branch
+          float o[N];
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             float t = rs * (d[i][j] - s1 - xv[i][j] * s2);
@@ -178,7 +177,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
               t *= gp[i][j];
               dbi[i][j] += t;
             }
-            o[j] = dres ? t + rsd[j] : t;
+            o[j] = t;
+          }
+          if constexpr (!GELU) {                          // (compiled out of the GELU variant: it sits at the 128-VGPR cap)
+            if (dres) {                                   // gradient arriving through the residual branch
+              float rsd[N];
+              load_vec<T>(dres + row * cols + c0 + c, rsd);
+#pragma unroll
+              for (int j = 0; j < N; ++j) o[j] += rsd[j];
+            }
           }
           store_vec<T>(dxr + c, o);
         }

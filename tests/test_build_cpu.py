@@ -1,0 +1,45 @@
+"""CPU: register-allocation guard for the hot kernels.  hipcc cross-compiles gfx950 here; a kernel that starts spilling
+(e.g. the GELU+LayerNorm backward at its 128-VGPR cap: 73 us -> 195 us per call when an innocent-looking change added
+16 registers) is a silent 10% step-time regression, so the spill counts in the code-object metadata are pinned."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ofasys_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+_CACHE = {}
+
+
+def _kernel_meta(src, tmp_path):
+    if src in _CACHE:
+        return _CACHE[src]
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, src),
+                    "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    meta = {}
+    for blk in open(out).read().split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+                      for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+    _CACHE[src] = meta
+    return meta
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,pattern,max_spill", [
+    ("layernorm.hip", r"ln_bwd_kernelItLi1ELi8ELb1E", 8),       # GELU + LayerNorm backward of the 4D FFN rows (bf16)
+    ("layernorm.hip", r"ln_bwd_kernelItLi2ELi1ELb0E", 0),       # LayerNorm backward, D = 768 rows (bf16)
+    ("attention.hip", r"attn_(fwd|bwd_dq|bwd_dkv)_lds_kernel", 0),
+    ("gemm_mfma.hip", r"gemm_mfma_kernelILi2ELi2ELb[01]ELb[01]ELb0ELb1E", 0),   # 128x128 LDS-DMA kernels, bf16 out
+])
+def test_hot_kernels_do_not_spill(tmp_path, src, pattern, max_spill):
+    meta = _kernel_meta(src, tmp_path)
+    hits = {k: v for k, v in meta.items() if re.search(pattern, k)}
+    assert hits, f"no kernel matching {pattern} in {src}"
+    for k, v in hits.items():
+        assert v["vgpr_spill_count"] <= max_spill, (k, v)

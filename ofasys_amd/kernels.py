@@ -688,3 +688,40 @@ def relu(x, gate=None):
     y = torch.empty_like(x)
     lib().call("ofa_relu", ptr(x), ptr(gate), ptr(y), x.numel(), dtype_code(x), stream())
     return y
+
+
+# ------------------------------------------------------------------ residual join (csrc/join.hip)
+def join_fwd(x, residual, ln_a, ln_b, eps, p, seed, offset, offset_base):
+    """y = residual + dropout_p(LN_a(x)); z = LN_b(y).  ln_a / ln_b: (gamma, beta) or None.  Returns y, z (or None), stats."""
+    x, residual = x.contiguous(), residual.contiguous()
+    rows, cols = _rows_cols(x)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x) if ln_b is not None else None
+    stats = torch.empty(4, rows, dtype=torch.float32, device=x.device)
+    ga, ba = ln_a if ln_a is not None else (None, None)
+    gb, bb = ln_b if ln_b is not None else (None, None)
+    lib().call("ofa_join_fwd", ptr(x), ptr(residual), ptr(ga), ptr(ba), ptr(gb), ptr(bb), ptr(y), ptr(z), ptr(stats), rows, cols,
+               float(eps), float(p), seed, offset, ptr(offset_base), dtype_code(x), stream())
+    return y, z, stats
+
+
+def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None):
+    """grads = (dgamma_a, dbeta_a, dgamma_b, dbeta_b) output tensors (accumulated into; None for an absent LayerNorm).
+    Returns dres, dx.  The column partials are folded by `fold` (a FoldQueue) or immediately."""
+    like = dy if dy is not None else dz
+    rows, cols = _rows_cols(like)
+    dres, dx = torch.empty_like(like), torch.empty_like(like)
+    ns = lib().cdll.ofa_join_bwd_slots(rows, cols, dtype_code(like))
+    ws = torch.empty(4 * ns * cols, dtype=torch.float32, device=like.device)
+    q = fold if fold is not None else FoldQueue()
+    for i, o in enumerate(grads):
+        if o is not None:
+            q.add(ws, i * ns * cols, o, cols, cols, ns)
+    lib().call("ofa_join_bwd", ptr(dy.contiguous() if dy is not None else None), ptr(dz.contiguous() if dz is not None else None),
+               ptr(x), ptr(y), ptr(ga), ptr(gb), ptr(stats), ptr(dres), ptr(dx), ptr(ws), rows, cols, float(p), seed, offset,
+               ptr(offset_base), dtype_code(like), stream())
+    if fold is None:
+        q.flush()
+    else:
+        fold.flush_if_large()
+    return dres, dx

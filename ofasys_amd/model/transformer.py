@@ -14,6 +14,7 @@ from .. import kernels as K
 from .. import ops
 from ..adaptor import AdaptorOutput, OFAGeneralAdaptor
 from ..module import LayerNorm, Linear, OfaLinear, TransformerDecoderLayer, TransformerEncoderLayer
+from ..module.transformer_layer import LayerChain
 from ..preprocessor import Dictionary, Slot
 
 
@@ -46,19 +47,25 @@ class TransformerEncoder(nn.Module):
         T = x.size(0)
         encoder_states = [x] if return_all_hiddens else []
         encoder_attention_states = []
+        chain = LayerChain()
         for idx, layer in enumerate(self.layers):
             if self.cfg.use_self_attn_bias:
                 b = adaptor_output.self_attn_bias[0 if self.cfg.share_attn_bias else idx]
                 self_attn_bias = b.view(-1, T, T)
             else:
                 self_attn_bias = None
+            chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
             x, self_attn_weights = layer(x, encoder_padding_mask=adaptor_output.masks, self_attn_bias=self_attn_bias,
-                                         need_attn=return_all_attention_weights, modal_mask=adaptor_output.modal_mask)
+                                         need_attn=return_all_attention_weights, modal_mask=adaptor_output.modal_mask,
+                                         chain=chain)
             if return_all_hiddens:
                 encoder_states.append(x)
             if return_all_attention_weights:
                 encoder_attention_states.append(self_attn_weights)
-        if self.layer_norm is not None:
+        normed = chain.take()
+        if normed is not None:
+            x = normed                                              # the last layer's join already applied layer_norm
+        elif self.layer_norm is not None:
             x = self.layer_norm(x)
         return {
             "encoder_out": [x],                                     # T x B x C
@@ -164,7 +171,9 @@ class TransformerDecoder(nn.Module):
         attn = None
         inner_states: List[Optional[Tensor]] = [x] if return_all_hiddens else []
         decoder_attentions, cross_attentions = [], []
+        chain = LayerChain()
         for idx, layer in enumerate(self.layers):
+            chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
             self_attn_mask = self.buffered_future_mask(x) if not full_context_alignment else None
             if self.cfg.use_self_attn_bias:
                 b = all_self_attn_bias[0 if self.cfg.share_attn_bias else idx]
@@ -175,7 +184,7 @@ class TransformerDecoder(nn.Module):
                 x, enc, padding_mask, None, self_attn_mask=self_attn_mask, self_attn_padding_mask=self_attn_padding_mask,
                 need_attn=bool((idx == alignment_layer) or return_all_attention_weights),
                 need_head_weights=bool(idx == alignment_layer), self_attn_bias=self_attn_bias,
-                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask)
+                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask, chain=chain)
             if return_all_attention_weights:
                 decoder_attentions.append(layer_self_attn)
                 cross_attentions.append(layer_cross_attn)
@@ -190,7 +199,10 @@ class TransformerDecoder(nn.Module):
                 A = w.shape[0]
             # mean over heads (:501-506) with the head-mean kernel: [A,B,T,S] view -> [B,A,T,S] storage
             attn = K.mean_heads(w.transpose(0, 1).reshape(B_ * A, Tt, Ts), B_, A)
-        if self.layer_norm is not None:
+        normed = chain.take()
+        if normed is not None:
+            x = normed                                                # the last layer's join already applied layer_norm
+        elif self.layer_norm is not None:
             x = self.layer_norm(x)
         x = x.transpose(0, 1)                                         # T x B x C -> B x T x C
         if self.project_out_dim is not None:

@@ -5,9 +5,12 @@ Fusions relative to the reference's op-by-op graph (same arithmetic, fewer HBM r
   * dropout + residual add                      -> one kernel   (transformer_layer.py:181-182, 203-206)
   * GELU + ffn_layernorm (LayerNorm over 4D)     -> one kernel   (:194-197); the pre-GELU fc1 output is what is saved
   * q/k/v/out projections, fc1, fc2              -> MFMA GEMM with bias in the epilogue
+  * [attn_ln] + dropout + residual add + the NEXT LayerNorm (this layer's final_layer_norm, or the next layer's first
+    pre-LN handed in through a LayerChain) -> one "residual join" kernel each way (csrc/join.hip); pre-LN stacks only
 Only the configuration space of OFASys' GeneralistModel is implemented: pre- or post-LN, scale_attn / scale_fc /
 scale_heads / scale_resids; modal_ffn (single-device MoE) and cross_self_attention are refused loudly.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -19,14 +22,47 @@ from .layers import Dropout, DropPath, LayerNorm, OfaLinear
 from .multihead_attention import MultiheadAttention
 
 
+_NO_JOIN = bool(os.environ.get("OFA_NO_JOIN"))
+
+
+class LayerChain:
+    """Threads `LN_first(x)` from one layer's closing residual join into the next layer of a pre-LN stack.
+
+    The stack sets `next_ln` to the LayerNorm that will consume this layer's output first (the next layer's
+    self_attn_layer_norm, or the stack's final layer_norm); the layer leaves that LayerNorm's output in `normed` and the
+    consumer takes it instead of normalising again.  Same arithmetic as the reference's op-by-op order."""
+    __slots__ = ("normed", "next_ln")
+
+    def __init__(self):
+        self.normed = None
+        self.next_ln = None
+
+    def take(self):
+        z, self.normed = self.normed, None
+        return z
+
+
 def _act_name(cfg):
     return getattr(cfg, "activation_fn", "gelu")
 
 
 class _FFNMixin:
-    def _ffn(self, x):
-        """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494."""
-        if self.normalize_before:
+    def _joinable(self):
+        """The fused residual joins cover the pre-LN layer without scale_resids / DropPath (OFASys' defaults)."""
+        return (self.normalize_before and self.w_resid is None and not _NO_JOIN
+                and (self.drop_path.drop_prob == 0.0 or not self.training))
+
+    def _join(self, x, residual, ln_a, ln_b):
+        """(residual + dropout(ln_a(x)), ln_b(that)) -- :181-186 / :203-208 fused; ln_a / ln_b may be None."""
+        return ops.residual_join(x, residual, ln_a, self.dropout_module.p, self.training, ln_b,
+                                 eps=(ln_b or ln_a or self.final_layer_norm).eps)
+
+    def _ffn(self, x, normed=None, chain=None):
+        """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494.
+        normed: final_layer_norm(x) when the preceding join already produced it; chain: see LayerChain."""
+        if normed is not None:
+            residual, x = x, normed
+        elif self.normalize_before:
             residual, x = self.final_layer_norm.fork(x)
         else:
             residual = x
@@ -43,6 +79,11 @@ class _FFNMixin:
             if self.ffn_layernorm is not None:
                 x = self.ffn_layernorm(x)
         x = self.fc2(x)
+        if normed is not None:
+            x, z = self._join(x, residual, None, chain.next_ln if chain is not None else None)
+            if chain is not None:
+                chain.normed = z
+            return x
         if self.w_resid is not None:
             residual = ops.mul_rowvec(residual, self.w_resid)                   # :204-205
         x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
@@ -87,16 +128,24 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         return ops.dropout_add(self.drop_path(x), residual, 0.0, False)
 
     def forward(self, x, encoder_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor] = None,
-                self_attn_bias: Optional[Tensor] = None, need_attn: bool = False, modal_mask=None):
-        """x: (seq_len, batch, embed_dim); see transformer_layer.py:141-158."""
+                self_attn_bias: Optional[Tensor] = None, need_attn: bool = False, modal_mask=None,
+                chain: Optional[LayerChain] = None):
+        """x: (seq_len, batch, embed_dim); see transformer_layer.py:141-158.  chain: LayerChain of the enclosing stack."""
         if attn_mask is not None:
             attn_mask = attn_mask.masked_fill(attn_mask.to(torch.bool), -1e8 if x.dtype == torch.float32 else -1e4)
-        if self.normalize_before:
+        join = self._joinable()
+        normed = chain.take() if chain is not None else None
+        if normed is not None and self.normalize_before:
+            residual, x = x, normed
+        elif self.normalize_before:
             residual, x = self.self_attn_layer_norm.fork(x)
         else:
             residual = x
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=encoder_padding_mask,
                                               need_weights=need_attn, attn_mask=attn_mask, attn_bias=self_attn_bias)
+        if join:
+            x, h = self._join(x, residual, self.attn_ln, self.final_layer_norm)
+            return self._ffn(x, normed=h, chain=chain), self_attn_weights
         if self.attn_ln is not None:
             x = self.attn_ln(x)
         x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)   # :181-182
@@ -170,27 +219,38 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 prev_attn_state: Optional[List[torch.Tensor]] = None, self_attn_mask: Optional[torch.Tensor] = None,
                 self_attn_padding_mask: Optional[torch.Tensor] = None, need_attn: bool = False,
                 need_head_weights: bool = False, self_attn_bias: Optional[Tensor] = None,
-                cross_attn_bias: Optional[Tensor] = None, modal_mask=None):
-        """x: (seq_len, batch, embed_dim); see transformer_layer.py:367-385."""
+                cross_attn_bias: Optional[Tensor] = None, modal_mask=None, chain: Optional[LayerChain] = None):
+        """x: (seq_len, batch, embed_dim); see transformer_layer.py:367-385.  chain: LayerChain of the enclosing stack."""
         if need_head_weights:
             need_attn = True
         if incremental_state is not None or prev_self_attn_state is not None or prev_attn_state is not None:
             raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
-        if self.normalize_before:
+        join = self._joinable()
+        cross = self.encoder_attn is not None and encoder_out is not None
+        normed = chain.take() if chain is not None else None
+        if normed is not None and self.normalize_before:
+            residual, x = x, normed
+        elif self.normalize_before:
             residual, x = self.self_attn_layer_norm.fork(x)
         else:
             residual = x
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask,
                                               incremental_state=None, need_weights=need_attn, attn_mask=self_attn_mask,
                                               attn_bias=self_attn_bias)
-        if self.self_attn_ln is not None:
-            x = self.self_attn_ln(x)
-        x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
-        if not self.normalize_before:
-            x = self.self_attn_layer_norm(x)
+        h = None
+        if join:
+            x, h = self._join(x, residual, self.self_attn_ln, self.encoder_attn_layer_norm if cross else self.final_layer_norm)
+        else:
+            if self.self_attn_ln is not None:
+                x = self.self_attn_ln(x)
+            x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
+            if not self.normalize_before:
+                x = self.self_attn_layer_norm(x)
         cross_attn_weights = None
-        if self.encoder_attn is not None and encoder_out is not None:
-            if self.normalize_before:
+        if cross:
+            if h is not None:
+                residual, x = x, h
+            elif self.normalize_before:
                 residual, x = self.encoder_attn_layer_norm.fork(x)
             else:
                 residual = x
@@ -199,12 +259,15 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 incremental_state=None, static_kv=True,
                 need_weights=need_attn or (not self.training and self.need_attn), need_head_weights=need_head_weights,
                 attn_bias=cross_attn_bias)
-            if self.cross_attn_ln is not None:
-                x = self.cross_attn_ln(x)
-            x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
-            if not self.normalize_before:
-                x = self.encoder_attn_layer_norm(x)
-        x = self._ffn(x)
+            if join:
+                x, h = self._join(x, residual, self.cross_attn_ln, self.final_layer_norm)
+            else:
+                if self.cross_attn_ln is not None:
+                    x = self.cross_attn_ln(x)
+                x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
+                if not self.normalize_before:
+                    x = self.encoder_attn_layer_norm(x)
+        x = self._ffn(x, normed=h, chain=chain)
         return x, cross_attn_weights, self_attn_weights       # (sic) the reference returns them in this order, :495
 
     def make_generation_fast_(self, need_attn: bool = False, **kwargs):

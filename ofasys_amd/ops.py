@@ -240,6 +240,61 @@ def layer_norm_fork(x, weight, bias, eps=1e-5):
     return restore(r), restore(y)
 
 
+class ResidualJoinFn(torch.autograd.Function):
+    """(y, z) = (residual + dropout_p(LN_a(x)), LN_b(y)) in one pass each way (csrc/join.hip); LN_a / LN_b optional."""
+
+    @staticmethod
+    def forward(ctx, x2d, r2d, wa, ba, wb, bb, p, eps):
+        seed, off, base = (0, 0, None)
+        if p > 0:
+            seed, off, base = _Rng.reserve(x2d.numel(), x2d.device)
+        y, z, stats = K.join_fwd(x2d, r2d, (wa, ba) if wa is not None else None, (wb, bb) if wb is not None else None, eps,
+                                 p, seed, off, base)
+        ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats)
+        ctx.refs = (ba, bb)
+        ctx.rng = (p, seed, off, base)
+        if z is None:
+            return y, None
+        return y, z
+
+    @staticmethod
+    def backward(ctx, dy, dz):
+        x2d, y, wa, wb, stats = ctx.saved_tensors
+        ba, bb = ctx.refs
+        p, seed, off, base = ctx.rng
+        if wb is None:
+            dz = None
+        elif dz is None:
+            dz = torch.zeros_like(y)
+        params = (wa, ba, wb, bb)
+        sinks = [(_sink(t) if t is not None else None) for t in params]
+        use_sinks = all((t is None) or (s_ is not None) for t, s_ in zip(params, sinks))
+        if use_sinks:
+            grads, fold = tuple(sinks), _fold()
+        else:
+            grads = tuple((torch.zeros_like(t) if t is not None else None) for t in params)
+            fold = None
+        dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold)
+        if use_sinks:
+            for t in params:
+                if t is not None:
+                    _sink_done(t)
+            return dx, dres, None, None, None, None, None, None
+        return dx, dres, grads[0], grads[1], grads[2], grads[3], None, None
+
+
+def residual_join(x, residual, ln_a, p, training, ln_b, eps=1e-5):
+    """Returns (y, z): y = residual + dropout(LN_a(x)) (LN_a: module or None), z = LN_b(y) (module or None -> z is None)."""
+    x2d, restore = rows_view(x)
+    r2d, _ = rows_view(residual)
+    if r2d.shape != x2d.shape:
+        raise OfaError("residual_join: shape mismatch")
+    wa, ba = (ln_a.weight, ln_a.bias) if ln_a is not None else (None, None)
+    wb, bb = (ln_b.weight, ln_b.bias) if ln_b is not None else (None, None)
+    y, z = ResidualJoinFn.apply(x2d, r2d, wa, ba, wb, bb, p if training else 0.0, eps)
+    return restore(y), (restore(z) if z is not None else None)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
     """F.layer_norm over the last dim (module/layer_norm.py:27-32); fuse_gelu: LayerNorm(gelu(x))."""
     x2d, restore = rows_view(x)

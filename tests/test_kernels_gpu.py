@@ -556,3 +556,50 @@ def test_label_smoothed_cross_entropy(K, dtype, name):
     assert abs(float(loss) - float(g[name + ".loss"][0])) <= t * abs(float(g[name + ".loss"][0]))
     assert abs(float(nll) - float(g[name + ".nll"][0])) <= t * abs(float(g[name + ".nll"][0]))
     assert rel(x.grad, torch.from_numpy(g[name + ".dlogits"]).to(DEV)) < (1e-5 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols,has_a,has_b,p", [(300, 768, True, True, 0.1), (70, 256, False, True, 0.1),
+                                                      (129, 768, True, False, 0.0), (64, 1024, True, True, 0.3),
+                                                      (33, 512, False, False, 0.1)])
+def test_residual_join_equals_unfused_chain(K, dtype, rows, cols, has_a, has_b, p):
+    """csrc/join.hip: y = residual + dropout(LN_a(x)), z = LN_b(y) and its backward must equal the op-by-op kernels
+    (LayerNorm, dropout+add, LayerNorm-with-residual-gradient): y bit for bit (same Philox positions, same rounding points),
+    everything else to rounding noise."""
+    from ofasys_amd import ops
+    torch.manual_seed(41)
+    x = torch.randn(rows, cols, device=DEV).to(dtype)
+    r = torch.randn(rows, cols, device=DEV).to(dtype)
+    lna = torch.nn.LayerNorm(cols).to(DEV).to(dtype) if has_a else None
+    lnb = torch.nn.LayerNorm(cols).to(DEV).to(dtype) if has_b else None
+    for ln in (lna, lnb):
+        if ln is not None:
+            with torch.no_grad():
+                ln.weight.copy_(1 + 0.1 * torch.randn(cols)); ln.bias.copy_(0.1 * torch.randn(cols))
+    dy = torch.randn(rows, cols, device=DEV).to(dtype)
+    dz = torch.randn(rows, cols, device=DEV).to(dtype)
+
+    def run(fused):
+        for ln in (lna, lnb):
+            if ln is not None:
+                ln.zero_grad()
+        xx, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        ops.manual_seed(99)
+        if fused:
+            y, z = ops.residual_join(xx, rr, lna, p, True, lnb)
+        else:
+            h = ops.layer_norm(xx, lna.weight, lna.bias, lna.eps) if has_a else xx
+            y = ops.dropout_add(h, rr, p, True)
+            z = None
+            if has_b:
+                y, z = ops.layer_norm_fork(y, lnb.weight, lnb.bias, lnb.eps)
+        outs = [y] + ([z] if z is not None else [])
+        torch.autograd.backward(outs, [dy] + ([dz] if z is not None else []))
+        g = [xx.grad, rr.grad] + [t.grad for ln in (lna, lnb) if ln is not None for t in (ln.weight, ln.bias)]
+        return [y.detach()] + ([z.detach()] if z is not None else []) + g
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    assert torch.equal(a[0], b[0])                            # y: same Philox positions, same rounding points -> bit-exact
+    for i, (u, v) in enumerate(zip(a, b)):                    # the rest: same maths, different summation grouping / FMA
+        assert rel(u, v.float()) < (2e-5 if dtype == torch.float32 else 2e-2), i      # contraction (rows split over waves)

@@ -975,7 +975,9 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   // big tiles (one 256-thread workgroup per CU, 128x128 or 96x128 per wave): whole K tiles only.  With one workgroup per
   // CU nothing overlaps a tile's output burst (the C write of a 14336 x 2304 x 768 product is 30% of its time, measured
   // by removing the epilogue) -- two co-resident 128x128 workgroups hide it -- so the big tile only pays off when the K
-  // loop is long enough to amortise it: K >= 4096 and a grid that fills the 256 CUs.
+  // loop is long enough to amortise it (K >= 4096), or when the whole product is ONE round of <= 256 workgroups (measured,
+  // 14336 x 768 outputs as 225 tiles of 192 x 256: K = 768 25.4 vs 27.7 us, K = 3072 71.7 vs 85.7 us) -- and the grid
+  // fills the 256 CUs.
   int big_tm = 0;
   const bool big_ok = (g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA) && g.N >= 256 && g.M >= 192;
   if (big_ok && force_tile != 22 && force_tile != 12 && force_tile != 11) {
@@ -986,7 +988,11 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
     const double f4 = fill(256), f3 = g.transA ? 0.0 : fill(192) * 0.97;
     if (force_tile == 44) big_tm = 4;
     else if (force_tile == 34) big_tm = g.transA ? 4 : 3;
-    else if (g.K >= 4096 && (f4 >= 0.8 || f3 >= 0.8)) big_tm = f4 >= f3 ? 4 : 3;
+    else if (f4 >= 0.8 || f3 >= 0.8) {
+      const int tm = f4 >= f3 ? 4 : 3;
+      const int64_t t = (int64_t)cdiv(g.M, tm * 64) * cdiv(g.N, 256) * batch;
+      if (g.K >= 4096 || t <= 256) big_tm = tm;
+    }
   }
   if (big_tm) {
     wm = wn = 0;

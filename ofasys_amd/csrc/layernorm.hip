@@ -78,19 +78,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // produced h, transformer_layer.py:194) come for free.  At the end the block folds its waves' partials through LDS
 // and writes ONE partial row per block to ws[q][block][cols]; a second small kernel folds the <= 256 block rows
 // (deterministic: fixed row->wave assignment and summation order).
-constexpr int LN_WPB = 16;          // waves per block
+//
+// When a row is split over waves the block synchronises twice per row, so no wave can run ahead and the load latency
+// of every iteration would be exposed (14336 x 3072: 28 iterations x ~3 us); the raw 16-byte vectors of the NEXT row are
+// therefore fetched before the current row's arithmetic (software prefetch, 8 registers per vector pair).  Rows of 6 x 512
+// columns (the base model's 3072-wide FFN LayerNorm) use 12 waves per block, 6 per row: every lane owns exactly one
+// vector (with 8 parts only 48 of 64 lanes would) and the 768-thread block has 170 registers per lane for the prefetch.
+constexpr int LN_WPB = 16;          // waves per block (default)
 constexpr int LN_BWD_BLOCKS = 256;  // one block per CU; also the workspace row count
 
-template <typename T, int NV, int WPR, bool GELU>
-__global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T> __device__ __forceinline__ void unpack_vec(const uint4& r, float* out);
+template <> __device__ __forceinline__ void unpack_vec<float>(const uint4& r, float* out) {
+  out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack_vec<bf16_t>(const uint4& r, float* out) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+template <typename T, int NV, int WPR, bool GELU, int WPB = LN_WPB>
+__global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const T* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const T* __restrict__ dres,
                                                       T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols,
                                                       int want_dbias) {
   constexpr int N = Vec<T>::N;
-  constexpr int RPB = LN_WPB / WPR;                  // rows per block iteration
-  __shared__ float red[2][LN_WPB];
-  __shared__ float fold[LN_WPB][64 * N];
+  constexpr int RPB = WPB / WPR;                     // rows per block iteration
+  // (only where the registers are there: at the 128-VGPR cap of the 16-wave block the GELU / 2-vector variants would spill)
+  constexpr bool PREFETCH = WPR > 1 && (WPB < 16 || (!GELU && NV == 1));
+  static_assert(WPB % WPR == 0, "waves per block must be a multiple of waves per row");
+  __shared__ float red[2][WPB];
+  __shared__ float fold[WPB][64 * N];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rib = wib / WPR, part = wib % WPR;       // row-in-block, column part
   const int cpp = cols / WPR;                        // columns per part (launcher guarantees divisibility by N)
@@ -109,12 +131,46 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
   }
   const int64_t stride = (int64_t)gridDim.x * RPB;
   const int64_t niter = (rows + stride - 1) / stride;
+  uint4 rx[NV], rd[NV];                              // raw vectors of the row being fetched
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int64_t it) {
+    const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
+    if (row < rows) {
+      nmu = mean[row];
+      nrs = rstd[row];
+      const T* xr = x + row * cols + c0;
+      const T* dyr = dy + row * cols + c0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * N;
+        if (c < cpp) {
+          rx[i] = *reinterpret_cast<const uint4*>(xr + c);
+          rd[i] = *reinterpret_cast<const uint4*>(dyr + c);
+        }
+      }
+    }
+  };
+  if (PREFETCH) fetch(0);
   for (int64_t it = 0; it < niter; ++it) {
     const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
     const bool live = row < rows;
     float xv[NV][N], gp[GELU ? NV : 1][N], d[NV][N];  // xv: LN input (gelu(h) or x); gp: gelu'(h)
     float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
-    if (live) {
+    if constexpr (PREFETCH) {
+      if (live) {
+        mu = nmu;
+        rs = nrs;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c = (i * 64 + lane) * N;
+          if (c < cpp) {
+            unpack_vec<T>(rx[i], xv[i]);
+            unpack_vec<T>(rd[i], d[i]);
+          }
+        }
+      }
+      if (it + 1 < niter) fetch(it + 1);
+    } else if (live) {
       mu = mean[row];
       rs = rstd[row];
       const T* xr = x + row * cols + c0;
@@ -127,6 +183,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const T* __restrict__ dy, 
           load_vec<T>(dyr + c, d[i]);
         }
       }
+    }
+    if (live) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * N;
@@ -264,6 +322,7 @@ static int ln_fwd_dispatch(const void* x, const void* g, const void* b, void* y,
 }
 
 static int ln_bwd_wpr(int cols, int n, bool gelu) {
+  if (gelu && cols == 6 * 64 * n) return 6;          // 12-wave blocks, one full vector per lane
   int wpr = 1;
   while (wpr < 8 && cdiv(cols / wpr, 64 * n) > (gelu ? 1 : 2) && (cols % (wpr * 2 * n)) == 0) wpr *= 2;
   return wpr;
@@ -279,11 +338,17 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
   // can be split evenly
   const int wpr = ln_bwd_wpr(cols, N, GELU);
   const int nv = cdiv(cols / wpr, 64 * N);
-  const int rpb = LN_WPB / wpr;
+  const int wpb = wpr == 6 ? 12 : LN_WPB;
+  const int rpb = wpb / wpr;
   int64_t nblk = (rows + rpb - 1) / rpb;
   nblk = nblk < 1 ? 1 : (nblk > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nblk);
   const int want_dbias = dbias != nullptr;
-  dim3 grid((unsigned)nblk), block(64 * LN_WPB);
+  dim3 grid((unsigned)nblk), block(64 * wpb);
+  if (wpr == 6) {
+    if constexpr (GELU)
+      hipLaunchKernelGGL((ln_bwd_kernel<T, 1, 6, true, 12>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)g,
+                         mean, rstd, (const T*)dres, (T*)dx, ws, rows, cols, want_dbias);
+  } else {
 #define LN_LAUNCH(NV, WPR)                                                                                           \
   hipLaunchKernelGGL((ln_bwd_kernel<T, NV, WPR, GELU>), grid, block, 0, st, (const T*)dy, (const T*)x, (const T*)g,  \
                      mean, rstd, (const T*)dres, (T*)dx, ws, rows, cols, want_dbias)
@@ -300,6 +365,7 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
   else LN_CASE(8);
 #undef LN_CASE
 #undef LN_LAUNCH
+  }
   int rc = check_launch("layernorm_bwd");
   if (rc || accumulate == OFA_DEFER_FOLD) return rc;          // deferred: the caller folds ws (ofa_fold_batched)
   hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(cdiv(cols, 32), want_dbias ? 3 : 2), dim3(256), 0, st,
@@ -329,7 +395,8 @@ using namespace ofa;
 extern "C" int ofa_layernorm_bwd_ws_rows(void) { return 3 * LN_BWD_BLOCKS; }
 
 extern "C" int ofa_layernorm_bwd_slots(int64_t rows, int cols, int dtype, int gelu) {
-  const int rpb = LN_WPB / ln_bwd_wpr(cols, dtype == OFA_F32 ? 4 : 8, gelu != 0);
+  const int wpr = ln_bwd_wpr(cols, dtype == OFA_F32 ? 4 : 8, gelu != 0);
+  const int rpb = (wpr == 6 ? 12 : LN_WPB) / wpr;
   int64_t nblk = (rows + rpb - 1) / rpb;
   return (int)(nblk < 1 ? 1 : (nblk > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nblk));
 }

@@ -121,12 +121,12 @@ int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, vo
 
 /* ---- fused attention (bf16, head_dim 64): multihead_attention.py:218-346 without materialising [BA,T,S].
  * q: [B, T, heads*64] rows (ld = ldq elements); k, v: [B, S, heads*64] rows (both with ld = ldk);
- * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional fp32
- * [heads] per-head output scale (:342-345). out: [B, T, heads*64] (ld = ldo); lse: fp32 [B*heads, Tpad].  scale
+ * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional
+ * [heads] per-head output scale (:342-345), fp32 or bf16 as c_attn_dtype says (the parameter itself, no cast kernel). out: [B, T, heads*64] (ld = ldo); lse: fp32 [B*heads, Tpad].  scale
  * multiplies q.k (the reference pre-scales q, :218).  Tpad: a multiple of 32 covering T.
  * Attention dropout is not supported here (the reference default is attention_dropout = 0.0). */
 int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
-                 const float* c_attn, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
+                 const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
                  int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream);
 /* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
  * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep; dout: [B,T,heads*64] rows (ld = ldo).
@@ -135,9 +135,13 @@ int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, 
 int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
                       int dtype, void* stream);
 int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
-                 const float* c_attn, const float* lse, const float* delta, void* dq, void* dk, void* dv, void* dbias,
-                 int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                 const void* c_attn, int c_attn_dtype, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                 void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
                  int causal, int dtype, void* stream);
+/* Gradient of the per-head scale (O = c * PV, so d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
+ * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */
+int ofa_c_attn_grad(const float* delta, const void* c_attn, void* dc, int B, int heads, int T, int64_t ld, int accumulate,
+                    int c_attn_dtype, void* stream);
 /* out[b][i] = mean over heads of p[b][a][i], i < n  (head-averaged attention weights, multihead_attention.py:347-351). */
 int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream);
 /* x: [B, T, C] rows (ld elements) -> xt: [B, C, Tpad] (zero-filled for t >= T). */

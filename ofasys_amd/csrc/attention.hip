@@ -45,13 +45,17 @@ constexpr int TILE_BYTES = 32 * HD * 2;   // 4 KiB: 32 rows x 64 bf16
 
 struct AttnL {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout; const bf16_t* bias; const uint8_t* kpm;
-  const float* c_attn; bf16_t* out; float* lse; const float* delta;
+  const void* c_attn; int c_bf16; bf16_t* out; float* lse; const float* delta;   // c_attn: fp32 or (c_bf16) bf16 [heads]
   bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dbias;
   int B, heads, T, S, Tpad;
   int64_t ldq, ldk, ldo;
   float scale; int causal;
 };
 
+__device__ __forceinline__ float head_scale(const AttnL& a, int h) {
+  if (!a.c_attn) return 1.0f;
+  return a.c_bf16 ? bf2f(((const bf16_t*)a.c_attn)[h]) : ((const float*)a.c_attn)[h];
+}
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ bf16x8 pack8f(const float* f) {
   union { uint4 u; bf16x8 v; } r;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   }
   if (qi < a.T) {
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    const float c = (a.c_attn ? a.c_attn[h] : 1.0f) * inv;
+    const float c = head_scale(a, h) * inv;
     bf16_t* op = a.out + ((int64_t)b * a.T + qi) * a.ldo + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   }
   const float lse_q = a.lse[(int64_t)bh * a.Tpad + qrow];
   const float delta_q = a.delta[(int64_t)bh * a.Tpad + qrow];
-  const float c = a.c_attn ? a.c_attn[h] : 1.0f;
+  const float c = head_scale(a, h);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
   const bf16_t* brow = a.bias ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
   }
   const bool key_dead = ki >= a.S || (a.kpm && a.kpm[(int64_t)b * a.S + krow] != 0);
   const float live = key_dead ? 0.f : 1.f;
-  const float c = a.c_attn ? a.c_attn[h] : 1.0f;
+  const float c = head_scale(a, h);
   const bf16_t* qbase = a.q + (int64_t)b * a.T * a.ldq;
   const bf16_t* dobase = a.dout + (int64_t)b * a.T * a.ldo;
   const float* lse_b = a.lse + (int64_t)bh * a.Tpad + 4 * hi;
@@ -729,27 +733,30 @@ static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, in
 using namespace ofa;
 
 extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
-                            const float* c_attn, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
-                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream) {
+                            const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S,
+                            int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype,
+                            void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(q && k && v && out, OFA_ERR_INVALID, "attn_fwd: null pointer");
+  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_fwd: bad c_attn dtype %d", c_attn_dtype);
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
-  a.c_attn = c_attn; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
+  a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal;
   hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(cdiv(T, 128), B * heads), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_fwd");
 }
 
 extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
-                            const uint8_t* kpm, const float* c_attn, const float* lse, const float* delta, void* dq,
-                            void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq,
-                            int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream) {
+                            const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, const float* delta,
+                            void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
+                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
+  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_bwd: bad c_attn dtype %d", c_attn_dtype);
   OFA_REQUIRE(q && k && v && dout && lse && delta && dq && dk && dv, OFA_ERR_INVALID, "attn_bwd: null pointer");
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
-  a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal;
   hipStream_t st = (hipStream_t)stream;

@@ -55,6 +55,29 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const T* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: d c_attn
+// dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c[h]: one 1024-thread block per head, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(1024) void c_attn_grad_kernel(const float* __restrict__ delta, const T* __restrict__ c,
+                                                           T* __restrict__ dc, int B, int heads, int Tq, int64_t ld,
+                                                           int accumulate) {
+  __shared__ float sw[16];
+  const int h = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int t = threadIdx.x; t < Tq; t += 1024) s += delta[((int64_t)b * heads + h) * ld + t];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += sw[i];
+    tot /= ld1<T>(c + h);
+    if (accumulate) tot += ld1<T>(dc + h);
+    st1<T>(dc + h, tot);
+  }
+}
 }  // namespace ofa
 using namespace ofa;
 
@@ -105,4 +128,18 @@ extern "C" int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C,
     hipLaunchKernelGGL((transpose_heads_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)xt, T,
                        C, Tpad, ld);
   return check_launch("transpose_heads");
+}
+
+extern "C" int ofa_c_attn_grad(const float* delta, const void* c_attn, void* dc, int B, int heads, int T, int64_t ld,
+                               int accumulate, int c_attn_dtype, void* stream) {
+  OFA_REQUIRE(delta && c_attn && dc && B > 0 && heads > 0 && T > 0 && ld >= T, OFA_ERR_INVALID, "c_attn_grad: bad argument");
+  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "c_attn_grad: bad dtype %d", c_attn_dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (c_attn_dtype == OFA_F32)
+    hipLaunchKernelGGL((c_attn_grad_kernel<float>), dim3(heads), dim3(1024), 0, st, delta, (const float*)c_attn, (float*)dc, B, heads,
+                       T, ld, accumulate);
+  else
+    hipLaunchKernelGGL((c_attn_grad_kernel<bf16_t>), dim3(heads), dim3(1024), 0, st, delta, (const bf16_t*)c_attn, (bf16_t*)dc, B,
+                       heads, T, ld, accumulate);
+  return check_launch("c_attn_grad");
 }

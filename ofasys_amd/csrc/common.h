@@ -103,15 +103,38 @@ struct Philox {
     return make_uint4(c0, c1, c2, c3);
   }
 };
-// keep-probability test on one 32-bit word: keep iff u < (1-p)
-__device__ __forceinline__ bool philox_keep(uint32_t word, float p) {
-  return (float)(word >> 8) * (1.0f / 16777216.0f) >= p;
+// Dropout masks: element e draws 16 bits -- Philox counter (offset + e/8), halfword e%8 of the 128-bit output -- and is
+// dropped iff they are below round(p * 65536).  One Philox call (40 32-bit multiplies) decides 8 elements: with 32 bits
+// per element the residual-join kernels were VALU-bound on the generator, not on HBM.  The drop probability is exact to
+// 2^-17 (p = 0.1 -> 0.100006).
+__device__ __forceinline__ uint32_t philox_thresh(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ bool philox_keep(const uint4& r, int j, uint32_t thresh) {     // j = e % 8
+  const uint32_t w = (j >> 1) == 0 ? r.x : ((j >> 1) == 1 ? r.y : ((j >> 1) == 2 ? r.z : r.w));
+  return ((j & 1 ? w >> 16 : w & 0xffffu)) >= thresh;
 }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float kInvSqrt2Pi = 0.39894228040143267794f;
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+// Gaussian cdf Phi(x) and e = exp(-x^2/2) together (gelu = x*Phi, gelu' = Phi + x*e/sqrt(2 pi)).  EXACT: libm erff (fp32
+// kernels).  Otherwise Abramowitz-Stegun 7.1.26 on the SAME exponential: |error| < 1.5e-7 absolute, one v_exp + one v_rcp
+// + 6 FMAs instead of erff's ~40 instructions -- the fused GELU+LayerNorm kernels were VALU-bound on erff (14336 x 3072:
+// 94 us of issue cycles against 41 us of HBM time); used by the bf16 kernels, whose 2^-9 output rounding is four orders
+// of magnitude coarser.  The tail uses 0.5*poly*e directly (no 1 - erf cancellation for negative x).
+template <bool EXACT> __device__ __forceinline__ void gauss_cdf(float x, float& cdf, float& e) {
+  e = __expf(-0.5f * x * x);
+  if (EXACT) {
+    cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return;
+  }
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float q = 0.5f * poly * e;
+  cdf = x > 0.f ? 1.0f - q : q;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

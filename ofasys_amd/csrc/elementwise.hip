@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ dy, con
   }
 }
 
-// element e uses Philox counter (offset + e/4), word e%4.
+// element e uses Philox counter (offset + e/8), halfword e%8 (philox_keep in common.h).
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                       int64_t n, float p, uint64_t seed, uint64_t offset,
@@ -38,15 +38,15 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
   if (offset_base) offset += (uint64_t)offset_base[0];   // device-resident stream position (hipGraph replays advance it)
   const Philox rng(seed);
   const float keep_scale = 1.0f / (1.0f - p);
-  const int64_t nq = (n + 3) / 4;
+  const uint32_t thresh = philox_thresh(p);
+  const int64_t nq = (n + 7) / 8;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
     const uint4 r = rng(offset + (uint64_t)q);
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t e = q * 4 + j;
+    for (int j = 0; j < 8; ++j) {
+      const int64_t e = q * 8 + j;
       if (e < n) {
-        float v = philox_keep(w[j], p) ? ld1<T>(x + e) * keep_scale : 0.f;
+        float v = philox_keep(r, j, thresh) ? ld1<T>(x + e) * keep_scale : 0.f;
         if (ADD) v += ld1<T>(res + e);
         st1<T>(y + e, v);
       }
@@ -369,7 +369,7 @@ extern "C" int ofa_dropout_add_fwd(const void* x, const void* residual, void* y,
   OFA_REQUIRE(n >= 0 && p >= 0.f && p < 1.f && (n == 0 || (x && y)), OFA_ERR_INVALID, "dropout_add_fwd: bad argument");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(grid_for((n + 3) / 4)), block(256);
+  dim3 grid(grid_for((n + 7) / 8)), block(256);
   if (dtype == OFA_F32) {
     if (residual) hipLaunchKernelGGL((dropout_kernel<float, true>), grid, block, 0, st, (const float*)x, (const float*)residual, (float*)y, n, p, seed, offset, offset_base);
     else hipLaunchKernelGGL((dropout_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (float*)y, n, p, seed, offset, offset_base);

@@ -15,17 +15,22 @@ template <typename T> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return bf2f(f2bf(v)); }
 
-// keep / drop decisions of the N elements starting at element index e0 (e0 % N == 0): dropout_kernel's rule
-// (element e <- Philox counter offset + e/4, word e%4)
+// keep / drop decisions of the N (4 or 8) elements starting at element index e0 (e0 % N == 0): dropout_kernel's rule
+// (element e <- Philox counter offset + e/8, halfword e%8)
 template <int N>
 __device__ __forceinline__ void keep_mask(const Philox& rng, uint64_t offset, int64_t e0, float p, bool (&keep)[N]) {
+  const uint4 r = rng(offset + (uint64_t)(e0 >> 3));
+  const uint32_t thresh = philox_thresh(p);
+  if (N == 8) {
 #pragma unroll
-  for (int q = 0; q < N / 4; ++q) {
-    const uint4 r = rng(offset + (uint64_t)(e0 / 4 + q));
-    keep[4 * q] = philox_keep(r.x, p);
-    keep[4 * q + 1] = philox_keep(r.y, p);
-    keep[4 * q + 2] = philox_keep(r.z, p);
-    keep[4 * q + 3] = philox_keep(r.w, p);
+    for (int j = 0; j < N; ++j) keep[j] = philox_keep(r, j, thresh);
+  } else {
+    const bool hi = (e0 & 4) != 0;                  // the upper four halfwords
+    const uint32_t w0 = hi ? r.z : r.x, w1 = hi ? r.w : r.y;
+    keep[0] = (w0 & 0xffffu) >= thresh;
+    keep[1] = (w0 >> 16) >= thresh;
+    keep[2] = (w1 & 0xffffu) >= thresh;
+    keep[3] = (w1 >> 16) >= thresh;
   }
 }
 
@@ -125,21 +130,36 @@ __global__ __launch_bounds__(256) void join_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-// backward: 16-wave blocks, a row split over WPR waves (one vector per lane), column partials folded through LDS into one
-// row per block of ws[q][block][cols], q = dgamma_a, dbeta_a, dgamma_b, dbeta_b.
-constexpr int JOIN_WPB = 16;
+// backward: 12-wave blocks (768 threads: 170 registers per lane, room for the next-row prefetch without spilling; 16
+// waves for rows split 8 ways), a row split over WPR waves (one vector per lane), column partials folded through LDS
+// into one row per block of ws[q][block][cols], q = dgamma_a, dbeta_a, dgamma_b, dbeta_b.
 constexpr int JOIN_BLOCKS = 256;
+constexpr int join_wpb(int wpr) { return wpr == 8 ? 16 : 12; }
+
+template <typename T> __device__ __forceinline__ void jn_unpack(const uint4& r, float* out);
+template <> __device__ __forceinline__ void jn_unpack<float>(const uint4& r, float* out) {
+  out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void jn_unpack<bf16_t>(const uint4& r, float* out) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
 
 template <typename T, int WPR>
-__global__ __launch_bounds__(1024) void join_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dz,
+__global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dz,
                                                         const T* __restrict__ x, const T* __restrict__ y,
                                                         const T* __restrict__ ga, const T* __restrict__ gb,
                                                         const float* __restrict__ stats, T* __restrict__ dres,
                                                         T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols,
                                                         JoinRng rg) {
   constexpr int N = Vec<T>::N;
+  constexpr int JOIN_WPB = join_wpb(WPR);
   constexpr int RPB = JOIN_WPB / WPR;
-  __shared__ float red[2][JOIN_WPB];
+  __shared__ float red[2][2][2][JOIN_WPB];          // [LN_b / LN_a exchange][row parity][s1, s2][wave]
   __shared__ float fold[JOIN_WPB][64 * N];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rib = wib / WPR, part = wib % WPR;
@@ -158,38 +178,68 @@ __global__ __launch_bounds__(1024) void join_bwd_kernel(const T* __restrict__ dy
   const uint64_t off = rg.offset + (rg.base ? (uint64_t)rg.base[0] : 0);
   const Philox rng(rg.seed);
   const float scale = rg.p > 0.f ? 1.0f / (1.0f - rg.p) : 1.0f;
-  auto row_sums = [&](float& s1, float& s2) {            // sums over the whole row (all WPR parts)
+  // sums over the whole row (all WPR parts): ONE barrier per exchange -- the buffer alternates with the row parity and
+  // between the two exchanges of a row, so a fast wave's next write never lands on a buffer a slow wave still reads
+  auto row_sums = [&](float& s1, float& s2, int which, int64_t it) {
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (WPR > 1) {
-      if (lane == 0) { red[0][wib] = s1; red[1][wib] = s2; }
+      float (*rb)[JOIN_WPB] = red[which][it & 1];
+      if (lane == 0) { rb[0][wib] = s1; rb[1][wib] = s2; }
       __syncthreads();
       s1 = 0.f; s2 = 0.f;
 #pragma unroll
-      for (int p2 = 0; p2 < WPR; ++p2) { s1 += red[0][rib * WPR + p2]; s2 += red[1][rib * WPR + p2]; }
-      __syncthreads();
+      for (int p2 = 0; p2 < WPR; ++p2) { s1 += rb[0][rib * WPR + p2]; s2 += rb[1][rib * WPR + p2]; }
     }
   };
   const int64_t stride = (int64_t)gridDim.x * RPB;
   const int64_t niter = (rows + stride - 1) / stride;
+  // The block synchronises on every row, so no wave runs ahead: the NEXT row's four vectors and statistics are fetched
+  // (raw, 16 registers) before this row's arithmetic, otherwise every iteration pays the full HBM latency twice.
+  uint4 r_dy, r_dz, r_y, r_x;
+  float pst[4] = {0.f, 0.f, 0.f, 0.f};
+  r_dy = r_dz = r_y = r_x = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](int64_t it) {
+    const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
+    if (row < rows && act) {
+      const int64_t e0 = row * cols + c0 + c;
+      if (dy) r_dy = *reinterpret_cast<const uint4*>(dy + e0);
+      if (gb) {
+        r_dz = *reinterpret_cast<const uint4*>(dz + e0);
+        r_y = *reinterpret_cast<const uint4*>(y + e0);
+        pst[2] = stats[2 * rows + row];
+        pst[3] = stats[3 * rows + row];
+      }
+      if (ga) {
+        r_x = *reinterpret_cast<const uint4*>(x + e0);
+        pst[0] = stats[row];
+        pst[1] = stats[rows + row];
+      }
+    }
+  };
+  fetch(0);
   for (int64_t it = 0; it < niter; ++it) {
     const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
     const bool live = row < rows && act;
     const int64_t e0 = row * cols + c0 + c;
-    float g[N];                                           // running gradient of this lane's N columns
+    float g[N], dzv[N], yv[N];                            // g: running gradient of this lane's N columns
+    jn_unpack<T>(r_dy, g);                                // (zeros when dy is absent)
+    jn_unpack<T>(r_dz, dzv);
+    jn_unpack<T>(r_y, yv);
+    const uint4 xraw = r_x;
+    const float mu_a = pst[0], rs_a = pst[1], mu_b = pst[2], rs_b = pst[3];
+    if (it + 1 < niter) fetch(it + 1);
+    if (!live) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) g[j] = 0.f;
-    if (live && dy) load_vec<T>(dy + e0, g);
+      for (int j = 0; j < N; ++j) g[j] = 0.f;
+    }
     if (gb) {                                             // LN_b backward (block-uniform branch)
-      float dzv[N], yh[N], s1 = 0.f, s2 = 0.f, rs = 0.f;
+      float yh[N], s1 = 0.f, s2 = 0.f, rs = 0.f;
 #pragma unroll
-      for (int j = 0; j < N; ++j) dzv[j] = yh[j] = 0.f;
+      for (int j = 0; j < N; ++j) yh[j] = 0.f;
       if (live) {
-        const float mu = stats[2 * rows + row];
-        rs = stats[3 * rows + row];
-        float yv[N];
-        load_vec<T>(dz + e0, dzv);
-        load_vec<T>(y + e0, yv);
+        const float mu = mu_b;
+        rs = rs_b;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           yh[j] = (yv[j] - mu) * rs;
@@ -200,7 +250,7 @@ __global__ __launch_bounds__(1024) void join_bwd_kernel(const T* __restrict__ dy
           acc[3][j] += dzv[j];
         }
       }
-      row_sums(s1, s2);
+      row_sums(s1, s2, 0, it);
       s1 /= (float)cols;
       s2 /= (float)cols;
       if (live) {
@@ -220,10 +270,10 @@ __global__ __launch_bounds__(1024) void join_bwd_kernel(const T* __restrict__ dy
 #pragma unroll
       for (int j = 0; j < N; ++j) xh[j] = 0.f;
       if (live) {
-        const float mu = stats[row];
-        rs = stats[rows + row];
+        const float mu = mu_a;
+        rs = rs_a;
         float xv[N];
-        load_vec<T>(x + e0, xv);
+        jn_unpack<T>(xraw, xv);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           xh[j] = (xv[j] - mu) * rs;
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(1024) void join_bwd_kernel(const T* __restrict__ dy
           acc[1][j] += g[j];
         }
       }
-      row_sums(s1, s2);
+      row_sums(s1, s2, 1, it);
       s1 /= (float)cols;
       s2 /= (float)cols;
       if (live) {
@@ -313,7 +363,8 @@ extern "C" int ofa_join_fwd(const void* x, const void* residual, const void* gam
 }
 
 extern "C" int ofa_join_bwd_slots(int64_t rows, int cols, int dtype) {
-  const int rpb = JOIN_WPB / join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
+  const int wpr = join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
+  const int rpb = join_wpb(wpr) / wpr;
   int64_t nblk = (rows + rpb - 1) / rpb;
   return (int)(nblk < 1 ? 1 : (nblk > JOIN_BLOCKS ? JOIN_BLOCKS : nblk));
 }
@@ -331,7 +382,7 @@ extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const
   hipStream_t st = (hipStream_t)stream;
   const JoinRng rg{p, seed, offset, offset_base};
   const int wpr = join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
-  dim3 grid(ofa_join_bwd_slots(rows, cols, dtype)), block(64 * JOIN_WPB);
+  dim3 grid(ofa_join_bwd_slots(rows, cols, dtype)), block(64 * join_wpb(wpr));
 #define JOIN_BWD(T, WPR)                                                                                              \
   hipLaunchKernelGGL((join_bwd_kernel<T, WPR>), grid, block, 0, st, (const T*)dy, (const T*)(gamma_b ? dz : nullptr),  \
                      (const T*)x, (const T*)y, (const T*)gamma_a, (const T*)gamma_b, stats, (T*)dres, (T*)dx, ws, rows, cols, rg)

@@ -1,5 +1,6 @@
 // LayerNorm forward/backward for gfx950: one 64-lane wavefront per row, the row lives in registers
-// (16-byte vector loads, two-pass mean/variance in fp32), optional fused exact-erf GELU in front of it.
+// (16-byte vector loads, two-pass mean/variance in fp32), optional fused erf-GELU in front of it
+// (libm erff in the fp32 kernels, a 1.5e-7-accurate rational form in the bf16 kernels: gauss_cdf in common.h).
 //
 // Reference arithmetic: torch.nn.LayerNorm(eps=1e-5, affine)  (module/layer_norm.py:27-32); the GELU+LN pair is
 // transformer_layer.py:194-197 / :480-483 (activation_fn(fc1(x)) -> ffn_layernorm), GELU per module/gelu.py:18-19.
@@ -27,7 +28,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       load_vec<T>(xr + c, v[i]);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        if (GELU) v[i][j] = gelu_f(v[i][j]);
+        if (GELU) {
+          float cdf, e;
+          gauss_cdf<sizeof(T) == 4>(v[i][j], cdf, e);
+          v[i][j] *= cdf;
+        }
         s += v[i][j];
       }
     } else {
@@ -84,8 +89,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // therefore fetched before the current row's arithmetic (software prefetch, 8 registers per vector pair).  Rows of 6 x 512
 // columns (the base model's 3072-wide FFN LayerNorm) use 12 waves per block, 6 per row: every lane owns exactly one
 // vector (with 8 parts only 48 of 64 lanes would) and the 768-thread block has 170 registers per lane for the prefetch.
+#ifndef LN_PF_DEPTH
+#define LN_PF_DEPTH 2
+#endif
 constexpr int LN_WPB = 16;          // waves per block (default)
 constexpr int LN_BWD_BLOCKS = 256;  // one block per CU; also the workspace row count
+
+template <int I, int E, typename F> __device__ __forceinline__ void static_for_ln(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for_ln<I + 1, E>(f);
+  }
+}
 
 template <typename T> __device__ __forceinline__ void unpack_vec(const uint4& r, float* out);
 template <> __device__ __forceinline__ void unpack_vec<float>(const uint4& r, float* out) {
@@ -109,9 +124,9 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
   constexpr int N = Vec<T>::N;
   constexpr int RPB = WPB / WPR;                     // rows per block iteration
   // (only where the registers are there: at the 128-VGPR cap of the 16-wave block the GELU / 2-vector variants would spill)
-  constexpr bool PREFETCH = WPR > 1 && (WPB < 16 || (!GELU && NV == 1));
+  constexpr int PF = WPR > 1 ? (WPB < 16 ? LN_PF_DEPTH : ((!GELU && NV == 1) ? 1 : 0)) : 0;   // rows fetched ahead
   static_assert(WPB % WPR == 0, "waves per block must be a multiple of waves per row");
-  __shared__ float red[2][WPB];
+  __shared__ float red[2][2][WPB];
   __shared__ float fold[WPB][64 * N];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int rib = wib / WPR, part = wib % WPR;       // row-in-block, column part
@@ -131,45 +146,52 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
   }
   const int64_t stride = (int64_t)gridDim.x * RPB;
   const int64_t niter = (rows + stride - 1) / stride;
-  uint4 rx[NV], rd[NV];                              // raw vectors of the row being fetched
-  float nmu = 0.f, nrs = 0.f;
-  auto fetch = [&](int64_t it) {
+  constexpr int RING = PF > 0 ? PF : 1;
+  uint4 rx[RING][NV], rd[RING][NV];                  // raw vectors of the rows in flight
+  float nmu[RING], nrs[RING];
+  auto fetch = [&](int64_t it, auto bc) {
+    constexpr int b = decltype(bc)::value;
     const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
     if (row < rows) {
-      nmu = mean[row];
-      nrs = rstd[row];
+      nmu[b] = mean[row];
+      nrs[b] = rstd[row];
       const T* xr = x + row * cols + c0;
       const T* dyr = dy + row * cols + c0;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * N;
         if (c < cpp) {
-          rx[i] = *reinterpret_cast<const uint4*>(xr + c);
-          rd[i] = *reinterpret_cast<const uint4*>(dyr + c);
+          rx[b][i] = *reinterpret_cast<const uint4*>(xr + c);
+          rd[b][i] = *reinterpret_cast<const uint4*>(dyr + c);
         }
       }
     }
   };
-  if (PREFETCH) fetch(0);
-  for (int64_t it = 0; it < niter; ++it) {
+  if constexpr (PF > 0) static_for_ln<0, PF>([&](auto bc) { if (decltype(bc)::value < niter) fetch(decltype(bc)::value, bc); });
+  // the loop is unrolled RING times so that the ring slot is a compile-time index (registers, no copies)
+  for (int64_t it0 = 0; it0 < niter; it0 += RING)
+  static_for_ln<0, RING>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const int64_t it = it0 + b;
+    if (it >= niter) return;                         // block-uniform
     const int64_t row = it * stride + (int64_t)blockIdx.x * RPB + rib;
     const bool live = row < rows;
     float xv[NV][N], gp[GELU ? NV : 1][N], d[NV][N];  // xv: LN input (gelu(h) or x); gp: gelu'(h)
     float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
-    if constexpr (PREFETCH) {
+    if constexpr (PF > 0) {
       if (live) {
-        mu = nmu;
-        rs = nrs;
+        mu = nmu[b];
+        rs = nrs[b];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int c = (i * 64 + lane) * N;
           if (c < cpp) {
-            unpack_vec<T>(rx[i], xv[i]);
-            unpack_vec<T>(rd[i], d[i]);
+            unpack_vec<T>(rx[b][i], xv[i]);
+            unpack_vec<T>(rd[b][i], d[i]);
           }
         }
       }
-      if (it + 1 < niter) fetch(it + 1);
+      if (it + PF < niter) fetch(it + PF, bc);
     } else if (live) {
       mu = mean[row];
       rs = rstd[row];
@@ -193,8 +215,9 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
           for (int j = 0; j < N; ++j) {
             if (GELU) {
               const float h = xv[i][j];
-              const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752440f));
-              gp[i][j] = cdf + h * 0.39894228040143267794f * __expf(-0.5f * h * h);
+              float cdf, e;
+              gauss_cdf<sizeof(T) == 4>(h, cdf, e);
+              gp[i][j] = cdf + h * 0.39894228040143267794f * e;
               xv[i][j] = h * cdf;
             }
             const float xh = (xv[i][j] - mu) * rs;
@@ -211,13 +234,13 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if (WPR > 1) {
-      if (lane == 0) { red[0][wib] = s1; red[1][wib] = s2; }
+    if (WPR > 1) {                                   // one barrier per row: the exchange buffer alternates
+      float (*rb)[WPB] = red[it & 1];
+      if (lane == 0) { rb[0][wib] = s1; rb[1][wib] = s2; }
       __syncthreads();
       s1 = 0.f; s2 = 0.f;
 #pragma unroll
-      for (int p = 0; p < WPR; ++p) { s1 += red[0][rib * WPR + p]; s2 += red[1][rib * WPR + p]; }
-      __syncthreads();
+      for (int p = 0; p < WPR; ++p) { s1 += rb[0][rib * WPR + p]; s2 += rb[1][rib * WPR + p]; }
     }
     s1 /= (float)cols;
     s2 /= (float)cols;
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
         }
       }
     }
-  }
+  });
   // fold the block's waves: quantity q of vector i goes through fold[wave][lane*N + j]; the rib == 0 wave of each
   // column part sums its RPB peers in fixed order and writes the block's partial row
   const int nq = (GELU && want_dbias) ? 3 : 2;

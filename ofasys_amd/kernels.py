@@ -326,6 +326,24 @@ def _same_ld(k, v):
     return k, v, ldk
 
 
+def _c_dtype(c_attn):
+    """dtype code of the per-head scale (fp32 or bf16 [heads], contiguous); fp32 when absent."""
+    if c_attn is None:
+        return dtype_code(torch.empty(0, dtype=torch.float32))
+    assert c_attn.is_contiguous()
+    return dtype_code(c_attn)
+
+
+def c_attn_grad(delta, c_attn, B, heads, T, out=None, accumulate=False):
+    """d c_attn[h] = sum_{b,t<T} delta[b*heads+h, t] / c_attn[h]  (delta: fp32 [B*heads, ld] from attn_bwd)."""
+    if out is None:
+        out = torch.empty_like(c_attn)
+        accumulate = False
+    lib().call("ofa_c_attn_grad", ptr(delta), ptr(c_attn), ptr(out), B, heads, T, delta.stride(0), int(accumulate),
+               dtype_code(c_attn), stream())
+    return out
+
+
 def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False):
     """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad]."""
     q, ldq = _rows3(q)
@@ -339,8 +357,8 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
         bias = bias.contiguous()
     if kpm is not None:
         kpm = _u8(kpm)
-    lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(kpm), ptr(c_attn), ptr(out), ptr(lse), B, heads, T,
-               S, Tpad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
+    lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(out), ptr(lse),
+               B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
     return out, lse
 
 
@@ -379,9 +397,9 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
         dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
         dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), ptr(lse), ptr(delta),
-               ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal),
-               dtype_code(q), stream())
+    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
+               ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
+               int(causal), dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
 
 

@@ -253,12 +253,15 @@ class ResidualJoinFn(torch.autograd.Function):
         ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats)
         ctx.refs = (ba, bb)
         ctx.rng = (p, seed, off, base)
+        ctx.set_materialize_grads(False)                    # an unused y (last layer of a stack) costs no zero fill
         if z is None:
             return y, None
         return y, z
 
     @staticmethod
     def backward(ctx, dy, dz):
+        if dy is None and dz is None:
+            return (None,) * 8
         x2d, y, wa, wb, stats = ctx.saved_tensors
         ba, bb = ctx.refs
         p, seed, off, base = ctx.rng
@@ -495,29 +498,37 @@ def embedding(ids, weight, padding_idx=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
+def _c_attn_grad(delta, c_attn, B, heads, T):
+    """d c_attn[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]  (O = c * PV): one kernel, straight into the gradient arena when
+    the parameter has a sink (returns None then)."""
+    g = _sink(c_attn)
+    if g is not None:
+        K.c_attn_grad(delta, c_attn, B, heads, T, out=g, accumulate=True)
+        _sink_done(c_attn)
+        return None
+    return K.c_attn_grad(delta, c_attn, B, heads, T)
+
+
 class FusedAttentionFn(torch.autograd.Function):
     """bf16 fused attention on [B,T,D] rows (csrc/attention.hip)."""
 
     @staticmethod
     def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal):
-        c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn)
+        ctx.c_ref = c_attn                                  # the Parameter object (carries the gradient sink)
         ctx.heads, ctx.scale, ctx.causal = heads, scale, causal
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, bias, kpm, c_attn = ctx.saved_tensors
-        c32 = c_attn.float() if c_attn is not None else None
         need_dbias = bias is not None and ctx.needs_input_grad[3]
         dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
-                                              c_attn=c32, causal=ctx.causal, need_dbias=need_dbias)
+                                              c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias)
         dc = None
         if c_attn is not None and ctx.needs_input_grad[5]:
-            # d c_attn[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]   (O = c * PV)
-            dsum = K.head_sum(delta, q.shape[0], ctx.heads, q.shape[1])
-            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+            dc = _c_attn_grad(delta, ctx.c_ref, q.shape[0], ctx.heads, q.shape[1])
         return dq, dk, dv, dbias, None, dc, None, None, None
 
 
@@ -557,9 +568,9 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         x2d = x.view(B * T, D)
         kvq = K.gemm(x2d, W, False, True, bias=Bv).view(B, T, 3 * D)
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
-        c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=causal)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal)
         ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W)
+        ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, causal, pack)
         return out
@@ -573,9 +584,8 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         D = D3 // 3
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
         dkvq = torch.empty_like(kvq)
-        c32 = c_attn.float() if c_attn is not None else None
         need_dbias = bias is not None and ctx.needs_input_grad[7]
-        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c32,
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=causal, need_dbias=need_dbias,
                                            outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
         d2 = dkvq.view(B * T, D3)
@@ -586,8 +596,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
                             lambda o, acc, f: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype, fold=f), (d2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[9]:
-            dsum = K.head_sum(delta, B, heads, T)
-            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+            dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
         return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None)
 
 
@@ -605,9 +614,9 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         q = K.gemm(xq2, wq, False, True, bias=bq).view(B, T, D)
         kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
-        c32 = c_attn.float() if c_attn is not None else None
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c32, causal=False)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False)
         ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
+        ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, pack)
         return out
@@ -622,9 +631,8 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        c32 = c_attn.float() if c_attn is not None else None
         need_dbias = bias is not None and ctx.needs_input_grad[8]
-        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c32,
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=False, need_dbias=need_dbias,
                                            outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
@@ -639,8 +647,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
                             lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[10]:
-            dsum = K.head_sum(delta, B, heads, T)
-            dc = K.mul(dsum.view(1, -1), (1.0 / c32).view(1, -1)).view(-1).to(c_attn.dtype)
+            dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
         return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None)
 
 

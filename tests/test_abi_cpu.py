@@ -40,7 +40,7 @@ def test_status_codes_not_asserts():
     with pytest.raises(L.OfaError, match="sk"):
         h.call("ofa_scaled_softmax_fwd", 1, 1, 1.0, 1, 1, 4, 5000, L.F32, None)                       # sk > 4096
     with pytest.raises(L.OfaError, match="bf16"):
-        h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, L.F32, None)
+        h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, L.F32, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, L.F32, None)
 
 
 def test_no_cpu_fallback():

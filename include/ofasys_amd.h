@@ -225,6 +225,11 @@ int ofa_probs_bwd(const float* dy, const float* y, void* dlogits, int64_t rows, 
 int ofa_sumsq_ws_floats(void);
 int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* ws /* ofa_sumsq_ws_floats() floats */,
               int64_t n, int dtype, void* stream);
+/* Scalar schedule of one update, on the device (one thread): gnorm = sqrt(gsq)/sample_size; sched[0] = (1/sample_size) *
+ * min(1, clip_norm/(gnorm + 1e-6)) (trainer.py:857-884; no clipping when clip_norm <= 0); step += 1; sched[1] =
+ * lr*sqrt(1-b2^step)/(1-b1^step); sched[2] = lr (adam.py:205-207).  sched feeds ofa_adam_step(step = 0). */
+int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
+                      float* gnorm, float clip_norm, double beta1, double beta2, void* stream);
 /* Adam on fp32 master weights with grads of `dtype`; coef[0] = grad multiplier (world/sample_size and clip folded
  * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p).
  * step >= 1: bias correction from (lr, step) on the host.  step == 0: coef is device fp32[3] = [grad multiplier,

@@ -273,6 +273,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
   }
 }
 
+// One thread: the scalar arithmetic between the gradient norm and the Adam update, kept on the device so that a captured
+// train step replays it (trainer.py:857-884 clip + 1/sample_size, adam.py:205-207 bias corrections).  ~25 tiny torch
+// kernels otherwise, ~4.5 us each inside a hipGraph.
+__global__ void step_schedule_kernel(const float* __restrict__ gsq, const double* __restrict__ sample_size,
+                                     double* __restrict__ step, const double* __restrict__ lr, float* __restrict__ sched,
+                                     float* __restrict__ gnorm, float clip_norm, double beta1, double beta2) {
+  if (threadIdx.x || blockIdx.x) return;
+  const float inv_n = (float)(1.0 / sample_size[0]);
+  const float gn = sqrtf(gsq[0]) * inv_n;
+  float coef = inv_n;
+  if (clip_norm > 0.f) coef *= fminf(clip_norm / (gn + 1e-6f), 1.0f);
+  const double t = step[0] + 1.0;
+  step[0] = t;
+  const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+  sched[0] = coef;
+  sched[1] = (float)(lr[0] * sqrt(bc2) / bc1);
+  sched[2] = (float)lr[0];
+  gnorm[0] = gn;
+}
 }  // namespace ofa
 using namespace ofa;
 
@@ -399,4 +418,12 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   else
     hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   return check_launch("adam_step");
+}
+
+extern "C" int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
+                                 float* gnorm, float clip_norm, double beta1, double beta2, void* stream) {
+  OFA_REQUIRE(gsq && sample_size && step && lr && sched && gnorm, OFA_ERR_INVALID, "step_schedule: null pointer");
+  hipLaunchKernelGGL(step_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gsq, sample_size, step, lr, sched, gnorm,
+                     clip_norm, beta1, beta2);
+  return check_launch("step_schedule");
 }

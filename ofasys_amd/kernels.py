@@ -545,6 +545,13 @@ def sumsq(x, out):
     return out
 
 
+def step_schedule(gsq, sample_size, step, lr, sched, gnorm, clip_norm, beta1, beta2):
+    """Device-side scalar schedule of one update (see ofa_step_schedule); all arguments are 1-element device tensors
+    (gsq fp32, sample_size / step / lr fp64, sched fp32[3], gnorm fp32)."""
+    lib().call("ofa_step_schedule", ptr(gsq), ptr(sample_size), ptr(step), ptr(lr), ptr(sched), ptr(gnorm), float(clip_norm),
+               float(beta1), float(beta2), stream())
+
+
 def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, beta2, eps, weight_decay, step):
     lib().call("ofa_adam_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), ptr(model_param), ptr(coef),
                master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),

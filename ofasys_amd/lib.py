@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_ACCUM, GEMM_FORCE_SIMPLE, GEMM_OUT_F32 = 1, 2, 4, 8, 16
 
 _CTYPES = {
-    "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
     "void": None,
 }
 

@@ -123,6 +123,7 @@ class Trainer:
         self.label_smoothing, self.constraint_range, self.drop_worst_ratio = label_smoothing, constraint_range, drop_worst_ratio
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)      # [sample_size, loss_sum, ntokens]
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._gnorm_t = torch.zeros(1, dtype=torch.float32, device=dev)
         # device-resident schedule: _step_t = number of updates done; _lr_t = learning rate; _sched = [grad multiplier,
         # lr*sqrt(1-b2^t)/(1-b1^t), lr] consumed by ofa_adam_step(step = 0)
         self._step_t = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -179,17 +180,9 @@ class Trainer:
         # coef = (1/sample_size) * min(1, clip / (||g/sample_size|| + 1e-6)), all on the device
         self._gsq.zero_()
         K.sumsq(self.fp.grad, self._gsq)
-        inv_n = (1.0 / self._stats[0]).float()
-        gnorm = self._gsq.sqrt() * inv_n
-        coef = inv_n.reshape(1)
-        if self.clip_norm > 0:
-            coef = coef * (self.clip_norm / (gnorm + 1e-6)).clamp(max=1.0)
-        self._step_t += 1                           # adam.py:205-207 on the device
-        bc1 = 1.0 - self.betas[0] ** self._step_t
-        bc2 = 1.0 - self.betas[1] ** self._step_t
-        self._sched[0:1] = coef
-        self._sched[1:2] = (self._lr_t * bc2.sqrt() / bc1).float()
-        self._sched[2:3] = self._lr_t.float()
+        K.step_schedule(self._gsq, self._stats, self._step_t, self._lr_t, self._sched, self._gnorm_t, self.clip_norm,
+                        self.betas[0], self.betas[1])       # adam.py:205-207 + the clip coefficient, one device thread
+        gnorm = self._gnorm_t
         K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.fp.grad, self.fp.flat, self._sched, 0.0,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, 0)
         self._gnorm = gnorm

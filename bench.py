@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg2b"],
                     help="cfg2 (headline: image_patch_embed, bias-free) or cfg2b (image_resnet101 + biased attention, 196+252 -> 64)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1: nccl (= RCCL, the product path); gloo only to smoke-test the N > 1 code path "
+                         "on a one-GPU box together with OFA_BENCH_DEVICE=0 (all ranks on one device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,11 +212,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if "OFA_BENCH_DEVICE" in os.environ:                          # test hook: several ranks on one GPU (gloo only)
+        local_rank = int(os.environ["OFA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
         dist.all_reduce(torch.zeros(1, device=device))            # communicator warm-up (distributed/utils.py:240-241)
 
     from ofasys_amd import kernels as K

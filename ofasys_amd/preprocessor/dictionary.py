@@ -41,6 +41,36 @@ class Dictionary:
         self.count.append(n)
         return idx
 
+    def get_start_end_idx(self, prefix: str):
+        """[start, end) of the symbols carrying `prefix` (preprocessor/dictionary.py:66-74)."""
+        start, end = -1, -2
+        for i, token in enumerate(self.symbols):
+            if token.startswith(prefix):
+                if start < 0:
+                    start = i
+                end = i
+        return start, end + 1
+
+    def encode_line(self, line, add_if_not_exist=True, append_eos=True, reverse_order=False):
+        """Whitespace-split symbols -> int32 ids (preprocessor/dictionary.py:322-347)."""
+        import torch
+        words = line.strip().split()
+        if reverse_order:
+            words = list(reversed(words))
+        ids = [self.add_symbol(w) if add_if_not_exist else self.index(w) for w in words]
+        if append_eos:
+            ids.append(self.eos_index)
+        return torch.tensor(ids, dtype=torch.int32)
+
+    def encode(self, words, add_if_not_exist=True, append_eos=True, reverse_order=False):
+        """Dictionary-relative text ids -> global ids: word w maps to the symbol '<text>_w' (preprocessor/dictionary.py:349-374)."""
+        import torch
+        words = [str(w) for w in (reversed(list(words)) if reverse_order else words)]
+        ids = [self.add_symbol(w) if add_if_not_exist else self.index("<text>_" + w) for w in words]
+        if append_eos:
+            ids.append(self.eos_index)
+        return torch.tensor(ids, dtype=torch.int32)
+
     def bos(self):
         return self.bos_index
 

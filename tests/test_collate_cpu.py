@@ -1,0 +1,136 @@
+"""CPU: slot collation against golden vectors produced by the REFERENCE's own collation code
+(oracle/gen_collate_golden.py).  Integer fields must be bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.collate_cases import BOX_CASES, CASES, N_TEXT, TOKEN_CASES, make_samples, make_token_lists
+from ofasys_amd.preprocessor import (DefaultBoxPreprocess, DefaultTextPreprocess, Dictionary, GeneralPreprocess, Instruction,
+                                     ModalityType, Slot, TensorPreprocess, collate_tokens, group_by_predicator, to_device)
+from ofasys_amd.preprocessor.collate import BoxPreprocessConfig, PreprocessConfig, TextPreprocessConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "collate.npz"), allow_pickle=False))
+
+
+def same(a, b):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", list(TOKEN_CASES))
+def test_collate_tokens_matches_reference(name):
+    spec = TOKEN_CASES[name]
+    same(collate_tokens(make_token_lists(spec), **spec["kwargs"]), G[f"tok.{name}"])
+
+
+def test_group_by_predicator():
+    assert group_by_predicator([1, 2, 2, 3, 4, 4, 4], lambda x, y: x == y) == [[1], [2, 2], [3], [4, 4, 4]]
+    assert group_by_predicator([], lambda x, y: True) == []
+
+
+def dictionary():
+    d = Dictionary()
+    for i in range(N_TEXT):
+        d.add_symbol(f"<text>_{i}")
+    d.add_symbol("<mask>")
+    return d
+
+
+def general(case):
+    d = dictionary()
+    cfg = TextPreprocessConfig(pad_to_multiple=case.get("pad_to_multiple", 1), max_src_length=case.get("max_src_length", 1024),
+                               max_tgt_length=case.get("max_tgt_length", 1024))
+    closed = [[4 + t for t in ans] for ans in case["closed_set"]] if case.get("closed_set") else None
+    pres = {"text": DefaultTextPreprocess(d, cfg, closed_set=closed), "box": DefaultBoxPreprocess(d, BoxPreprocessConfig()),
+            "image": TensorPreprocess(d, PreprocessConfig(), ModalityType.IMAGE)}
+    return GeneralPreprocess(d, pres)
+
+
+def run_case(case):
+    gp = general(case)
+    samples = []
+    for raw in make_samples(case):
+        slots = [Slot(ModalityType[m], is_src, v, global_position=i, attributes=attrs, split=case.get("split", "train"),
+                      is_plaintext=plain) for i, (m, is_src, v, attrs, plain) in enumerate(raw)]
+        samples.append(gp(Instruction(slots, case["template"], {"uid": len(samples)})))
+    return gp, samples
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_instruction_collation_matches_reference(name):
+    case = CASES[name]
+    gp, samples = run_case(case)
+    assert len(samples[0].slots) == int(G[f"{name}.n_slots"][0])
+    seen = 0
+    for si, s in enumerate(samples):                       # per-sample grouped values (bos/eos, prefix, truncation rules)
+        for gi, slot in enumerate(s.slots):
+            assert slot.global_position == gi
+            if isinstance(slot.value, dict):
+                for k, v in slot.value.items():
+                    key = f"{name}.group.{si}.{gi}.{k}"
+                    if v is None:
+                        assert key not in G, key
+                    else:
+                        same(v, G[key])
+                        seen += 1
+    assert seen > 0
+    res = gp.collate(samples)
+    n_in = len([k for k in G if k.startswith(f"{name}.net_input.") and not k.endswith("is_src")])
+    assert len(res["net_input"]["slots"]) == n_in
+    for gi, slot in enumerate(res["net_input"]["slots"]):
+        same(slot.value, G[f"{name}.net_input.{gi}"])
+        assert int(slot.is_src) == int(G[f"{name}.net_input.{gi}.is_src"][0])
+    for gi, slot in enumerate(res["net_target"]["slots"]):
+        same(slot.value, G[f"{name}.net_target.{gi}"])
+    for k in ("target", "prefix_tokens", "constraint_masks"):
+        if f"{name}.extra.{k}" in G:
+            same(res[k], G[f"{name}.extra.{k}"])
+        else:
+            assert k not in res
+    assert res["ntokens"] == int(G[f"{name}.extra.ntokens"][0])
+    assert [res["dict_start"], res["dict_end"]] == [int(x) for x in G[f"{name}.extra.dict_range"]]
+    same(res["uid"], G[f"{name}.uid"])
+    assert res["nsentences"] == case["batch"] and res["template"] == case["template"]
+
+
+@pytest.mark.parametrize("name", list(BOX_CASES))
+def test_box_binning_matches_reference(name):
+    d = dictionary()
+    box = DefaultBoxPreprocess(d, BoxPreprocessConfig())
+    s = box.map(Slot(ModalityType.BOX, True, torch.tensor([BOX_CASES[name]], dtype=torch.float32), global_position=0))
+    same(s.value, G[f"box.{name}"])
+    back = box.decode(torch.cat([s.value, torch.tensor([d.eos()])]), 0.5, 2.0)
+    assert np.allclose(back.numpy(), G[f"box.{name}.decode"], rtol=0, atol=0)
+    assert box.group_key(s) == ModalityType.TEXT
+
+
+def test_collate_rejects_ragged_slot_lists_and_strings():
+    gp, samples = run_case(CASES["caption"])
+    samples[1].slots = samples[1].slots[:-1]
+    with pytest.raises(ValueError, match="various modality"):
+        gp.collate(samples)
+    assert gp.collate([]) == {}
+    with pytest.raises(NotImplementedError, match="BPE"):
+        gp.name2pre["text"].map(Slot(ModalityType.TEXT, True, "a raw string", global_position=0))
+
+
+def test_to_device_packs_all_integer_fields_into_one_buffer():
+    """One staging buffer / one copy for every integer tensor; values and dtypes survive (CPU device here)."""
+    gp, samples = run_case(CASES["closed_set"])
+    res = gp.collate(samples)
+    ref = {"prev": res["net_input"]["slots"][-1].value.clone(), "target": res["target"].clone(),
+           "cm": res["constraint_masks"].clone(), "src": res["net_input"]["slots"][0].value.clone()}
+    out = to_device(res, "cpu")
+    assert torch.equal(out["net_input"]["slots"][-1].value, ref["prev"]) and out["target"].dtype == torch.int64
+    assert torch.equal(out["target"], ref["target"]) and torch.equal(out["net_input"]["slots"][0].value, ref["src"])
+    assert out["constraint_masks"].dtype == torch.bool and torch.equal(out["constraint_masks"], ref["cm"])
+    total = sum(n for _, _, n, _, _ in out["segments"])
+    assert total == ref["prev"].numel() + 2 * ref["target"].numel() + ref["cm"].numel() + ref["src"].numel() + res["prefix_tokens"].numel()
+    # int64 views share ONE storage
+    ptrs = {out["target"].untyped_storage().data_ptr(), out["net_input"]["slots"][0].value.untyped_storage().data_ptr()}
+    assert len(ptrs) == 1

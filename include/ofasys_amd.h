@@ -142,6 +142,15 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, 
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */
 int ofa_c_attn_grad(const float* delta, const void* c_attn, void* dc, int B, int heads, int T, int64_t ld, int accumulate,
                     int c_attn_dtype, void* stream);
+/* Decode-time attention (incremental branch, multihead_attention.py:241-279 + 308-346): ONE query row per (batch, head)
+ * against a key/value cache.  q, out: [B, heads*64]; k, v: rows of a [B, capacity, ld] cache -- element (b, s, c) at
+ * b*k_batch_stride + s*ldk + c -- of which the first S rows are valid; bias: optional [B*heads, S] additive row (the last
+ * row of the relative-position bias); kpm: optional uint8 [B, kpm_ld] (non-zero = padded key); c_attn: optional per-head
+ * scale (fp32 or bf16 per c_attn_dtype); probs: optional [B*heads, S] softmax output (need_weights).  Softmax in fp32;
+ * fp32 and bf16 tensors; head_dim must be 64. */
+int ofa_attn_decode(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm, const void* c_attn,
+                    int c_attn_dtype, void* out, void* probs, int B, int heads, int head_dim, int S, int64_t ldk,
+                    int64_t k_batch_stride, int64_t kpm_ld, float scale, int dtype, void* stream);
 /* out[b][i] = mean over heads of p[b][a][i], i < n  (head-averaged attention weights, multihead_attention.py:347-351). */
 int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream);
 /* x: [B, T, C] rows (ld elements) -> xt: [B, C, Tpad] (zero-filled for t >= T). */

@@ -403,6 +403,28 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     return dq, dk, dv, dbias, delta
 
 
+def attn_decode(q, k_cache, v_cache, S, heads, scale, bias=None, kpm=None, c_attn=None, need_probs=False):
+    """One query row per batch entry against a KV cache (csrc/attention_decode.hip).
+    q: [B, D]; k_cache, v_cache: [B, capacity, D] (same strides, last dim contiguous), the first S rows valid;
+    bias: [B*heads, S] or None; kpm: bool/uint8 [B, >= S] or None.  Returns out [B, D] and probs [B*heads, S] (or None)."""
+    B, D = q.shape
+    q = q.contiguous()
+    assert k_cache.dim() == 3 and k_cache.shape == v_cache.shape and k_cache.stride() == v_cache.stride()
+    assert k_cache.stride(2) == 1 and k_cache.shape[0] == B and k_cache.shape[1] >= S and k_cache.dtype == q.dtype
+    out = torch.empty(B, D, dtype=q.dtype, device=q.device)
+    probs = torch.empty(B * heads, S, dtype=q.dtype, device=q.device) if need_probs else None
+    if bias is not None:
+        bias = bias.reshape(B * heads, S).to(q.dtype).contiguous()
+    kpm_ld = 0
+    if kpm is not None:
+        kpm = _u8(kpm)
+        kpm_ld = kpm.stride(0)
+    lib().call("ofa_attn_decode", ptr(q), ptr(k_cache), ptr(v_cache), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn),
+               ptr(out), ptr(probs), B, heads, D // heads, S, k_cache.stride(1), k_cache.stride(0), kpm_ld, float(scale),
+               dtype_code(q), stream())
+    return out, probs
+
+
 # ------------------------------------------------------------------ elementwise / embedding
 def gelu_fwd(x):
     x = x.contiguous()

@@ -145,8 +145,6 @@ class TransformerDecoder(nn.Module):
     def extract_features(self, slots: List[Slot], encoder_out, incremental_state=None, full_context_alignment: bool = False,
                          alignment_layer: Optional[int] = None, alignment_heads: Optional[int] = None,
                          return_all_hiddens: bool = False, return_all_attention_weights: bool = False):
-        if incremental_state is not None:
-            raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
         adaptor_output = AdaptorOutput(*self.adaptor(slots))
         bsz, slen = adaptor_output.embed.size()[:2]
         if alignment_layer is None:
@@ -167,6 +165,10 @@ class TransformerDecoder(nn.Module):
             cross_abs_pos_bias = cross_abs_pos_bias.reshape(-1, *cross_abs_pos_bias.size()[-2:])
         else:
             cross_abs_pos_bias = None
+        if incremental_state is not None:                            # one step: the last target position only (:447-450)
+            tgt_embed = tgt_embed[:, -1:]
+            cross_abs_pos_bias = cross_abs_pos_bias[:, -1:, :] if cross_abs_pos_bias is not None else None
+            self_attn_padding_mask = self_attn_padding_mask[:, -1:] if self_attn_padding_mask is not None else None
         x = tgt_embed.transpose(0, 1)                                 # T x B x C (view)
         attn = None
         inner_states: List[Optional[Tensor]] = [x] if return_all_hiddens else []
@@ -174,14 +176,18 @@ class TransformerDecoder(nn.Module):
         chain = LayerChain()
         for idx, layer in enumerate(self.layers):
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
-            self_attn_mask = self.buffered_future_mask(x) if not full_context_alignment else None
+            self_attn_mask = (self.buffered_future_mask(x) if incremental_state is None and not full_context_alignment
+                              else None)
             if self.cfg.use_self_attn_bias:
                 b = all_self_attn_bias[0 if self.cfg.share_attn_bias else idx]
                 self_attn_bias = b.view(-1, *b.size()[-2:])
+                if incremental_state is not None:
+                    self_attn_bias = self_attn_bias[:, -1:, :]        # the new position's row against every cached key
             else:
                 self_attn_bias = False                                # forces the slow attention path, :477
             x, layer_self_attn, layer_cross_attn = layer(
-                x, enc, padding_mask, None, self_attn_mask=self_attn_mask, self_attn_padding_mask=self_attn_padding_mask,
+                x, enc, padding_mask, incremental_state, self_attn_mask=self_attn_mask,
+                self_attn_padding_mask=self_attn_padding_mask,
                 need_attn=bool((idx == alignment_layer) or return_all_attention_weights),
                 need_head_weights=bool(idx == alignment_layer), self_attn_bias=self_attn_bias,
                 cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask, chain=chain)
@@ -209,6 +215,15 @@ class TransformerDecoder(nn.Module):
             x = self.project_out_dim(x)
         return x, {"attn": [attn], "inner_states": inner_states, "decoder_attentions": decoder_attentions,
                    "cross_attentions": cross_attentions}
+
+    def reorder_incremental_state_scripting(self, incremental_state, new_order):
+        """Beam reorder of every attention cache (model/incremental_decoder.py:81-96)."""
+        for module in self.modules():
+            if module is not self and hasattr(module, "reorder_incremental_state"):
+                result = module.reorder_incremental_state(incremental_state, new_order)
+                if result is not None:
+                    incremental_state = result
+        return incremental_state
 
     def max_positions(self):
         return self.cfg.max_target_positions

@@ -10,6 +10,7 @@ Both run the same fused kernel (bf16) or the exact unfused kernels (fp32 / need_
 only `scale`, `c_attn` and `bias` differ.  Tensors at the boundary are Time x Batch x Channel like the reference.
 """
 import math
+import uuid
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -50,6 +51,7 @@ class MultiheadAttention(nn.Module):
         # filled by ofasys_amd.trainer.FlatParams when k|v|q (or k|v) weights sit next to each other in the flat arena:
         # zero-copy packed projection weights / gradient sinks for the single N = 3D (2D) GEMM
         self._pack = {}
+        self._incremental_state_id = str(uuid.uuid4())     # module/incremental_decoding_utils.py:16-17
         self.reset_parameters()
 
     def reset_parameters(self):                                             # :93-111
@@ -69,8 +71,8 @@ class MultiheadAttention(nn.Module):
         if need_head_weights:
             need_weights = True
         if incremental_state is not None:
-            raise NotImplementedError("incremental decoding (KV cache) is outside the train-step hot path "
-                                      "(SURVEY.md section 8f-4)")
+            return self._forward_incremental(query, key, key_padding_mask, incremental_state, need_weights, static_kv,
+                                             attn_mask, need_head_weights, attn_bias)
         tgt_len, bsz, embed_dim = query.size()
         assert embed_dim == self.embed_dim, f"query dim {embed_dim} != {self.embed_dim}"
         fast = (not static_kv) and attn_bias is None                       # :155-162
@@ -127,6 +129,129 @@ class MultiheadAttention(nn.Module):
                 attn_weights = probs.view(bsz, self.num_heads, tgt_len, src_len).transpose(1, 0)   # :348
             else:
                 attn_weights = K.mean_heads(probs.detach(), bsz, self.num_heads)                   # :349-351
+        return out, attn_weights
+
+    # ------------------------------------------------------------------ incremental decoding
+    # The cache of one attention module lives in incremental_state[<module uuid>.attn_state] as
+    #   {"k", "v": [B, capacity, D] row buffers (the layout the kernels read; appending a step never moves the cache),
+    #    "len": valid rows, "kpm": bool [B, capacity] or None}
+    # `_get_input_buffer` / `_set_input_buffer` present it in the reference's form (prev_key / prev_value of shape
+    # (bsz, heads, len, head_dim), prev_key_padding_mask (bsz, len); multihead_attention.py:254-279, 393-409).
+    def _state_key(self):
+        return "{}.{}".format(self._incremental_state_id, "attn_state")
+
+    def _cache(self, incremental_state):
+        return incremental_state.get(self._state_key()) if incremental_state is not None else None
+
+    def _get_input_buffer(self, incremental_state) -> Dict[str, Optional[Tensor]]:
+        c = self._cache(incremental_state)
+        if c is None:
+            return {}
+        B, n, H, hd = c["k"].shape[0], c["len"], self.num_heads, self.head_dim
+        out = {"prev_key": c["k"][:, :n].view(B, n, H, hd).transpose(1, 2),
+               "prev_value": c["v"][:, :n].view(B, n, H, hd).transpose(1, 2)}
+        out["prev_key_padding_mask"] = c["kpm"][:, :n] if c["kpm"] is not None else None
+        return out
+
+    def _set_input_buffer(self, incremental_state, buffer: Dict[str, Optional[Tensor]]):
+        if incremental_state is None:
+            return incremental_state
+        if not buffer or "prev_key" not in buffer:
+            incremental_state.pop(self._state_key(), None)
+            return incremental_state
+        pk, pv = buffer["prev_key"], buffer["prev_value"]                    # (bsz, heads, len, head_dim)
+        B, H, n, hd = pk.shape
+        k = pk.transpose(1, 2).reshape(B, n, H * hd).contiguous()
+        v = pv.transpose(1, 2).reshape(B, n, H * hd).contiguous()
+        m = buffer.get("prev_key_padding_mask")
+        incremental_state[self._state_key()] = {"k": k, "v": v, "len": n, "kpm": m.bool().contiguous() if m is not None else None}
+        return incremental_state
+
+    def reorder_incremental_state(self, incremental_state, new_order: Tensor):
+        """Beam reorder (multihead_attention.py:393-409): rows follow `new_order`; the static encoder-decoder cache is
+        left alone when its batch size already matches (every beam of a sentence holds the same keys)."""
+        c = self._cache(incremental_state)
+        if c is not None:
+            if self.encoder_decoder_attention and c["k"].size(0) == new_order.size(0):
+                return incremental_state
+            # (whole buffers, spare capacity included: the gather is the one copy of this step, no regrow afterwards)
+            c["k"] = c["k"].index_select(0, new_order)
+            c["v"] = c["v"].index_select(0, new_order)
+            if c["kpm"] is not None:
+                c["kpm"] = c["kpm"].index_select(0, new_order)
+        return incremental_state
+
+    @staticmethod
+    def _grow(buf, need, dim=1):
+        """Capacity doubling along `dim` (rows are appended in place; a reallocation copies the valid prefix once)."""
+        cap = buf.shape[dim]
+        if need <= cap:
+            return buf
+        new_cap = max(need, 2 * cap, 64)
+        shape = list(buf.shape)
+        shape[dim] = new_cap
+        nb = buf.new_zeros(shape)
+        nb.narrow(dim, 0, cap).copy_(buf)
+        return nb
+
+    def _forward_incremental(self, query, key, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
+                             need_head_weights, attn_bias):
+        """One decoding step (multihead_attention.py:188-353 with incremental_state): always the slow-path arithmetic
+        (scaling (head_dim*scale_factor)^-0.5, additive bias row, fp32 softmax, c_attn).  Inference only."""
+        tgt_len, bsz, embed_dim = query.size()
+        if tgt_len != 1:
+            raise NotImplementedError("incremental decoding feeds one target position per call (model/transformer.py:447-450)")
+        if attn_mask is not None:
+            raise NotImplementedError("attn_mask together with incremental_state (the reference passes None, :464-467)")
+        H, D = self.num_heads, self.embed_dim
+        xq = query.reshape(bsz, D)                                            # T == 1: [1,B,D] -> [B,D]
+        c = self._cache(incremental_state)
+        q = self.q_proj(xq)
+        if static_kv:                                                         # encoder-decoder attention: keys computed once
+            assert self.encoder_decoder_attention and not self.self_attention
+            if c is None:
+                assert key is not None
+                xk = ops.batch_major(key)                                     # [B,S,D]
+                S = xk.shape[1]
+                k = self.k_proj(xk).contiguous()
+                v = self.v_proj(xk).contiguous()
+                m = key_padding_mask.bool().contiguous() if key_padding_mask is not None and key_padding_mask.dim() > 0 else None
+                c = {"k": k, "v": v, "len": S, "kpm": m}
+                incremental_state[self._state_key()] = c
+        else:
+            assert self.self_attention, "incremental decoding: self-attention or static encoder-decoder attention"
+            k_new, v_new = self.k_proj(xq), self.v_proj(xq)                   # [B,D]
+            cur = key_padding_mask if key_padding_mask is not None and key_padding_mask.dim() > 0 else None
+            if c is None:
+                c = {"k": k_new.new_zeros(bsz, 64, D), "v": k_new.new_zeros(bsz, 64, D), "len": 0, "kpm": None}
+                incremental_state[self._state_key()] = c
+            n = c["len"]
+            c["k"], c["v"] = self._grow(c["k"], n + 1), self._grow(c["v"], n + 1)
+            c["k"][:, n].copy_(k_new)
+            c["v"][:, n].copy_(v_new)
+            # key padding across steps (multihead_attention.py:356-391): absent masks count as "not padded"
+            if cur is not None or c["kpm"] is not None:
+                if c["kpm"] is None:
+                    c["kpm"] = torch.zeros(bsz, c["k"].shape[1], dtype=torch.bool, device=query.device)
+                c["kpm"] = self._grow(c["kpm"], n + 1)
+                if cur is not None:
+                    c["kpm"][:, n] = cur.reshape(bsz).bool()
+                else:
+                    c["kpm"][:, n] = False
+            c["len"] = n + 1
+        S = c["len"]
+        bias = attn_bias if torch.is_tensor(attn_bias) else None
+        if bias is not None:
+            bias = bias.reshape(bsz * H, S)
+        out, probs = K.attn_decode(q, c["k"], c["v"], S, H, self.scaling, bias=bias, kpm=c["kpm"], c_attn=self.c_attn,
+                                   need_probs=need_weights or need_head_weights)
+        out = self.out_proj(out).view(1, bsz, D)
+        attn_weights = None
+        if need_weights or need_head_weights:
+            if need_head_weights:
+                attn_weights = probs.view(bsz, H, 1, S).transpose(1, 0)
+            else:
+                attn_weights = K.mean_heads(probs.view(bsz * H, 1, S), bsz, H)
         return out, attn_weights
 
     def upgrade_state_dict_named(self, state_dict, name):

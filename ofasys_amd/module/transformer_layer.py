@@ -223,8 +223,13 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         """x: (seq_len, batch, embed_dim); see transformer_layer.py:367-385.  chain: LayerChain of the enclosing stack."""
         if need_head_weights:
             need_attn = True
-        if incremental_state is not None or prev_self_attn_state is not None or prev_attn_state is not None:
-            raise NotImplementedError("incremental decoding is outside the train-step hot path (SURVEY.md section 8f-4)")
+        for attn_mod, prev in ((self.self_attn, prev_self_attn_state), (self.encoder_attn, prev_attn_state)):
+            if prev is not None:                                          # externally supplied cache (:392-402, :446-456)
+                assert incremental_state is not None
+                saved = {"prev_key": prev[0], "prev_value": prev[1]}
+                if len(prev) >= 3:
+                    saved["prev_key_padding_mask"] = prev[2]
+                attn_mod._set_input_buffer(incremental_state, saved)
         join = self._joinable()
         cross = self.encoder_attn is not None and encoder_out is not None
         normed = chain.take() if chain is not None else None
@@ -235,8 +240,8 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         else:
             residual = x
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask,
-                                              incremental_state=None, need_weights=need_attn, attn_mask=self_attn_mask,
-                                              attn_bias=self_attn_bias)
+                                              incremental_state=incremental_state, need_weights=need_attn,
+                                              attn_mask=self_attn_mask, attn_bias=self_attn_bias)
         h = None
         if join:
             x, h = self._join(x, residual, self.self_attn_ln, self.encoder_attn_layer_norm if cross else self.final_layer_norm)
@@ -256,7 +261,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 residual = x
             x, cross_attn_weights = self.encoder_attn(
                 query=x, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
-                incremental_state=None, static_kv=True,
+                incremental_state=incremental_state, static_kv=True,
                 need_weights=need_attn or (not self.training and self.need_attn), need_head_weights=need_head_weights,
                 attn_bias=cross_attn_bias)
             if join:

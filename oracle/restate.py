@@ -534,6 +534,121 @@ def model_forward(state, cfg, slots, record=None):
     return logits, extra
 
 
+# --------------------------------------------------------------------------------------------
+# incremental decoding: multihead_attention.py:188-279 with incremental_state,
+# transformer_layer.py:386-470, model/transformer.py:447-490, beam reorder multihead_attention.py:393-409
+# --------------------------------------------------------------------------------------------
+def mha_step(state, prefix, cfg, query, key, key_padding_mask, attn_bias, cache, static_kv, need_head_weights=False):
+    """One decoding step.  query [1,B,D]; cache: dict with prev_key / prev_value [B,A,n,hd] and prev_key_padding_mask,
+    updated in place (saved_state, :254-279)."""
+    T, B, D = query.shape
+    A = cfg.heads
+    hd = D // A
+    scaling = float(hd * cfg.attn_scale_factor) ** -0.5
+    q = linear(state, prefix + ".q_proj", query) * scaling
+    q = q.contiguous().view(T, B * A, hd).transpose(0, 1)
+    if static_kv and "prev_key" in cache:                                 # :188-195: keys are static, nothing to compute
+        k = cache["prev_key"].view(B * A, -1, hd)
+        v = cache["prev_value"].view(B * A, -1, hd)
+        kpm = cache.get("prev_key_padding_mask")
+    else:
+        src = key if static_kv else query
+        k = linear(state, prefix + ".k_proj", src)
+        v = linear(state, prefix + ".v_proj", src)
+        k = k.contiguous().view(-1, B * A, hd).transpose(0, 1)
+        v = v.contiguous().view(-1, B * A, hd).transpose(0, 1)
+        kpm = key_padding_mask
+        if "prev_key" in cache:                                           # :244-262 concatenate with the cached steps
+            k = torch.cat([cache["prev_key"].view(B * A, -1, hd), k], dim=1)
+            v = torch.cat([cache["prev_value"].view(B * A, -1, hd), v], dim=1)
+            prev_m = cache.get("prev_key_padding_mask")
+            S_ = k.shape[1]
+            if prev_m is not None and kpm is not None:                    # :356-391
+                kpm = torch.cat([prev_m.float(), kpm.float()], dim=1)
+            elif prev_m is not None:
+                kpm = torch.cat([prev_m.float(), torch.zeros(B, S_ - prev_m.shape[1])], dim=1)
+            elif kpm is not None:
+                kpm = torch.cat([torch.zeros(B, S_ - kpm.shape[1]), kpm.float()], dim=1)
+    S = k.shape[1]
+    cache["prev_key"] = k.view(B, A, S, hd)
+    cache["prev_value"] = v.view(B, A, S, hd)
+    cache["prev_key_padding_mask"] = kpm
+    w = torch.bmm(q, k.transpose(1, 2))
+    if attn_bias is not None and attn_bias is not False:
+        w = w + attn_bias
+    if kpm is not None:
+        w = w.view(B, A, T, S).masked_fill(kpm.unsqueeze(1).unsqueeze(2).to(torch.bool), float("-inf")).view(B * A, T, S)
+    p = F.softmax(w, dim=-1, dtype=torch.float32).type_as(w)
+    o = torch.bmm(p, v).transpose(0, 1).contiguous().view(T, B, D)
+    c = state.get(prefix + ".c_attn")
+    if c is not None:
+        o = (o.view(T, B, A, hd) * c.view(1, 1, A, 1)).reshape(T, B, D)
+    o = linear(state, prefix + ".out_proj", o)
+    return o, (p.view(B, A, T, S).transpose(1, 0) if need_head_weights else None)
+
+
+def decoder_step(state, cfg, slots, enc_out, inc):
+    """One incremental decoder call: `slots` hold the WHOLE target prefix (the adaptor embeds it all, the layers only see
+    its last position, model/transformer.py:447-450); `inc` = {(layer, "self"|"cross"): cache}.  Returns logits [B,1,V]."""
+    embed, masks, pos_embed, bias = general_adaptor(state, cfg, "decoder", slots)
+    B, Tt, D = embed.shape
+    A = cfg.heads
+    enc = enc_out["encoder_out"]
+    cross_bias = None
+    if not cfg.entangle_position_embedding:
+        src_pos = enc_out["position_embeddings"]
+        Ts = src_pos.shape[1]
+        pos_scaling = float(D / cfg.heads * cfg.attn_scale_factor) ** -0.5
+        pq = linear(state, "decoder.cross_pos_q_linear", pos_embed).view(B, Tt, A, -1).transpose(1, 2) * pos_scaling
+        pk = linear(state, "decoder.cross_pos_k_linear", src_pos).view(B, Ts, A, -1).transpose(1, 2)
+        cross_bias = torch.matmul(pq, pk.transpose(2, 3)).reshape(-1, Tt, Ts)[:, -1:, :]
+    x = embed[:, -1:].transpose(0, 1)
+    m = masks[:, -1:]
+    attn = None
+    for l in range(cfg.dec_layers):
+        p = f"decoder.layers.{l}"
+        sb = bias[0 if cfg.share_attn_bias else l].view(-1, Tt, Tt)[:, -1:, :] if cfg.use_self_attn_bias else False
+        r = x
+        h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
+        h, _ = mha_step(state, p + ".self_attn", cfg, h, h, m, sb, inc.setdefault((l, "self"), {}), False)
+        if (p + ".self_attn_ln.weight") in state:
+            h = layer_norm(state, p + ".self_attn_ln", h, cfg.eps)
+        x = r + h
+        r = x
+        h = layer_norm(state, p + ".encoder_attn_layer_norm", x, cfg.eps)
+        last = l == cfg.dec_layers - 1
+        h, cw = mha_step(state, p + ".encoder_attn", cfg, h, enc, enc_out["encoder_padding_mask"], cross_bias,
+                         inc.setdefault((l, "cross"), {}), True, need_head_weights=last)
+        if (p + ".cross_attn_ln.weight") in state:
+            h = layer_norm(state, p + ".cross_attn_ln", h, cfg.eps)
+        x = _ffn(state, p, cfg, r + h)
+        if last:
+            attn = cw.float().mean(dim=0)
+    x = layer_norm(state, "decoder.layer_norm", x, cfg.eps).transpose(0, 1)
+    return F.linear(x, state["decoder.adaptor.embed_tokens.weight"]), {"attn": attn}
+
+
+def reorder_incremental_state(inc, new_order):
+    """multihead_attention.py:393-409: every cached tensor follows new_order along the batch; a static (cross) cache whose
+    batch size already equals len(new_order) is left untouched."""
+    for (l, kind), cache in inc.items():
+        for k in list(cache.keys()):
+            t = cache[k]
+            if t is None:
+                continue
+            if kind == "cross" and t.size(0) == new_order.size(0):
+                break
+            cache[k] = t.index_select(0, new_order)
+    return inc
+
+
+def reorder_encoder_out(enc_out, new_order):
+    """model/transformer.py:158-196 on the fields this restatement carries."""
+    return {"encoder_out": enc_out["encoder_out"].index_select(1, new_order),
+            "encoder_padding_mask": enc_out["encoder_padding_mask"].index_select(0, new_order),
+            "position_embeddings": enc_out["position_embeddings"].index_select(0, new_order)}
+
+
 def cross_entropy(logits, target, pad_idx=1):
     """engine/criterion/cross_entropy.py:50-67, 27-41: fp32 log-softmax, NLL sum, ignore pad;
     sample_size = number of non-pad targets."""

@@ -603,3 +603,60 @@ def test_residual_join_equals_unfused_chain(K, dtype, rows, cols, has_a, has_b, 
     assert torch.equal(a[0], b[0])                            # y: same Philox positions, same rounding points -> bit-exact
     for i, (u, v) in enumerate(zip(a, b)):                    # the rest: same maths, different summation grouping / FMA
         assert rel(u, v.float()) < (2e-5 if dtype == torch.float32 else 2e-2), i      # contraction (rows split over waves)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,S,cap,use_bias,use_kpm,use_c", [
+    (3, 4, 1, 64, False, False, False),          # the first decoding step: one key
+    (2, 12, 7, 64, True, False, True),
+    (5, 4, 64, 64, True, True, True),            # cache exactly full
+    (2, 12, 449, 512, False, True, True),        # encoder-decoder cache of the cfg-2 source length + 1
+    (1, 16, 1500, 2048, True, True, False),
+])
+def test_attn_decode_matches_reference(K, B, H, S, cap, use_bias, use_kpm, use_c, dtype):
+    """csrc/attention_decode.hip: one query row per (batch, head) against the first S rows of a [B, capacity, D] cache --
+    softmax(q.k*scale + bias, masked) @ v * c_attn, with the probabilities as a second output."""
+    torch.manual_seed(S)
+    D = H * 64
+    q = torch.randn(B, D, device=DEV).to(dtype)
+    kc = torch.randn(B, cap, D, device=DEV).to(dtype)
+    vc = torch.randn(B, cap, D, device=DEV).to(dtype)
+    bias = (torch.randn(B * H, S, device=DEV)).to(dtype) if use_bias else None
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(B, cap, dtype=torch.bool, device=DEV)
+        kpm[:, S // 2:S // 2 + max(S // 5, 0)] = True
+        kpm[0, S - 1:] = S > 1                                            # row 0: last key padded too (never all of them)
+    c = (torch.rand(H, device=DEV) + 0.5).to(dtype) if use_c else None
+    scale = 0.0884
+    out, probs = K.attn_decode(q, kc, vc, S, H, scale, bias=bias, kpm=kpm, c_attn=c, need_probs=True)
+    qf = q.float().view(B, H, 1, 64)
+    kf = kc[:, :S].float().view(B, S, H, 64).transpose(1, 2)
+    vf = vc[:, :S].float().view(B, S, H, 64).transpose(1, 2)
+    w = (qf @ kf.transpose(2, 3)) * scale
+    if bias is not None:
+        w = w + bias.float().view(B, H, 1, S)
+    if kpm is not None:
+        w = w.masked_fill(kpm[:, :S].view(B, 1, 1, S), float("-inf"))
+    p = torch.softmax(w, dim=-1)
+    o = p @ vf
+    if c is not None:
+        o = o * c.float().view(1, H, 1, 1)
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel(out.float(), o.transpose(1, 2).reshape(B, D)) < tol
+    assert rel(probs.float(), p.reshape(B * H, S)) < tol
+    # a strided cache view (ld > D) reads the same rows
+    big = torch.zeros(B, cap, D + 64, device=DEV, dtype=dtype)
+    big[:, :, :D] = kc
+    big2 = torch.zeros(B, cap, D + 64, device=DEV, dtype=dtype)
+    big2[:, :, :D] = vc
+    out2, _ = K.attn_decode(q, big[:, :, :D], big2[:, :, :D], S, H, scale, bias=bias, kpm=kpm, c_attn=c)
+    assert torch.equal(out2, out)
+
+
+def test_attn_decode_fully_masked_row_is_zero(K):
+    q = torch.randn(1, 64, device=DEV)
+    kc, vc = torch.randn(1, 64, 64, device=DEV), torch.randn(1, 64, 64, device=DEV)
+    kpm = torch.ones(1, 64, dtype=torch.bool, device=DEV)
+    out, probs = K.attn_decode(q, kc, vc, 5, 1, 1.0, kpm=kpm, need_probs=True)
+    assert float(out.abs().max()) == 0.0 and float(probs.abs().max()) == 0.0

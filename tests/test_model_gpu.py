@@ -296,3 +296,83 @@ def test_two_graph_replay_path_of_data_parallel_steps():
     entry = [e for e in tr1._graphs.values() if "graphs" in e]
     assert entry and len(entry[0]["graphs"]) == 2
     assert l0 == l1 and torch.equal(m0, m1)
+
+
+# ------------------------------------------------------------------------------------------------ incremental decoding
+def _incremental_hip(dtype):
+    """The scenario of oracle/incremental_case.py through the HIP model: encoder once, beams, KV-cache steps, reorder."""
+    from oracle.cases import VOCAB_EXTRA
+    from oracle.incremental_case import BEAM_ORDER, NEW_ORDER, REORDER_AT, STEPS, beam_prefix
+    from ofasys_amd import ModalityType, Slot
+    case = CASES["tiny_text"]
+    model, d = build_model(case, DEV, dtype)
+    model.eval()
+    vals, _ = case_inputs(case)
+    src = [s for s in make_slots(vals, DEV, dtype) if s.is_src]
+    prev = beam_prefix(4 + VOCAB_EXTRA).to(DEV)
+    with torch.no_grad():
+        enc = model.encoder(src)
+        enc = model.encoder.reorder_encoder_out(enc, torch.tensor(BEAM_ORDER, device=DEV))
+        inc, logits, extra = {}, [], None
+        for t in range(STEPS):
+            out, extra = model.decoder([Slot(ModalityType.TEXT, False, prev[:, :t + 1])], encoder_out=enc, incremental_state=inc)
+            assert out.shape[1] == 1
+            logits.append(out[:, -1].float().clone())
+            if t == REORDER_AT:
+                order = torch.tensor(NEW_ORDER, device=DEV)
+                model.decoder.reorder_incremental_state_scripting(inc, order)
+                enc = model.encoder.reorder_encoder_out(enc, order)
+                prev = prev.index_select(0, order)
+        full, _ = model.decoder([Slot(ModalityType.TEXT, False, prev)], encoder_out=enc)
+        buf = model.decoder.layers[0].self_attn._get_input_buffer(inc)
+    torch.cuda.synchronize()
+    return torch.stack(logits).cpu(), extra["attn"][0].float().cpu(), full[:, -1].float().cpu(), buf
+
+
+def test_incremental_decoding_fp32_matches_reference():
+    """KV-cache decoding with the decode attention kernel (csrc/attention_decode.hip) + beam reorder against the reference
+    run step by step (oracle/gen_incremental_golden.py)."""
+    gi = load_golden("tiny_text_incremental")
+    logits, attn, full_last, buf = _incremental_hip(torch.float32)
+    assert rel_err(logits, gi["logits"]) < FP32_TOL
+    assert rel_err(attn, gi["attn"]) < FP32_TOL
+    assert rel_err(full_last, gi["full_last"]) < FP32_TOL
+    assert rel_err(logits[-1], full_last) < FP32_TOL
+    # the cache in the reference's form: (bsz, heads, len, head_dim)
+    assert tuple(buf["prev_key"].shape) == tuple(gi["prev_key_l0"].shape)
+    assert rel_err(buf["prev_key"].cpu(), gi["prev_key_l0"]) < FP32_TOL
+    assert rel_err(buf["prev_value"].cpu(), gi["prev_value_l0"]) < FP32_TOL
+
+
+def test_incremental_decoding_bf16_matches_reference():
+    gi = load_golden("tiny_text_incremental")
+    logits, attn, full_last, _ = _incremental_hip(torch.bfloat16)
+    assert rel_err(logits, gi["logits"]) < BF16_TOL
+    assert rel_err(attn, gi["attn"]) < BF16_TOL
+    assert rel_err(logits[-1], full_last) < BF16_TOL
+
+
+def test_incremental_equals_teacher_forcing_at_base_size():
+    """Size-independent property at the cfg-2 decoder size (OFA-base, bf16, 448 source positions): the logits of step t
+    from the KV cache equal row t of the teacher-forced decoder pass."""
+    import bench
+    import argparse
+    from ofasys_amd import ModalityType, Slot
+    args = argparse.Namespace(arch="base", workload="cfg2", batch=4)
+    model, d = bench.build(args, torch.device(DEV))
+    model.eval()
+    batch, _ = bench.make_batch(d, 4, 191, 24, 0, torch.device(DEV), "cfg2")
+    src = [s for s in batch["slots"] if s.is_src]
+    prev = batch["slots"][-1].value
+    with torch.no_grad():
+        enc = model.encoder(src)
+        full, _ = model.decoder([Slot(ModalityType.TEXT, False, prev)], encoder_out=enc)
+        inc = {}
+        worst = 0.0
+        for t in range(prev.shape[1]):
+            out, _ = model.decoder([Slot(ModalityType.TEXT, False, prev[:, :t + 1])], encoder_out=enc, incremental_state=inc)
+            # rows whose prefix already contains padding are not comparable position by position
+            live = prev[:, t].ne(d.pad())
+            if live.any():
+                worst = max(worst, rel_err(out[live, -1].float().cpu(), full[live, t].float().cpu()))
+    assert worst < BF16_TOL, worst

@@ -104,3 +104,43 @@ def test_label_smoothed_cross_entropy_matches_reference(name):
     assert ntok == int(g[name + ".ntokens"][0])
     assert rel_err(loss.detach(), g[name + ".loss"][0]) < 1e-6 and rel_err(nll.detach(), g[name + ".nll"][0]) < 1e-6
     assert rel_err(x.grad, g[name + ".dlogits"]) < 1e-5
+
+
+def _incremental_oracle(state, cfg, vals, V):
+    """Drive oracle/restate.py's incremental decoder through the scenario of oracle/incremental_case.py."""
+    from oracle.incremental_case import BEAM_ORDER, NEW_ORDER, REORDER_AT, STEPS, beam_prefix
+    from oracle.restate import OSlot
+    enc = restate.encoder_forward(state, cfg, [s for s in oracle_slots(vals) if s.is_src])
+    enc = restate.reorder_encoder_out(enc, torch.tensor(BEAM_ORDER))
+    prev = beam_prefix(V)
+    inc, logits, extra = {}, [], None
+    for t in range(STEPS):
+        out, extra = restate.decoder_step(state, cfg, [OSlot("TEXT", False, prev[:, :t + 1], None)], enc, inc)
+        logits.append(out[:, -1])
+        if t == REORDER_AT:
+            order = torch.tensor(NEW_ORDER)
+            restate.reorder_incremental_state(inc, order)
+            enc = restate.reorder_encoder_out(enc, order)
+            prev = prev.index_select(0, order)
+    full, _ = restate.decoder_forward(state, cfg, [OSlot("TEXT", False, prev, None)], enc)
+    return torch.stack(logits), extra["attn"], full[:, -1], inc
+
+
+def test_incremental_decoding_matches_reference():
+    """KV-cache decoding + beam reorder against the reference run step by step."""
+    from oracle.cases import VOCAB_EXTRA
+    torch.set_num_threads(8)
+    case = CASES["tiny_text"]
+    g = load_golden("tiny_text")
+    gi = load_golden("tiny_text_incremental")
+    state = state_from_golden(g)
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    vals, _ = case_inputs(case)
+    with torch.no_grad():
+        logits, attn, full_last, inc = _incremental_oracle(state, oracle_cfg(case), vals, 4 + VOCAB_EXTRA)
+    assert rel_err(logits, gi["logits"]) < TOL
+    assert rel_err(attn, gi["attn"]) < TOL
+    assert rel_err(full_last, gi["full_last"]) < TOL
+    assert rel_err(logits[-1], full_last) < TOL                      # incremental == teacher-forced on the final beams
+    assert rel_err(inc[(0, "self")]["prev_key"], gi["prev_key_l0"]) < TOL
+    assert rel_err(inc[(0, "self")]["prev_value"], gi["prev_value_l0"]) < TOL

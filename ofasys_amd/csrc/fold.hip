@@ -80,8 +80,22 @@ __global__ __launch_bounds__(256) void fold_batched_kernel(FoldJobs J) {
     if (c >= cols) return;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     if (vec) {
-      for (int s = 0; s < ns; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * stride + c);
+      // four independent 16-byte loads in flight per thread (the slot count is a run-time value: without the manual
+      // unroll every load waited for the previous add); the additions keep the slot order
+      const float* r = p + c;
+      int s = 0;
+      for (; s + 4 <= ns; s += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 1) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 2) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 3) * stride);
+        t[0] = (((t[0] + v0.x) + v1.x) + v2.x) + v3.x;
+        t[1] = (((t[1] + v0.y) + v1.y) + v2.y) + v3.y;
+        t[2] = (((t[2] + v0.z) + v1.z) + v2.z) + v3.z;
+        t[3] = (((t[3] + v0.w) + v1.w) + v2.w) + v3.w;
+      }
+      for (; s < ns; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
         t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
       }
     } else {
@@ -96,8 +110,20 @@ __global__ __launch_bounds__(256) void fold_batched_kernel(FoldJobs J) {
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < cols) {
     if (vec) {
-      for (int s = sl; s < ns; s += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)s * stride + c);
+      const float* r = p + c;
+      int s = sl;
+      for (; s + 24 < ns; s += 32) {                      // slots s, s+8, s+16, s+24: four loads in flight
+        const float4 v0 = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 8) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 16) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(r + (int64_t)(s + 24) * stride);
+        a.x = (((a.x + v0.x) + v1.x) + v2.x) + v3.x;
+        a.y = (((a.y + v0.y) + v1.y) + v2.y) + v3.y;
+        a.z = (((a.z + v0.z) + v1.z) + v2.z) + v3.z;
+        a.w = (((a.w + v0.w) + v1.w) + v2.w) + v3.w;
+      }
+      for (; s < ns; s += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
       }
     } else {

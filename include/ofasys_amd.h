@@ -76,14 +76,15 @@ int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, con
  * stats: fp32 [4][rows] = mean_a, rstd_a, mean_b, rstd_b (kept for the backward).  Dropout as ofa_dropout_add_fwd
  * (Philox position offset + *offset_base).  Rounding points match the unfused kernels, results are bit-identical.
  * Backward: dy / dz = gradients of y / z (NULL = zero); dres = gradient of residual (== total gradient of y), dx = gradient
- * of x; ws: fp32 [4][ofa_join_bwd_slots()][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b for ofa_fold_batched. */
+ * of x; ws: fp32 [5][ofa_join_bwd_slots()][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b and (want_dx_colsum) the
+ * column sums of dx -- the bias gradient of the Linear that produced x -- for ofa_fold_batched. */
 int ofa_join_fwd(const void* x, const void* residual, const void* gamma_a, const void* beta_a, const void* gamma_b,
                  const void* beta_b, void* y, void* z, float* stats, int64_t rows, int cols, float eps, float p, uint64_t seed,
                  uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
 int ofa_join_bwd_slots(int64_t rows, int cols, int dtype);
 int ofa_join_bwd(const void* dy, const void* dz, const void* x, const void* y, const void* gamma_a, const void* gamma_b,
                  const float* stats, void* dres, void* dx, float* ws, int64_t rows, int cols, float p, uint64_t seed,
-                 uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
+                 uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream);
 
 /* ---- GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+bias) (+C).  Replaces F.linear / torch.bmm / matmul:
  * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* _
                                                         const T* __restrict__ ga, const T* __restrict__ gb,
                                                         const float* __restrict__ stats, T* __restrict__ dres,
                                                         T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols,
-                                                        JoinRng rg) {
+                                                        JoinRng rg, int want_xsum) {
   constexpr int N = Vec<T>::N;
   constexpr int JOIN_WPB = join_wpb(WPR);
   constexpr int RPB = JOIN_WPB / WPR;
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* _
   const int cpp = cols / WPR, c0 = part * cpp;
   const int c = lane * N;
   const bool act = c < cpp;
-  float gA[N], gB[N], acc[4][N];
+  float gA[N], gB[N], acc[5][N];                          // dgamma_a, dbeta_a, dgamma_b, dbeta_b, column sums of dx
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     gA[j] = gB[j] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q][j] = 0.f;
+    for (int q = 0; q < 5; ++q) acc[q][j] = 0.f;
   }
   if (act && ga) load_vec<T>(ga + c0 + c, gA);
   if (act && gb) load_vec<T>(gb + c0 + c, gB);
@@ -292,12 +292,18 @@ __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* _
         for (int j = 0; j < N; ++j) g[j] = rs * (g[j] * gA[j] - s1 - xh[j] * s2);
       }
     }
-    if (live) store_vec<T>(dx + e0, g);
+    if (live) {
+      store_vec<T>(dx + e0, g);
+      if (want_xsum) {                                    // gradient of the bias of the Linear that produced x
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[4][j] += g[j];
+      }
+    }
   }
   // fold the block's waves (same scheme as ln_bwd_kernel)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if ((q < 2 && !ga) || (q >= 2 && !gb)) continue;      // (block-uniform)
+  for (int q = 0; q < 5; ++q) {
+    if ((q < 2 && !ga) || (q >= 2 && q < 4 && !gb) || (q == 4 && !want_xsum)) continue;      // (block-uniform)
 #pragma unroll
     for (int j = 0; j < N; ++j) fold[wib][lane * N + j] = acc[q][j];
     __syncthreads();
@@ -370,11 +376,12 @@ extern "C" int ofa_join_bwd_slots(int64_t rows, int cols, int dtype) {
 }
 
 // dy / dz: gradients of y / z (either may be NULL = zero; dz must be NULL iff gamma_b is); dres: gradient of the residual
-// input; dx: gradient of x; ws: fp32 [4][ofa_join_bwd_slots][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b
-// (fold with ofa_fold_batched; quantities of an absent LayerNorm are not written).
+// input; dx: gradient of x; ws: fp32 [5][ofa_join_bwd_slots][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b and,
+// with want_dx_colsum, the column sums of dx (= the bias gradient of the Linear that produced x, so that Linear needs no
+// separate column-sum pass); fold with ofa_fold_batched; quantities that do not apply are not written.
 extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const void* y, const void* gamma_a, const void* gamma_b,
                             const float* stats, void* dres, void* dx, float* ws, int64_t rows, int cols, float p, uint64_t seed,
-                            uint64_t offset, const int64_t* offset_base, int dtype, void* stream) {
+                            uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream) {
   if (int rc = join_check(rows, cols, dtype, "join_bwd")) return rc;
   OFA_REQUIRE(stats && dres && dx && ws && (!gamma_a || x) && (!gamma_b || (y && dz)) && (dy || dz), OFA_ERR_INVALID,
               "join_bwd: bad argument");
@@ -385,7 +392,8 @@ extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const
   dim3 grid(ofa_join_bwd_slots(rows, cols, dtype)), block(64 * join_wpb(wpr));
 #define JOIN_BWD(T, WPR)                                                                                              \
   hipLaunchKernelGGL((join_bwd_kernel<T, WPR>), grid, block, 0, st, (const T*)dy, (const T*)(gamma_b ? dz : nullptr),  \
-                     (const T*)x, (const T*)y, (const T*)gamma_a, (const T*)gamma_b, stats, (T*)dres, (T*)dx, ws, rows, cols, rg)
+                     (const T*)x, (const T*)y, (const T*)gamma_a, (const T*)gamma_b, stats, (T*)dres, (T*)dx, ws, rows, cols, rg, \
+                     want_dx_colsum)
 #define JOIN_BWD_T(T)                  \
   do {                                 \
     if (wpr == 1) JOIN_BWD(T, 1);      \

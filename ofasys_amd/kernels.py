@@ -753,20 +753,22 @@ def join_fwd(x, residual, ln_a, ln_b, eps, p, seed, offset, offset_base):
 
 
 def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None):
-    """grads = (dgamma_a, dbeta_a, dgamma_b, dbeta_b) output tensors (accumulated into; None for an absent LayerNorm).
+    """grads = (dgamma_a, dbeta_a, dgamma_b, dbeta_b[, dx_colsum]) output tensors (accumulated into; None for an absent
+    LayerNorm; dx_colsum: the bias gradient of the Linear that produced x, optional).
     Returns dres, dx.  The column partials are folded by `fold` (a FoldQueue) or immediately."""
     like = dy if dy is not None else dz
     rows, cols = _rows_cols(like)
     dres, dx = torch.empty_like(like), torch.empty_like(like)
     ns = lib().cdll.ofa_join_bwd_slots(rows, cols, dtype_code(like))
-    ws = torch.empty(4 * ns * cols, dtype=torch.float32, device=like.device)
+    ws = torch.empty(5 * ns * cols, dtype=torch.float32, device=like.device)
     q = fold if fold is not None else FoldQueue()
     for i, o in enumerate(grads):
         if o is not None:
             q.add(ws, i * ns * cols, o, cols, cols, ns)
+    want_xsum = len(grads) > 4 and grads[4] is not None
     lib().call("ofa_join_bwd", ptr(dy.contiguous() if dy is not None else None), ptr(dz.contiguous() if dz is not None else None),
                ptr(x), ptr(y), ptr(ga), ptr(gb), ptr(stats), ptr(dres), ptr(dx), ptr(ws), rows, cols, float(p), seed, offset,
-               ptr(offset_base), dtype_code(like), stream())
+               ptr(offset_base), int(want_xsum), dtype_code(like), stream())
     if fold is None:
         q.flush()
     else:

@@ -34,8 +34,10 @@ def LayerNorm(normalized_shape, eps=1e-5, elementwise_affine=True, export=False)
 
 
 class OfaLinear(nn.Linear):
-    def forward(self, x, alpha=1.0):
-        return ops.linear(x, self.weight, self.bias, alpha)
+    def forward(self, x, alpha=1.0, skip_bias_grad=False):
+        """skip_bias_grad: the caller guarantees that a downstream `ops.residual_join(..., x_bias=self.bias)` produces
+        the bias gradient (column sums of the output gradient) inside its backward kernel."""
+        return ops.linear(x, self.weight, self.bias, alpha, skip_bias_grad)
 
 
 def Linear(in_features, out_features, bias=True):

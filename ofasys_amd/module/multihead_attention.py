@@ -66,8 +66,9 @@ class MultiheadAttention(nn.Module):
     def forward(self, query, key: Optional[Tensor], value: Optional[Tensor], key_padding_mask: Optional[Tensor] = None,
                 incremental_state: Optional[Dict[str, Dict[str, Optional[Tensor]]]] = None, need_weights: bool = True,
                 static_kv: bool = False, attn_mask: Optional[Tensor] = None, need_head_weights: bool = False,
-                attn_bias: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-        """Input shape: Time x Batch x Channel (see the reference docstring, :126-140)."""
+                attn_bias: Optional[Tensor] = None, out_proj_skip_bias_grad: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+        """Input shape: Time x Batch x Channel (see the reference docstring, :126-140).  out_proj_skip_bias_grad (not in
+        the reference): the caller's residual join produces out_proj's bias gradient (see OfaLinear.forward)."""
         if need_head_weights:
             need_weights = True
         if incremental_state is not None:
@@ -122,7 +123,7 @@ class MultiheadAttention(nn.Module):
             v = self.v_proj(xv)
             out, probs = ops.attention(q, k, v, self.num_heads, scale, bias=bias, key_padding_mask=key_padding_mask,
                                        c_attn=c_attn, causal=causal, dropout_p=p_drop, need_weights=need_weights)
-        out = self.out_proj(out).transpose(0, 1)                            # back to T x B x C (a view)
+        out = self.out_proj(out, skip_bias_grad=out_proj_skip_bias_grad).transpose(0, 1)   # back to T x B x C (a view)
         attn_weights = None
         if need_weights:
             if need_head_weights:

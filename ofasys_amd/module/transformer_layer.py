@@ -23,6 +23,7 @@ from .multihead_attention import MultiheadAttention
 
 
 _NO_JOIN = bool(os.environ.get("OFA_NO_JOIN"))
+_NO_JOIN_BIAS = bool(os.environ.get("OFA_NO_JOIN_BIAS"))          # experiments: keep the Linears' own bias column sums
 
 
 class LayerChain:
@@ -52,10 +53,18 @@ class _FFNMixin:
         return (self.normalize_before and self.w_resid is None and not _NO_JOIN
                 and (self.drop_path.drop_prob == 0.0 or not self.training))
 
-    def _join(self, x, residual, ln_a, ln_b):
-        """(residual + dropout(ln_a(x)), ln_b(that)) -- :181-186 / :203-208 fused; ln_a / ln_b may be None."""
+    def _join(self, x, residual, ln_a, ln_b, x_bias=None):
+        """(residual + dropout(ln_a(x)), ln_b(that)) -- :181-186 / :203-208 fused; ln_a / ln_b may be None.
+        x_bias: see _join_owns_bias."""
         return ops.residual_join(x, residual, ln_a, self.dropout_module.p, self.training, ln_b,
-                                 eps=(ln_b or ln_a or self.final_layer_norm).eps)
+                                 eps=(ln_b or ln_a or self.final_layer_norm).eps, x_bias=x_bias)
+
+    def _join_owns_bias(self, bias, ln_a, ln_b):
+        """May the join that consumes a Linear's output also produce that Linear's bias gradient (the column sums of dx
+        are free in the join's backward kernel; a separate pass re-reads the whole gradient)?  Training with gradient
+        sinks on every parameter involved only."""
+        ps = [bias] + [q for ln in (ln_a, ln_b) if ln is not None for q in (ln.weight, ln.bias)]
+        return self.training and not _NO_JOIN_BIAS and ops.join_takes_bias_grad(*ps)
 
     def _ffn(self, x, normed=None, chain=None):
         """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494.
@@ -78,12 +87,15 @@ class _FFNMixin:
             x = self.activation_dropout_module(x)
             if self.ffn_layernorm is not None:
                 x = self.ffn_layernorm(x)
-        x = self.fc2(x)
         if normed is not None:
-            x, z = self._join(x, residual, None, chain.next_ln if chain is not None else None)
+            next_ln = chain.next_ln if chain is not None else None
+            own = self._join_owns_bias(self.fc2.bias, None, next_ln)
+            x = self.fc2(x, skip_bias_grad=own)
+            x, z = self._join(x, residual, None, next_ln, x_bias=self.fc2.bias if own else None)
             if chain is not None:
                 chain.normed = z
             return x
+        x = self.fc2(x)
         if self.w_resid is not None:
             residual = ops.mul_rowvec(residual, self.w_resid)                   # :204-205
         x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
@@ -141,10 +153,13 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
             residual, x = self.self_attn_layer_norm.fork(x)
         else:
             residual = x
+        own = join and self._join_owns_bias(self.self_attn.out_proj.bias, self.attn_ln, self.final_layer_norm)
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=encoder_padding_mask,
-                                              need_weights=need_attn, attn_mask=attn_mask, attn_bias=self_attn_bias)
+                                              need_weights=need_attn, attn_mask=attn_mask, attn_bias=self_attn_bias,
+                                              out_proj_skip_bias_grad=own)
         if join:
-            x, h = self._join(x, residual, self.attn_ln, self.final_layer_norm)
+            x, h = self._join(x, residual, self.attn_ln, self.final_layer_norm,
+                              x_bias=self.self_attn.out_proj.bias if own else None)
             return self._ffn(x, normed=h, chain=chain), self_attn_weights
         if self.attn_ln is not None:
             x = self.attn_ln(x)
@@ -239,12 +254,14 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
             residual, x = self.self_attn_layer_norm.fork(x)
         else:
             residual = x
+        ln_next = self.encoder_attn_layer_norm if cross else self.final_layer_norm
+        own = join and self._join_owns_bias(self.self_attn.out_proj.bias, self.self_attn_ln, ln_next)
         x, self_attn_weights = self.self_attn(query=x, key=x, value=x, key_padding_mask=self_attn_padding_mask,
                                               incremental_state=incremental_state, need_weights=need_attn,
-                                              attn_mask=self_attn_mask, attn_bias=self_attn_bias)
+                                              attn_mask=self_attn_mask, attn_bias=self_attn_bias, out_proj_skip_bias_grad=own)
         h = None
         if join:
-            x, h = self._join(x, residual, self.self_attn_ln, self.encoder_attn_layer_norm if cross else self.final_layer_norm)
+            x, h = self._join(x, residual, self.self_attn_ln, ln_next, x_bias=self.self_attn.out_proj.bias if own else None)
         else:
             if self.self_attn_ln is not None:
                 x = self.self_attn_ln(x)
@@ -259,13 +276,15 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 residual, x = self.encoder_attn_layer_norm.fork(x)
             else:
                 residual = x
+            own = join and self._join_owns_bias(self.encoder_attn.out_proj.bias, self.cross_attn_ln, self.final_layer_norm)
             x, cross_attn_weights = self.encoder_attn(
                 query=x, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
                 incremental_state=incremental_state, static_kv=True,
                 need_weights=need_attn or (not self.training and self.need_attn), need_head_weights=need_head_weights,
-                attn_bias=cross_attn_bias)
+                attn_bias=cross_attn_bias, out_proj_skip_bias_grad=own)
             if join:
-                x, h = self._join(x, residual, self.cross_attn_ln, self.final_layer_norm)
+                x, h = self._join(x, residual, self.cross_attn_ln, self.final_layer_norm,
+                                  x_bias=self.encoder_attn.out_proj.bias if own else None)
             else:
                 if self.cross_attn_ln is not None:
                     x = self.cross_attn_ln(x)

@@ -244,14 +244,14 @@ class ResidualJoinFn(torch.autograd.Function):
     """(y, z) = (residual + dropout_p(LN_a(x)), LN_b(y)) in one pass each way (csrc/join.hip); LN_a / LN_b optional."""
 
     @staticmethod
-    def forward(ctx, x2d, r2d, wa, ba, wb, bb, p, eps):
+    def forward(ctx, x2d, r2d, wa, ba, wb, bb, p, eps, x_bias=None):
         seed, off, base = (0, 0, None)
         if p > 0:
             seed, off, base = _Rng.reserve(x2d.numel(), x2d.device)
         y, z, stats = K.join_fwd(x2d, r2d, (wa, ba) if wa is not None else None, (wb, bb) if wb is not None else None, eps,
                                  p, seed, off, base)
         ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats)
-        ctx.refs = (ba, bb)
+        ctx.refs = (ba, bb, x_bias)
         ctx.rng = (p, seed, off, base)
         ctx.set_materialize_grads(False)                    # an unused y (last layer of a stack) costs no zero fill
         if z is None:
@@ -261,9 +261,9 @@ class ResidualJoinFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dz):
         if dy is None and dz is None:
-            return (None,) * 8
+            return (None,) * 9
         x2d, y, wa, wb, stats = ctx.saved_tensors
-        ba, bb = ctx.refs
+        ba, bb, x_bias = ctx.refs
         p, seed, off, base = ctx.rng
         if wb is None:
             dz = None
@@ -272,29 +272,42 @@ class ResidualJoinFn(torch.autograd.Function):
         params = (wa, ba, wb, bb)
         sinks = [(_sink(t) if t is not None else None) for t in params]
         use_sinks = all((t is None) or (s_ is not None) for t, s_ in zip(params, sinks))
+        xb_sink = _sink(x_bias) if (x_bias is not None and use_sinks) else None      # bias gradient of x's Linear, fused
         if use_sinks:
-            grads, fold = tuple(sinks), _fold()
+            grads, fold = tuple(sinks) + (xb_sink,), _fold()
         else:
             grads = tuple((torch.zeros_like(t) if t is not None else None) for t in params)
             fold = None
         dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold)
+        if xb_sink is not None:
+            _sink_done(x_bias)
+        elif x_bias is not None:
+            raise OfaError("residual_join: x_bias needs gradient sinks (the Linear skipped its own bias gradient)")
         if use_sinks:
             for t in params:
                 if t is not None:
                     _sink_done(t)
-            return dx, dres, None, None, None, None, None, None
-        return dx, dres, grads[0], grads[1], grads[2], grads[3], None, None
+            return dx, dres, None, None, None, None, None, None, None
+        return dx, dres, grads[0], grads[1], grads[2], grads[3], None, None, None
 
 
-def residual_join(x, residual, ln_a, p, training, ln_b, eps=1e-5):
-    """Returns (y, z): y = residual + dropout(LN_a(x)) (LN_a: module or None), z = LN_b(y) (module or None -> z is None)."""
+def join_takes_bias_grad(*params):
+    """True when a residual join may own the bias gradient of the Linear that feeds it: training with gradient sinks on
+    every parameter involved (otherwise the Linear keeps its own column-sum pass)."""
+    return torch.is_grad_enabled() and all(p is not None and p.requires_grad and _sink(p) is not None for p in params)
+
+
+def residual_join(x, residual, ln_a, p, training, ln_b, eps=1e-5, x_bias=None):
+    """Returns (y, z): y = residual + dropout(LN_a(x)) (LN_a: module or None), z = LN_b(y) (module or None -> z is None).
+    x_bias: bias Parameter of the Linear that produced x when that Linear was called with skip_bias_grad=True -- its
+    gradient (column sums of dx) then comes out of the join's backward kernel."""
     x2d, restore = rows_view(x)
     r2d, _ = rows_view(residual)
     if r2d.shape != x2d.shape:
         raise OfaError("residual_join: shape mismatch")
     wa, ba = (ln_a.weight, ln_a.bias) if ln_a is not None else (None, None)
     wb, bb = (ln_b.weight, ln_b.bias) if ln_b is not None else (None, None)
-    y, z = ResidualJoinFn.apply(x2d, r2d, wa, ba, wb, bb, p if training else 0.0, eps)
+    y, z = ResidualJoinFn.apply(x2d, r2d, wa, ba, wb, bb, p if training else 0.0, eps, x_bias)
     return restore(y), (restore(z) if z is not None else None)
 
 
@@ -307,10 +320,10 @@ def layer_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
 # ---------------------------------------------------------------------------------------------- Linear
 class LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2d, weight, bias, alpha):
+    def forward(ctx, x2d, weight, bias, alpha, skip_bias_grad=False):
         ctx.save_for_backward(x2d, weight)
         ctx.alpha = alpha
-        ctx.has_bias = bias is not None
+        ctx.has_bias = bias is not None and not skip_bias_grad      # (skipped: a downstream residual join produces it)
         ctx.bias_ref = bias
         N = weight.shape[0]
         out = None
@@ -347,13 +360,13 @@ class LinearFn(torch.autograd.Function):
                 _sink_done(ctx.bias_ref)
             else:
                 db = K.colsum(dy, alpha=ctx.alpha, out_dtype=weight.dtype)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, alpha=1.0):
+def linear(x, weight, bias=None, alpha=1.0, skip_bias_grad=False):
     """alpha * F.linear(x, weight, bias)."""
     x2d, restore = rows_view(x)
-    return restore(LinearFn.apply(x2d, weight, bias, alpha))
+    return restore(LinearFn.apply(x2d, weight, bias, alpha, skip_bias_grad))
 
 
 class LinearGeluLayerNormFn(torch.autograd.Function):

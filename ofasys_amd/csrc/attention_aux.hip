@@ -64,8 +64,11 @@ __global__ __launch_bounds__(1024) void c_attn_grad_kernel(const float* __restri
   __shared__ float sw[16];
   const int h = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int t = threadIdx.x; t < Tq; t += 1024) s += delta[((int64_t)b * heads + h) * ld + t];
+  const int64_t n = (int64_t)B * Tq;                  // one flat index over (b, t): independent loads, fixed order
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const int64_t b = i / Tq, t = i - b * Tq;
+    s += delta[(b * heads + h) * ld + t];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
   __syncthreads();

@@ -139,7 +139,8 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, 
                  const void* c_attn, int c_attn_dtype, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                  void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
                  int causal, int dtype, void* stream);
-/* Gradient of the per-head scale (O = c * PV, so d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
+/* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
+ * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */
 int ofa_c_attn_grad(const float* delta, const void* c_attn, void* dc, int B, int heads, int T, int64_t ld, int accumulate,
                     int c_attn_dtype, void* stream);

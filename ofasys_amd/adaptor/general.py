@@ -159,7 +159,7 @@ def _unexpand(b):
     per-sample bias (no adaptor in scope produces one) is rejected."""
     if b is None:
         return None
-    if b.dim() == 4 and b.stride(0) == 0:
+    if b.dim() == 4 and (b.stride(0) == 0 or b.size(0) == 1):      # (a batch of one: nothing to expand, any stride)
         return b[0].permute(1, 2, 0)
     if b.dim() == 3:
         return b

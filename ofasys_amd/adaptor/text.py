@@ -67,6 +67,8 @@ class TextAdaptor(BaseAdaptor):
 
     def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
         """table_l[bucket[:T,:T]] -> [T,T,A]  (adaptor/text.py:101-104)."""
+        if seq_length > self.token_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
+            raise ValueError(f"sequence length {seq_length} exceeds the {self.token_rp_bucket.size(0)} positions of token_rp_bucket")
         rp_bucket = self.token_rp_bucket[:seq_length, :seq_length].contiguous()
         return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight)
 

@@ -53,6 +53,8 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         return a
 
     def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
+        if seq_length > self.video_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
+            raise ValueError(f"sequence length {seq_length} exceeds the {self.video_rp_bucket.size(0)} positions of video_rp_bucket")
         rp_bucket = self.video_rp_bucket[:seq_length, :seq_length].contiguous()
         return ops.embedding(rp_bucket, self.video_rel_pos_table_list[idx].weight)        # [F,F,A]
 

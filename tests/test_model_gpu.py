@@ -384,3 +384,34 @@ def test_incremental_equals_teacher_forcing_at_base_size():
             if live.any():
                 worst = max(worst, rel_err(out[live, -1].float().cpu(), full[live, t].float().cpu()))
     assert worst < BF16_TOL, worst
+
+
+def test_maximum_positions_match_oracle():
+    """Edge of the position tables: 1024 source and 1024 target tokens (max_source/target_positions, bucket tables of
+    2*256-1 relative distances) through the tiny model, fp32, against the CPU oracle on the same recipe weights."""
+    from oracle import recipe, restate
+    from oracle.cases import VOCAB_EXTRA
+    from oracle.restate import OSlot
+    from tests.golden_util import oracle_cfg, state_from_golden
+    from ofasys_amd import ModalityType, Slot
+    torch.set_num_threads(8)
+    case = CASES["tiny_text"]
+    V = 4 + VOCAB_EXTRA
+    src = recipe.tokens("input.max_src", (1, 1024), V, [1024])
+    prev = recipe.tokens("input.max_prev", (1, 1024), V, [1024], bos=0)
+    model, d = build_model(case, DEV, torch.float32)
+    model.eval()
+    with torch.no_grad():
+        logits, extra = model([Slot(ModalityType.TEXT, True, src.to(DEV)), Slot(ModalityType.TEXT, False, prev.to(DEV))])
+    state = state_from_golden(load_golden("tiny_text"))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    with torch.no_grad():
+        ref, rextra = restate.model_forward(state, oracle_cfg(case), [OSlot("TEXT", True, src, None), OSlot("TEXT", False, prev, None)])
+    assert rel_err(logits.cpu(), ref) < FP32_TOL
+    assert rel_err(extra["attn"][0].cpu(), rextra["attn"]) < FP32_TOL
+    # one position more than the tables hold is refused, not wrapped
+    too_long = torch.cat([src, src[:, :1]], 1).to(DEV)
+    with pytest.raises(Exception):
+        with torch.no_grad():
+            model([Slot(ModalityType.TEXT, True, too_long), Slot(ModalityType.TEXT, False, prev.to(DEV))])
+        torch.cuda.synchronize()

@@ -415,3 +415,86 @@ def test_maximum_positions_match_oracle():
         with torch.no_grad():
             model([Slot(ModalityType.TEXT, True, too_long), Slot(ModalityType.TEXT, False, prev.to(DEV))])
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Ts,Tt,slen,tlen", [
+    (1, 1, 1, [1], [1]),                       # one source token, one target position (bos only)
+    (1, 33, 65, [33], [65]),                   # batch of one, lengths that are no multiple of any tile
+    (3, 5, 2, [5, 1, 3], [2, 1, 2]),           # rows with a single real token next to longer ones
+    (2, 129, 31, [129, 2], [31, 30]),          # one row almost entirely padding
+])
+def test_ragged_and_degenerate_shapes_match_oracle(B, Ts, Tt, slen, tlen, dtype):
+    """Edge shapes of the text path (tiny model, biased attention): logits, loss and every gradient norm against the CPU
+    oracle run on the same recipe weights and inputs."""
+    from oracle import recipe, restate
+    from oracle.cases import VOCAB_EXTRA, make_target
+    from oracle.restate import OSlot
+    from tests.golden_util import oracle_cfg, state_from_golden
+    from ofasys_amd import ModalityType, Slot, ops
+    torch.set_num_threads(8)
+    case = CASES["tiny_text"]
+    V = 4 + VOCAB_EXTRA
+    src = recipe.tokens(f"input.edge_src{B}{Ts}", (B, Ts), V, slen)
+    prev = recipe.tokens(f"input.edge_prev{B}{Tt}", (B, Tt), V, tlen, bos=0)
+    target = make_target(prev)
+    model, d = build_model(case, DEV, dtype)
+    model.eval()
+    logits, extra = model([Slot(ModalityType.TEXT, True, src.to(DEV)), Slot(ModalityType.TEXT, False, prev.to(DEV))])
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    state = state_from_golden(load_golden("tiny_text"))
+    params = {k: v.requires_grad_(True) for k, v in state.items() if v.is_floating_point() and not k.endswith("version")}
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    ref, _ = restate.model_forward(state, oracle_cfg(case), [OSlot("TEXT", True, src, None), OSlot("TEXT", False, prev, None)])
+    rloss, n = restate.cross_entropy(ref, target)
+    rloss.backward()
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    live = target.ne(d.pad())                                         # rows of padded targets are not part of the contract
+    assert rel_err(logits.detach().float().cpu()[live], ref.detach()[live]) < tol
+    assert rel_err(loss.detach().float().cpu(), rloss.detach()) < tol
+    mine = dict(model.named_parameters())
+    scale = max(float(p.grad.norm()) for p in params.values() if p.grad is not None)
+    for k, p in params.items():
+        if k == "decoder.adaptor.embed_tokens.weight" or p.grad is None:
+            continue
+        want = float(p.grad.double().norm())
+        got = float(mine[k].grad.double().norm()) if mine[k].grad is not None else 0.0
+        assert abs(got - want) <= 2.5 * tol * want + 2e-3 * scale, (k, got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batch_of_one_image_patch_base_matches_oracle(dtype):
+    """cfg-2 family at batch 1 (OFA-base, image_patch_embed + text -> text): the packed projections, the fused attention
+    and the 192x256 / 128x128 GEMM plans at their smallest row counts, against the CPU oracle."""
+    from oracle import recipe, restate
+    from oracle.cases import VOCAB_EXTRA, make_target
+    from oracle.restate import OSlot
+    from tests.golden_util import oracle_cfg, state_from_golden
+    from ofasys_amd import ModalityType, Slot, ops
+    torch.set_num_threads(8)
+    case = CASES["base_patch"]
+    V = 4 + VOCAB_EXTRA
+    img = recipe.floats("input.b1_image", (1, 3, 224, 224))
+    src = recipe.tokens("input.b1_src", (1, 7), V, [7])
+    prev = recipe.tokens("input.b1_prev", (1, 5), V, [5], bos=0)
+    target = make_target(prev)
+    attrs = ["adaptor=image_patch_embed"]
+    model, d = build_model(case, DEV, dtype)
+    model.eval()
+    logits, _ = model([Slot(ModalityType.IMAGE, True, img.to(DEV).to(dtype), attributes=attrs),
+                       Slot(ModalityType.TEXT, True, src.to(DEV)), Slot(ModalityType.TEXT, False, prev.to(DEV))])
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    loss.backward()
+    torch.cuda.synchronize()
+    state = state_from_golden(load_golden("base_patch"))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    with torch.no_grad():
+        ref, _ = restate.model_forward(state, oracle_cfg(case), [OSlot("IMAGE", True, img, attrs), OSlot("TEXT", True, src, None),
+                                                               OSlot("TEXT", False, prev, None)])
+        rloss, _ = restate.cross_entropy(ref, target)
+    tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel_err(logits.detach().float().cpu(), ref) < tol
+    assert rel_err(loss.detach().float().cpu(), rloss) < tol

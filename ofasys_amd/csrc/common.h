@@ -74,6 +74,36 @@ template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p =
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
 // ---------------------------------------------------------------- wave64 reductions
+// DPP data sharing instead of __shfl_xor: a shuffle compiles to ds_bpermute_b32 -- an LDS-pipe instruction with ~100+
+// cycles of latency, six of them back to back per reduction -- while the DPP forms are ordinary VALU operands (quad_perm,
+// row_half_mirror, row_mirror inside a 16-lane row; row_bcast15 / row_bcast31 across the four rows, gfx9 encodings).  The
+// row kernels (LayerNorm, residual join, softmax, criterion) do 2-6 wave reductions per row and were latency-bound on them.
+// Summation order is fixed (deterministic); every lane receives the result (v_readlane of lane 63).
+#ifndef OFA_WAVE_REDUCE_SHFL
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1, 0xf>(0.f, v);          // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(0.f, v);          // quad_perm [2,3,0,1]  -> every quad holds its sum
+  v += dpp_f<0x141, 0xf>(0.f, v);         // row_half_mirror      -> every 8 lanes
+  v += dpp_f<0x140, 0xf>(0.f, v);         // row_mirror           -> every row of 16
+  v += dpp_f<0x142, 0xa>(0.f, v);         // row_bcast15 into rows 1, 3
+  v += dpp_f<0x143, 0xc>(0.f, v);         // row_bcast31 into rows 2, 3 -> lanes 48..63 hold the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));  // (lanes outside the row mask keep `old` = v: max(v, v) = v)
+  v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -84,6 +114,7 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+#endif
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based dropout masks)
 struct Philox {

@@ -34,6 +34,19 @@ __device__ __forceinline__ void keep_mask(const Philox& rng, uint64_t offset, in
   }
 }
 
+template <typename T> __device__ __forceinline__ void jn_unpack(const uint4& r, float* out);
+template <> __device__ __forceinline__ void jn_unpack<float>(const uint4& r, float* out) {
+  out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void jn_unpack<bf16_t>(const uint4& r, float* out) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
 struct JoinRng { float p; uint64_t seed, offset; const int64_t* base; };
 
 // forward: one wave per row, the row in registers
@@ -48,12 +61,17 @@ __global__ __launch_bounds__(256) void join_fwd_kernel(const T* __restrict__ x, 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float v[NV][N];
+  uint4 rraw[NV];                                       // the residual row is fetched together with x: one HBM latency, not two
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * N;
 #pragma unroll
     for (int j = 0; j < N; ++j) v[i][j] = 0.f;
-    if (c < cols) load_vec<T>(x + row * cols + c, v[i]);
+    rraw[i] = make_uint4(0, 0, 0, 0);
+    if (c < cols) {
+      load_vec<T>(x + row * cols + c, v[i]);
+      rraw[i] = *reinterpret_cast<const uint4*>(res + row * cols + c);
+    }
   }
   if (ga) {                                             // LN_a, two-pass statistics in registers
     float s = 0.f;
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(256) void join_fwd_kernel(const T* __restrict__ x, 
     const int c = (i * 64 + lane) * N;
     if (c < cols) {
       float r[N];
-      load_vec<T>(res + row * cols + c, r);
+      jn_unpack<T>(rraw[i], r);
       if (rg.p > 0.f) {
         bool keep[N];
         keep_mask<N>(rng, off, row * cols + c, rg.p, keep);
@@ -135,19 +153,6 @@ __global__ __launch_bounds__(256) void join_fwd_kernel(const T* __restrict__ x, 
 // into one row per block of ws[q][block][cols], q = dgamma_a, dbeta_a, dgamma_b, dbeta_b.
 constexpr int JOIN_BLOCKS = 256;
 constexpr int join_wpb(int wpr) { return wpr == 8 ? 16 : 12; }
-
-template <typename T> __device__ __forceinline__ void jn_unpack(const uint4& r, float* out);
-template <> __device__ __forceinline__ void jn_unpack<float>(const uint4& r, float* out) {
-  out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
-}
-template <> __device__ __forceinline__ void jn_unpack<bf16_t>(const uint4& r, float* out) {
-  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    out[2 * i] = __uint_as_float(w[i] << 16);
-    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-  }
-}
 
 template <typename T, int WPR>
 __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dz,

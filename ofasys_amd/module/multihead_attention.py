@@ -176,10 +176,29 @@ class MultiheadAttention(nn.Module):
             if self.encoder_decoder_attention and c["k"].size(0) == new_order.size(0):
                 return incremental_state
             # (whole buffers, spare capacity included: the gather is the one copy of this step, no regrow afterwards)
-            c["k"] = c["k"].index_select(0, new_order)
-            c["v"] = c["v"].index_select(0, new_order)
-            if c["kpm"] is not None:
-                c["kpm"] = c["kpm"].index_select(0, new_order)
+            inplace = bool(incremental_state.get("__static__")) and c["k"].size(0) == new_order.size(0)
+            for name in ("k", "v", "kpm"):
+                if c[name] is None:
+                    continue
+                g = c[name].index_select(0, new_order)
+                if inplace:
+                    c[name].copy_(g)                      # captured decode steps hold the buffer addresses
+                else:
+                    c[name] = g
+        return incremental_state
+
+    def reset_incremental_state(self, incremental_state):
+        """Start a new sequence in the SAME buffers (ofasys_amd.generator.StepDecoder: hipGraphs of the decode steps keep
+        the cache addresses): the self-attention cache is emptied, the static encoder-decoder cache is marked stale and
+        recomputed in place by the next call."""
+        c = self._cache(incremental_state)
+        if c is not None:
+            if self.encoder_decoder_attention:
+                c["stale"] = True
+            else:
+                c["len"] = 0
+                if c["kpm"] is not None:
+                    c["kpm"].zero_()
         return incremental_state
 
     @staticmethod
@@ -210,21 +229,30 @@ class MultiheadAttention(nn.Module):
         q = self.q_proj(xq)
         if static_kv:                                                         # encoder-decoder attention: keys computed once
             assert self.encoder_decoder_attention and not self.self_attention
-            if c is None:
+            if c is None or c.get("stale"):
                 assert key is not None
                 xk = ops.batch_major(key)                                     # [B,S,D]
                 S = xk.shape[1]
                 k = self.k_proj(xk).contiguous()
                 v = self.v_proj(xk).contiguous()
                 m = key_padding_mask.bool().contiguous() if key_padding_mask is not None and key_padding_mask.dim() > 0 else None
-                c = {"k": k, "v": v, "len": S, "kpm": m}
-                incremental_state[self._state_key()] = c
+                if c is None:
+                    c = {"k": k, "v": v, "len": S, "kpm": m, "static": True}
+                    incremental_state[self._state_key()] = c
+                else:                                                         # a new sequence in the same (static) buffers
+                    assert c["k"].shape == k.shape and (c["kpm"] is None) == (m is None)
+                    c["k"].copy_(k)
+                    c["v"].copy_(v)
+                    if m is not None:
+                        c["kpm"].copy_(m)
+                    c["stale"] = False
         else:
             assert self.self_attention, "incremental decoding: self-attention or static encoder-decoder attention"
             k_new, v_new = self.k_proj(xq), self.v_proj(xq)                   # [B,D]
             cur = key_padding_mask if key_padding_mask is not None and key_padding_mask.dim() > 0 else None
             if c is None:
-                c = {"k": k_new.new_zeros(bsz, 64, D), "v": k_new.new_zeros(bsz, 64, D), "len": 0, "kpm": None}
+                cap = int(incremental_state.get("__capacity__", 64))          # (StepDecoder: the whole sequence up front)
+                c = {"k": k_new.new_zeros(bsz, cap, D), "v": k_new.new_zeros(bsz, cap, D), "len": 0, "kpm": None}
                 incremental_state[self._state_key()] = c
             n = c["len"]
             c["k"], c["v"] = self._grow(c["k"], n + 1), self._grow(c["v"], n + 1)

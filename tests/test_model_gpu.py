@@ -498,3 +498,42 @@ def test_batch_of_one_image_patch_base_matches_oracle(dtype):
     tol = FP32_TOL if dtype == torch.float32 else BF16_TOL
     assert rel_err(logits.detach().float().cpu(), ref) < tol
     assert rel_err(loss.detach().float().cpu(), rloss) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_decoder_graph_replay_equals_eager(dtype):
+    """ofasys_amd.generator.StepDecoder: decoding through the per-length hipGraphs (sequence 0 runs eagerly, sequence 1
+    records, sequence 2 replays) must give exactly the eager logits, for new batches of the same shape and across an
+    in-place beam reorder."""
+    from oracle import recipe
+    from oracle.cases import VOCAB_EXTRA
+    from ofasys_amd import ModalityType, Slot
+    from ofasys_amd.generator import StepDecoder
+    case = CASES["tiny_text"]
+    V = 4 + VOCAB_EXTRA
+    model, d = build_model(case, DEV, dtype)
+    model.eval()
+    steps, order = 6, torch.tensor([0, 0, 1, 1], device=DEV)
+    new_order = torch.tensor([1, 0, 3, 3], device=DEV)
+
+    def run(dec, seed):
+        src = recipe.tokens(f"input.sd_src{seed}", (2, 9), V, [9, 6]).to(DEV)
+        dec.begin([Slot(ModalityType.TEXT, True, src)], beam_order=order)
+        nxt = torch.full((4,), d.bos(), dtype=torch.long, device=DEV)
+        out = []
+        for t in range(steps):
+            logits = dec.step(nxt).float().clone()
+            out.append(logits)
+            nxt = logits.argmax(-1) + torch.tensor([0, 1, 0, 2], device=DEV)      # distinct beams
+            nxt = nxt.clamp(max=V - 1)
+            if t == 2:
+                dec.reorder(new_order)
+                nxt = nxt.index_select(0, new_order)
+        return torch.stack(out)
+
+    eager, graph = StepDecoder(model, 16, use_graph=False), StepDecoder(model, 16, use_graph=True)
+    for seed in range(3):                                   # graph decoder: eager warm-up, capture, replay
+        a, b = run(eager, seed), run(graph, seed)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (seed, float((a - b).abs().max()))
+    assert len(graph._graphs) == steps

@@ -190,6 +190,10 @@ int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int6
 
 /* y = a * b, b either [rows,cols] or a [cols] row vector (c_attn head scale, multihead_attention.py:342-345). */
 int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream);
+/* y[r, :] = x[r, :] * scale[r / group] (fp32 scale per group of `group` consecutive rows): DropPath (module/droppath.py:
+ * 40-60) on batch-major rows -- one keep/(1-p) factor per sample. */
+int ofa_scale_row_groups(const void* x, const float* scale, void* y, int64_t rows, int cols, int64_t group, int dtype,
+                         void* stream);
 /* out[0] = sum(x[0..n)) in one deterministic pass (loss = sum of per-row losses). */
 int ofa_reduce_sum_f32(const float* x, float* out, int64_t n, void* stream);
 /* out[h] = sum_b sum_{t<T} x[(b*heads+h)*ld + t]  (gradient of c_attn from the attention row sums). */

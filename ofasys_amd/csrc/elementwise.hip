@@ -549,6 +549,24 @@ __global__ __launch_bounds__(256) void mul_kernel(const T* __restrict__ a, const
     store_vec<T>(y + r * cols + c, x);
   }
 }
+// y[r, :] = x[r, :] * scale[r / group]   (DropPath: one keep/scale factor per sample = per group of T batch-major rows)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_row_groups_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                               T* __restrict__ y, int64_t rows, int cols, int64_t group) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = cols / N;
+  const int64_t total = rows * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    const float s = scale[r / group];
+    float a[N];
+    load_vec<T>(x + r * cols + c, a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[j] *= s;
+    store_vec<T>(y + r * cols + c, a);
+  }
+}
 // out[0] = sum(x[0..n))   single block, deterministic
 __global__ __launch_bounds__(256) void reduce_sum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
   __shared__ float sw[4];
@@ -585,6 +603,20 @@ extern "C" int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int 
   else
     hipLaunchKernelGGL((mul_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, cols, b_rowvec);
   return check_launch("mul");
+}
+
+extern "C" int ofa_scale_row_groups(const void* x, const float* scale, void* y, int64_t rows, int cols, int64_t group, int dtype,
+                                    void* stream) {
+  OFA_DT_CHECK("scale_row_groups");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && group > 0 && x && scale && y, OFA_ERR_INVALID, "scale_row_groups: bad argument");
+  OFA_REQUIRE(cols % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "scale_row_groups: cols=%d not vectorizable", cols);
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((scale_row_groups_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)x, scale, (float*)y, rows, cols, group);
+  else
+    hipLaunchKernelGGL((scale_row_groups_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const bf16_t*)x, scale, (bf16_t*)y, rows, cols, group);
+  return check_launch("scale_row_groups");
 }
 
 extern "C" int ofa_reduce_sum_f32(const float* x, float* out, int64_t n, void* stream) {

@@ -619,6 +619,16 @@ def mul_rowvec(a, vec):
     return y
 
 
+def scale_row_groups(x, scale, group):
+    """y[r, :] = x[r, :] * scale[r // group]; x: [rows, cols] rows, scale: fp32 [rows // group]."""
+    x = x.contiguous()
+    rows, cols = _rows_cols(x)
+    assert scale.dtype == torch.float32 and scale.numel() * group == rows
+    y = torch.empty_like(x)
+    lib().call("ofa_scale_row_groups", ptr(x), ptr(scale.contiguous()), ptr(y), rows, cols, group, dtype_code(x), stream())
+    return y
+
+
 def sum_f32(x):
     x = x.contiguous()
     out = torch.empty((), dtype=torch.float32, device=x.device)

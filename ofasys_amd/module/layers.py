@@ -82,8 +82,7 @@ class Dropout(nn.Module):
 
 
 class DropPath(nn.Module):
-    """module/droppath.py:13-60 (per-sample stochastic depth).  The reference's default rate is 0 (identity); a non-zero
-    rate in training is not on the measured path and is refused loudly rather than silently ignored."""
+    """module/droppath.py:13-60 (per-sample stochastic depth; the reference's default rate is 0 = identity)."""
 
     def __init__(self, drop_prob: float = 0.0, batch_axis: int = 0, scale_by_keep: bool = True):
         super().__init__()
@@ -96,7 +95,11 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        raise NotImplementedError("DropPath with drop_prob > 0 in training is not implemented in ofasys_amd yet")
+        if self.batch_axis >= x.ndim:
+            raise ValueError("droppath batch_axis has to be less than input.ndim, but got {} >= {}".format(self.batch_axis, x.ndim))
+        if x.ndim != 3 or self.batch_axis not in (0, 1):
+            raise NotImplementedError("DropPath is implemented for [T,B,C] / [B,T,C] activations")
+        return ops.drop_path(x, self.drop_prob, self.batch_axis, self.scale_by_keep)
 
     def extra_repr(self):
         return "p={}".format(self.drop_prob)

@@ -484,6 +484,34 @@ def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
     return restore(AddFn.apply(a2d, b2d, vec, m))
 
 
+class DropPathFn(torch.autograd.Function):
+    """x * scale[sample] on batch-major rows (module/droppath.py:40-60: scale = floor(keep + U[0,1)) / keep per sample)."""
+
+    @staticmethod
+    def forward(ctx, x2d, scale, group):
+        ctx.save_for_backward(scale)
+        ctx.group = group
+        return K.scale_row_groups(x2d, scale, group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        return K.scale_row_groups(dy.contiguous(), scale, ctx.group), None, None
+
+
+def drop_path(x, drop_prob, batch_axis=1, scale_by_keep=True):
+    """Per-sample stochastic depth of a [T,B,C] (batch_axis=1) or [B,T,C] (batch_axis=0) activation."""
+    keep = 1.0 - drop_prob
+    B = x.shape[batch_axis]
+    mask = (keep + torch.rand(B, dtype=torch.float32, device=x.device)).floor_()
+    if keep > 0.0 and scale_by_keep:
+        mask = mask / keep
+    xb = batch_major(x) if batch_axis == 1 else x.contiguous()          # [B,T,C]: one sample = T consecutive rows
+    T, C = xb.shape[1], xb.shape[2]
+    y = DropPathFn.apply(xb.view(B * T, C), mask, T).view(B, T, C)
+    return y.transpose(0, 1) if batch_axis == 1 else y
+
+
 # ---------------------------------------------------------------------------------------------- embedding
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod

@@ -660,3 +660,41 @@ def test_attn_decode_fully_masked_row_is_zero(K):
     kpm = torch.ones(1, 64, dtype=torch.bool, device=DEV)
     out, probs = K.attn_decode(q, kc, vc, 5, 1, 1.0, kpm=kpm, need_probs=True)
     assert float(out.abs().max()) == 0.0 and float(probs.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["tbc_view", "tbc_contig", "btc"])
+def test_drop_path_per_sample(K, dtype, layout):
+    """module/droppath.py:40-60: every sample is either dropped entirely or scaled by 1/keep; the gradient takes the same
+    factors; identity in eval mode."""
+    from ofasys_amd.module.layers import DropPath
+    torch.manual_seed(3)
+    B, T, C = 64, 5, 256
+    base = torch.randn(B, T, C, device=DEV).to(dtype)
+    if layout == "tbc_view":
+        x, axis = base.transpose(0, 1), 1                     # [T,B,C] view of batch-major storage (the model's layout)
+    elif layout == "tbc_contig":
+        x, axis = base.transpose(0, 1).contiguous(), 1
+    else:
+        x, axis = base, 0
+    x = x.detach().requires_grad_(True)
+    m = DropPath(0.25, batch_axis=axis).train()
+    y = m(x)
+    assert y.shape == x.shape
+    yb = (y if axis == 0 else y.transpose(0, 1)).float()
+    xb = (x if axis == 0 else x.transpose(0, 1)).detach().float()
+    kept = 0
+    for b in range(B):
+        if float(yb[b].abs().max()) == 0.0:
+            continue
+        kept += 1
+        assert rel(yb[b], xb[b] / 0.75) < tol(dtype)
+    assert 30 <= kept <= 60                                   # keep = 0.75 of 64 samples
+    g = torch.randn_like(y)
+    (dx,) = torch.autograd.grad(y, x, g)
+    gb = (g if axis == 0 else g.transpose(0, 1)).float()
+    dxb = (dx if axis == 0 else dx.transpose(0, 1)).float()
+    for b in range(B):
+        want = gb[b] / 0.75 if float(yb[b].abs().max()) > 0 else torch.zeros_like(gb[b])
+        assert float((dxb[b] - want).abs().max()) <= tol(dtype) * float(gb[b].abs().max())
+    assert m.eval()(x) is x

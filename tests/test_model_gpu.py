@@ -537,3 +537,28 @@ def test_step_decoder_graph_replay_equals_eager(dtype):
         torch.cuda.synchronize()
         assert torch.equal(a, b), (seed, float((a - b).abs().max()))
     assert len(graph._graphs) == steps
+
+
+def test_drop_path_model_trains_and_is_identity_in_eval():
+    """encode_drop_path_rate > 0 (module/droppath.py, model/transformer.py:58-59, 249-252): the layers leave the fused
+    residual joins for the op-by-op order; eval mode is unaffected, train mode gives finite loss and gradients."""
+    import copy
+    from ofasys_amd import ops
+    case = copy.deepcopy(CASES["tiny_text"])
+    g = load_golden("tiny_text")
+    case["overrides"] = dict(case["overrides"], encode_drop_path_rate=0.3, dropout=0.0)
+    model, d = build_model(case, DEV, torch.float32)
+    assert model.encoder.layers[-1].drop_path.drop_prob > 0 and model.decoder.layers[-1].drop_path.drop_prob > 0
+    vals, target = case_inputs(case)
+    model.eval()
+    logits, _ = model(make_slots(vals, DEV))
+    assert rel_err(logits.detach().cpu(), g["logits"]) < FP32_TOL          # identity in eval
+    model.train()
+    torch.manual_seed(0)
+    logits, _ = model(make_slots(vals, DEV))
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    loss.backward()
+    assert torch.isfinite(loss) and rel_err(logits.detach().cpu(), g["logits"]) > 1e-3     # paths were dropped
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k

@@ -173,7 +173,7 @@ def cpu_baseline(args):
 
 def pmc_traffic():
     """HBM bytes per launch of the MFMA GEMM kernels from the committed rocprofv3 PMC passes (profiles/, produced by
-    scratch/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on gfx950)."""
+    tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on gfx950)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
     try:
         rows = json.load(open(path))

@@ -18,7 +18,7 @@ BF16_TOL = 2e-2
 BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2}
 # fp32 gradients INSIDE the ResNet backbone: 16 bottlenecks of conv / BatchNorm over as few as 32 values per channel /
 # ReLU make the backward chain ill-conditioned -- torch's own CPU and GPU (MIOpen) fp32 implementations of this exact
-# backbone differ by 0.9% element-wise / 0.06% in norm (scratch/bn_noise.py, run on the MI355X box); this build differs
+# backbone differ by 0.9% element-wise / 0.06% in norm (tools/bn_noise.py, run on the MI355X box); this build differs
 # from the CPU reference by <= 2.4% / 0.1%.  Outputs (logits 4e-6) and every gradient outside the backbone keep 1e-3.
 # bf16 gradient NORMS inside the backbone: the reference's own bf16-vs-fp32 gap there (oracle/ref_bf16_grad_gap.py, torch
 # CPU) is 41.6% on tiny_resnet and 22.8% on tiny_video (worst parameter: the stem's bn1) -- a one-ulp change of a single

@@ -1,0 +1,37 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE): average per launch, gfx950 correction
+(FETCH_SIZE counts 64 B per 128-B request: doubled) as MI355X_MICROARCH.md section HBM prescribes; both are in KiB."""
+import sqlite3, sys, json, collections
+def load(db, counter):
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if 'kernel_dispatch' in t][0]
+    pm = [t for t in tabs if t.startswith('rocpd_pmc_event')][0]
+    sym = [t for t in tabs if 'kernel_symbol' in t][0]
+    info = [t for t in tabs if t.startswith('rocpd_info_pmc')][0]
+    names = {r[0]: r[1] for r in c.execute(f"select id, name from {info}")}
+    out = collections.defaultdict(lambda: [0.0, 0])
+    q = f"select s.kernel_name, p.pmc_id, p.value, d.id from {pm} p join {kd} d on p.event_id = d.event_id join {sym} s on d.kernel_id = s.id"
+    per = collections.defaultdict(float)
+    kn = {}
+    for name, pid, val, did in c.execute(q):
+        if names.get(pid) == counter:
+            per[did] += val
+            kn[did] = name
+    for did, v in per.items():
+        out[kn[did]][0] += v
+        out[kn[did]][1] += 1
+    return out
+f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
+rows = []
+for k in f:
+    n = f[k][1]
+    fetch = 2.0 * f[k][0] * 1024 / n
+    write = (w[k][0] * 1024 / w[k][1]) if k in w and w[k][1] else 0.0
+    rows.append((fetch + write, k, n, fetch, write))
+rows.sort(reverse=True)
+res = {}
+print(f"{'kernel':90s} {'launches':>8s} {'fetch MB/launch':>16s} {'write MB/launch':>16s}")
+for tot, k, n, fe, wr in rows[:40]:
+    print(f"{k[:90]:90s} {n:8d} {fe/1e6:16.2f} {wr/1e6:16.2f}")
+    res[k] = {"launches": n, "fetch_bytes_per_launch": fe, "write_bytes_per_launch": wr}
+json.dump(res, open(sys.argv[3], "w"), indent=1)

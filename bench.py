@@ -181,7 +181,7 @@ def pmc_traffic():
         return None, None
     n = tot = 0.0
     for name, r in rows.items():
-        if "gemm_mfma_kernel" in name or "gemm_big_kernel" in name:
+        if "gemm_mfma_kernel" in name or "gemm_big_kernel" in name or "gemm_ring_kernel" in name:
             n += r["launches"]
             tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
     return (tot / n, "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA GEMM "
@@ -281,7 +281,7 @@ def main():
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
+                "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
                 "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS}
         if prof and prof["time_ms"] > 0:
             ach = prof["flops"] / (prof["time_ms"] * 1e-3) / 1e12

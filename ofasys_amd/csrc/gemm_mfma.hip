@@ -581,6 +581,184 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   }
 }
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring-staged kernel for SMALL grids (<= ~2 workgroups per CU: every decoder-side product of the model, 2048 rows).
+// With one or two waves per SIMD nothing hides the global->LDS latency of the double-buffered loop above: a K-step
+// computes for ~0.35 us and then waits ~1 us for the next tile (2048 x 768 x 768: 12 K-steps, 13.7 us at every tile
+// size -- the latency chain, not the flops).  Here four stages are in flight: tiles kt+1..kt+3 are already travelling
+// while tile kt multiplies; the wait in front of the stage barrier is `vmcnt(2 * pieces)` -- only the OLDEST tile has to
+// have landed.  Same tile geometry, swizzle, fragment reads and epilogue as gemm_mfma_kernel (LDS-DMA path: whole K
+// tiles); the stage select is an add on the fragment address registers instead of an offset immediate.
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
+                                                               float* __restrict__ ws) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN, S = 4;
+  typedef TileGeom<BM, A_KMAJ> GA;
+  typedef TileGeom<BN, B_KMAJ> GB;
+  constexpr int NVA = GA::NVEC / NT, NVB = GB::NVEC / NT, P = NVA + NVB;
+  constexpr int EA = BM * BK, EB = BN * BK;
+  constexpr uint32_t STG = (uint32_t)(EA + EB) * 2u;                  // bytes per stage: [A tile | B tile]
+  static_assert(2 * P <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = tiles_m * tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  constexpr int GM = 8;
+  const int gsz = GM * tiles_n;
+  const int gid = t / gsz, first_m = gid * GM;
+  const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z, ks = blockIdx.y;
+  const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
+  const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
+  const int kbeg = ks * ksplit;
+  const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
+  const int nk = (kend - kbeg) / BK;                                   // launcher guarantees whole K tiles
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bf16_t* pa[NVA];
+  const bf16_t* pb[NVB];
+  glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
+  const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
+  int knext = kbeg;
+  auto dma = [&](int stage) {
+    if (!B_KMAJ && knext + BK > g.b_krows)                            // zero-padded contraction tail: clamp B's k rows
+      glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
+    bf16_t* st = reinterpret_cast<bf16_t*>(smem_raw + (size_t)stage * STG);
+    glds_issue<NT, NVA>(pa, stepA, st, wave_u);
+    glds_issue<NT, NVB>(pb, stepB, st + EA, wave_u);
+    knext += BK;
+  };
+  int issued = 0;
+  for (; issued < S - 1 && issued < nk; ++issued) dma(issued);
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+  FragAddr<BM, A_KMAJ> fax[2];
+  FragAddr<BN, B_KMAJ> faw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fax[i].init(lds0, wm * 64 + i * 32, lane);
+    faw[i].init(lds0 + (uint32_t)EA * 2u, wn * 64 + i * 32, lane);
+  }
+  constexpr int NA = A_KMAJ ? 4 : 1, NB = B_KMAJ ? 4 : 1;
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int later = issued - kt - 1;                                 // tiles issued behind tile kt (block-uniform)
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the bare barrier instruction: __syncthreads() is fence + barrier and hipcc materialises the fence as
+    // `s_waitcnt vmcnt(0)` -- every tile in flight would be drained at every step (seen in the ISA; the ring then ran
+    // SLOWER than two stages).  What the barrier has to order is covered explicitly: this wave's tile kt by the vmcnt
+    // above, its fragment reads of tile kt-1 by the lgkmcnt waits in front of the MFMAs.
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                       // tile kt is complete; everybody is done reading tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    // refill the stage tile kt-1 lived in -- ONE QUARTER of the tile's DMA pieces behind each k-slice's MFMAs: a piece
+    // costs the wave ~60 issue cycles, and with one wave per SIMD (small grids) a burst of P pieces in front of the
+    // MFMAs is as long as the MFMAs themselves (the ring tolerates the later issue: the tile is not needed for 3 steps)
+    const bool refill = issued < nk;
+    bf16_t* rst = reinterpret_cast<bf16_t*>(smem_raw + (size_t)((stage + S - 1) % S) * STG);
+    if (refill && !B_KMAJ && knext + BK > g.b_krows)
+      glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
+    u64x2 x0[2], w0[2], x1[2], w1[2];
+#define RING_ISSUE(KK, X, W)                        \
+    frag_issue<BM, A_KMAJ, KK, 0>(X[0], fax[0]);    \
+    frag_issue<BM, A_KMAJ, KK, 0>(X[1], fax[1]);    \
+    frag_issue<BN, B_KMAJ, KK, 0>(W[0], faw[0]);    \
+    frag_issue<BN, B_KMAJ, KK, 0>(W[1], faw[1])
+#define RING_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
+#define RING_MMA(X, W)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
+                                                            __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
+#define RING_DMA(Q)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (refill) {                                                                                                      \
+      static_for<(Q) * P / 4, ((Q) + 1) * P / 4>([&](auto pc) {                                                        \
+        constexpr int pi = decltype(pc)::value;                                                                        \
+        if constexpr (pi < NVA) {                                                                                      \
+          __builtin_amdgcn_global_load_lds((gvoid_t*)pa[pi], (lvoid_t*)(rst + (wave_u * 64 + pi * NT) * 8), 16, 0, 0); \
+          pa[pi] += stepA;                                                                                             \
+        } else {                                                                                                       \
+          __builtin_amdgcn_global_load_lds((gvoid_t*)pb[pi - NVA], (lvoid_t*)(rst + EA + (wave_u * 64 + (pi - NVA) * NT) * 8), 16, 0, 0); \
+          pb[pi - NVA] += stepB;                                                                                       \
+        }                                                                                                              \
+      });                                                                                                              \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0)
+    RING_ISSUE(0, x0, w0);
+    RING_WAIT(x0, w0);
+    RING_ISSUE(1, x1, w1);
+    RING_MMA(x0, w0);
+    RING_DMA(0);
+    RING_WAIT(x1, w1);
+    RING_ISSUE(2, x0, w0);
+    RING_MMA(x1, w1);
+    RING_DMA(1);
+    RING_WAIT(x0, w0);
+    RING_ISSUE(3, x1, w1);
+    RING_MMA(x0, w0);
+    RING_DMA(2);
+    RING_WAIT(x1, w1);
+    RING_MMA(x1, w1);
+    RING_DMA(3);
+    if (refill) {
+      knext += BK;
+      ++issued;
+    }
+#undef RING_DMA
+#undef RING_ISSUE
+#undef RING_WAIT
+#undef RING_MMA
+    // next stage: wrap the fragment addresses around the ring
+    const bool wrap = stage == S - 1;
+    const uint32_t delta = wrap ? (uint32_t)(0u - (uint32_t)(S - 1) * STG) : STG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < NA; ++q) fax[i].a[q] += delta;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) faw[i].a[q] += delta;
+    }
+    stage = wrap ? 0 : stage + 1;
+  }
+  __syncthreads();                                     // every wave is done with the fragment reads
+  {
+    const bool split = gridDim.y > 1;
+    constexpr int REGION = ((int)(S * STG) / (WM * WN)) & ~1023;
+    unsigned char* wl = smem_raw + wave * REGION;
+    const int m_w = m0 + wm * 64, n_w = n0 + wn * 64;
+    if (split) {
+      const int64_t n4 = (g.N + 3) & ~3;
+      float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
+      epilogue_lds<2, 2, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+    } else {
+      const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
+      void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
+      epilogue_lds<2, 2, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Big-tile kernel: 4 waves, each owning a (32*TM) x (32*TN) block of accumulators (TM x TN MFMA tiles; 4 x 4 = 256 fp32
 // registers per lane, the unified VGPR/AccVGPR file of CDNA3/4 holds 512).  Why: with 64x64 per wave every K-step moves
@@ -589,12 +767,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 // One workgroup per CU (128 KiB of LDS: 2 stages x (A 32 KiB + B 32 KiB)), one wave per SIMD, so the overlap is built
 // into the wave's own instruction stream: fragments of k-slice kk+1 are read while slice kk multiplies, the barrier that
 // retires an LDS stage sits in front of the LAST slice's MFMAs, and the DMA of tile t+2 is issued right behind it.
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // per-lane LDS byte addresses (relative to LDS base, buffer 0 of the operand)
 template <int R, bool KMAJ> struct BigAddr {
@@ -909,7 +1081,35 @@ static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, fl
 }
 
 template <int WM, int WN, bool AK, bool BKM, bool OF>
+static void launch_ring(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+  const size_t lds = 4 * (size_t)(BM + BN) * BK * sizeof(bf16_t);
+  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(tiles_m * tiles_n, splits, batch), block(WM * WN * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
+}
+
+// small grids take the 4-stage ring (see gemm_ring_kernel); OFA_GEMM_RING=0 disables, =2 forces it wherever legal
+static bool use_ring(const GemmArgs& g, int wm, int wn, int64_t blocks, int ksplit) {
+  static const int mode = getenv("OFA_GEMM_RING") ? atoi(getenv("OFA_GEMM_RING")) : 1;
+  if (mode == 0 || (g.K % BK) != 0 || (ksplit % BK) != 0 || (g.flags & OFA_GEMM_NO_LDS_DMA)) return false;
+  if (mode == 2) return true;
+  const int64_t cap = (wm == 1 && wn == 1) ? 512 : 256;              // 64 KiB of LDS: two per CU; 96 / 128 KiB: one
+  return blocks <= cap && ksplit >= 4 * BK;
+}
+
+template <int WM, int WN, bool AK, bool BKM, bool OF>
 static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+  if (use_ring(g, WM, WN, (int64_t)cdiv(g.M, 64 * WM) * cdiv(g.N, 64 * WN) * splits * batch, ksplit)) {
+    launch_ring<WM, WN, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+    return;
+  }
   // LDS-DMA staging needs full K tiles (no zero fill); anything else takes the register-staged loop
   if ((g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA)) launch_cfg2<WM, WN, AK, BKM, OF, true>(g, batch, splits, ksplit, ws, st);
   else launch_cfg2<WM, WN, AK, BKM, OF, false>(g, batch, splits, ksplit, ws, st);

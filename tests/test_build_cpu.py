@@ -36,6 +36,7 @@ def _kernel_meta(src, tmp_path):
     ("layernorm.hip", r"ln_bwd_kernelItLi2ELi1ELb0E", 0),       # LayerNorm backward, D = 768 rows (bf16)
     ("attention.hip", r"attn_(fwd|bwd_dq|bwd_dkv)_lds_kernel", 0),
     ("gemm_mfma.hip", r"gemm_mfma_kernelILi2ELi2ELb[01]ELb[01]ELb0ELb1E", 0),   # 128x128 LDS-DMA kernels, bf16 out
+    ("gemm_mfma.hip", r"gemm_ring_kernelILi[12]ELi[12]ELb[01]ELb[01]ELb0E", 0),  # 4-stage ring kernels, bf16 out
 ])
 def test_hot_kernels_do_not_spill(tmp_path, src, pattern, max_spill):
     meta = _kernel_meta(src, tmp_path)

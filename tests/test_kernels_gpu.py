@@ -698,3 +698,37 @@ def test_drop_path_per_sample(K, dtype, layout):
         want = gb[b] / 0.75 if float(yb[b].abs().max()) > 0 else torch.zeros_like(gb[b])
         assert float((dxb[b] - want).abs().max()) <= tol(dtype) * float(gb[b].abs().max())
     assert m.eval()(x) is x
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_c_attn_grad_kernel(K, dtype):
+    """ofa_c_attn_grad: dc[h] (+)= sum_{b, t < T} delta[b*heads+h, t] / c[h]; the padded tail of each delta row is ignored."""
+    torch.manual_seed(5)
+    B, H, T, ld = 7, 12, 45, 64
+    delta = torch.randn(B * H, ld, device=DEV)
+    c = (torch.rand(H, device=DEV) + 0.5).to(dtype)
+    want = delta.view(B, H, ld)[:, :, :T].double().sum(dim=(0, 2)) / c.double()
+    got = K.c_attn_grad(delta, c, B, H, T)
+    assert got.dtype == dtype and rel(got.float(), want.float()) < (1e-5 if dtype == torch.float32 else 8e-3)
+    acc = torch.randn(H, device=DEV).to(dtype)
+    base = acc.double().clone()
+    K.c_attn_grad(delta, c, B, H, T, out=acc, accumulate=True)
+    assert rel(acc.float(), (base + want).float()) < (1e-5 if dtype == torch.float32 else 1.6e-2)
+
+
+@pytest.mark.parametrize("clip", [0.0, 1.0, 100.0])
+def test_step_schedule_kernel(K, clip):
+    """ofa_step_schedule against the host arithmetic of the reference (engine/trainer.py:857-884, optim/adam.py:205-207)."""
+    gsq = torch.tensor([37.5], device=DEV)
+    stats = torch.tensor([24.0, 3.0, 24.0], dtype=torch.float64, device=DEV)
+    step = torch.tensor([4.0], dtype=torch.float64, device=DEV)
+    lr = torch.tensor([3e-4], dtype=torch.float64, device=DEV)
+    sched, gnorm = torch.zeros(3, device=DEV), torch.zeros(1, device=DEV)
+    K.step_schedule(gsq, stats, step, lr, sched, gnorm, clip, 0.9, 0.999)
+    gn = math.sqrt(37.5) / 24.0
+    coef = (1 / 24.0) * (min(1.0, clip / (gn + 1e-6)) if clip > 0 else 1.0)
+    t = 5.0
+    want = [coef, 3e-4 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t), 3e-4]
+    assert float(step) == 5.0 and abs(float(gnorm) - gn) < 1e-6 * gn
+    for a, b in zip(sched.tolist(), want):
+        assert abs(a - b) <= 1e-6 * abs(b), (sched.tolist(), want)

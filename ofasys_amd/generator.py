@@ -69,7 +69,7 @@ class StepDecoder:
         elif graphed:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.no_grad(), torch.cuda.graph(g, pool=self._pool):
+            with torch.no_grad(), torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                 logits = self._run(t)
             if self._pool is None:
                 self._pool = g.pool()

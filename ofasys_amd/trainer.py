@@ -92,6 +92,11 @@ class FlatParams:
                 p._ofa_grad = p.grad
 
 
+# Capture mode: other threads of the process (the RCCL watchdog of torch.distributed polls events) must not invalidate a
+# capture in progress -- only this thread's stream is being recorded.
+_CAPTURE_MODE = "thread_local"
+
+
 class Trainer:
     """One optimisation step = `train_step(samples)`.
 
@@ -209,15 +214,15 @@ class Trainer:
         entry = {"static": samples, "graphs": []}
         if self.world == 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._fwd_bwd(samples, overlap_reduce=False)
                 self._update()
             entry["graphs"] = [g]
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=pool):
+            with torch.cuda.graph(ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._fwd_bwd(samples, overlap_reduce=False)
-            with torch.cuda.graph(gb, pool=pool):
+            with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._update()
             entry["graphs"] = [ga, gb]
         return entry

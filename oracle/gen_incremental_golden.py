@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import recipe  # noqa: E402
 from oracle.cases import CASES, VOCAB_EXTRA, make_value  # noqa: E402
-from oracle.incremental_case import BEAM_ORDER, NEW_ORDER, REORDER_AT, STEPS, beam_prefix  # noqa: E402
+from oracle.incremental_case import BEAM_ORDER, NEW_ORDER, REORDER_AT, STEPS, beam_prefix, padded_prefix  # noqa: E402
 from oracle.ref_import import build_reference_model, install  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "tiny_text_incremental.npz")
@@ -52,8 +52,17 @@ def main():
                 prev = prev.index_select(0, order)
         full, _ = model.decoder([Slot(ModalityType.TEXT, False, prev)], encoder_out=enc)     # teacher-forced, same final beams
         buf = model.decoder.layers[0].self_attn._get_input_buffer(inc)
+        # scenario 2: finished beams (pad tokens in the prefix), no reorder
+        enc2 = model.encoder.reorder_encoder_out(model.encoder(src), torch.tensor(BEAM_ORDER))
+        prev2, inc2, logits2 = padded_prefix(V), {}, []
+        for t in range(STEPS):
+            out, _ = model.decoder([Slot(ModalityType.TEXT, False, prev2[:, :t + 1])], encoder_out=enc2, incremental_state=inc2)
+            logits2.append(out[:, -1].clone())
+        buf2 = model.decoder.layers[1].self_attn._get_input_buffer(inc2)
     np.savez_compressed(OUT, logits=torch.stack(logits).numpy(), attn=attn.numpy(), full_last=full[:, -1].numpy(),
-                        prev_key_l0=buf["prev_key"].numpy(), prev_value_l0=buf["prev_value"].numpy())
+                        prev_key_l0=buf["prev_key"].numpy(), prev_value_l0=buf["prev_value"].numpy(),
+                        logits_padded=torch.stack(logits2).numpy(),
+                        kpm_padded_l1=buf2["prev_key_padding_mask"].float().numpy())
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB; max |incremental - full| at the last step:",
           float((logits[-1] - full[:, -1]).abs().max()))
 

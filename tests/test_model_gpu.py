@@ -584,3 +584,28 @@ def test_overfit_one_batch_loss_goes_down():
     assert all(map(lambda v: v == v and v < 1e6, losses + gnorms)), (losses[-5:], gnorms[-5:])
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert sum(losses[-5:]) < sum(losses[:5])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_incremental_decoding_with_finished_beams_matches_reference(dtype):
+    """Pad tokens inside the prefix (finished hypotheses): the cached key-padding mask reaches ofa_attn_decode on every
+    later step; logits against the reference run step by step, the mask bit-exact in the reference's form."""
+    from oracle.cases import VOCAB_EXTRA
+    from oracle.incremental_case import BEAM_ORDER, STEPS, padded_prefix
+    from ofasys_amd import ModalityType, Slot
+    case = CASES["tiny_text"]
+    gi = load_golden("tiny_text_incremental")
+    model, d = build_model(case, DEV, dtype)
+    model.eval()
+    vals, _ = case_inputs(case)
+    src = [s for s in make_slots(vals, DEV, dtype) if s.is_src]
+    prev = padded_prefix(4 + VOCAB_EXTRA).to(DEV)
+    with torch.no_grad():
+        enc = model.encoder.reorder_encoder_out(model.encoder(src), torch.tensor(BEAM_ORDER, device=DEV))
+        inc, logits = {}, []
+        for t in range(STEPS):
+            out, _ = model.decoder([Slot(ModalityType.TEXT, False, prev[:, :t + 1])], encoder_out=enc, incremental_state=inc)
+            logits.append(out[:, -1].float().clone())
+        buf = model.decoder.layers[1].self_attn._get_input_buffer(inc)
+    assert rel_err(torch.stack(logits).cpu(), gi["logits_padded"]) < (FP32_TOL if dtype == torch.float32 else BF16_TOL)
+    assert np.array_equal(buf["prev_key_padding_mask"].float().cpu().numpy(), gi["kpm_padded_l1"])

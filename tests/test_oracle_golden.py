@@ -144,3 +144,26 @@ def test_incremental_decoding_matches_reference():
     assert rel_err(logits[-1], full_last) < TOL                      # incremental == teacher-forced on the final beams
     assert rel_err(inc[(0, "self")]["prev_key"], gi["prev_key_l0"]) < TOL
     assert rel_err(inc[(0, "self")]["prev_value"], gi["prev_value_l0"]) < TOL
+
+
+def test_incremental_decoding_with_finished_beams_matches_reference():
+    """Pad tokens inside the prefix (finished hypotheses): the cached key-padding mask takes part in every later step."""
+    from oracle.cases import VOCAB_EXTRA
+    from oracle.incremental_case import BEAM_ORDER, STEPS, padded_prefix
+    from oracle.restate import OSlot
+    torch.set_num_threads(8)
+    case = CASES["tiny_text"]
+    gi = load_golden("tiny_text_incremental")
+    state = state_from_golden(load_golden("tiny_text"))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    vals, _ = case_inputs(case)
+    cfg = oracle_cfg(case)
+    with torch.no_grad():
+        enc = restate.encoder_forward(state, cfg, [s for s in oracle_slots(vals) if s.is_src])
+        enc = restate.reorder_encoder_out(enc, torch.tensor(BEAM_ORDER))
+        prev, inc, logits = padded_prefix(4 + VOCAB_EXTRA), {}, []
+        for t in range(STEPS):
+            out, _ = restate.decoder_step(state, cfg, [OSlot("TEXT", False, prev[:, :t + 1], None)], enc, inc)
+            logits.append(out[:, -1])
+    assert rel_err(torch.stack(logits), gi["logits_padded"]) < TOL
+    assert np.array_equal(inc[(1, "self")]["prev_key_padding_mask"].float().numpy(), gi["kpm_padded_l1"])

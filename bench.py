@@ -230,6 +230,8 @@ def main():
     if world > 1:                                                  # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
+    from ofasys_amd import ops
+    ops.manual_seed(1 + rank)                                      # dropout streams differ per rank (fairseq: seed + rank)
     trainer = Trainer(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph)
     Ts_text, Tt = (191, 64) if args.workload == "cfg2" else (252, 64)
     batch, ntok = make_batch(d, args.batch, Ts_text, Tt, rank, device, args.workload)

@@ -60,6 +60,7 @@ def build(args, device):
             a = getattr(m.cfg.adaptor, name)
             a.is_active = True
             a.entangle_position_embedding = True
+        m.cfg.adaptor.image_patch_embed.embed_dim = m.cfg.encoder_embed_dim      # the adaptor's own default is 768 (base)
     m.initialize(d)
     m = m.to(device).to(torch.bfloat16)
     return m, d

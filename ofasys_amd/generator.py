@@ -31,6 +31,9 @@ class StepDecoder:
         static buffers at the new batch."""
         m = self.model
         m.eval()
+        for mod in m.decoder.modules():                   # packed decode projections follow the current parameters
+            if getattr(mod, "_decode_pack_cache", None) is not None:
+                mod._decode_pack()
         with torch.no_grad():
             enc = m.encoder(src_slots)
             if beam_order is not None:

@@ -123,3 +123,15 @@ def test_dp_bucket_reducer_gloo_world2():
     want = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 8)) for p in model.parameters()])
     got = res[0][1]
     assert torch.allclose(got[: want.numel()], want, atol=1e-5) and float(got[want.numel():].abs().sum()) == 0.0
+
+
+def test_tool_scripts_compile():
+    """tools/*.py (profiling / analysis helpers referenced by DESIGN.md) must at least parse."""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(scripts) >= 15
+    for s in scripts:
+        py_compile.compile(s, doraise=True)

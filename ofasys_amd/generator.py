@@ -99,6 +99,9 @@ class StepDecoder:
     def reorder(self, new_order: torch.Tensor):
         """Beam reorder between steps: caches, encoder output and the token prefix follow `new_order` (in place)."""
         m = self.model
+        if new_order.numel() != self._shape[0]:
+            raise ValueError("StepDecoder.reorder keeps the row count (the buffers of the captured steps are fixed): "
+                             f"got {new_order.numel()} indices for {self._shape[0]} rows")
         m.decoder.reorder_incremental_state_scripting(self.inc, new_order)
         enc = m.encoder.reorder_encoder_out(self.enc, new_order)
         for k, v in enc.items():

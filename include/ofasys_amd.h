@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-typedef enum { OFA_F32 = 0, OFA_BF16 = 1 } ofa_dtype;
+/* OFA_F16 is accepted by the fused-softmax entry points (the dtype the reference routes to them, multihead_attention.py:83-91,
+ * scaled_masked_softmax.cpp:45-47); every other entry point computes in fp32 or bf16 and returns OFA_ERR_INVALID for it. */
+typedef enum { OFA_F32 = 0, OFA_BF16 = 1, OFA_F16 = 2 } ofa_dtype;
 
 enum {
   OFA_OK = 0,
@@ -109,9 +111,19 @@ int ofa_scaled_softmax_bwd(const void* dy, const void* y, void* dx, float scale,
 /* mask: uint8 [mask_b (b or 1), 1, sq, sk]; masked scores are replaced by -10000.0 (scaled_masked_softmax.h:269-273). */
 int ofa_scaled_masked_softmax_fwd(const void* x, const uint8_t* mask, void* y, float scale, int b, int np, int sq,
                                   int sk, int mask_b, int dtype, void* stream);
+/* replaces scaled_masked_softmax.cpp:60-77 `backward(output_grads, softmax_results, scale)`: same arithmetic as
+ * ofa_scaled_softmax_bwd (the mask does not enter the backward); dx may alias dy -- the reference's backward is completely
+ * in place on output_grads (scaled_masked_softmax_cuda.cu:98-117). */
+int ofa_scaled_masked_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int b, int np, int sq, int sk,
+                                  int dtype, void* stream);
 /* x,y: [attn_batches, sq, sq]; implicit causal mask, masked outputs are zero (scaled_upper_triang_masked_softmax.h:113-230). */
 int ofa_scaled_upper_triang_masked_softmax_fwd(const void* x, void* y, float scale, int attn_batches, int sq,
                                                int dtype, void* stream);
+/* replaces scaled_upper_triang_masked_softmax.cpp:49-64 `backward`: dy,y,dx [attn_batches, sq, sq]; the strictly upper triangle
+ * of dy is never read and dx is zero there (scaled_upper_triang_masked_softmax.h:232-329); dx may alias dy (in place,
+ * scaled_upper_triang_masked_softmax_cuda.cu:68-95). */
+int ofa_scaled_upper_triang_masked_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int attn_batches,
+                                               int sq, int dtype, void* stream);
 int ofa_get_batch_per_block(int sq, int sk, int b, int np); /* scaled_masked_softmax.h:426-438, kept for API parity */
 
 /* ---- attention-score softmax of the slow path, multihead_attention.py:311-334:

@@ -36,6 +36,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// fp16: the dtype the reference routes to its fused-softmax extensions (multihead_attention.py:83-91); _Float16 <-> float are the
+// hardware conversions (v_cvt_f32_f16 / v_cvt_f16_f32, round-to-nearest-even)
+typedef _Float16 f16_t;
+
 template <typename T> struct Vec;  // 16-byte vector of T
 template <> struct Vec<float> { static constexpr int N = 4; typedef float4 type; };
 template <> struct Vec<bf16_t> { static constexpr int N = 8; typedef uint4 type; };
@@ -69,7 +73,9 @@ template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 

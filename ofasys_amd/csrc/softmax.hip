@@ -70,22 +70,28 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// dy and dx are NOT __restrict__: the reference's backward is "completely in place" on the output-gradient buffer
+// (scaled_masked_softmax_cuda.cu:98-117, scaled_upper_triang_masked_softmax_cuda.cu:68-95) and callers may pass dx == dy; each
+// lane reads all of its own elements of the row before the first store, so aliasing is safe.
+// causal != 0 (sq == sk): columns above the diagonal are never read and their gradient is written as zero
+// (scaled_upper_triang_masked_softmax.h:232-329 -- the forward's outputs are zero there).
 template <typename T, int NI>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                                                          T* __restrict__ dx, float scale, int64_t rows, int sk) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* dy, const T* __restrict__ y, T* dx, float scale,
+                                                          int64_t rows, int sk, int causal) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* dyr = dy + row * sk;
   const T* yr = y + row * sk;
   T* dxr = dx + row * sk;
+  const int last = causal ? (int)(row % sk) : sk - 1;       // last column with a non-zero probability
   float g[NI], p[NI];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int c = i * 64 + lane;
     g[i] = p[i] = 0.f;
-    if (c < sk) {
+    if (c <= last) {
       p[i] = ld1<T>(yr + c);
       g[i] = ld1<T>(dyr + c) * p[i];
       s += g[i];
@@ -102,7 +108,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
 template <int MODE>
 static int softmax_launch(const void* x, const void* bias, const uint8_t* mask, void* y, float scale, int64_t rows,
                           int sq, int sk, int np, int mask_b, int causal, int dtype, hipStream_t st) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "softmax: bad dtype %d", dtype);
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16 || (dtype == OFA_F16 && MODE != SM_ATTN), OFA_ERR_INVALID,
+              "softmax: bad dtype %d", dtype);
   OFA_REQUIRE(sk > 0 && sk <= 64 * SM_MAX_PER_LANE, OFA_ERR_UNSUPPORTED, "softmax: sk=%d must be in [1,4096]", sk);
   OFA_REQUIRE(x && y, OFA_ERR_INVALID, "softmax: null pointer");
   if (rows == 0) return 0;
@@ -113,9 +120,12 @@ static int softmax_launch(const void* x, const void* bias, const uint8_t* mask, 
     if (dtype == OFA_F32)                                                                                            \
       hipLaunchKernelGGL((softmax_fwd_kernel<float, MODE, NI>), grid, block, 0, st, (const float*)x,                 \
                          (const float*)bias, mask, (float*)y, scale, rows, sq, sk, np, mask_b, causal);              \
-    else                                                                                                             \
+    else if (dtype == OFA_BF16)                                                                                      \
       hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t, MODE, NI>), grid, block, 0, st, (const bf16_t*)x,               \
                          (const bf16_t*)bias, mask, (bf16_t*)y, scale, rows, sq, sk, np, mask_b, causal);            \
+    else                                                                                                             \
+      hipLaunchKernelGGL((softmax_fwd_kernel<f16_t, MODE, NI>), grid, block, 0, st, (const f16_t*)x,                 \
+                         (const f16_t*)bias, mask, (f16_t*)y, scale, rows, sq, sk, np, mask_b, causal);              \
   } while (0)
   if (ni <= 1) SM_CASE(1);
   else if (ni <= 2) SM_CASE(2);
@@ -137,24 +147,25 @@ extern "C" int ofa_scaled_softmax_fwd(const void* x, void* y, float scale, int b
                                   (hipStream_t)stream);
 }
 
-extern "C" int ofa_scaled_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int b, int np, int sq, int sk,
-                                      int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "softmax_bwd: bad dtype %d", dtype);
+static int softmax_bwd_launch(const void* dy, const void* y, void* dx, float scale, int64_t rows, int sk, int causal,
+                              int dtype, hipStream_t st) {
+  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_INVALID, "softmax_bwd: bad dtype %d", dtype);
   OFA_REQUIRE(sk > 0 && sk <= 64 * SM_MAX_PER_LANE, OFA_ERR_UNSUPPORTED, "softmax_bwd: sk=%d must be in [1,4096]", sk);
-  OFA_REQUIRE(dy && y && dx, OFA_ERR_INVALID, "softmax_bwd: null pointer");
-  const int64_t rows = (int64_t)b * np * sq;
+  OFA_REQUIRE(rows >= 0 && dy && y && dx, OFA_ERR_INVALID, "softmax_bwd: null pointer / negative size");
   if (rows == 0) return 0;
   dim3 grid(cdiv(rows, 4)), block(256);
   const int ni = (sk + 63) / 64;
-  hipStream_t st = (hipStream_t)stream;
 #define SM_CASE(NI)                                                                                              \
   do {                                                                                                           \
     if (dtype == OFA_F32)                                                                                        \
       hipLaunchKernelGGL((softmax_bwd_kernel<float, NI>), grid, block, 0, st, (const float*)dy, (const float*)y, \
-                         (float*)dx, scale, rows, sk);                                                           \
-    else                                                                                                         \
+                         (float*)dx, scale, rows, sk, causal);                                                   \
+    else if (dtype == OFA_BF16)                                                                                  \
       hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t, NI>), grid, block, 0, st, (const bf16_t*)dy,                \
-                         (const bf16_t*)y, (bf16_t*)dx, scale, rows, sk);                                        \
+                         (const bf16_t*)y, (bf16_t*)dx, scale, rows, sk, causal);                                \
+    else                                                                                                         \
+      hipLaunchKernelGGL((softmax_bwd_kernel<f16_t, NI>), grid, block, 0, st, (const f16_t*)dy,                  \
+                         (const f16_t*)y, (f16_t*)dx, scale, rows, sk, causal);                                  \
   } while (0)
   if (ni <= 1) SM_CASE(1);
   else if (ni <= 2) SM_CASE(2);
@@ -165,6 +176,24 @@ extern "C" int ofa_scaled_softmax_bwd(const void* dy, const void* y, void* dx, f
   else SM_CASE(64);
 #undef SM_CASE
   return check_launch("softmax_bwd");
+}
+
+extern "C" int ofa_scaled_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int b, int np, int sq, int sk,
+                                      int dtype, void* stream) {
+  return softmax_bwd_launch(dy, y, dx, scale, (int64_t)b * np * sq, sk, 0, dtype, (hipStream_t)stream);
+}
+
+extern "C" int ofa_scaled_masked_softmax_bwd(const void* dy, const void* y, void* dx, float scale, int b, int np, int sq,
+                                             int sk, int dtype, void* stream) {
+  // scaled_masked_softmax.cpp:60-77 -> scaled_masked_softmax_cuda.cu:84-117: the mask does not enter the backward (masked
+  // probabilities are ~exp(-10000) = 0 and carry their own zero)
+  return softmax_bwd_launch(dy, y, dx, scale, (int64_t)b * np * sq, sk, 0, dtype, (hipStream_t)stream);
+}
+
+extern "C" int ofa_scaled_upper_triang_masked_softmax_bwd(const void* dy, const void* y, void* dx, float scale,
+                                                          int attn_batches, int sq, int dtype, void* stream) {
+  // scaled_upper_triang_masked_softmax.cpp:49-64 -> _cuda.cu:68-95: [attn_batches, sq, sq], zero above the diagonal
+  return softmax_bwd_launch(dy, y, dx, scale, (int64_t)attn_batches * sq, sq, 1, dtype, (hipStream_t)stream);
 }
 
 extern "C" int ofa_scaled_masked_softmax_fwd(const void* x, const uint8_t* mask, void* y, float scale, int b, int np,

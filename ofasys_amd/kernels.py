@@ -241,11 +241,13 @@ def gemm_heads(a, b, out, M, N, K, trans_a, trans_b, lda, ldb, ldc, B, heads, sa
 
 
 # ------------------------------------------------------------------ softmax family
+# (the reference's three pybind extensions, fused_kernels/fused_softmax.py:12-92: forward(inputs, [mask,] scale) and
+#  backward(output_grads, softmax_results, scale), fp32 / bf16 / fp16)
 def scaled_softmax(x, scale):
     x = x.contiguous()
     b, np_, sq, sk = x.shape
     y = torch.empty_like(x)
-    lib().call("ofa_scaled_softmax_fwd", ptr(x), ptr(y), float(scale), b, np_, sq, sk, dtype_code(x), stream())
+    lib().call("ofa_scaled_softmax_fwd", ptr(x), ptr(y), float(scale), b, np_, sq, sk, dtype_code(x, True), stream())
     return y
 
 
@@ -254,7 +256,7 @@ def scaled_softmax_bwd(dy, y, scale, inplace=False):
     y = y.contiguous()
     rows = y.numel() // y.shape[-1]
     dx = dy if inplace else torch.empty_like(dy)
-    lib().call("ofa_scaled_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), 1, 1, rows, y.shape[-1], dtype_code(y),
+    lib().call("ofa_scaled_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), 1, 1, rows, y.shape[-1], dtype_code(y, True),
                stream())
     return dx
 
@@ -265,8 +267,18 @@ def scaled_masked_softmax(x, mask, scale):
     b, np_, sq, sk = x.shape
     y = torch.empty_like(x)
     lib().call("ofa_scaled_masked_softmax_fwd", ptr(x), ptr(mask), ptr(y), float(scale), b, np_, sq, sk, mask.shape[0],
-               dtype_code(x), stream())
+               dtype_code(x, True), stream())
     return y
+
+
+def scaled_masked_softmax_bwd(dy, y, scale, inplace=True):
+    """In place on dy by default, as the reference's extension (scaled_masked_softmax_cuda.cu:98-117)."""
+    assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and y.dim() == 4
+    b, np_, sq, sk = y.shape
+    dx = dy if inplace else torch.empty_like(dy)
+    lib().call("ofa_scaled_masked_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), b, np_, sq, sk, dtype_code(y, True),
+               stream())
+    return dx
 
 
 def scaled_upper_triang_masked_softmax(x, scale):
@@ -274,8 +286,17 @@ def scaled_upper_triang_masked_softmax(x, scale):
     ab, sq, sk = x.shape
     assert sq == sk
     y = torch.empty_like(x)
-    lib().call("ofa_scaled_upper_triang_masked_softmax_fwd", ptr(x), ptr(y), float(scale), ab, sq, dtype_code(x), stream())
+    lib().call("ofa_scaled_upper_triang_masked_softmax_fwd", ptr(x), ptr(y), float(scale), ab, sq, dtype_code(x, True), stream())
     return y
+
+
+def scaled_upper_triang_masked_softmax_bwd(dy, y, scale, inplace=True):
+    """In place on dy by default (scaled_upper_triang_masked_softmax_cuda.cu:68-95); dx is zero above the diagonal."""
+    assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and y.dim() == 3 and y.shape[1] == y.shape[2]
+    dx = dy if inplace else torch.empty_like(dy)
+    lib().call("ofa_scaled_upper_triang_masked_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), y.shape[0], y.shape[1],
+               dtype_code(y, True), stream())
+    return dx
 
 
 def get_batch_per_block(sq, sk, b, np_):

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ofasys_amd.h")
 LIB_PATH = os.environ.get("OFASYS_AMD_LIB") or os.path.join(_HERE, "libofasys_amd.so")   # override: kernel experiments
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_ACCUM, GEMM_FORCE_SIMPLE, GEMM_OUT_F32 = 1, 2, 4, 8, 16
 
 _CTYPES = {
@@ -79,11 +79,14 @@ def lib():
     return _lib
 
 
-def dtype_code(t):
+def dtype_code(t, allow_f16=False):
+    """ofa_dtype of a tensor.  fp16 is accepted only where the C ABI declares it (the fused-softmax entry points)."""
     if t.dtype == torch.float32:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if allow_f16 and t.dtype == torch.float16:
+        return F16
     raise OfaError(f"ofasys_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
 
 

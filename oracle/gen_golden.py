@@ -126,6 +126,33 @@ def softmax_vectors():
     print("fused_softmax ok")
 
 
+def softmax_bwd_vectors():
+    """Golden vectors for the BACKWARD entry points of the three fused-softmax extensions and for their fp16 dtype
+    (scaled_masked_softmax.cpp:60-77, scaled_upper_triang_masked_softmax.cpp:49-64, scaled_softmax_cuda.cu:84-117): autograd
+    through the reference's own forward_torch_softmax (fused_kernels/fused_softmax.py:187-202), in fp32 and with fp16 inputs
+    (input_in_fp16, softmax_in_fp32 -- the configuration the reference routes to the kernels, multihead_attention.py:83-91)."""
+    install()
+    from ofasys.module.fused_kernels.fused_softmax import FusedScaleMaskSoftmax
+    fill = lambda a, mask: a.masked_fill(mask.bool(), -10000.0)        # noqa: E731
+    scale = 0.37
+    b, np_, sq = 2, 3, 40
+    x = recipe.floats("softmax_bwd.x", (b, np_, sq, sq), 2.0)
+    dy = recipe.floats("softmax_bwd.dy", (b, np_, sq, sq), 1.0)
+    mask = recipe.floats("softmax_bwd.mask", (b, 1, sq, sq)) > 0.8
+    causal = torch.triu(torch.ones(sq, sq, dtype=torch.bool), 1).expand(b, 1, sq, sq)
+    out = {"x": x.numpy(), "dy": dy.numpy(), "mask": mask.numpy().astype(np.uint8), "scale": np.array([scale], dtype=np.float32)}
+    for tag, half in (("f32", False), ("f16", True)):
+        m = FusedScaleMaskSoftmax(half, False, "pad", True, fill, True, scale)
+        for name, mk in (("plain", None), ("masked", mask), ("causal", causal)):
+            xi = (x.half() if half else x.clone()).requires_grad_(True)
+            y = m.forward_torch_softmax(xi, mk)
+            y.backward(dy.half() if half else dy)
+            out[f"{tag}.{name}.y"] = y.detach().numpy()
+            out[f"{tag}.{name}.dx"] = xi.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "fused_softmax_bwd.npz"), **out)
+    print("fused_softmax_bwd ok")
+
+
 def ls_ce_vectors():
     """Golden vectors of the label-smoothed criterion: the reference's own label_smoothed_nll_loss
     (engine/criterion/label_smoothed_cross_entropy.py:62-94) on log-probs prepared exactly as get_constraint_masks /
@@ -188,6 +215,9 @@ def box_vectors():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) == 2 and sys.argv[1] == "--softmax-bwd":
+        softmax_bwd_vectors()
+        sys.exit(0)
     if len(sys.argv) == 3 and sys.argv[1] == "--case":
         run_case(sys.argv[2], CASES[sys.argv[2]])
         sys.exit(0)
@@ -197,6 +227,7 @@ if __name__ == "__main__":
     for name in CASES:
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
     softmax_vectors()
+    softmax_bwd_vectors()
     ls_ce_vectors()
     box_vectors()
     manifest = {

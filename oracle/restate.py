@@ -658,6 +658,38 @@ def cross_entropy(logits, target, pad_idx=1):
 
 
 # --------------------------------------------------------------------------------------------
+# train-step update arithmetic -- pinned by tests/golden/trainstep.npz
+# --------------------------------------------------------------------------------------------
+def multiply_clip(grads, sample_size, clip_norm, world=1):
+    """engine/trainer.py:849-860 `multiply_grads(world / sum(task_sample_size))` (after DDP's division by world the net factor on
+    the SUM of gradients is 1/sum sample_size) + module/utils.py:342-384 `clip_grad_norm_`: total_norm = || [ ||g||_2 per tensor ] ||_2
+    in fp32, clip_coef = clamp(max_norm / (total_norm + 1e-6), max=1).  grads: {key: tensor or None}, modified copies returned.
+    -> (grads, total_norm, clip_coef)"""
+    c = world / (sample_size or 1.0) / world
+    out = {k: (None if g is None else g.detach().float() * c) for k, g in grads.items()}
+    norms = [torch.norm(g, p=2, dtype=torch.float32) for g in out.values() if g is not None]
+    total = torch.norm(torch.stack(norms)) if norms else torch.tensor(0.0)
+    coef = 1.0
+    if clip_norm > 0:
+        coef = float((clip_norm / (total + 1e-6)).clamp(max=1))
+        out = {k: (None if g is None else g * coef) for k, g in out.items()}
+    return out, float(total), coef
+
+
+def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay):
+    """engine/optim/adam.py:192-212 (class `Adam`, the AdamW-style decoupled decay), one tensor, in place; `step` is the
+    1-based update count.  fp32 throughout (the reference keeps fp32 copies of low-precision params, :163-165, :214-215)."""
+    b1, b2 = betas
+    exp_avg.mul_(b1).add_(grad, alpha=1 - b1)
+    exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+    denom = exp_avg_sq.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    if weight_decay != 0:
+        param.add_(param, alpha=-weight_decay * lr)
+    param.addcdiv_(exp_avg, denom, value=-step_size)
+
+
+# --------------------------------------------------------------------------------------------
 # the reference's fused-softmax extensions (SURVEY.md section 2a) restated
 # --------------------------------------------------------------------------------------------
 def label_smoothed_cross_entropy(logits, target, eps, pad_idx=1, constraint_range=None, constraint_masks=None,

@@ -13,6 +13,7 @@ def test_header_parses_and_library_exports_every_symbol():
     assert len(protos) >= 40
     for must in ("ofa_gemm", "ofa_attn_fwd", "ofa_attn_bwd", "ofa_layernorm_fwd", "ofa_layernorm_bwd",
                  "ofa_scaled_softmax_fwd", "ofa_scaled_masked_softmax_fwd", "ofa_scaled_upper_triang_masked_softmax_fwd",
+                 "ofa_scaled_softmax_bwd", "ofa_scaled_masked_softmax_bwd", "ofa_scaled_upper_triang_masked_softmax_bwd",
                  "ofa_get_batch_per_block", "ofa_embedding_bwd", "ofa_cross_entropy_fwd", "ofa_adam_step", "ofa_version",
                  "ofa_last_error", "ofa_im2col_patch", "ofa_bias_block_add"):
         assert must in protos
@@ -39,6 +40,12 @@ def test_status_codes_not_asserts():
         h.call("ofa_layernorm_fwd", None, None, None, None, None, None, 4, 6, 1e-5, L.BF16, None)   # cols % 8 != 0
     with pytest.raises(L.OfaError, match="sk"):
         h.call("ofa_scaled_softmax_fwd", 1, 1, 1.0, 1, 1, 4, 5000, L.F32, None)                       # sk > 4096
+    with pytest.raises(L.OfaError, match="sk"):                                                        # same precondition, backward
+        h.call("ofa_scaled_masked_softmax_bwd", 1, 1, 1, 1.0, 1, 1, 4, 5000, L.F16, None)
+    with pytest.raises(L.OfaError, match="dtype"):
+        h.call("ofa_scaled_upper_triang_masked_softmax_bwd", 1, 1, 1, 1.0, 1, 8, 7, None)
+    with pytest.raises(L.OfaError, match="dtype"):                                                     # fp16: softmax entry points only
+        h.call("ofa_layernorm_fwd", 1, 1, 1, 1, 1, 1, 4, 8, 1e-5, L.F16, None)
     with pytest.raises(L.OfaError, match="bf16"):
         h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, L.F32, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, L.F32, None)
 

@@ -127,13 +127,52 @@ def test_gemm_splitk_and_batched(K):
     assert rel(out[:, :, :40], ref) < 1e-2 and float(out[:, :, 40:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_softmax_backward_golden(K, golden_dir):
+    """The three backward entry points + the fp16 dtype against autograd through the reference's own forward_torch_softmax
+    (tests/golden/fused_softmax_bwd.npz): in place on dy, zero above the diagonal for the causal variant."""
+    import numpy as np
+    g = np.load(golden_dir + "/fused_softmax_bwd.npz")
+    scale = float(g["scale"][0])
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    b, np_, sq, _ = g["x"].shape
+    for tag, dt, ytol, dtol in (("f32", torch.float32, 1e-6, 5e-6), ("f16", torch.float16, 1e-3, 2e-3)):
+        x = torch.from_numpy(g["x"]).to(DEV).to(dt)
+        dy = torch.from_numpy(g["dy"]).to(DEV).to(dt)
+        for name in ("plain", "masked", "causal"):
+            if name == "plain":
+                y = K.scaled_softmax(x, scale)
+            elif name == "masked":
+                y = K.scaled_masked_softmax(x, mask, scale)
+            else:
+                y = K.scaled_upper_triang_masked_softmax(x.view(-1, sq, sq), scale).view(b, np_, sq, sq)
+            assert y.dtype == dt
+            assert rel(y.float().cpu(), torch.from_numpy(g[f"{tag}.{name}.y"].astype(np.float32))) < ytol, (tag, name)
+            d = dy.clone()
+            if name == "plain":
+                dx = K.scaled_softmax_bwd(d, y, scale, inplace=True)
+            elif name == "masked":
+                dx = K.scaled_masked_softmax_bwd(d, y, scale)
+            else:
+                d3 = d.view(-1, sq, sq)
+                d3 += torch.triu(torch.full_like(d3, float("nan")), 1)          # never read above the diagonal
+                dx = K.scaled_upper_triang_masked_softmax_bwd(d3, y.view(-1, sq, sq), scale).view(b, np_, sq, sq)
+                assert float(torch.triu(dx.float(), 1).abs().max()) == 0.0
+            assert dx.data_ptr() == d.data_ptr()                                 # completely in place, as the reference
+            assert rel(dx.float().cpu(), torch.from_numpy(g[f"{tag}.{name}.dx"].astype(np.float32))) < dtol, (tag, name)
+            if name != "plain":                                                  # out-of-place form gives the same bits
+                fn = K.scaled_masked_softmax_bwd if name == "masked" else K.scaled_upper_triang_masked_softmax_bwd
+                shp = y.shape if name == "masked" else (-1, sq, sq)
+                src = dy.clone().view(shp) if name == "masked" else dy.clone().view(shp)
+                assert torch.equal(fn(src, y.view(shp), scale, inplace=False).view(dx.shape), dx)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sk", [16, 40, 129, 448, 1000])
 def test_softmax_family(K, dtype, sk):
     from oracle import restate
     torch.manual_seed(3)
     x = (2 * torch.randn(2, 3, 8, sk, device=DEV)).to(dtype)
-    t = 1e-6 if dtype == torch.float32 else 1e-2
+    t = 1e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)
     y = K.scaled_softmax(x, 0.37)
     assert rel(y, restate.scaled_softmax(x.cpu(), 0.37).to(DEV)) < max(t, 1e-6)
     mask = torch.rand(2, 1, 8, sk, device=DEV) > 0.8

@@ -167,3 +167,25 @@ def test_incremental_decoding_with_finished_beams_matches_reference():
             logits.append(out[:, -1])
     assert rel_err(torch.stack(logits), gi["logits_padded"]) < TOL
     assert np.array_equal(inc[(1, "self")]["prev_key_padding_mask"].float().numpy(), gi["kpm_padded_l1"])
+
+
+def test_fused_softmax_backward_restatement_matches_reference():
+    """restate.scaled_*softmax* + scaled_softmax_bwd against autograd through the reference's forward_torch_softmax, fp32 and
+    fp16 (tests/golden/fused_softmax_bwd.npz).  In fp16 the extension's backward reads the ROUNDED fp16 probabilities
+    (scaled_masked_softmax.h:329-423) while the torch fallback differentiates through fp32 probabilities: <= 2e-3 apart."""
+    g = load_golden("fused_softmax_bwd")
+    scale = float(g["scale"][0])
+    x32, dy32 = torch.from_numpy(g["x"]), torch.from_numpy(g["dy"])
+    mask = torch.from_numpy(g["mask"])
+    b, np_, sq, _ = x32.shape
+    for tag, dt, tol in (("f32", torch.float32, 2e-6), ("f16", torch.float16, 2e-3)):
+        x, dy = x32.to(dt), dy32.to(dt)
+        ys = {"plain": restate.scaled_softmax(x, scale), "masked": restate.scaled_masked_softmax(x, mask, scale),
+              "causal": restate.scaled_upper_triang_masked_softmax(x.view(-1, sq, sq), scale).view(b, np_, sq, sq)}
+        for name, y in ys.items():
+            assert y.dtype == dt
+            assert rel_err(y.float(), g[f"{tag}.{name}.y"].astype(np.float32)) < (1e-6 if dt == torch.float32 else 1e-3), (tag, name)
+            dx = restate.scaled_softmax_bwd(dy, y, scale).to(dt)
+            assert rel_err(dx.float(), g[f"{tag}.{name}.dx"].astype(np.float32)) < tol, (tag, name)
+            if name == "causal":
+                assert float(torch.triu(dx.float(), 1).abs().max()) == 0.0

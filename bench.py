@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2:1 sparsity excluded)
+PEAK_HBM_GBPS = 8000.0        # HBM3E, same guide
 V_TEXT = 50260                # 4 specials + 50260 <text>_i + <mask> + 1000 <bin>_i = 51265
 
 
@@ -48,9 +49,9 @@ def build(args, device):
     m = GeneralistModel()
     m.cfg.arch = args.arch
     m.__init__(m.cfg)
-    if getattr(args, "workload", "cfg2") == "cfg2b":
-        # cfg-2b: the default IMAGE adaptor (ResNet backbone) with the default biased attention
-        for name in ("text", "image_resnet"):
+    if getattr(args, "workload", "cfg2") in ("cfg2b", "cfg4"):
+        # cfg-2b / cfg-4: the default IMAGE / VIDEO adaptors (ResNet backbone) with the default biased attention
+        for name in ("text", "image_resnet") + (("video_image_sequence",) if args.workload == "cfg4" else ()):
             getattr(m.cfg.adaptor, name).is_active = True
         m.cfg.adaptor.image_resnet.resnet_type = "resnet101"
     else:
@@ -71,7 +72,17 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2"):
     from ofasys_amd import ModalityType, Slot
     g = torch.Generator().manual_seed(1234 + rank)
     V = len(d)
-    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16)
+    if workload == "cfg4":                                    # [VIDEO][TEXT] -> [TEXT]: 8 frames of 224 x 224, one zero frame in ~10% of rows
+        img = torch.randn(B, 3, 8, 224, 224, generator=g)
+        zero = torch.rand(B, generator=g) < 0.1
+        zero[min(1, B - 1)] = True
+        for b in range(B):
+            if zero[b]:
+                img[b, :, int(torch.randint(0, 8, (1,), generator=g))] = 0.0
+        img = img.to(torch.bfloat16)
+        nvis = B * 8 * 196 - int(zero.sum()) * 196
+    else:
+        img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16)
     src = torch.randint(4, V, (B, Ts_text), generator=g)
     slen = torch.randint(Ts_text // 2, Ts_text + 1, (B,), generator=g)
     slen[0] = Ts_text
@@ -86,11 +97,11 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2"):
         prev[b, n:] = d.pad()
         target[b, :n - 1] = prev[b, 1:n]
         target[b, n - 1] = d.eos()
-    patch = workload != "cfg2b"
-    slots = [Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"] if patch else None),
-             Slot(ModalityType.TEXT, True, src.to(device)),
-             Slot(ModalityType.TEXT, False, prev.to(device))]
-    ntok = B * (257 if patch else 196) + int(slen.sum()) + int(tlen.sum())
+    patch = workload == "cfg2"
+    first = Slot(ModalityType.VIDEO, True, img.to(device)) if workload == "cfg4" else \
+        Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"] if patch else None)
+    slots = [first, Slot(ModalityType.TEXT, True, src.to(device)), Slot(ModalityType.TEXT, False, prev.to(device))]
+    ntok = (nvis if workload == "cfg4" else B * (257 if patch else 196)) + int(slen.sum()) + int(tlen.sum())
     return {"slots": slots, "target": target.to(device)}, ntok
 
 
@@ -173,51 +184,99 @@ def cpu_baseline(args):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the MFMA GEMM kernels from the committed rocprofv3 PMC passes (profiles/, produced by
-    tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on gfx950)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    try:
-        rows = json.load(open(path))
-    except (OSError, ValueError):
-        return None, None
-    n = tot = 0.0
-    for name, r in rows.items():
-        if "gemm_mfma_kernel" in name or "gemm_big_kernel" in name or "gemm_ring_kernel" in name:
-            n += r["launches"]
-            tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
-    return (tot / n, "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA GEMM "
-                     "instantiations of the eager cfg-2 step)") if n else (None, None)
+    """(HBM bytes per launch of the MFMA GEMM kernels, HBM bytes of one whole step, source) from the committed rocprofv3 PMC
+    passes (profiles/, produced by tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on
+    gfx950, tools/pmc_traffic.py)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        try:
+            rows = json.load(open(os.path.join(here, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        meta = rows.pop("__meta__", {})
+        n = tot = 0.0
+        for kname, r in rows.items():
+            if "gemm_" in kname and "_kernel" in kname and "simple" not in kname:
+                n += r["launches"]
+                tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
+        if n:
+            return tot / n, meta.get("bytes_per_step"), (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA "
+                                                         "GEMM instantiations of the eager cfg-2 step)")
+    return None, None, None
+
+
+WORKLOADS = {   # name -> (source text length, target length, visual tokens per sample, description)
+    "cfg2": (191, 64, 257, "cfg-2 image_caption: image_patch_embed 224x224 (257 tok) + text<=191 -> text<=64"),
+    "cfg2b": (252, 64, 196, "cfg-2b image_caption: image_resnet101 224x224 (196 tok, rel-pos biased attention) + text<=252 -> text<=64"),
+    "cfg4": (32, 32, 1568, "cfg-4 video_caption: 8 frames 224x224 through image_resnet101 (1568 tok, frame+image rel-pos bias) + "
+                           "text<=32 -> text<=32"),
+}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, 127.0.0.1 rendezvous."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: what RCCL needs on this host driver
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="base")
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 4 for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--profile-gemm", type=int, default=1, help="instrumented steps after the timed region")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg2b"],
-                    help="cfg2 (headline: image_patch_embed, bias-free) or cfg2b (image_resnet101 + biased attention, 196+252 -> 64)")
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS),
+                    help="cfg2 (headline: image_patch_embed, bias-free), cfg2b (image_resnet101 + biased attention, 196+252 -> 64) "
+                         "or cfg4 (video 8x224x224 -> 1568 tokens + 32 text -> 32, micro-batch 4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--dp-graph", default=None, choices=["full", "split"],
+                    help="N > 1: 'full' (default) captures the bucketed RCCL all-reduces inside the step graph, overlapped with "
+                         "backward; 'split' = two graphs around an eager all-reduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL, the product path); gloo only to smoke-test the N > 1 code path "
                          "on a one-GPU box together with OFA_BENCH_DEVICE=0 (all ranks on one device)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher plumbing only: init the process group, one all-reduce, print the JSON skeleton (runs without a GPU)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.workload == "cfg4" else 32
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import torch.distributed as dist
+    if args.launch_check:
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "launch-check", "n_gpus": int(t.item()), "world": world, "backend": "gloo"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if "OFA_BENCH_DEVICE" in os.environ:                          # test hook: several ranks on one GPU (gloo only)
         local_rank = int(os.environ["OFA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
@@ -226,31 +285,40 @@ def main():
         dist.all_reduce(torch.zeros(1, device=device))            # communicator warm-up (distributed/utils.py:240-241)
 
     from ofasys_amd import kernels as K
-    from ofasys_amd.trainer import Trainer
+    from ofasys_amd.trainer import TrainStep
     model, d = build(args, device)
     if world > 1:                                                  # identical initial weights on every rank
-        for p in model.parameters():
+        for p in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(p.data, 0)
     from ofasys_amd import ops
     ops.manual_seed(1 + rank)                                      # dropout streams differ per rank (fairseq: seed + rank)
-    trainer = Trainer(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph)
-    Ts_text, Tt = (191, 64) if args.workload == "cfg2" else (252, 64)
-    batch, ntok = make_batch(d, args.batch, Ts_text, Tt, rank, device, args.workload)
+    trainer = TrainStep(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph, dp_graph=args.dp_graph)
+    Ts_text, Tt, nvis, desc = WORKLOADS[args.workload]
+    # a few distinct batches of the same structure: replays copy each new batch into the graph's static inputs
+    batches = [make_batch(d, args.batch, Ts_text, Tt, rank + 97 * i, device, args.workload) for i in range(4)]
+    ntok = sum(n for _, n in batches) / len(batches)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_i = 0
+
+    def step():
+        nonlocal step_i
+        trainer.train_step([batches[step_i % len(batches)][0]])
+        step_i += 1
+
     if trainer.use_graph:                                          # setup: eager priming steps + the one-time graph capture
         for _ in range(trainer.graph_warmup + 1):
-            trainer.train_step([batch])
+            step()
     for _ in range(args.warmup):
-        trainer.train_step([batch])
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step([batch])
+        step()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -261,31 +329,41 @@ def main():
     dt = float(tmax)
     total_tokens = float(toks)
     ms_per_step = dt / args.steps * 1e3
+    graph_mode = "eager"
+    for e in trainer._graphs.values():
+        if "graphs" in e:
+            graph_mode = {1: "one hipGraph (collectives captured)" if world > 1 else "one hipGraph", 2: "two hipGraphs + eager all-reduce"}[len(e["graphs"])]
+    trainer.check()
 
     # dominant kernel: every MFMA GEMM launch of one step bracketed by HIP events on the launch stream
     prof = None
     if args.profile_gemm > 0:
         K.gemm_profile_begin()
         for _ in range(args.profile_gemm):
-            trainer.train_step([batch], eager=True)                # HIP events around each launch: not inside a graph
+            trainer.train_step([batches[0][0]], eager=True)        # HIP events around each launch: not inside a graph
         torch.cuda.synchronize()
         prof = K.gemm_profile_end()
 
     if rank == 0:
         cfg = model.cfg
-        if args.workload == "cfg2b":       # ResNet-101 stride-16 trunk ~ 6.9 GMAC/img + Linear(1024, D), biased attention
-            fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
-                                       cfg.encoder.layers, cfg.decoder.layers, 196 + Ts_text, Tt, len(d), patch_tokens=0,
-                                       bias=True) + 2 * 6.9e9 + 2 * 196 * 1024 * cfg.encoder.embed_dim
-        else:
-            fwd = fwd_flops_per_sample(cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim,
-                                       cfg.encoder.layers, cfg.decoder.layers, 257 + Ts_text, Tt, len(d))
+        dims = (cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim, cfg.encoder.layers, cfg.decoder.layers)
+        if args.workload == "cfg2":
+            fwd = fwd_flops_per_sample(*dims, 257 + Ts_text, Tt, len(d))
+        else:          # ResNet-101 stride-16 trunk ~ 6.9 GMAC per 224x224 image + Linear(1024, D), biased attention
+            frames = 8 if args.workload == "cfg4" else 1
+            fwd = fwd_flops_per_sample(*dims, nvis + Ts_text, Tt, len(d), patch_tokens=0, bias=True) + \
+                frames * (2 * 6.9e9 + 2 * 196 * 1024 * cfg.encoder.embed_dim)
         step_flops = 3 * fwd * args.batch                          # backward = 2x forward
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
+        traffic, step_bytes, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
                 "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS}
+        if step_bytes and args.workload == "cfg2":
+            roof["hbm"] = {"step_bytes": step_bytes, "achieved_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
+                           "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                           "how": "sum over every kernel of the step of rocprofv3 PMC FETCH_SIZE + WRITE_SIZE bytes (committed profile, "
+                                  "same command) / this run's step time"}
         if prof and prof["time_ms"] > 0:
             ach = prof["flops"] / (prof["time_ms"] * 1e-3) / 1e12
             roof.update({"achieved": ach, "frac": ach / PEAK_BF16_TFLOPS, "launches_per_step": prof["launches"] // args.profile_gemm,
@@ -303,14 +381,11 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "tokens_per_sec_per_gpu": total_tokens * args.steps / dt / world,
-            "config": {"workload": ("cfg-2 image_caption: image_patch_embed 224x224 (257 tok) + text<=191 -> text<=64, "
-                                    if args.workload == "cfg2" else
-                                    "cfg-2b image_caption: image_resnet101 224x224 (196 tok, rel-pos biased attention) + "
-                                    "text<=252 -> text<=64, ") +
-                                   "OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
+            "config": {"workload": desc + ", OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "padded_positions_per_sample": (257 if args.workload == "cfg2" else 196) + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
-                       "vocab": len(d), "parallelism": f"dp{world}", "random_init": True},
+                       "padded_positions_per_sample": nvis + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
+                       "vocab": len(d), "parallelism": f"dp{world}", "random_init": True, "step_mode": graph_mode,
+                       "distinct_batches": len(batches)},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -254,13 +254,17 @@ int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* 
               int64_t n, int dtype, void* stream);
 /* Scalar schedule of one update, on the device (one thread): gnorm = sqrt(gsq)/sample_size; sched[0] = (1/sample_size) *
  * min(1, clip_norm/(gnorm + 1e-6)) (trainer.py:857-884; no clipping when clip_norm <= 0); step += 1; sched[1] =
- * lr*sqrt(1-b2^step)/(1-b1^step); sched[2] = lr (adam.py:205-207).  sched feeds ofa_adam_step(step = 0). */
+ * lr*sqrt(1-b2^step)/(1-b1^step); sched[2] = lr (adam.py:205-207).  sched (fp32[5]) feeds ofa_adam_step(step = 0).
+ * Guard (trainer.py:866-876 raises FloatingPointError and skips optimizer.step): a non-finite gnorm or sample_size <= 0 gives
+ * sched = [0, 0, lr, skip = 1], leaves `step` unchanged and adds 1 to sched[4] (count of skipped updates, for the host to poll);
+ * otherwise sched[3] = 0. */
 int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
                       float* gnorm, float clip_norm, double beta1, double beta2, void* stream);
 /* Adam on fp32 master weights with grads of `dtype`; coef[0] = grad multiplier (world/sample_size and clip folded
  * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p).
- * step >= 1: bias correction from (lr, step) on the host.  step == 0: coef is device fp32[3] = [grad multiplier,
- * lr*sqrt(1-b2^t)/(1-b1^t), lr] -- the schedule state stays on the device (captured train steps). */
+ * step >= 1: bias correction from (lr, step) on the host.  step == 0: coef is device fp32[>=4] = [grad multiplier,
+ * lr*sqrt(1-b2^t)/(1-b1^t), lr, skip] -- the schedule state stays on the device (captured train steps); skip != 0 (set by
+ * ofa_step_schedule on a non-finite gradient norm) leaves master weights, both moments and the model copy untouched. */
 int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
                   const float* coef, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, int dtype, void* stream);

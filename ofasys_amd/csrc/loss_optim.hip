@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
                                                    const float* __restrict__ coef, int64_t n, float lr, float beta1,
                                                    float beta2, float eps, float wd, float step_size, int dev_sched) {
   const float gmul = coef ? coef[0] : 1.0f;
-  if (dev_sched) {                       // schedule state lives on the device: coef = [grad multiplier, step size, lr]
+  if (dev_sched) {                       // schedule state lives on the device: coef = [grad multiplier, step size, lr, skip]
+    if (coef[3] != 0.f) return;          // non-finite gradient norm / empty batch: parameters and both moments stay untouched
     step_size = coef[1];
     lr = coef[2];
   }
@@ -313,12 +314,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
 // One thread: the scalar arithmetic between the gradient norm and the Adam update, kept on the device so that a captured
 // train step replays it (trainer.py:857-884 clip + 1/sample_size, adam.py:205-207 bias corrections).  ~25 tiny torch
 // kernels otherwise, ~4.5 us each inside a hipGraph.
+// Guard (engine/trainer.py:866-876 raises FloatingPointError("gradients are Nan/Inf") and never reaches optimizer.step): when the
+// gradient norm is not finite or the step saw no target token (sample_size <= 0), sched = [0, 0, lr, 1] -- ofa_adam_step(step = 0)
+// then returns without touching master weights or moments -- the update counter does not advance, and sched[4] (a running count
+// of skipped updates) is incremented for the host to poll.
 __global__ void step_schedule_kernel(const float* __restrict__ gsq, const double* __restrict__ sample_size,
                                      double* __restrict__ step, const double* __restrict__ lr, float* __restrict__ sched,
                                      float* __restrict__ gnorm, float clip_norm, double beta1, double beta2) {
   if (threadIdx.x || blockIdx.x) return;
-  const float inv_n = (float)(1.0 / sample_size[0]);
+  const double n = sample_size[0];
+  const float inv_n = n > 0.0 ? (float)(1.0 / n) : 0.f;
   const float gn = sqrtf(gsq[0]) * inv_n;
+  gnorm[0] = n > 0.0 ? gn : __builtin_nanf("");
+  if (!(n > 0.0) || !isfinite(gn)) {
+    sched[0] = 0.f;
+    sched[1] = 0.f;
+    sched[2] = (float)lr[0];
+    sched[3] = 1.f;
+    sched[4] += 1.f;
+    return;
+  }
+  sched[3] = 0.f;
   float coef = inv_n;
   if (clip_norm > 0.f) coef *= fminf(clip_norm / (gn + 1e-6f), 1.0f);
   const double t = step[0] + 1.0;

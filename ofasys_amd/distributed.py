@@ -6,9 +6,11 @@ MI355X design: gradients already live in ONE flat arena (ofasys_amd/trainer.py),
 slice of it -- no gather/scatter copies.  Buckets are cut in reverse parameter order (the order backward produces
 them).  Every gradient contribution -- whether a HIP kernel accumulated it straight into the arena (ops._sink) or
 autograd's AccumulateGrad did -- calls `notify(i)`; once a parameter has received as many contributions as it did in
-the first (learning) step its bucket counts down, and a full bucket fires `all_reduce(async_op=True)` on its slice,
-so RCCL traffic over xGMI overlaps the remaining backward kernels.  Whatever is left (unused parameters, a step whose
-task mix differs from the learned one) is reduced at `finish()`, so the result never depends on the learned counts.
+the learning step of the SAME step structure its bucket counts down, and a full bucket fires `all_reduce(async_op=True)` on
+its slice, so RCCL traffic over xGMI overlaps the remaining backward kernels.  Counts are keyed on the step's full structure
+(trainer.sample_structure: slot modalities / attributes, every tensor shape) -- two steps with the same key run the same
+autograd graph, so the counts are exact; a contribution that still arrives for a bucket already in flight raises instead of
+racing the collective.  Whatever is left (unused parameters, the learning step itself) is reduced at `finish()`.
 Bucket size defaults to 64 MiB: xGMI rings are per-link bound (~153 GB/s/link), large messages amortise the
 per-collective latency, and 288 GB of HBM makes the arena free.
 """
@@ -57,11 +59,14 @@ class GradBucketReducer:
     def _make_notify(self, i):
         return lambda: self.notify(i)
 
+    def knows(self, signature):
+        return signature is not None and signature in self._learned
+
     def begin_step(self, signature=None):
-        """`signature` identifies the step's structure (which tasks / how many micro-batches); early bucket launches are
-        only armed for a structure whose contribution counts were learned on an earlier, identical step."""
+        """`signature` identifies the step's structure (trainer.sample_structure); early bucket launches are only armed for a
+        structure whose contribution counts were learned on an earlier, identical step (None: never armed, never learned)."""
         self._sig = signature
-        self.expected = self._learned.get(signature) if self.overlap else None
+        self.expected = self._learned.get(signature) if (self.overlap and signature is not None) else None
         self._reset()
 
     def notify(self, i):
@@ -69,6 +74,11 @@ class GradBucketReducer:
         self._count[i] += 1
         if self.world == 1 or self.expected is None:
             return
+        if self._count[i] > self.expected[i] or self._launched[self.param_bucket[i]]:
+            raise RuntimeError(
+                f"GradBucketReducer: parameter {i} received contribution #{self._count[i]} but {self.expected[i]} were learned "
+                "for this step structure (its bucket's all-reduce may already be in flight): the structure key does not "
+                "determine the autograd graph -- pass a distinguishing 'task' entry in the samples")
         if self._count[i] == self.expected[i]:
             b = self.param_bucket[i]
             self._pending[b] -= 1
@@ -78,9 +88,6 @@ class GradBucketReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self._launched[b] = True
-        if self.flat_grad.is_cuda:
-            from . import ops
-            ops.side_join()                        # weight-gradient kernels run on a side stream: order them before the collective
         self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _reset(self):
@@ -103,7 +110,7 @@ class GradBucketReducer:
                     self._launch(b)
             for h in self._handles:
                 h.wait()
-        if self.expected is None and self.overlap:
+        if self.expected is None and self.overlap and self._sig is not None:
             self._learned[self._sig] = list(self._count)
         self._reset()
 

@@ -1,0 +1,159 @@
+"""`Trainer().fit(model, tasks)`: the user-facing training entry point (reference: engine/trainer.py:60-140 `Trainer.fit`,
+:737-979 `train_step`; scripts/trainer_api.py:1-27).  A thin facade over what the hot path needs:
+
+    dictionary <- tasks           task.initialize(global_dict)                      (trainer.py:118-121)
+    adaptors   <- instructions    Task.upgrade_model_adaptor_cfg(tasks, model.cfg)  (trainer.py:124)
+    model.initialize(global_dict) ; model -> GPU, bf16 (fp32 on request)            (trainer.py:125, 214-221)
+    every update: one micro-batch list per task -> TrainStep.train_step             (trainer.py:747-884)
+    lr: polynomial decay with linear warm-up (default_trainer.yaml:27-28, lr_scheduler/ofa_polynomial_decay)
+
+Out of scope: CLI / hydra config tree, checkpoints, metrics / logging back-ends, validation loops, EMA,
+FSDP / BMUF.  One process per GPU: when WORLD_SIZE > 1 (torch.distributed.run) the process group is initialised on RCCL.
+"""
+import logging
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from .preprocessor import Dictionary, to_device
+from .task import Task
+from .trainer import TrainStep
+
+logger = logging.getLogger("ofasys_amd")
+
+
+@dataclass
+class CommonConfig:
+    seed: int = 1
+    bf16: bool = True              # the reference defaults to fp16 + dynamic loss scaling (default_trainer.yaml:7-8); the MI355X
+    fp32: bool = False             # build computes in bf16 (same 8-bit exponent as fp32: no loss scaler needed) or fp32
+    log_interval: int = 10
+    use_graph: bool = True
+
+
+@dataclass
+class OptimizationConfig:          # default_trainer.yaml:16-28
+    max_update: int = 10000
+    clip_norm: float = 1.0
+    lr: List[float] = field(default_factory=lambda: [1e-5])
+    warmup_ratio: float = 0.06
+    end_learning_rate: float = 0.0
+    power: float = 1.0
+
+
+@dataclass
+class OptimizerConfig:
+    adam_betas: tuple = (0.9, 0.999)
+    adam_eps: float = 1e-8
+    weight_decay: float = 0.01
+
+
+@dataclass
+class TrainerConfig:
+    common: CommonConfig = field(default_factory=CommonConfig)
+    optimization: OptimizationConfig = field(default_factory=OptimizationConfig)
+    optimizer: OptimizerConfig = field(default_factory=OptimizerConfig)
+
+
+def polynomial_decay_lr(step, base_lr, max_update, warmup_ratio, end_lr=0.0, power=1.0):
+    """Linear warm-up over warmup_ratio*max_update updates, then polynomial decay to end_lr at max_update."""
+    warm = int(warmup_ratio * max_update)
+    if warm > 0 and step <= warm:
+        return base_lr * step / warm
+    if step >= max_update:
+        return end_lr
+    frac = 1.0 - (step - warm) / max(1, max_update - warm)
+    return (base_lr - end_lr) * frac ** power + end_lr
+
+
+class Trainer:
+    def __init__(self, cfg: Optional[TrainerConfig] = None, **overrides):
+        """overrides: max_update=, lr=, clip_norm=, seed=, fp32=, use_graph=, log_interval=, weight_decay= (flat shortcuts)."""
+        self.cfg = cfg or TrainerConfig()
+        for k, v in overrides.items():
+            for section in (self.cfg.common, self.cfg.optimization, self.cfg.optimizer):
+                if hasattr(section, k):
+                    setattr(section, k, [v] if k == "lr" and not isinstance(v, (list, tuple)) else v)
+                    break
+            else:
+                raise TypeError(f"unknown trainer option {k}")
+        self.global_dict = None
+        self.step_engine: Optional[TrainStep] = None
+        self.history = []
+
+    # ------------------------------------------------------------------ set-up
+    def _init_distributed(self):
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
+        return rank, world, torch.device("cuda", local)
+
+    def setup(self, model, tasks: List[Task]):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ofasys_amd.Trainer needs an MI355X: the HIP path is the only path (no CPU fallback)")
+        cfg = self.cfg
+        rank, world, device = self._init_distributed()
+        torch.manual_seed(cfg.common.seed)
+        self.global_dict = Dictionary()
+        for task in tasks:
+            task.initialize(self.global_dict, is_train=True)
+        Task.upgrade_model_adaptor_cfg(tasks, model.cfg)
+        model.initialize(self.global_dict)
+        model.to(device)
+        if not cfg.common.fp32:
+            model.to(torch.bfloat16)
+        if world > 1:
+            import torch.distributed as dist
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0)
+        from . import ops
+        ops.manual_seed(cfg.common.seed + rank)                     # dropout streams differ per rank (fairseq: seed + rank)
+        crit = tasks[0].cfg.criterion
+        self.step_engine = TrainStep(model, lr=cfg.optimization.lr[0], betas=tuple(cfg.optimizer.adam_betas), eps=cfg.optimizer.adam_eps,
+                                     weight_decay=cfg.optimizer.weight_decay, clip_norm=cfg.optimization.clip_norm,
+                                     use_graph=cfg.common.use_graph, label_smoothing=crit.label_smoothing,
+                                     drop_worst_ratio=crit.drop_worst_ratio)
+        for task in tasks:
+            task.init_data_iterator("train", rank, world)
+        self._device, self._rank, self._world = device, rank, world
+        self._float_dtype = torch.float32 if cfg.common.fp32 else torch.bfloat16
+        return self.step_engine
+
+    def _micro_batches(self, tasks):
+        """samples[task][i] of engine/trainer.py:747-766, flattened: update_freq micro-batches of every task, on the device."""
+        out = []
+        for task in tasks:
+            for _ in range(task.cfg.dataset.update_freq):
+                s = to_device(task.get_sample("train"), self._device, self._float_dtype)
+                mb = {"slots": s["net_input"]["slots"], "target": s["target"], "task": task.name}
+                if s.get("constraint_masks") is not None:
+                    mb["constraint_masks"] = s["constraint_masks"]
+                out.append(mb)
+        return out
+
+    # ------------------------------------------------------------------ the loop
+    def fit(self, model, tasks: List[Task]):
+        cfg = self.cfg
+        engine = self.setup(model, tasks)
+        base_lr = cfg.optimization.lr[0]
+        for update in range(1, cfg.optimization.max_update + 1):
+            engine.lr = polynomial_decay_lr(update, base_lr, cfg.optimization.max_update, cfg.optimization.warmup_ratio,
+                                            cfg.optimization.end_learning_rate, cfg.optimization.power)
+            out = engine.train_step(self._micro_batches(tasks))
+            if update % cfg.common.log_interval == 0 or update == cfg.optimization.max_update:
+                engine.check()                                       # FloatingPointError on Nan/Inf gradients (trainer.py:866-876)
+                n, loss = float(out["stats"][0]), float(out["stats"][1])
+                rec = {"update": update, "loss": loss / max(n, 1.0) / 0.6931471805599453, "sample_size": n,
+                       "gnorm": float(out["gnorm"]), "lr": engine.lr}
+                self.history.append(rec)
+                if self._rank == 0:
+                    logger.info("update %(update)d | loss %(loss).4f (base 2 per token) | sample_size %(sample_size)d | "
+                                "gnorm %(gnorm).3f | lr %(lr).3g", rec)
+        torch.cuda.synchronize()
+        return self.history

@@ -11,10 +11,6 @@ import torch.nn as nn
 from .. import ops
 
 
-import os
-_NO_FORK = bool(os.environ.get("OFA_NO_LN_FORK"))          # A/B switch: separate residual-gradient add
-
-
 class OfaLayerNorm(nn.LayerNorm):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
@@ -22,8 +18,6 @@ class OfaLayerNorm(nn.LayerNorm):
     def fork(self, x):
         """(residual, LayerNorm(x)) for the pre-LN pattern `residual = x; x = LN(x)`: one autograd node whose backward adds
         the residual-branch gradient inside the LayerNorm kernel."""
-        if _NO_FORK:
-            return x, self.forward(x)
         return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
 
 

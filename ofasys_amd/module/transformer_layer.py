@@ -10,7 +10,6 @@ Fusions relative to the reference's op-by-op graph (same arithmetic, fewer HBM r
 Only the configuration space of OFASys' GeneralistModel is implemented: pre- or post-LN, scale_attn / scale_fc /
 scale_heads / scale_resids; modal_ffn (single-device MoE) and cross_self_attention are refused loudly.
 """
-import os
 from typing import Dict, List, Optional
 
 import torch
@@ -20,10 +19,6 @@ from torch import Tensor
 from .. import ops
 from .layers import Dropout, DropPath, LayerNorm, OfaLinear
 from .multihead_attention import MultiheadAttention
-
-
-_NO_JOIN = bool(os.environ.get("OFA_NO_JOIN"))
-_NO_JOIN_BIAS = bool(os.environ.get("OFA_NO_JOIN_BIAS"))          # experiments: keep the Linears' own bias column sums
 
 
 class LayerChain:
@@ -50,7 +45,7 @@ def _act_name(cfg):
 class _FFNMixin:
     def _joinable(self):
         """The fused residual joins cover the pre-LN layer without scale_resids / DropPath (OFASys' defaults)."""
-        return (self.normalize_before and self.w_resid is None and not _NO_JOIN
+        return (self.normalize_before and self.w_resid is None
                 and (self.drop_path.drop_prob == 0.0 or not self.training))
 
     def _join(self, x, residual, ln_a, ln_b, x_bias=None):
@@ -64,7 +59,7 @@ class _FFNMixin:
         are free in the join's backward kernel; a separate pass re-reads the whole gradient)?  Training with gradient
         sinks on every parameter involved only."""
         ps = [bias] + [q for ln in (ln_a, ln_b) if ln is not None for q in (ln.weight, ln.bias)]
-        return self.training and not _NO_JOIN_BIAS and ops.join_takes_bias_grad(*ps)
+        return self.training and ops.join_takes_bias_grad(*ps)
 
     def _ffn(self, x, normed=None, chain=None):
         """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494.

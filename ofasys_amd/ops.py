@@ -121,66 +121,6 @@ def _fold():
     return q
 
 
-# Weight / bias gradients that land in the arena have no consumer until the end of backward (reducer, clip, Adam), so
-# they run on a SIDE HIP stream: the MFMA-bound wgrad GEMMs overlap the HBM-bound LayerNorm / dropout / attention
-# backward kernels and the dgrad chain on the main stream, and each GEMM's output burst hides under the other stream's
-# work.  Ordering: side waits for main at every launch (its inputs were just produced there); main waits for side once,
-# in a callback at the end of the backward pass (`side_join`, also called by the bucket reducer before an all-reduce).
-class _Side:
-    enabled = False                                # measured on cfg-2 (graph replay): 20.8 ms with, 20.4 ms without -> off by default
-    stream = None
-    pending = False
-    queued = False
-    keep = []                                      # inputs of in-flight side kernels, released at the join
-
-    @classmethod
-    def get(cls):
-        if cls.stream is None:
-            cls.stream = torch.cuda.Stream()
-        return cls.stream
-
-
-def side_stream():
-    """The side stream (created on first use; call before a graph capture begins)."""
-    return _Side.get()
-
-
-def side_stream_enabled(flag=None):
-    if flag is not None:
-        _Side.enabled = bool(flag)
-    return _Side.enabled
-
-
-def side_join():
-    """Make the current stream wait for every side-stream gradient kernel queued so far."""
-    _Side.queued = False
-    if _Side.pending:
-        torch.cuda.current_stream().wait_stream(_Side.get())
-        _Side.pending = False
-    _Side.keep.clear()                             # freed blocks return to the main stream, which is now ordered behind side
-
-
-def _on_side(fn, *inputs):
-    """Run fn() (kernel launches that only WRITE arena gradients) on the side stream, after everything already queued on
-    the current stream; `inputs` are the tensors it reads (kept alive until the side stream is done with them)."""
-    if not _Side.enabled:
-        fn()
-        return
-    cur = torch.cuda.current_stream()
-    side = _Side.get()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        fn()
-    _Side.keep.append(inputs)                      # (not record_stream: that is not capturable into a hipGraph)
-    _Side.pending = True
-    if not _Side.queued:
-        try:                                       # only legal while the autograd engine is running a backward pass
-            torch.autograd.Variable._execution_engine.queue_callback(side_join)
-            _Side.queued = True
-        except RuntimeError:
-            side_join()
-
-
 # ---------------------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
@@ -349,14 +289,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _sink(weight)
             if gw is not None:                                                       # dW += dY^T X, in the arena
-                _on_side(lambda: K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True, fold=_fold()), dy, x2d)
+                K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True, fold=_fold())
                 _sink_done(weight)
             else:
                 dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                   # dW = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _sink(ctx.bias_ref)
             if gb is not None:
-                _on_side(lambda: K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True, fold=_fold()), dy)
+                K.colsum(dy, alpha=ctx.alpha, out=gb, accumulate=True, fold=_fold())
                 _sink_done(ctx.bias_ref)
             else:
                 db = K.colsum(dy, alpha=ctx.alpha, out_dtype=weight.dtype)
@@ -398,7 +338,7 @@ class LinearGeluLayerNormFn(torch.autograd.Function):
         gw = _sink(weight)
         dw = None
         if gw is not None:
-            _on_side(lambda: K.gemm(dh, x2d, True, False, out=gw, accumulate=True, fold=_fold()), dh, x2d)
+            K.gemm(dh, x2d, True, False, out=gw, accumulate=True, fold=_fold())
             _sink_done(weight)
         else:
             dw = K.gemm(dh, x2d, True, False)
@@ -580,10 +520,9 @@ def _packed(ws, arena_view):
 
 
 def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
-    """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (on the side stream; and
-    notify the sinks); otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
+    """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (and notify the sinks); otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
     if gview is not None:
-        _on_side(lambda: grad_packed_fn(gview, True, _fold()), *inputs)
+        grad_packed_fn(gview, True, _fold())
         for w in ws:
             _sink_done(w)
         return [None] * len(ws)

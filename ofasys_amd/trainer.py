@@ -12,6 +12,8 @@ Step arithmetic reproduced:
 The multiply, the clip coefficient and Adam are ONE kernel pass over the flat arena (coef stays on the device: no host
 sync anywhere in the step).
 """
+import os
+import warnings
 from typing import List, Optional
 
 import torch
@@ -97,20 +99,75 @@ class FlatParams:
 _CAPTURE_MODE = "thread_local"
 
 
-class Trainer:
+class _Uncapturable(Exception):
+    """A sample holds something the static-input walker does not understand: the step must stay eager."""
+
+
+def _walk(obj, path, out):
+    """Collect every tensor of a sample (slot values may be tensors, dicts or lists of tensors -- audio slots carry
+    {fbank, fbank_lengths, mask_indices}) as (path, tensor), depth first, in a deterministic order."""
+    if torch.is_tensor(obj):
+        out.append((path, obj))
+    elif isinstance(obj, dict):
+        for k in obj:                                  # insertion order: the same code builds every batch of a structure
+            _walk(obj[k], path + (k,), out)
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            _walk(v, path + (i,), out)
+    elif hasattr(obj, "modality") and hasattr(obj, "is_src"):           # a Slot
+        _walk(obj.value, path + ("value",), out)
+    elif obj is None or isinstance(obj, (str, int, float, bool)):
+        pass
+    else:
+        raise _Uncapturable(f"{'/'.join(map(str, path))}: {type(obj).__name__}")
+
+
+def sample_tensors(samples):
+    """[(path, tensor)] over every micro-batch: all slot values, `target`, `constraint_masks` and any other tensor-valued
+    entry of the sample dict (what a replay must copy into the graph's static inputs)."""
+    out = []
+    for i, s in enumerate(samples):
+        for k in s:
+            _walk(s[k], (i, k), out)
+    return out
+
+
+def sample_structure(samples):
+    """Hashable structure of a step: per micro-batch the task key, per slot (modality, side, attributes), and per tensor
+    (path, shape, dtype).  Two steps with the same structure run the same kernels on the same shapes -- the key of the graph
+    cache and of the reducer's learned contribution counts."""
+    sig = []
+    for i, s in enumerate(samples):
+        slots = tuple((getattr(sl.modality, "name", str(sl.modality)), bool(sl.is_src), tuple(sl.attributes or ()))
+                      for sl in s["slots"])
+        scal = tuple((k, s[k]) for k in sorted(s) if isinstance(s[k], (str, int, float, bool)))
+        sig.append((slots, scal))
+    tens = tuple((p, tuple(t.shape), str(t.dtype)) for p, t in sample_tensors(samples))
+    return (tuple(sig), tens)
+
+
+class TrainStep:
     """One optimisation step = `train_step(samples)`.
 
     use_graph: capture the step into a hipGraph (torch.cuda.graphs) and replay it.  The eager step is HOST-bound on an
     MI355X (~600 kernel launches + autograd bookkeeping take as long as the kernels themselves); a replay costs one
     launch.  Everything a replay must see fresh lives on the device: the Philox stream position (ops._Rng.base), the
     Adam step counter / bias corrections / lr (self._sched), the clip coefficient.  Each distinct batch structure
-    (slot and target shapes) gets its own graph after `graph_warmup` eager steps; new batches of a captured structure are
-    copied into the graph's static input tensors.  With world_size > 1 the step is two graphs (forward+backward,
-    clip+Adam) around an eager all-reduce of the gradient arena: collectives are kept out of the captured region."""
+    (`sample_structure`: slot modalities / attributes, every tensor's shape and dtype) gets its own graph after
+    `graph_warmup` eager steps; new batches of a captured structure are copied into the graph's static input tensors (every
+    tensor of the sample: slot values incl. dict-valued audio slots, target, constraint masks).
+
+    Data parallel (world > 1), `dp_graph`:
+      "full"  (default) ONE graph holds forward, backward, the bucketed gradient all-reduces -- launched from inside backward
+              as each bucket completes, so RCCL traffic over xGMI overlaps the remaining backward kernels -- the scalar
+              all-reduce, clip and Adam.  RCCL collectives are captured like any other stream work.
+      "split" two graphs (forward+backward, clip+Adam) around an eager bucket-by-bucket all-reduce: no overlap; the fallback
+              when capturing collectives fails.
+      The chain full -> split -> eager is walked on capture failure (identically on every rank: the failure is structural)."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
                  bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2,
-                 label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0):
+                 label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0, dp_graph: str = None):
         self.model = model
         self.fp = FlatParams(model)
         dev = self.fp.flat.device
@@ -130,14 +187,17 @@ class Trainer:
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._gnorm_t = torch.zeros(1, dtype=torch.float32, device=dev)
         # device-resident schedule: _step_t = number of updates done; _lr_t = learning rate; _sched = [grad multiplier,
-        # lr*sqrt(1-b2^t)/(1-b1^t), lr] consumed by ofa_adam_step(step = 0)
+        # lr*sqrt(1-b2^t)/(1-b1^t), lr, skip flag of this update, count of skipped updates] consumed by ofa_adam_step(step = 0)
         self._step_t = torch.zeros(1, dtype=torch.float64, device=dev)
         self._lr_t = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
-        self._sched = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._sched = torch.zeros(5, dtype=torch.float32, device=dev)
         self._lr = float(lr)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self.graph_warmup = graph_warmup
+        self.dp_graph = dp_graph or os.environ.get("OFA_DP_GRAPH", "full")
+        assert self.dp_graph in ("full", "split"), self.dp_graph
         self._graphs = {}                           # batch structure -> dict(graphs, static samples, seen count)
+        self._skipped_seen = 0.0
         self.last = {}
 
     # ------------------------------------------------------------------ learning rate (host -> device scalar)
@@ -151,7 +211,7 @@ class Trainer:
         self._lr_t.fill_(self._lr)                  # outside any captured region: replays read the new value
 
     # ------------------------------------------------------------------ the three phases of a step
-    def _fwd_bwd(self, samples, overlap_reduce):
+    def _fwd_bwd(self, samples, overlap_reduce, structure=None):
         model = self.model
         model.train()
         self.fp.zero_grad()
@@ -159,7 +219,7 @@ class Trainer:
         self.reducer.overlap = overlap_reduce
         # gradients are only read after backward unless buckets are all-reduced from inside it: fold lazily, in batches
         ops.defer_reductions(self.world == 1 or not overlap_reduce)
-        self.reducer.begin_step(tuple(s.get("task", len(s["slots"])) for s in samples))
+        self.reducer.begin_step(structure)
         for s in samples:
             logits = model(s["slots"])[0]
             cm = s.get("constraint_masks")
@@ -174,7 +234,6 @@ class Trainer:
             self._stats[1] += loss.detach().double()
             self._stats[2] += n
         ops.flush_folds()
-        ops.side_join()                             # side-stream weight gradients are complete beyond this point
         ops.rng_advance()
 
     def _reduce(self):
@@ -182,40 +241,35 @@ class Trainer:
         all_reduce_scalars(self._stats, self.group)
 
     def _update(self):
-        # coef = (1/sample_size) * min(1, clip / (||g/sample_size|| + 1e-6)), all on the device
+        # coef = (1/sample_size) * min(1, clip / (||g/sample_size|| + 1e-6)), all on the device; a non-finite norm or an empty
+        # batch sets the skip flag instead (ofa_step_schedule) and ofa_adam_step leaves weights and moments untouched
         self._gsq.zero_()
         K.sumsq(self.fp.grad, self._gsq)
         K.step_schedule(self._gsq, self._stats, self._step_t, self._lr_t, self._sched, self._gnorm_t, self.clip_norm,
                         self.betas[0], self.betas[1])       # adam.py:205-207 + the clip coefficient, one device thread
-        gnorm = self._gnorm_t
         K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.fp.grad, self.fp.flat, self._sched, 0.0,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, 0)
-        self._gnorm = gnorm
+        self._gnorm = self._gnorm_t
+
+    def check(self):
+        """Host-side poll of the device guard (ONE sync): raises FloatingPointError as engine/trainer.py:866-876 does when an
+        update since the last call saw a non-finite gradient norm or no target token (that update was skipped on the device)."""
+        skipped = float(self._sched[4])
+        if skipped > self._skipped_seen:
+            n = int(skipped - self._skipped_seen)
+            self._skipped_seen = skipped
+            raise FloatingPointError(f"gradients are Nan/Inf (or sample_size == 0) in {n} update(s): skipped on the device")
 
     # ------------------------------------------------------------------ graph plumbing
-    @staticmethod
-    def _tensors_of(samples):
-        out = []
-        for s in samples:
-            for sl in s["slots"]:
-                v = getattr(sl, "value", None)
-                if torch.is_tensor(v):
-                    out.append(v)
-            out.append(s["target"])
-        return out
-
-    def _signature(self, samples):
-        return tuple((s.get("task", len(s["slots"])),) + tuple((tuple(t.shape), t.dtype) for t in self._tensors_of([s]))
-                     for s in samples)
-
-    def _capture(self, samples):
-        ops.side_stream()                           # streams / RNG bases must exist before capture starts
+    def _capture(self, samples, structure, mode):
         pool = torch.cuda.graph_pool_handle()
-        entry = {"static": samples, "graphs": []}
-        if self.world == 1:
+        entry = {"static": samples, "graphs": [], "mode": mode}
+        if self.world == 1 or mode == "full":
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
-                self._fwd_bwd(samples, overlap_reduce=False)
+                self._fwd_bwd(samples, overlap_reduce=self.world > 1, structure=structure)
+                if self.world > 1:
+                    self._reduce()
                 self._update()
             entry["graphs"] = [g]
         else:
@@ -229,48 +283,66 @@ class Trainer:
 
     def _replay(self, entry, samples):
         if samples is not entry["static"]:
-            for dst, src in zip(self._tensors_of(entry["static"]), self._tensors_of(samples)):
+            for (_, dst), (_, src) in zip(entry["static_tensors"], sample_tensors(samples)):
                 if dst is not src:
                     dst.copy_(src, non_blocking=True)
         entry["graphs"][0].replay()
-        if self.world > 1:
+        if len(entry["graphs"]) == 2:
             self.reducer.overlap = False
             self.reducer.begin_step(None)
             self._reduce()
             entry["graphs"][1].replay()
 
     def train_step(self, samples: List[dict], eager: bool = False):
-        """samples: one dict per (task, micro-batch): {"slots": [...], "target": LongTensor[B,Tt]}."""
+        """samples: one dict per (task, micro-batch): {"slots": [...], "target": LongTensor[B,Tt], optional
+        "constraint_masks", "task"}."""
         done = False
-        if self.use_graph and not eager:
-            sig = self._signature(samples)
-            entry = self._graphs.get(sig)
+        structure = None
+        if (self.use_graph and not eager) or self.world > 1:
+            try:
+                structure = sample_structure(samples)
+            except _Uncapturable as e:
+                if self.use_graph:
+                    warnings.warn(f"ofasys_amd.TrainStep: a sample holds an object the static-input walker does not know ({e}); "
+                                  "running eagerly")
+                    self.use_graph = False
+        if self.use_graph and not eager and structure is not None:
+            entry = self._graphs.get(structure)
             if entry is None:
-                entry = self._graphs[sig] = {"seen": 0}
+                entry = self._graphs[structure] = {"seen": 0}
             if "graphs" in entry:
                 self._replay(entry, samples)
                 done = True
-            elif entry["seen"] >= self.graph_warmup:
-                rng_state = (ops._Rng.offset,)
-                try:
-                    torch.cuda.synchronize()
-                    cap = self._capture(samples)
-                except Exception as e:              # anything uncapturable in a custom adaptor: stay eager, loudly
-                    import warnings
-                    warnings.warn(f"ofasys_amd.Trainer: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
-                    self.use_graph = False
-                    ops._Rng.offset = rng_state[0]
-                    ops.side_join()
-                else:
+            elif entry["seen"] >= self.graph_warmup and (self.world == 1 or self.dp_graph != "full"
+                                                         or self.reducer.knows(structure) or self.graph_warmup == 0):
+                modes = ["full", "split"] if (self.world > 1 and self.dp_graph == "full") else ["split"]
+                for mode in modes:
+                    rng_state = ops._Rng.offset
+                    try:
+                        torch.cuda.synchronize()
+                        cap = self._capture(samples, structure, mode)
+                    except Exception as e:          # anything uncapturable (a custom adaptor, a collective): next mode, loudly
+                        warnings.warn(f"ofasys_amd.TrainStep: hipGraph capture ({mode}) failed ({type(e).__name__}: {e})")
+                        ops._Rng.offset = rng_state
+                        ops.defer_reductions(False)
+                        continue
+                    cap["static_tensors"] = sample_tensors(cap["static"])
                     entry.update(cap)
                     self._replay(entry, samples)
                     done = True
+                    break
+                else:
+                    warnings.warn("ofasys_amd.TrainStep: running eagerly")
+                    self.use_graph = False
             else:
                 entry["seen"] += 1
         if not done:
-            self._fwd_bwd(samples, overlap_reduce=True)
+            self._fwd_bwd(samples, overlap_reduce=True, structure=structure)
             self._reduce()
             self._update()
         self.num_updates += 1
-        self.last = {"stats": self._stats, "gnorm": self._gnorm}
+        self.last = {"stats": self._stats, "gnorm": self._gnorm, "skipped": self._sched[3:5]}
         return self.last
+
+
+Trainer = TrainStep            # the name round-1 code and tests use; `ofasys_amd.Trainer` is the fit() facade (engine.py)

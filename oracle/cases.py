@@ -90,9 +90,18 @@ CASES = {
                     "encoder.adaptor.audio_fbank.audio_rel_pos_table_list.1.weight",
                     "encoder.adaptor.audio_fbank.embed_audio_positions.weight"],
     ),
+    # cfg-5 family: OFA-large (D=1024, 16 heads, 12+12 layers, model/ofa.py:604-610), text + box-as-tokens -> text, short T
+    "large_multislot": dict(
+        arch="large", active={"text"}, overrides={}, adaptor_overrides={},
+        slots=[("TEXT", True, ("tok", "src", (2, 12), [12, 8]), None),
+               ("BOX", True, ("tok", "box", (2, 4), None), None),
+               ("TEXT", False, ("tok", "prev", (2, 9), [9, 6]), None)],
+        full_grads=["encoder.layers.11.self_attn.c_attn", "encoder.adaptor.text.token_rel_pos_table_list.7.weight",
+                    "decoder.layers.11.ffn_layernorm.weight", "decoder.cross_pos_q_linear.bias",
+                    "decoder.layers.6.encoder_attn.out_proj.bias", "encoder.adaptor.text.type_embedding.weight",
+                    "decoder.layer_norm.weight"],
+    ),
 }
-
-
 
 
 def make_value(spec, vocab):

@@ -74,7 +74,7 @@ def run_case(name, case):
         "attn": extra["attn"][0].detach(), "encoder_out": enc_out["encoder_out"][0].detach(),
         "encoder_padding_mask": enc_out["encoder_padding_mask"][0].to(torch.uint8),
     }
-    big = case["arch"] == "base"
+    big = case["arch"] in ("base", "large")
     for k, v in rec.items():
         if big and v.numel() > 200000:
             v = v.reshape(-1)[::97]          # strided sample keeps the file small; the test applies the same stride

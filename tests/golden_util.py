@@ -79,3 +79,31 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def oracle_state_for(model):
+    """Oracle state (reference key schema, fp32, CPU) for a built ofasys_amd model: float entries from the shared recipe (the
+    model itself was filled from the same recipe by tests/model_util.build_model), integer buffers copied from the model (their
+    bit-exactness is tested separately), the tied decoder embedding aliased to the encoder's as in the reference."""
+    state = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("version"):
+            state[k] = torch.tensor([3.0])
+        elif k.endswith("num_batches_tracked"):
+            state[k] = torch.zeros((), dtype=torch.long)
+        elif not v.is_floating_point():
+            state[k] = v.detach().cpu().clone()
+        else:
+            state[k] = recipe.value_for(k, tuple(v.shape))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    return state
+
+
+def oracle_params(state):
+    """Leaf tensors of an oracle state that take gradients (the shared embedding once)."""
+    out = {}
+    for k, v in state.items():
+        if v.is_floating_point() and not k.endswith(("version", "running_mean", "running_var")) \
+                and not k.startswith("decoder.adaptor.embed_tokens"):
+            out[k] = v.requires_grad_(True)
+    return out

@@ -115,8 +115,12 @@ def test_collate_rejects_ragged_slot_lists_and_strings():
     with pytest.raises(ValueError, match="various modality"):
         gp.collate(samples)
     assert gp.collate([]) == {}
-    with pytest.raises(NotImplementedError, match="BPE"):
-        gp.name2pre["text"].map(Slot(ModalityType.TEXT, True, "a raw string", global_position=0))
+    # strings are tokenised (GPT-2 BPE over user files, else the documented hash stand-in): ids land in the <text>_i range
+    got = gp.name2pre["text"].map(Slot(ModalityType.TEXT, True, "a raw string", global_position=0)).value["inputs"]
+    lo, hi = gp.global_dict.get_start_end_idx("<text>")
+    assert got.dtype == torch.int64 and len(got) == 3 and bool(((got >= lo) & (got < hi)).all())
+    with pytest.raises(ValueError, match="Incorrect input for text"):
+        gp.name2pre["text"].map(Slot(ModalityType.TEXT, True, 3.5, global_position=0))
 
 
 def test_to_device_packs_all_integer_fields_into_one_buffer():

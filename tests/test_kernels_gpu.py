@@ -762,7 +762,7 @@ def test_step_schedule_kernel(K, clip):
     stats = torch.tensor([24.0, 3.0, 24.0], dtype=torch.float64, device=DEV)
     step = torch.tensor([4.0], dtype=torch.float64, device=DEV)
     lr = torch.tensor([3e-4], dtype=torch.float64, device=DEV)
-    sched, gnorm = torch.zeros(3, device=DEV), torch.zeros(1, device=DEV)
+    sched, gnorm = torch.zeros(5, device=DEV), torch.zeros(1, device=DEV)
     K.step_schedule(gsq, stats, step, lr, sched, gnorm, clip, 0.9, 0.999)
     gn = math.sqrt(37.5) / 24.0
     coef = (1 / 24.0) * (min(1.0, clip / (gn + 1e-6)) if clip > 0 else 1.0)
@@ -771,3 +771,16 @@ def test_step_schedule_kernel(K, clip):
     assert float(step) == 5.0 and abs(float(gnorm) - gn) < 1e-6 * gn
     for a, b in zip(sched.tolist(), want):
         assert abs(a - b) <= 1e-6 * abs(b), (sched.tolist(), want)
+    assert sched[3:].tolist() == [0.0, 0.0]
+    # guard: non-finite norm / empty batch -> skip flag, step counter untouched, running count of skipped updates
+    for bad_gsq, bad_n in ((float("inf"), 24.0), (float("nan"), 24.0), (37.5, 0.0)):
+        K.step_schedule(torch.tensor([bad_gsq], device=DEV), torch.tensor([bad_n, 0.0, 0.0], dtype=torch.float64, device=DEV),
+                        step, lr, sched, gnorm, clip, 0.9, 0.999)
+        assert float(step) == 5.0 and sched[:2].tolist() == [0.0, 0.0] and float(sched[3]) == 1.0
+    assert float(sched[4]) == 3.0
+    master = torch.randn(1000, device=DEV)
+    m, v, g = torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV), torch.randn(1000, device=DEV)
+    w0 = master.clone()
+    model = master.clone()
+    K.adam_step(master, m, v, g, model, sched, 0.0, 0.9, 0.999, 1e-8, 0.01, 0)          # skip flag set: nothing moves
+    assert torch.equal(master, w0) and float(m.abs().sum()) == 0.0 and float(v.abs().sum()) == 0.0

@@ -54,7 +54,7 @@ def test_fp32_matches_reference(name):
     assert rel_err(logits.detach().cpu(), g["logits"]) < FP32_TOL
     assert rel_err(loss.detach().cpu(), g["loss"][0]) < FP32_TOL
     assert rel_err(extra["attn"][0].cpu(), g["attn"]) < FP32_TOL
-    big = CASES[name]["arch"] == "base"
+    big = CASES[name]["arch"] in ("base", "large")
     e = enc["encoder_out"][0].detach().cpu().contiguous()
     assert rel_err(e.reshape(-1)[::97] if big else e, g["encoder_out"]) < FP32_TOL
     assert np.array_equal(enc["encoder_padding_mask"][0].cpu().numpy().astype(np.uint8), g["encoder_padding_mask"])
@@ -174,7 +174,7 @@ def test_arena_sinks_match_autograd(name):
 
 
 def case_layers(case):
-    return {"tiny": 4 + 8, "base": 6 + 12}[case["arch"]]
+    return {"tiny": 4 + 8, "base": 6 + 12, "large": 12 + 24}[case["arch"]]
 
 
 def test_graph_replay_matches_eager_steps():

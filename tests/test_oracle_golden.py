@@ -31,7 +31,7 @@ def test_forward_backward_matches_reference(name):
     assert rel_err(logits.detach(), g["logits"]) < TOL
     assert rel_err(loss.detach(), g["loss"][0]) < TOL
     assert rel_err(extra["attn"].detach(), g["attn"]) < TOL
-    big = case["arch"] == "base"
+    big = case["arch"] in ("base", "large")
     enc = rec["encoder_out"].detach()
     assert rel_err(enc.reshape(-1)[::97] if big else enc, g["encoder_out"]) < TOL
     for k in g:

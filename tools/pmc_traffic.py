@@ -31,7 +31,12 @@ for k in f:
 rows.sort(reverse=True)
 res = {}
 print(f"{'kernel':90s} {'launches':>8s} {'fetch MB/launch':>16s} {'write MB/launch':>16s}")
-for tot, k, n, fe, wr in rows[:40]:
-    print(f"{k[:90]:90s} {n:8d} {fe/1e6:16.2f} {wr/1e6:16.2f}")
+for i, (tot, k, n, fe, wr) in enumerate(rows):
+    if i < 40:
+        print(f"{k[:90]:90s} {n:8d} {fe/1e6:16.2f} {wr/1e6:16.2f}")
     res[k] = {"launches": n, "fetch_bytes_per_launch": fe, "write_bytes_per_launch": wr}
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # train steps the profiled command ran (warm-up + timed)
+total = sum(r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) for r in res.values())
+res["__meta__"] = {"steps": steps, "total_bytes": total, "bytes_per_step": total / steps if steps else None}
+print(f"all kernels: {total/1e9:.2f} GB over {steps} steps" + (f" = {total/steps/1e9:.2f} GB/step" if steps else ""))
 json.dump(res, open(sys.argv[3], "w"), indent=1)

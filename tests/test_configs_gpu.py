@@ -391,3 +391,39 @@ def test_nonfinite_or_empty_step_is_skipped_on_the_device():
     out = tr.train_step([good])                                    # and training continues
     torch.cuda.synchronize()
     assert float(out["skipped"][0]) == 0.0 and float(tr._step_t) == t + 1 and not torch.equal(tr.master, w)
+
+
+# ------------------------------------------------------------------------------------------------------------ data parallel
+def test_dp_step_graph_with_captured_rccl_collectives():
+    """The benchmarked multi-GPU mode: ONE hipGraph holding forward, backward, the bucketed all-reduces launched from inside
+    backward, the scalar all-reduce, clip and Adam.  One GPU here, so the process group is a 1-rank RCCL group and the step
+    engine is told world = 2 (the reducer launches every collective it would launch on 2 ranks; a 1-rank sum is the identity,
+    so the captured trajectory must equal the eager data-parallel one).  What this proves: torch + RCCL capture the collectives on their own
+    stream inside the step graph and the replayed graph is correct; what it cannot prove: xGMI traffic."""
+    import os
+    import torch.distributed as dist
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import TrainStep
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        case = CASES["tiny_multislot"]
+        vals, target = case_inputs(case)
+        runs = []
+        for dp in (False, True):
+            model, d = build_model(case, DEV, torch.bfloat16)
+            tr = TrainStep(model, lr=1e-3, clip_norm=1.0, use_graph=dp, graph_warmup=1, bucket_bytes=1 << 20, dp_graph="full")
+            tr.world = tr.reducer.world = 2          # both runs: eager overlapped reduce vs the captured one (same fold order)
+            batch = {"slots": make_slots(vals, DEV, torch.bfloat16), "target": target.to(DEV)}
+            ops.manual_seed(5)
+            losses = [float(tr.train_step([batch])["stats"][1]) for _ in range(6)]
+            torch.cuda.synchronize()
+            runs.append((losses, tr.master.clone(), tr))
+        (l0, m0, _), (l1, m1, tr1) = runs
+        entries = [e for e in tr1._graphs.values() if "graphs" in e]
+        assert len(entries) == 1 and entries[0]["mode"] == "full" and len(entries[0]["graphs"]) == 1
+        assert len(tr1.reducer.buckets) > 3 and tr1.reducer.knows(next(iter(tr1._graphs)))
+        assert l0 == l1 and torch.equal(m0, m1)
+    finally:
+        dist.destroy_process_group()

@@ -135,3 +135,22 @@ def test_tool_scripts_compile():
     assert len(scripts) >= 15
     for s in scripts:
         py_compile.compile(s, doraise=True)
+
+
+def test_bench_self_launches_ranks_when_no_launcher_started_it():
+    """`python bench.py --gpus 2` run BARE (no torch.distributed.run, no WORLD_SIZE): bench.py re-executes itself under
+    torch.distributed.run with a 127.0.0.1 rendezvous, one rank per GPU, and rank 0 prints one JSON line.  --launch-check stops
+    after the process-group round trip (gloo; the train step itself needs GPUs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world"] == 2

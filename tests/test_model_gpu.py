@@ -15,7 +15,8 @@ FP32_TOL = 1e-3
 BF16_TOL = 2e-2
 # 2x the reference's own bf16-vs-fp32 gap where that is larger (oracle/ref_bf16_gap.py: 4.7e-2 through the 50-layer
 # BatchNorm backbone of tiny_resnet, 3.0e-2 on tiny_video, 1.0e-2 on tiny_text)
-BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2}
+# ... and 2.1e-2 through the 24 layers of OFA-large (large_multislot)
+BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2, "large_multislot": 4.2e-2}
 # fp32 gradients INSIDE the ResNet backbone: 16 bottlenecks of conv / BatchNorm over as few as 32 values per channel /
 # ReLU make the backward chain ill-conditioned -- torch's own CPU and GPU (MIOpen) fp32 implementations of this exact
 # backbone differ by 0.9% element-wise / 0.06% in norm (tools/bn_noise.py, run on the MI355X box); this build differs

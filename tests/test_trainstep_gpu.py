@@ -62,14 +62,20 @@ def test_train_step_matches_reference_recording(use_graph):
             assert abs(got_m - want_m) <= 2e-3 * want_m + 1e-9, (k, got_m, want_m)
             assert abs(got_v - want_v) <= 4e-3 * want_v + 1e-14, (k, got_v, want_v)
         params = dict(model.named_parameters())
+        # absolute floor: gradients that are zero in exact arithmetic (cross_pos_k_linear.bias: a per-row constant under the
+        # softmax) are 1e-13-sized rounding noise on both sides
+        m_floor = 1e-6 * max(float(np.abs(g[p + "exp_avg." + k]).max()) for k in TC.FULL)
         for k in TC.FULL:
             o, cnt = views[k]
             gc = g[p + "grad_clip." + k]
             gm = float(np.abs(gc).max())
-            m_got = TC.sample(tr.exp_avg[o:o + cnt].view(params[k].shape)).cpu()
-            v_got = TC.sample(tr.exp_avg_sq[o:o + cnt].view(params[k].shape)).cpu()
-            assert rel_err(m_got, g[p + "exp_avg." + k]) < 2e-3, k
-            assert rel_err(v_got, g[p + "exp_avg_sq." + k]) < 4e-3, k
+            m_got = TC.sample(tr.exp_avg[o:o + cnt].view(params[k].shape)).cpu().numpy()
+            v_got = TC.sample(tr.exp_avg_sq[o:o + cnt].view(params[k].shape)).cpu().numpy()
+            m_want, v_want = g[p + "exp_avg." + k], g[p + "exp_avg_sq." + k]
+            assert np.abs(m_got - m_want).max() <= 2e-3 * np.abs(m_want).max() + m_floor, k
+            assert np.abs(v_got - v_want).max() <= 4e-3 * np.abs(v_want).max() + m_floor ** 2, k
+            if gm < 1e3 * m_floor:
+                continue
             # the parameter after the update, where m / (sqrt(v) + eps) is determined (gradient above rounding noise)
             want, mine = g[p + "param." + k], TC.sample(params[k].detach()).cpu().numpy()
             sel = np.abs(gc) > 1e-2 * gm

@@ -67,7 +67,7 @@ def build(args, device):
     return m, d
 
 
-def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2"):
+def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2", pack=False):
     """Synthetic instruction batch [IMAGE,adaptor=image_patch_embed][TEXT] -> [TEXT], seed 1234 + rank."""
     from ofasys_amd import ModalityType, Slot
     g = torch.Generator().manual_seed(1234 + rank)
@@ -102,7 +102,12 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2"):
         Slot(ModalityType.IMAGE, True, img.to(device), attributes=["adaptor=image_patch_embed"] if patch else None)
     slots = [first, Slot(ModalityType.TEXT, True, src.to(device)), Slot(ModalityType.TEXT, False, prev.to(device))]
     ntok = (nvis if workload == "cfg4" else B * (257 if patch else 196)) + int(slen.sum()) + int(tlen.sum())
-    return {"slots": slots, "target": target.to(device)}, ntok
+    sample = {"slots": slots, "target": target.to(device)}
+    if pack:        # ragged row packing (ofasys_amd/packing.py): only the non-pad positions go through the stack
+        from ofasys_amd.packing import build_pack_plan
+        enc_mask = torch.cat([torch.zeros(B, 257, dtype=torch.bool), src.eq(d.pad())], 1)
+        sample["pack"] = build_pack_plan(enc_mask, prev.eq(d.pad()), bucket=512, dec_bucket=256).to(device)
+    return sample, ntok, (slen.tolist(), tlen.tolist())
 
 
 def cpu_baseline(args):
@@ -241,6 +246,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS),
                     help="cfg2 (headline: image_patch_embed, bias-free), cfg2b (image_resnet101 + biased attention, 196+252 -> 64) "
                          "or cfg4 (video 8x224x224 -> 1568 tokens + 32 text -> 32, micro-batch 4)")
+    ap.add_argument("--no-pack", action="store_true",
+                    help="cfg2 only: run the padded batch (every sample computed at 448 + 64 positions, as the reference does) instead "
+                         "of packing the non-pad positions")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--dp-graph", default=None, choices=["full", "split"],
                     help="N > 1: 'full' (default) captures the bucketed RCCL all-reduces inside the step graph, overlapped with "
@@ -295,8 +303,9 @@ def main():
     trainer = TrainStep(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph, dp_graph=args.dp_graph)
     Ts_text, Tt, nvis, desc = WORKLOADS[args.workload]
     # a few distinct batches of the same structure: replays copy each new batch into the graph's static inputs
-    batches = [make_batch(d, args.batch, Ts_text, Tt, rank + 97 * i, device, args.workload) for i in range(4)]
-    ntok = sum(n for _, n in batches) / len(batches)
+    packed = args.workload == "cfg2" and not args.no_pack
+    batches = [make_batch(d, args.batch, Ts_text, Tt, rank + 97 * i, device, args.workload, pack=packed) for i in range(4)]
+    ntok = sum(b[1] for b in batches) / len(batches)
 
     def barrier():
         if world > 1:
@@ -310,9 +319,10 @@ def main():
         trainer.train_step([batches[step_i % len(batches)][0]])
         step_i += 1
 
-    if trainer.use_graph:                                          # setup: eager priming steps + the one-time graph capture
-        for _ in range(trainer.graph_warmup + 1):
-            step()
+    if trainer.use_graph:                   # setup: eager priming steps + the one-time graph capture of every batch STRUCTURE
+        for b in batches:                   # (packed batches fall into a few row-count buckets, each with its own hipGraph)
+            for _ in range(trainer.graph_warmup + 1):
+                trainer.train_step([b[0]])
     for _ in range(args.warmup):
         step()
     barrier()
@@ -347,18 +357,27 @@ def main():
     if rank == 0:
         cfg = model.cfg
         dims = (cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim, cfg.encoder.layers, cfg.decoder.layers)
+        fwd_exec = None
         if args.workload == "cfg2":
             fwd = fwd_flops_per_sample(*dims, 257 + Ts_text, Tt, len(d))
+            # the same formulas at every sample's OWN lengths: what a ragged (packed) step actually has to compute
+            fwd_exec = sum(fwd_flops_per_sample(*dims, 257 + sl, tl, len(d)) for _, _, (sls, tls) in batches
+                           for sl, tl in zip(sls, tls)) / len(batches)
         else:          # ResNet-101 stride-16 trunk ~ 6.9 GMAC per 224x224 image + Linear(1024, D), biased attention
             frames = 8 if args.workload == "cfg4" else 1
             fwd = fwd_flops_per_sample(*dims, nvis + Ts_text, Tt, len(d), patch_tokens=0, bias=True) + \
                 frames * (2 * 6.9e9 + 2 * 196 * 1024 * cfg.encoder.embed_dim)
-        step_flops = 3 * fwd * args.batch                          # backward = 2x forward
+        step_flops_padded = 3 * fwd * args.batch                   # backward = 2x forward, padded shape
+        # a packed step is priced at the flops of the positions it computes (never at the padded count it skips)
+        step_flops = 3 * fwd_exec if (packed and fwd_exec) else step_flops_padded
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
         traffic, step_bytes, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
-                "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS}
+                "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS, "step_flops": step_flops,
+                "step_flops_padded_shape": step_flops_padded,
+                "step_flops_basis": ("non-pad positions only (ragged row packing: each sample at its own lengths)" if packed else
+                                     "padded shape (every sample at the longest lengths)")}
         if step_bytes and args.workload == "cfg2":
             roof["hbm"] = {"step_bytes": step_bytes, "achieved_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                            "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBPS,
@@ -384,7 +403,7 @@ def main():
             "config": {"workload": desc + ", OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "padded_positions_per_sample": nvis + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
-                       "vocab": len(d), "parallelism": f"dp{world}", "random_init": True, "step_mode": graph_mode,
+                       "vocab": len(d), "parallelism": f"dp{world}", "random_init": True, "step_mode": graph_mode, "ragged_row_packing": packed,
                        "distinct_batches": len(batches)},
             "roofline": roof,
         }

@@ -137,20 +137,27 @@ int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, vo
  * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional
  * [heads] per-head output scale (:342-345), fp32 or bf16 as c_attn_dtype says (the parameter itself, no cast kernel). out: [B, T, heads*64] (ld = ldo); lse: fp32 [B*heads, Tpad].  scale
  * multiplies q.k (the reference pre-scales q, :218).  Tpad: a multiple of 32 covering T.
- * Attention dropout is not supported here (the reference default is attention_dropout = 0.0). */
+ * Attention dropout is not supported here (the reference default is attention_dropout = 0.0).
+ * Ragged ("packed rows") mode, seg != NULL: the reference pads every sample to the longest and masks the padding
+ * (multihead_attention.py:319-326); here the batch may arrive packed instead.  seg: device int32 [B][4] = {q_off, q_len, k_off,
+ * k_len} (16-byte aligned; q_off a multiple of 4).  q / out are [rows_q, ld] with sample b's queries in rows q_off .. q_off+q_len-1,
+ * k / v are [rows_k, ld] likewise; lse is fp32 [heads, Tpad] indexed by the packed query row (Tpad >= rows_q); T, S are upper
+ * bounds of q_len, k_len (they size the launch grid); bias and kpm must be NULL.  Rows outside every segment are not touched. */
 int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
                  const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
-                 int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream);
+                 int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int dtype, void* stream);
 /* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
  * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep; dout: [B,T,heads*64] rows (ld = ldo).
  * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS.
- * No transposed operand copies are needed: the kernels transpose tiles on the LDS read (ds_read_b64_tr_b16). */
+ * No transposed operand copies are needed: the kernels transpose tiles on the LDS read (ds_read_b64_tr_b16).
+ * seg != NULL: ragged mode as in ofa_attn_fwd (delta from ofa_attn_bwd_prep(B = 1, T = rows_q): [heads, Tpad] by packed row;
+ * dq / dk / dv rows outside every segment are not written -- the caller zero-fills them). */
 int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
                       int dtype, void* stream);
 int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
                  const void* c_attn, int c_attn_dtype, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                  void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
-                 int causal, int dtype, void* stream);
+                 int causal, const int32_t* seg, int dtype, void* stream);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */
@@ -174,6 +181,11 @@ int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, 
  * (a wave per (vocabulary row, id-list slice) scans the ids with ballots; no atomics). ids: int64.
  * present_ws: optional V bytes of scratch (rows that do not occur are skipped); slice_ws: optional fp32 scratch of
  * ofa_embedding_bwd_slices(V, D) * V * D floats -- small tables with thousands of hits per row are then reduced in slices. */
+/* Row gather with zero fill: out[r, :] = index[r] >= 0 ? src[index[r], :] : 0 (index int64 [n]; src [src_rows, D]).  Packs the
+ * non-pad rows of a padded batch (ofasys_amd/packing.py; the reference computes the padding, preprocessor/utils.py:75-113) and,
+ * with the inverse index, scatters gradients back. */
+int ofa_gather_rows(const void* src, const int64_t* index, void* out, int64_t n, int D, int64_t src_rows, int dtype,
+                    void* stream);
 int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
                       void* stream);
 int ofa_embedding_bwd_slices(int64_t V, int D);

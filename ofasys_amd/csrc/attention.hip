@@ -50,7 +50,34 @@ struct AttnL {
   int B, heads, T, S, Tpad;
   int64_t ldq, ldk, ldo;
   float scale; int causal;
+  const int* seg;   // ragged ("packed rows") mode: int32 [B][4] = {q_off, q_len, k_off, k_len}, see seg_enter()
 };
+
+// Ragged mode.  The reference pads every sample of a batch to the longest one and masks (multihead_attention.py:319-326); the
+// metric counts non-pad positions only, so here a batch may arrive PACKED: q / out / dout / dq are [rows_q, ld] with sample b's
+// queries in rows q_off .. q_off + q_len - 1, k / v / dk / dv are [rows_k, ld] likewise, lse / delta are [heads, Tpad] indexed by
+// the packed query row.  A workgroup (q-tile x, (b, h)) rebases every pointer to its sample and then runs the dense code with
+// B = 1, T = q_len, S = k_len: keys beyond k_len are never loaded, tiles beyond q_len exit.  Returns false when the tile is empty.
+__device__ __forceinline__ bool seg_enter(AttnL& a, int& b, int& bh, int h, int tile0, bool tile_is_query) {
+  if (!a.seg) return true;
+  const int4 s = reinterpret_cast<const int4*>(a.seg)[b];
+  if (s.y <= 0 || s.w <= 0 || tile0 >= (tile_is_query ? s.y : s.w)) return false;
+  a.q += (int64_t)s.x * a.ldq;
+  if (a.out) a.out += (int64_t)s.x * a.ldo;
+  if (a.dout) a.dout += (int64_t)s.x * a.ldo;
+  if (a.dq) a.dq += (int64_t)s.x * a.ldq;
+  if (a.lse) a.lse += s.x;
+  if (a.delta) a.delta += s.x;
+  a.k += (int64_t)s.z * a.ldk;
+  a.v += (int64_t)s.z * a.ldk;
+  if (a.dk) a.dk += (int64_t)s.z * a.ldk;
+  if (a.dv) a.dv += (int64_t)s.z * a.ldk;
+  a.T = s.y;
+  a.S = s.w;
+  b = 0;
+  bh = h;
+  return true;
+}
 
 __device__ __forceinline__ float head_scale(const AttnL& a, int h) {
   if (!a.c_attn) return 1.0f;
@@ -297,8 +324,10 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.heads, h = bh % a.heads;
+  int bh = blockIdx.y, b = bh / a.heads;
+  const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
+  if (!seg_enter(a, b, bh, h, qb0, true)) return;        // (workgroup-uniform)
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
   const int qrow = qi < a.T ? qi : a.T - 1;
@@ -454,8 +483,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.heads, h = bh % a.heads;
+  int bh = blockIdx.y, b = bh / a.heads;
+  const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
+  if (!seg_enter(a, b, bh, h, qb0, true)) return;
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
   const int qrow = qi < a.T ? qi : a.T - 1;
@@ -628,8 +659,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.heads, h = bh % a.heads;
+  int bh = blockIdx.y, b = bh / a.heads;
+  const int h = bh % a.heads;
   const int kb0 = blockIdx.x * 128;
+  if (!seg_enter(a, b, bh, h, kb0, false)) return;
   const int key0 = kb0 + wave * 32;
   const int ki = key0 + i;
   const int krow = ki < a.S ? ki : a.S - 1;
@@ -734,15 +767,17 @@ using namespace ofa;
 
 extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
                             const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S,
-                            int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype,
-                            void* stream) {
+                            int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
+                            int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(q && k && v && out, OFA_ERR_INVALID, "attn_fwd: null pointer");
+  OFA_REQUIRE(!seg || (!bias && !kpm && lse && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
+              "attn_fwd: the ragged (seg) mode takes no bias / key-padding mask, needs lse and a 16-byte aligned table");
   OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_fwd: bad c_attn dtype %d", c_attn_dtype);
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
   a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
-  a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal;
+  a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(cdiv(T, 128), B * heads), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_fwd");
 }
@@ -750,15 +785,18 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
 extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
                             const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, const float* delta,
                             void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
-                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, int dtype, void* stream) {
+                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int dtype,
+                            void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
+  OFA_REQUIRE(!seg || (!bias && !kpm && !dbias && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
+              "attn_bwd: the ragged (seg) mode takes no bias / key-padding mask / dbias and a 16-byte aligned table");
   OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_bwd: bad c_attn dtype %d", c_attn_dtype);
   OFA_REQUIRE(q && k && v && dout && lse && delta && dq && dk && dv, OFA_ERR_INVALID, "attn_bwd: null pointer");
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
   a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
-  a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal;
+  a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(cdiv(T, 128), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_bwd_dq");

@@ -100,6 +100,24 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict_
   }
 }
 
+// out[r] = index[r] >= 0 ? src[index[r]] : 0   -- the pack / unpack step of the ragged row layout (ofasys_amd/packing.py): the
+// forward gathers the non-pad rows of the padded [B*T, D] adaptor output, the backward is the same kernel with the inverse index
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ index,
+                                                          T* __restrict__ out, int64_t n, int D, int64_t src_rows) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = D / N;
+  const int64_t total = n * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    const int64_t id = index[r];
+    typename Vec<T>::type val = {};
+    if (id >= 0 && id < src_rows) val = *reinterpret_cast<const typename Vec<T>::type*>(src + id * D + c);
+    *reinterpret_cast<typename Vec<T>::type*>(out + r * D + c) = val;
+  }
+}
+
 // narrow tables (rel-pos bias tables are [n_rel, heads], heads = 4..16): element-wise gather
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_fwd_scalar_kernel(const T* __restrict__ w, const int64_t* __restrict__ ids,
@@ -423,6 +441,22 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
     hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)weight,
                        ids, (bf16_t*)out, n, D, V);
   return check_launch("embedding_fwd");
+}
+
+extern "C" int ofa_gather_rows(const void* src, const int64_t* index, void* out, int64_t n, int D, int64_t src_rows, int dtype,
+                               void* stream) {
+  OFA_DT_CHECK("gather_rows");
+  OFA_REQUIRE(n >= 0 && D > 0 && src_rows > 0 && src && index && out, OFA_ERR_INVALID, "gather_rows: bad argument");
+  OFA_REQUIRE(D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_INVALID, "gather_rows: D=%d must be a multiple of the 16-byte vector width", D);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)src, index,
+                       (float*)out, n, D, src_rows);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)src, index,
+                       (bf16_t*)out, n, D, src_rows);
+  return check_launch("gather_rows");
 }
 
 // slices for a table of V rows of D columns (<= 64 slices)

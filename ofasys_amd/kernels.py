@@ -365,13 +365,23 @@ def c_attn_grad(delta, c_attn, B, heads, T, out=None, accumulate=False):
     return out
 
 
-def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False):
-    """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad]."""
+def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, seg=None):
+    """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad].
+    seg (packing.Segments): ragged mode -- q [1,rows_q,D], k, v [1,rows_k,D] hold the samples back to back, out rows outside
+    every segment are zero, lse is [heads, pad32(rows_q)] by packed row."""
     q, ldq = _rows3(q)
     k, v, ldk = _same_ld(k, v)
     B, T, D = q.shape
     S = k.shape[1]
     Tpad = pad32(T)
+    if seg is not None:
+        assert B == 1 and bias is None and kpm is None and seg.rows_q == T and seg.rows_k == S, (B, T, S, seg.rows_q, seg.rows_k)
+        out = torch.zeros(1, T, D, dtype=q.dtype, device=q.device)
+        lse = torch.zeros(heads, Tpad, dtype=torch.float32, device=q.device)
+        lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(out), ptr(lse),
+                   seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, D, float(scale), int(causal), ptr(seg.table),
+                   dtype_code(q), stream())
+        return out, lse
     out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
     if bias is not None:
@@ -379,12 +389,12 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
     if kpm is not None:
         kpm = _u8(kpm)
     lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(out), ptr(lse),
-               B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), dtype_code(q), stream())
+               B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), None, dtype_code(q), stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False,
-             outs=None):
+             outs=None, seg=None):
     """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
     packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
     q, ldq = _rows3(q)
@@ -415,12 +425,19 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         if ldk != D:
             k, v = k.contiguous(), v.contiguous()
             ldk = D
-        dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
-        dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-        dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+        mk = torch.zeros if seg is not None else torch.empty          # ragged mode: rows outside every segment stay zero
+        dq = mk(B, T, D, dtype=q.dtype, device=q.device)
+        dk = mk(B, S, D, dtype=q.dtype, device=q.device)
+        dv = mk(B, S, D, dtype=q.dtype, device=q.device)
+    if seg is not None:
+        assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
+        lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
+                   ptr(delta), ptr(dq), ptr(dk), ptr(dv), None, seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo,
+                   float(scale), int(causal), ptr(seg.table), dtype_code(q), stream())
+        return dq, dk, dv, None, delta
     lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
-               int(causal), dtype_code(q), stream())
+               int(causal), None, dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
 
 
@@ -497,6 +514,15 @@ def embedding_fwd(weight, ids):
     V, D = weight.shape
     out = torch.empty(*ids.shape, D, dtype=weight.dtype, device=weight.device)
     lib().call("ofa_embedding_fwd", ptr(weight), ptr(ids), ptr(out), ids.numel(), D, V, dtype_code(weight), stream())
+    return out
+
+
+def gather_rows(src2d, index):
+    """out[r] = index[r] >= 0 ? src2d[index[r]] : 0  (index: int64 [n] on the device)."""
+    assert src2d.dim() == 2 and src2d.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
+    out = torch.empty(index.numel(), src2d.shape[1], dtype=src2d.dtype, device=src2d.device)
+    lib().call("ofa_gather_rows", ptr(src2d), ptr(index), ptr(out), index.numel(), src2d.shape[1], src2d.shape[0],
+               dtype_code(src2d), stream())
     return out
 
 

@@ -113,17 +113,19 @@ class OFAEncoderDecoderExecutor(OFAExecutor):
     def forward(self, ofa_model, slots: List[Slot], features_only: bool = False, full_context_alignment: bool = False,
                 alignment_layer: Optional[int] = None, alignment_heads: Optional[int] = None,
                 return_all_hiddens: bool = False, return_encoder_out: bool = False, return_hf_dict: bool = False,
-                return_all_attention_weights: bool = False):
-        """model/ofa.py:165-285."""
+                return_all_attention_weights: bool = False, pack=None):
+        """model/ofa.py:165-285.  pack (not in the reference): a packing.PackPlan -- the stack runs on the non-pad positions only
+        and the logits come back packed, [1, plan.dec rows, V] (row r = padded position plan.dec_index[r])."""
         encoder = ofa_model.get_model_by_name(self.encoder_name)
         decoder = ofa_model.get_model_by_name(self.decoder_name)
+        pk = {} if pack is None else {"pack": pack}
         encoder_out = encoder([s for s in slots if s.is_src], return_all_hiddens=return_all_hiddens,
-                              return_all_attention_weights=return_all_attention_weights)
+                              return_all_attention_weights=return_all_attention_weights, **pk)
         decoder_out, decoder_extra_out = decoder(
             [s for s in slots if not s.is_src], encoder_out=encoder_out, features_only=features_only,
             full_context_alignment=full_context_alignment, alignment_layer=alignment_layer,
             alignment_heads=alignment_heads, return_all_hiddens=return_all_hiddens,
-            return_all_attention_weights=return_all_attention_weights)
+            return_all_attention_weights=return_all_attention_weights, **pk)
         if return_hf_dict:
             ret = {"last_hidden_state": decoder_extra_out["last_hidden_state"]}
             if return_all_attention_weights:
@@ -217,12 +219,14 @@ class GeneralistModel(Module):
     def forward(self, slots: List[Slot], features_only: bool = False, full_context_alignment: bool = False,
                 alignment_layer: Optional[int] = None, alignment_heads: Optional[int] = None,
                 return_all_hiddens: bool = False, return_encoder_out: bool = False, return_hf_dict: bool = False,
-                return_all_attention_weights: bool = False):
+                return_all_attention_weights: bool = False, pack=None):
+        """The reference's keyword list (model/ofa.py:410-421) + `pack` (ofasys_amd/packing.py: ragged row packing)."""
+        kw = {} if pack is None else {"pack": pack}
         return self.active_executor.forward(
             self, slots=slots, features_only=features_only, full_context_alignment=full_context_alignment,
             alignment_layer=alignment_layer, alignment_heads=alignment_heads, return_all_hiddens=return_all_hiddens,
             return_encoder_out=return_encoder_out, return_hf_dict=return_hf_dict,
-            return_all_attention_weights=return_all_attention_weights)
+            return_all_attention_weights=return_all_attention_weights, **kw)
 
     def get_normalized_probs(self, net_output, log_probs: bool, sample=None):
         return self.active_executor.get_normalized_probs(self, net_output=net_output, log_probs=log_probs, sample=sample)

@@ -100,7 +100,7 @@ class MultiheadAttention(nn.Module):
             else:                                                            # arbitrary additive mask: fold into the bias
                 m = attn_mask.to(xq.dtype).unsqueeze(0).expand(bsz * self.num_heads, tgt_len, src_len).contiguous()
                 bias = m if bias is None else ops.add_rowvec_mask(bias.contiguous(), m)
-        if key_padding_mask is not None and key_padding_mask.dim() == 0:
+        if torch.is_tensor(key_padding_mask) and key_padding_mask.dim() == 0:
             key_padding_mask = None
         p_drop = self.dropout_module.p if (self.training or self.dropout_module.apply_during_inference) else 0.0
         fused = (xq.dtype == torch.bfloat16 and self.head_dim == 64 and p_drop == 0.0 and not need_weights

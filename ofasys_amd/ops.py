@@ -490,15 +490,45 @@ def _c_attn_grad(delta, c_attn, B, heads, T):
     return K.c_attn_grad(delta, c_attn, B, heads, T)
 
 
+def _split_seg(kpm):
+    """The key-padding argument of the attention functions is either a mask tensor (padded batches) or a packing.Segments
+    table (ragged batches, ofasys_amd/packing.py).  -> (mask tensor or None, Segments or None)"""
+    if kpm is not None and not torch.is_tensor(kpm):
+        return None, kpm
+    return kpm, None
+
+
+class PackRowsFn(torch.autograd.Function):
+    """[rows_in, D] -> [rows_out, D] row gather with zero fill (index -1); backward = the same gather with the inverse index
+    (packing.PackPlan.*_index / *_inverse)."""
+
+    @staticmethod
+    def forward(ctx, x2d, index, inverse):
+        ctx.save_for_backward(inverse)
+        return K.gather_rows(x2d, index)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (inverse,) = ctx.saved_tensors
+        return K.gather_rows(dout.contiguous(), inverse), None, None
+
+
+def pack_rows(x, index, inverse):
+    """x [B, T, D] (padded) -> [1, R, D] packed rows."""
+    B, T, D = x.shape
+    return PackRowsFn.apply(x.reshape(B * T, D), index, inverse).view(1, -1, D)
+
+
 class FusedAttentionFn(torch.autograd.Function):
     """bf16 fused attention on [B,T,D] rows (csrc/attention.hip)."""
 
     @staticmethod
     def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal):
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal)
+        kpm, seg = _split_seg(kpm)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg)
         ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn)
         ctx.c_ref = c_attn                                  # the Parameter object (carries the gradient sink)
-        ctx.heads, ctx.scale, ctx.causal = heads, scale, causal
+        ctx.heads, ctx.scale, ctx.causal, ctx.seg = heads, scale, causal, seg
         return out
 
     @staticmethod
@@ -506,7 +536,7 @@ class FusedAttentionFn(torch.autograd.Function):
         q, k, v, out, lse, bias, kpm, c_attn = ctx.saved_tensors
         need_dbias = bias is not None and ctx.needs_input_grad[3]
         dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
-                                              c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias)
+                                              c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias, seg=ctx.seg)
         dc = None
         if c_attn is not None and ctx.needs_input_grad[5]:
             dc = _c_attn_grad(delta, ctx.c_ref, q.shape[0], ctx.heads, q.shape[1])
@@ -548,11 +578,13 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         x2d = x.view(B * T, D)
         kvq = K.gemm(x2d, W, False, True, bias=Bv).view(B, T, 3 * D)
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal)
+        kpm, seg = _split_seg(kpm)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg)
         ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W)
         ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, causal, pack)
+        ctx.seg = seg
         return out
 
     @staticmethod
@@ -563,10 +595,10 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         B, T, D3 = kvq.shape
         D = D3 // 3
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
-        dkvq = torch.empty_like(kvq)
+        dkvq = torch.zeros_like(kvq) if ctx.seg is not None else torch.empty_like(kvq)      # ragged: filler rows stay zero
         need_dbias = bias is not None and ctx.needs_input_grad[7]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
-                                           causal=causal, need_dbias=need_dbias,
+                                           causal=causal, need_dbias=need_dbias, seg=ctx.seg,
                                            outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
@@ -594,11 +626,13 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         q = K.gemm(xq2, wq, False, True, bias=bq).view(B, T, D)
         kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
-        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False)
+        kpm, seg = _split_seg(kpm)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False, seg=seg)
         ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
         ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, pack)
+        ctx.seg = seg
         return out
 
     @staticmethod
@@ -609,11 +643,12 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         B, T, D = q.shape
         S = kv.shape[1]
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
-        dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        mk = torch.zeros_like if ctx.seg is not None else torch.empty_like                   # ragged: filler rows stay zero
+        dq = mk(q)
+        dkv = mk(kv)
         need_dbias = bias is not None and ctx.needs_input_grad[8]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
-                                           causal=False, need_dbias=need_dbias,
+                                           causal=False, need_dbias=need_dbias, seg=ctx.seg,
                                            outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
@@ -706,6 +741,9 @@ def attention(q, k, v, heads, scale, bias=None, key_padding_mask=None, c_attn=No
         bias = bias.to(q.dtype)
     if fused_ok:
         return FusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal), None
+    if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):
+        raise NotImplementedError("packed (ragged) batches run on the fused bf16 attention kernels only "
+                                  "(bf16, head_dim 64, no attention dropout, no attention-weight output)")
     out, p = UnfusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal, dropout_p)
     return out, p
 

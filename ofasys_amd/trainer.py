@@ -116,6 +116,9 @@ def _walk(obj, path, out):
             _walk(v, path + (i,), out)
     elif hasattr(obj, "modality") and hasattr(obj, "is_src"):           # a Slot
         _walk(obj.value, path + ("value",), out)
+    elif hasattr(obj, "tensors") and hasattr(obj, "structure"):         # a packing.PackPlan: index / segment tables
+        for i, t in enumerate(obj.tensors()):
+            out.append((path + (i,), t))
     elif obj is None or isinstance(obj, (str, int, float, bool)):
         pass
     else:
@@ -141,7 +144,8 @@ def sample_structure(samples):
         slots = tuple((getattr(sl.modality, "name", str(sl.modality)), bool(sl.is_src), tuple(sl.attributes or ()))
                       for sl in s["slots"])
         scal = tuple((k, s[k]) for k in sorted(s) if isinstance(s[k], (str, int, float, bool)))
-        sig.append((slots, scal))
+        plan = s["pack"].structure() if s.get("pack") is not None else None          # launch bounds of a ragged batch
+        sig.append((slots, scal, plan))
     tens = tuple((p, tuple(t.shape), str(t.dtype)) for p, t in sample_tensors(samples))
     return (tuple(sig), tens)
 
@@ -221,14 +225,25 @@ class TrainStep:
         ops.defer_reductions(self.world == 1 or not overlap_reduce)
         self.reducer.begin_step(structure)
         for s in samples:
-            logits = model(s["slots"])[0]
+            plan = s.get("pack")
+            target = s["target"]
+            if plan is None:
+                logits = model(s["slots"])[0]
+            else:                                    # ragged batch (packing.py): logits and targets by packed decoder row
+                logits = model(s["slots"], pack=plan)[0]
+                target = s.get("target_packed")
+                if target is None:
+                    idx = plan.dec_index
+                    target = s["target"].reshape(-1)[idx.clamp_min(0)].masked_fill(idx < 0, self.pad).view(1, -1)
             cm = s.get("constraint_masks")
+            if plan is not None and cm is not None:
+                raise NotImplementedError("constraint masks are laid out by padded position: run such samples without a pack plan")
             if self.label_smoothing > 0 or self.constraint_range is not None or self.drop_worst_ratio > 0 or cm is not None:
-                loss, _, n = ops.label_smoothed_cross_entropy(logits, s["target"], self.pad, self.label_smoothing,
+                loss, _, n = ops.label_smoothed_cross_entropy(logits, target, self.pad, self.label_smoothing,
                                                               self.constraint_range, cm, self.drop_worst_ratio)
             else:
-                loss = ops.cross_entropy_sum(logits, s["target"], self.pad)
-                n = s["target"].ne(self.pad).sum()
+                loss = ops.cross_entropy_sum(logits, target, self.pad)
+                n = target.ne(self.pad).sum()
             loss.backward()
             self._stats[0] += n
             self._stats[1] += loss.detach().double()

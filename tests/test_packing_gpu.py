@@ -1,0 +1,128 @@
+"""GPU: ragged row packing (ofasys_amd/packing.py) against the padded path it replaces.  No non-pad output of the reference
+depends on a padded position (padding is zeroed, masked as a key and ignored by the criterion: model/transformer.py:110-112,
+multihead_attention.py:319-326, cross_entropy.py:27-41), so the packed stack must reproduce the padded stack's logits at every
+non-pad position and its gradients; the padded stack itself is pinned to the reference by tests/test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe
+from oracle.cases import VOCAB_EXTRA, make_target
+from tests.model_util import build_model, make_slots
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")]
+DEV = "cuda"
+V = 4 + VOCAB_EXTRA
+CASE = {"arch": "tiny", "active": {"text"}, "overrides": {"use_self_attn_bias": False, "entangle_position_embedding": True, "dropout": 0.0},
+        "adaptor_overrides": {"text": {"entangle_position_embedding": True}}}
+
+
+def _tok(key, shape, lengths=None, bos=False):
+    return recipe.tokens("pack." + key, shape, V, lengths, bos=0 if bos else None)
+
+
+def _batch(two_slots):
+    B = 5
+    src_a = _tok("srcA", (B, 37), [37, 12, 30, 1, 22])
+    prev = _tok("prev", (B, 19), [19, 3, 11, 19, 7], bos=True)
+    vals = [("TEXT", True, src_a, None)]
+    if two_slots:                     # a second ragged source slot: the valid positions of a row are no longer a prefix
+        vals.append(("STRUCT", True, _tok("srcB", (B, 9), [4, 9, 1, 9, 6]), None))
+    vals.append(("TEXT", False, prev, None))
+    enc_tokens = torch.cat([v for m, s, v, a in vals if s], 1)
+    return vals, make_target(prev), enc_tokens.eq(1), prev.eq(1)
+
+
+@pytest.mark.parametrize("two_slots", [False, True])
+def test_packed_forward_backward_equals_padded(two_slots):
+    from ofasys_amd import ops
+    from ofasys_amd.packing import build_pack_plan
+    vals, target, enc_mask, dec_mask = _batch(two_slots)
+    plan = build_pack_plan(enc_mask, dec_mask, bucket=64)
+    assert plan.enc_tokens == int((~enc_mask).sum()) and plan.dec_tokens == int((~dec_mask).sum())
+    assert plan.enc_index.numel() % 64 == 0 and plan.enc_index.numel() < enc_mask.numel()       # really fewer rows
+    assert all(int(o) % 8 == 0 for o in plan.enc_self.table[:, 0])
+    res = {}
+    for mode in ("padded", "packed"):
+        model, d = build_model(CASE, DEV, torch.bfloat16)
+        model.train()                                          # dropout 0: train mode only matters for the fused kernels' choice
+        slots = make_slots(vals, DEV, torch.bfloat16)
+        if mode == "padded":
+            logits = model(slots)[0]
+            tgt = target.to(DEV)
+        else:
+            p = plan.to(DEV)
+            logits = model(slots, pack=p)[0]
+            assert logits.shape == (1, plan.dec_index.numel(), len(d))
+            idx = p.dec_index
+            tgt = target.to(DEV).reshape(-1)[idx.clamp_min(0)].masked_fill(idx < 0, d.pad()).view(1, -1)
+        loss = ops.cross_entropy_sum(logits, tgt, d.pad())
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (logits.detach().float().cpu(), float(loss), {k: p_.grad.detach().float().cpu() for k, p_ in model.named_parameters()
+                                                                   if p_.grad is not None})
+    lp, losp, gp = res["padded"]
+    lk, losk, gk = res["packed"]
+    # logits at every non-pad decoder position
+    di = plan.dec_index
+    valid = di >= 0
+    want = lp.reshape(-1, lp.shape[-1])[di[valid]]
+    got = lk[0][valid]
+    scale = float(want.abs().max())
+    # (same arithmetic per row; with several ragged slots the keys of a sample sit in different 32-key blocks than in the padded
+    #  layout, so the online-softmax partial sums round differently: a couple of bf16 ulps)
+    assert float((got - want).abs().max()) <= 2e-2 * scale
+    assert float(lk[0][~valid].abs().max()) < 1e30                        # filler rows: finite (they are inert)
+    assert abs(losp - losk) <= 2e-3 * abs(losp)
+    gmax = max(float(g.norm()) for g in gp.values())
+    assert set(gp) == set(gk)
+    for k in gp:
+        a, b = gp[k], gk[k]
+        assert float((a - b).norm()) <= 3e-2 * float(a.norm()) + 2e-3 * gmax, k
+
+
+def test_packed_train_step_and_graph_replay():
+    """TrainStep on ragged batches: the pack plan is part of the step's static inputs (new batches of the same bucketed row count
+    replay the same hipGraph), and a run of steps matches the padded run (bf16, dropout 0) within rounding."""
+    from ofasys_amd.packing import build_pack_plan
+    from ofasys_amd.trainer import TrainStep
+    runs = {}
+    for mode in ("padded", "packed-eager", "packed-graph"):
+        model, d = build_model(CASE, DEV, torch.bfloat16)
+        tr = TrainStep(model, lr=1e-3, clip_norm=1.0, use_graph=mode == "packed-graph", graph_warmup=1)
+        losses = []
+        for step in range(6):
+            g = np.random.Generator(np.random.Philox(key=100 + step))
+            B = 6
+            sl = g.integers(5, 40, B)
+            tl = g.integers(2, 20, B)
+            sl[0], tl[0] = 39, 19                                           # same padded shape every step
+            src = recipe.tokens(f"pack.s{step}", (B, 39), V, sl.tolist())
+            prev = recipe.tokens(f"pack.p{step}", (B, 19), V, tl.tolist(), bos=0)
+            sample = {"slots": make_slots([("TEXT", True, src, None), ("TEXT", False, prev, None)], DEV, torch.bfloat16),
+                      "target": make_target(prev).to(DEV)}
+            if mode != "padded":
+                sample["pack"] = build_pack_plan(src.eq(1), prev.eq(1), bucket=256).to(DEV)
+            losses.append(float(tr.train_step([sample])["stats"][1]))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, tr)
+    lp, lke, lkg = runs["padded"][0], runs["packed-eager"][0], runs["packed-graph"][0]
+    assert lke == lkg                                                        # replays == eager, bit for bit
+    tr = runs["packed-graph"][1]
+    assert sum(1 for e in tr._graphs.values() if "graphs" in e) == 1        # one bucketed structure -> one graph for all batches
+    for a, b in zip(lp, lke):
+        assert abs(a - b) <= 2e-2 * abs(a)
+
+
+def test_packing_refuses_what_it_cannot_run():
+    from ofasys_amd.packing import build_pack_plan
+    vals, target, enc_mask, dec_mask = _batch(False)
+    plan = build_pack_plan(enc_mask, dec_mask, bucket=64).to(DEV)
+    biased = {"arch": "tiny", "active": {"text"}, "overrides": {"dropout": 0.0}, "adaptor_overrides": {}}
+    model, d = build_model(biased, DEV, torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="row packing"):
+        model(make_slots(vals, DEV, torch.bfloat16), pack=plan)
+    model, d = build_model(CASE, DEV, torch.float32)                         # fp32: no fused ragged attention kernel
+    with pytest.raises(NotImplementedError, match="fused"):
+        model(make_slots(vals, DEV), pack=plan)

@@ -142,22 +142,24 @@ int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, vo
  * (multihead_attention.py:319-326); here the batch may arrive packed instead.  seg: device int32 [B][4] = {q_off, q_len, k_off,
  * k_len} (16-byte aligned; q_off a multiple of 4).  q / out are [rows_q, ld] with sample b's queries in rows q_off .. q_off+q_len-1,
  * k / v are [rows_k, ld] likewise; lse is fp32 [heads, Tpad] indexed by the packed query row (Tpad >= rows_q); T, S are upper
- * bounds of q_len, k_len (they size the launch grid); bias and kpm must be NULL.  Rows outside every segment are not touched. */
+ * bounds of q_len, k_len (they size the launch grid); rows_q / rows_k: total packed rows; bias and kpm must be NULL.  The rows of
+ * `out` outside every segment (alignment / bucket filler) are written as zeros. */
 int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
                  const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
-                 int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int dtype, void* stream);
+                 int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k,
+                 int dtype, void* stream);
 /* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
  * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep; dout: [B,T,heads*64] rows (ld = ldo).
  * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS.
  * No transposed operand copies are needed: the kernels transpose tiles on the LDS read (ds_read_b64_tr_b16).
  * seg != NULL: ragged mode as in ofa_attn_fwd (delta from ofa_attn_bwd_prep(B = 1, T = rows_q): [heads, Tpad] by packed row;
- * dq / dk / dv rows outside every segment are not written -- the caller zero-fills them). */
+ * dq / dk / dv rows outside every segment are written as zeros). */
 int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
                       int dtype, void* stream);
 int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
                  const void* c_attn, int c_attn_dtype, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                  void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
-                 int causal, const int32_t* seg, int dtype, void* stream);
+                 int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */

@@ -51,7 +51,37 @@ struct AttnL {
   int64_t ldq, ldk, ldo;
   float scale; int causal;
   const int* seg;   // ragged ("packed rows") mode: int32 [B][4] = {q_off, q_len, k_off, k_len}, see seg_enter()
+  int rows_q, rows_k;   // ragged mode: total packed rows (filler rows between / behind the segments are zero-filled here)
 };
+
+// Ragged mode: the rows between sample b's last row and sample b+1's first (alignment filler, and behind the last sample the
+// bucket filler up to `rows`) belong to no segment.  They must hold finite values -- they flow through the row-wise kernels
+// downstream, where 0 * NaN would poison the weight gradients -- so the workgroups of ONE extra grid column zero them: 64
+// columns (head h) of rows [off + len, next_off) of up to two outputs.  Replaces a memset of the whole output per call.
+__device__ __forceinline__ void seg_zero_fill(const int* seg, int B, int b, int h, bool k_side, int rows, bf16_t* o1, int64_t ld1,
+                                              bf16_t* o2, int64_t ld2, int tid) {
+  const int4 s = reinterpret_cast<const int4*>(seg)[b];
+  const int lo = k_side ? s.z + s.w : s.x + s.y;
+  int hi = rows;
+  if (b + 1 < B) {
+    const int4 n = reinterpret_cast<const int4*>(seg)[b + 1];
+    hi = k_side ? n.z : n.x;
+  }
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < (hi - lo) * 8; i += 256) {                 // 8 x 16-byte chunks per (row, head)
+    const int r = lo + (i >> 3), c = (i & 7) * 8;
+    if (o1) *reinterpret_cast<uint4*>(o1 + (int64_t)r * ld1 + h * HD + c) = z;
+    if (o2) *reinterpret_cast<uint4*>(o2 + (int64_t)r * ld2 + h * HD + c) = z;
+  }
+  if (b == 0) {                                                     // rows in front of the first segment (normally none)
+    const int first = k_side ? s.z : s.x;
+    for (int i = tid; i < first * 8; i += 256) {
+      const int r = i >> 3, c = (i & 7) * 8;
+      if (o1) *reinterpret_cast<uint4*>(o1 + (int64_t)r * ld1 + h * HD + c) = z;
+      if (o2) *reinterpret_cast<uint4*>(o2 + (int64_t)r * ld2 + h * HD + c) = z;
+    }
+  }
+}
 
 // Ragged mode.  The reference pads every sample of a batch to the longest one and masks (multihead_attention.py:319-326); the
 // metric counts non-pad positions only, so here a batch may arrive PACKED: q / out / dout / dq are [rows_q, ld] with sample b's
@@ -327,6 +357,10 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   int bh = blockIdx.y, b = bh / a.heads;
   const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
+  if (a.seg && blockIdx.x == gridDim.x - 1) {            // ragged mode: the extra grid column zero-fills the filler rows
+    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.out, a.ldo, nullptr, 0, tid);
+    return;
+  }
   if (!seg_enter(a, b, bh, h, qb0, true)) return;        // (workgroup-uniform)
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
@@ -486,6 +520,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   int bh = blockIdx.y, b = bh / a.heads;
   const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
+  if (a.seg && blockIdx.x == gridDim.x - 1) {
+    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, nullptr, 0, tid);
+    return;
+  }
   if (!seg_enter(a, b, bh, h, qb0, true)) return;
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
@@ -662,6 +700,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
   int bh = blockIdx.y, b = bh / a.heads;
   const int h = bh % a.heads;
   const int kb0 = blockIdx.x * 128;
+  if (a.seg && blockIdx.x == gridDim.x - 1) {
+    seg_zero_fill(a.seg, a.B, b, h, true, a.rows_k, a.dk, a.ldk, a.dv, a.ldk, tid);
+    return;
+  }
   if (!seg_enter(a, b, bh, h, kb0, false)) return;
   const int key0 = kb0 + wave * 32;
   const int ki = key0 + i;
@@ -768,7 +810,7 @@ using namespace ofa;
 extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, const uint8_t* kpm,
                             const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S,
                             int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
-                            int dtype, void* stream) {
+                            int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(q && k && v && out, OFA_ERR_INVALID, "attn_fwd: null pointer");
   OFA_REQUIRE(!seg || (!bias && !kpm && lse && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
@@ -777,16 +819,17 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
   a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
-  a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
-  hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(cdiv(T, 128), B * heads), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
+  OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_fwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
+  hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(cdiv(T, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_fwd");
 }
 
 extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
                             const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, const float* delta,
                             void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
-                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int dtype,
-                            void* stream) {
+                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
+                            int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(!seg || (!bias && !kpm && !dbias && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
               "attn_bwd: the ragged (seg) mode takes no bias / key-padding mask / dbias and a 16-byte aligned table");
@@ -797,10 +840,12 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
+  a.rows_q = rows_q; a.rows_k = rows_k;
+  OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_bwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(cdiv(T, 128), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
+  hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(cdiv(T, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, dim3(cdiv(S, 128), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, dim3(cdiv(S, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
   return check_launch("attn_bwd_dkv");
 }

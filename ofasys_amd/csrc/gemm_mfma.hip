@@ -1193,7 +1193,9 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
     const double f4 = fill(256), f3 = g.transA ? 0.0 : fill(192) * 0.97;
     if (force_tile == 44) big_tm = 4;
     else if (force_tile == 34) big_tm = g.transA ? 4 : 3;
-    else if (f4 >= 0.8 || f3 >= 0.8) {
+    // (0.7: a packed batch of 12800 / 13312 rows x 768 columns fills 201 / 210 of the 256 CUs with 192 x 256 tiles and still beats
+    //  the two partial rounds of 128 x 128 tiles by 6-28 %, profiles/round2_gemm_tile_sweep.txt)
+    else if (f4 >= 0.7 || f3 >= 0.7) {
       const int tm = f4 >= f3 ? 4 : 3;
       const int64_t t = (int64_t)cdiv(g.M, tm * 64) * cdiv(g.N, 256) * batch;
       if (g.K >= 4096 || t <= 256) big_tm = tm;

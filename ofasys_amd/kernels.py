@@ -376,11 +376,11 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
     Tpad = pad32(T)
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and seg.rows_q == T and seg.rows_k == S, (B, T, S, seg.rows_q, seg.rows_k)
-        out = torch.zeros(1, T, D, dtype=q.dtype, device=q.device)
-        lse = torch.zeros(heads, Tpad, dtype=torch.float32, device=q.device)
+        out = torch.empty(1, T, D, dtype=q.dtype, device=q.device)          # filler rows are zeroed by the kernel
+        lse = torch.empty(heads, Tpad, dtype=torch.float32, device=q.device)
         lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(out), ptr(lse),
                    seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, D, float(scale), int(causal), ptr(seg.table),
-                   dtype_code(q), stream())
+                   T, S, dtype_code(q), stream())
         return out, lse
     out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
@@ -389,7 +389,7 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
     if kpm is not None:
         kpm = _u8(kpm)
     lib().call("ofa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(out), ptr(lse),
-               B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), None, dtype_code(q), stream())
+               B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), None, 0, 0, dtype_code(q), stream())
     return out, lse
 
 
@@ -425,19 +425,18 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         if ldk != D:
             k, v = k.contiguous(), v.contiguous()
             ldk = D
-        mk = torch.zeros if seg is not None else torch.empty          # ragged mode: rows outside every segment stay zero
-        dq = mk(B, T, D, dtype=q.dtype, device=q.device)
-        dk = mk(B, S, D, dtype=q.dtype, device=q.device)
-        dv = mk(B, S, D, dtype=q.dtype, device=q.device)
+        dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)     # (ragged mode: the kernels zero the filler rows)
+        dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+        dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
         lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                    ptr(delta), ptr(dq), ptr(dk), ptr(dv), None, seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo,
-                   float(scale), int(causal), ptr(seg.table), dtype_code(q), stream())
+                   float(scale), int(causal), ptr(seg.table), T, S, dtype_code(q), stream())
         return dq, dk, dv, None, delta
     lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
-               int(causal), None, dtype_code(q), stream())
+               int(causal), None, 0, 0, dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
 
 

@@ -595,7 +595,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         B, T, D3 = kvq.shape
         D = D3 // 3
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
-        dkvq = torch.zeros_like(kvq) if ctx.seg is not None else torch.empty_like(kvq)      # ragged: filler rows stay zero
+        dkvq = torch.empty_like(kvq)                                   # (ragged mode: the kernels zero the filler rows)
         need_dbias = bias is not None and ctx.needs_input_grad[7]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=causal, need_dbias=need_dbias, seg=ctx.seg,
@@ -643,9 +643,8 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         B, T, D = q.shape
         S = kv.shape[1]
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
-        mk = torch.zeros_like if ctx.seg is not None else torch.empty_like                   # ragged: filler rows stay zero
-        dq = mk(q)
-        dkv = mk(kv)
+        dq = torch.empty_like(q)                                       # (ragged mode: the kernels zero the filler rows)
+        dkv = torch.empty_like(kv)
         need_dbias = bias is not None and ctx.needs_input_grad[8]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=False, need_dbias=need_dbias, seg=ctx.seg,

@@ -47,7 +47,7 @@ def test_status_codes_not_asserts():
     with pytest.raises(L.OfaError, match="dtype"):                                                     # fp16: softmax entry points only
         h.call("ofa_layernorm_fwd", 1, 1, 1, 1, 1, 1, 4, 8, 1e-5, L.F16, None)
     with pytest.raises(L.OfaError, match="bf16"):
-        h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, L.F32, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, None, L.F32, None)
+        h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, L.F32, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, None, 0, 0, L.F32, None)
 
 
 def test_no_cpu_fallback():

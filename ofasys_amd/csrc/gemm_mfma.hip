@@ -561,9 +561,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 
   // epilogue through the wave's slice of the (idle) LDS stages: see epilogue_lds
   __syncthreads();                                     // every wave is done with the fragment reads / the last DMA
-#ifdef OFA_EXP_NOEPI
-  if (g.alpha == 12345.f)
-#endif
   {
     const bool split = gridDim.y > 1;
     constexpr int REGION = ((GLDS ? 2 * (EA + EB) * 2 : 2 * (GA::ELEMS + GB::ELEMS) * 2) / (WM * WN)) & ~1023;
@@ -791,12 +788,6 @@ template <int R, bool KMAJ> struct BigAddr {
 // issue the reads of fragment `TI` (32 rows) of k-slice KK from the buffer at byte offset BUFOFF
 template <int R, bool KMAJ, int KK, int TI, int BUFOFF>
 __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
-#ifdef OFA_EXP_NOREAD
-  if (OFA_EXP_NOREAD == 2 || KMAJ == (OFA_EXP_NOREAD == 1)) {      // 2: no reads at all; 1: skip k-major operands; 0: skip m-major
-    asm volatile("; no read" : "=v"(d) : "v"(fa.a[0]));
-    return;
-  }
-#endif
   if constexpr (KMAJ) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(fa.a[KK]), "i"(BUFOFF + TI * 32 * 128));
   } else {
@@ -808,26 +799,13 @@ __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
   }
 }
 
-// which fragment read (0..nr-1, or -1) follows MFMA number t of a slice
-#ifndef OFA_BIG_PAT
-#define OFA_BIG_PAT 1
-#endif
-__host__ __device__ constexpr int big_read_after(int t, int nr) {
-  return OFA_BIG_PAT == 1 ? (t < nr ? t : -1)                      // one read behind each of the first nr MFMAs
-                          : ((t % 2) == 0 && t / 2 < nr ? t / 2 : -1);   // one read per two MFMAs
-}
+// which fragment read (0..nr-1, or -1) follows MFMA number t of a slice: one read behind each of the first nr MFMAs
+__host__ __device__ constexpr int big_read_after(int t, int nr) { return t < nr ? t : -1; }
 
 template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                        float* __restrict__ ws) {
   constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
-#ifdef OFA_EXP_STAMP
-  unsigned long long stamp[6];
-#define STAMP(i) stamp[i] = __builtin_readcyclecounter()
-#else
-#define STAMP(i)
-#endif
-  STAMP(0);
   static_assert(A_KMAJ || BM == 256, "m-major tiles are 256 wide (swizzle)");
   static_assert(B_KMAJ || BN == 256, "m-major tiles are 256 wide (swizzle)");
   constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
@@ -853,11 +831,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
   const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
-#ifdef OFA_EXP_NOLOOP
-  const int nk = g.alpha == 12345.f ? 1 : 0;
-#else
   const int nk = (kend - kbeg) / BK;                        // launcher guarantees whole K tiles
-#endif
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -881,7 +855,6 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
     glds_issue<NT, NVB>(pb, stepB, db, wave_u);
     knext += BK;
   };
-  STAMP(1);
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
   BigAddr<BM, A_KMAJ> fax;
   BigAddr<BN, B_KMAJ> faw;
@@ -892,11 +865,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
 #define BIG_ISSUE(KK, SET)                                                                                        \
   static_for<0, TM>([&](auto ic) { big_frag<BM, A_KMAJ, KK, decltype(ic)::value, 0>(xa[SET][decltype(ic)::value], fax); }); \
   static_for<0, TN>([&](auto ic) { big_frag<BN, B_KMAJ, KK, decltype(ic)::value, 0>(wb[SET][decltype(ic)::value], faw); })
-#ifdef OFA_EXP_NOWAIT
-#define BIG_WAITCNT "; nowait"
-#else
 #define BIG_WAITCNT "s_waitcnt lgkmcnt(0)"
-#endif
 #define BIG_WAIT(SET)                                                                  \
   if constexpr (TM == 4)                                                               \
     asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]), "+v"(xa[SET][3]),   \
@@ -942,11 +911,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-#ifndef OFA_EXP_NODMA
       const bool more2 = kt + 2 < nk;     // refill the retired stage with tile kt+2 ...
-#else
-      const bool more2 = false;
-#endif
       if (more2 && !B_KMAJ && knext + BK > g.b_krows)          // zero-padded contraction tail: clamp B's k rows
         glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
 #pragma unroll
@@ -990,22 +955,12 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
 #undef BIG_SB
 #undef BIG_WAIT
 #undef BIG_ISSUE
-
-  STAMP(2);
   __syncthreads();                                     // every wave is done with the fragment reads
-  STAMP(3);
-#ifdef OFA_EXP_NOEPI
-  if (g.alpha == 12345.f)
-#endif
   {
     const bool split = gridDim.y > 1;
     constexpr int REGION = 4 * STAGE * 2 / 4;          // 32 KiB per wave
     unsigned char* wl = smem_raw + wave * REGION;
-#ifdef OFA_EXP_SAMEOUT
-    const int m_w = wm * TM * 32, n_w = wn * TN * 32;
-#else
     const int m_w = m0 + wm * TM * 32, n_w = n0 + wn * TN * 32;
-#endif
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
@@ -1016,15 +971,6 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
       epilogue_lds<TM, TN, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
-  STAMP(4);
-#ifdef OFA_EXP_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  STAMP(5);
-  if (tid == 0 && ws) {
-    unsigned long long* o = (unsigned long long*)ws + (size_t)blockIdx.x * 8;
-    for (int i = 0; i < 6; ++i) o[i] = stamp[i];
-  }
-#endif
 }
 
 template <bool OUT_F32>

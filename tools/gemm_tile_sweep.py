@@ -29,6 +29,11 @@ for M in Ms:
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20
-            print(f"tile{tile} {kind} {m} {n} {k} {us:8.1f} us {2.0*m*n*k/us/1e6:7.1f} TF", flush=True)
+            err = ""
+            if os.environ.get("OFA_SWEEP_CHECK"):
+                A = (a.t() if ta else a).float(); Bm = (b.t() if tb else b).float()
+                ref = A[:512] @ Bm
+                err = f" err {float((out[:512].float() - ref).abs().max() / ref.abs().max()):.2e}"
+            print(f"tile{tile} {kind} {m} {n} {k} {us:8.1f} us {2.0*m*n*k/us/1e6:7.1f} TF{err}", flush=True)
         except Exception as e:
             print(f"tile{tile} {kind} {m} {n} {k} ERR {str(e)[:60]}", flush=True)

@@ -211,12 +211,24 @@ __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int 
   }
 }
 
+// Chunk swizzle of the [32 x 64] LDS tile images: chunk c (16 bytes, 8 per 128-byte row) of row r lives at c ^ tile_swz(r),
+// tile_swz(r) = ((r>>1)&7) rotated right by one bit.  Any bijection of (r>>1)&7 makes the 16 rows of a ds_read_b128 lane group hit
+// 16 distinct 16-byte slots; the rotation is for the TRANSPOSING reads: a 32-lane pass of ds_read_b64_tr_b16 covers rows
+// base + 0..3 x 64 bytes, rows {0,1} and {2,3} differ in bit 0 of (r>>1), and that bit must move the chunk to the OTHER aligned
+// group of four (xor 4) -- with the plain (r>>1)&7 it only xors chunk bit 0, rows 2,3 land on the slots of rows 0,1 and every
+// pass is a 2-way bank conflict (round-1 PMC: SQ_LDS_BANK_CONFLICT = 25-33% of SQ_LDS_IDX_ACTIVE in all three kernels).
+// (Measured: the conflicts were not what bounds these kernels -- same times before and after, profiles/round2_attention_experiments.txt.)
+__device__ __forceinline__ int tile_swz(int row) {
+  const int x = (row >> 1) & 7;
+  return ((x & 1) << 2) | (x >> 1);
+}
+
 // One workgroup-wide DMA of a [32 x 64] tile: rows row0.. of a [*, ld] matrix, columns col0..col0+63.
-// 256 granules of 16 B, one per thread; LDS image row-major 128-B rows, chunk c of row r stored at c ^ ((r>>1)&7).
+// 256 granules of 16 B, one per thread; LDS image row-major 128-B rows, chunk c of row r stored at c ^ tile_swz(r).
 __device__ __forceinline__ void tile_dma(const bf16_t* __restrict__ base, int64_t ld, int row0, int rmax, int col0,
                                          bf16_t* __restrict__ lds_tile, int tid, int wave_u) {
   const int r = tid >> 3, pc = tid & 7;
-  const int c = pc ^ ((r >> 1) & 7);
+  const int c = pc ^ tile_swz(r);
   int rr = row0 + r;
   rr = rr < rmax ? rr : rmax - 1;
   const bf16_t* src = base + (int64_t)rr * ld + col0 + c * 8;
@@ -231,7 +243,7 @@ struct TileAddr {
   __device__ __forceinline__ void init(uint32_t lds0, int lane) {
     const int row = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) km[kk] = lds0 + (uint32_t)(row * 128 + (((kk * 2 + hi) ^ ((row >> 1) & 7)) << 4));
+    for (int kk = 0; kk < 4; ++kk) km[kk] = lds0 + (uint32_t)(row * 128 + (((kk * 2 + hi) ^ tile_swz(row)) << 4));
     // transposing read: lane q' of a 16-lane group supplies the address of 4 contiguous elements (row kb + (q'>>2),
     // col cb + 4*(q'&3)) and receives column cb + q' of the 4-row block.  Row swizzle ((row>>1)&7) of
     // row = 16j + 8m + 4hi + t is 4m + 2hi + (t>>1): independent of j, bit 2 set by m.
@@ -240,9 +252,9 @@ struct TileAddr {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int col = dt * 32 + (g & 1) * 16 + 4 * (q & 3);
-      const int sw = (trow >> 1) & 3;
+      const int sw = tile_swz(trow);          // trow < 8; the immediates add 16j rows (swizzle unchanged) ...
       tr[dt] = lds0 + (uint32_t)(trow * 128 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2);
-      trx[dt] = lds0 + (uint32_t)(trow * 128 + (((col >> 3) ^ sw ^ 4) << 4) + (col & 7) * 2);
+      trx[dt] = lds0 + (uint32_t)(trow * 128 + (((col >> 3) ^ sw ^ 2) << 4) + (col & 7) * 2);   // ... or 16j + 8: bit 2 of (r>>1) -> xor 2
     }
   }
 };

@@ -283,9 +283,10 @@ def test_train_step_arithmetic_two_tasks():
 
 
 def test_two_graph_replay_path_of_data_parallel_steps():
-    """With world_size > 1 the captured step is TWO graphs (forward+backward, clip+Adam) around an eager all-reduce.  There
-    is one GPU here, so the path is driven with the world size forced to 2 (the reducer itself stays single-rank): the
-    trajectory must equal the eager one."""
+    """dp_graph="split" (the fallback of the data-parallel step when collectives cannot be captured): TWO graphs
+    (forward+backward, clip+Adam) around an eager all-reduce.  There is one GPU here, so the path is driven with the world size
+    forced to 2 (the reducer itself stays single-rank): the trajectory must equal the eager one.  The default, one graph with
+    the RCCL collectives captured, is covered by tests/test_configs_gpu.py::test_dp_step_graph_with_captured_rccl_collectives."""
     from ofasys_amd import ops
     from ofasys_amd.trainer import Trainer
     case = CASES["tiny_multislot"]
@@ -293,7 +294,7 @@ def test_two_graph_replay_path_of_data_parallel_steps():
     runs = []
     for two_graphs in (False, True):
         model, d = build_model(case, DEV, torch.bfloat16)
-        tr = Trainer(model, lr=1e-3, clip_norm=1.0, use_graph=two_graphs, graph_warmup=1)
+        tr = Trainer(model, lr=1e-3, clip_norm=1.0, use_graph=two_graphs, graph_warmup=1, dp_graph="split")
         if two_graphs:
             tr.world = 2
         batch = {"slots": make_slots(vals, DEV, torch.bfloat16), "target": target.to(DEV)}
@@ -370,7 +371,7 @@ def test_incremental_equals_teacher_forcing_at_base_size():
     args = argparse.Namespace(arch="base", workload="cfg2", batch=4)
     model, d = bench.build(args, torch.device(DEV))
     model.eval()
-    batch, _ = bench.make_batch(d, 4, 191, 24, 0, torch.device(DEV), "cfg2")
+    batch, _, _ = bench.make_batch(d, 4, 191, 24, 0, torch.device(DEV), "cfg2")
     src = [s for s in batch["slots"] if s.is_src]
     prev = batch["slots"][-1].value
     with torch.no_grad():

@@ -10,7 +10,7 @@ model, d = bench.build(args, dev)
 model.eval()
 steps = 32
 for rows in (32, 160):
-    batch, _ = bench.make_batch(d, rows, 191, 8, 0, dev, "cfg2")
+    batch, _, _ = bench.make_batch(d, rows, 191, 8, 0, dev, "cfg2")
     src = [s for s in batch["slots"] if s.is_src]
     for use_graph in (False, True):
         dec = StepDecoder(model, steps, use_graph=use_graph)

@@ -7,7 +7,7 @@ dev = torch.device("cuda")
 model, d = bench.build(argparse.Namespace(arch="base", workload="cfg2", batch=32), dev)
 model.eval()
 rows, steps = 160, 16
-batch, _ = bench.make_batch(d, rows, 191, 8, 0, dev, "cfg2")
+batch, _, _ = bench.make_batch(d, rows, 191, 8, 0, dev, "cfg2")
 src = [s for s in batch["slots"] if s.is_src]
 dec = StepDecoder(model, steps, use_graph=True)
 for rep in range(6):                                  # 1 eager + 1 capture + 4 replayed sequences

@@ -10,7 +10,7 @@ args = argparse.Namespace(arch="base", workload="cfg2", batch=32)
 dev = torch.device("cuda", 0)
 model, d = bench.build(args, dev)
 tr = Trainer(model, lr=1e-4, clip_norm=1.0, use_graph=False)
-batch, ntok = bench.make_batch(d, 32, 191, 64, 0, dev, "cfg2")
+batch, ntok, _ = bench.make_batch(d, 32, 191, 64, 0, dev, "cfg2")
 for _ in range(3):
     tr.train_step([batch])
 torch.cuda.synchronize()

@@ -228,6 +228,22 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return start + local;
 }
 
+// (tile, K-slice) of this workgroup.  Workgroups are dispatched in linear order (x fastest, then y) round-robin over the 8 XCDs, and
+// each XCD has its own L2.  Without split-K the tile ids of an XCD are made contiguous (xcd_remap).  With split-K (gridDim.y
+// slices) the remap runs over the FLATTENED (slice, tile) index, slice-major: an XCD then works through whole K-slices -- every
+// tile of a slice reads the same [ksplit x M] / [ksplit x N] operand panels, which stay in that XCD's L2 -- instead of every
+// XCD touching every slice of a weight-gradient product (round-1 PMC: 2.7x the algorithmic bytes fetched per GEMM launch).
+__device__ __forceinline__ void tile_and_slice(int ntiles, int& t, int& ks) {
+  if (gridDim.y == 1) {
+    t = xcd_remap(blockIdx.x, ntiles);
+    ks = 0;
+    return;
+  }
+  const int id = xcd_remap((int)(blockIdx.x + blockIdx.y * gridDim.x), ntiles * (int)gridDim.y);
+  ks = id / ntiles;
+  t = id - ks * ntiles;
+}
+
 // epilogue on 4 consecutive columns n..n+3 of row m
 template <bool OUT_F32>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int m, int n, float v0, float v1, float v2,
@@ -425,7 +441,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = tiles_m * tiles_n;
-  const int t = xcd_remap(blockIdx.x, ntiles);
+  int t, ks;
+  tile_and_slice(ntiles, t, ks);
   // grouped order inside the XCD's run: consecutive ids walk GM tile-rows before moving to the next tile-column, so the
   // ~64 workgroups resident on an XCD cover a GM x (64/GM) block of tiles and every A / B panel they pull into the
   // XCD's 4 MiB L2 is shared by ~8 of them.
@@ -435,7 +452,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
   const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int bz = blockIdx.z, ks = blockIdx.y;
+  const int bz = blockIdx.z;
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
@@ -607,14 +624,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = tiles_m * tiles_n;
-  const int t = xcd_remap(blockIdx.x, ntiles);
+  int t, ks;
+  tile_and_slice(ntiles, t, ks);
   constexpr int GM = 8;
   const int gsz = GM * tiles_n;
   const int gid = t / gsz, first_m = gid * GM;
   const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
   const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int bz = blockIdx.z, ks = blockIdx.y;
+  const int bz = blockIdx.z;
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
@@ -819,14 +837,15 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = tiles_m * tiles_n;
-  const int t = xcd_remap(blockIdx.x, ntiles);
+  int t, ks;
+  tile_and_slice(ntiles, t, ks);
   constexpr int GM = 8;
   const int gsz = GM * tiles_n;
   const int gid = t / gsz, first_m = gid * GM;
   const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
   const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int bz = blockIdx.z, ks = blockIdx.y;
+  const int bz = blockIdx.z;
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;

@@ -60,6 +60,7 @@ CASES = {
                     "encoder.adaptor.image_resnet.image_proj.weight",
                     "encoder.adaptor.image_resnet.image_rel_pos_table_list.2.weight",
                     "encoder.adaptor.image_resnet.embed_image_positions.weight"],
+        block_grads=["layer3.5", "layer3.0", "layer2.0", "layer1.0"],
         buffers=["encoder.adaptor.image_resnet.embed_images.bn1.running_mean",
                  "encoder.adaptor.image_resnet.embed_images.layer3.5.bn3.running_var",
                  "encoder.adaptor.image_resnet.embed_images.layer2.0.downsample.1.running_mean",

@@ -23,7 +23,7 @@ BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2, "large_multislot": 4.2
 # from the CPU reference by <= 2.4% / 0.1%.  Outputs (logits 4e-6) and every gradient outside the backbone keep 1e-3.
 # bf16 gradient NORMS inside the backbone: the reference's own bf16-vs-fp32 gap there (oracle/ref_bf16_grad_gap.py, torch
 # CPU) is 41.6% on tiny_resnet and 22.8% on tiny_video (worst parameter: the stem's bn1) -- a one-ulp change of a single
-# conv output (e.g. a different split-K plan) moves the stem gradients of THIS build by 10 points as well.  Bound = 2x that
+# conv output (e.g. a different split-K plan) moves the stem gradients of THIS build by 10 points as well.  Bound = 1.25x that
 # gap; every parameter outside the backbone keeps 2.5 * tol.
 BF16_BACKBONE_GRAD_GAP = {"tiny_resnet": 0.416, "tiny_video": 0.228}
 FP32_GRAD_TOL_DEEP = 5e-3
@@ -104,10 +104,62 @@ def test_bf16_matches_reference(name):
         got = float(params[k].grad.double().norm())
         rel = 2.5 * tol
         if ".embed_images." in k and name in BF16_BACKBONE_GRAD_GAP:
-            rel = max(rel, 2 * BF16_BACKBONE_GRAD_GAP[name])
+            rel = max(rel, 1.25 * BF16_BACKBONE_GRAD_GAP[name])
         if abs(got - want) > rel * want + 2e-3 * scale:
             bad.append((k, got, want))
     assert not bad, bad[:8]
+
+
+def _rows(t):
+    """reference [B, C, h, w] -> the NHWC rows [B*h*w, C] this build's blocks exchange"""
+    B, C, h, w = t.shape
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(t, (0, 2, 3, 1)).reshape(B * h * w, C)))
+
+
+def test_resnet_block_backward_pinned_per_bottleneck():
+    """the backward through 16 conv / BatchNorm / ReLU bottlenecks is ill-conditioned as a CHAIN (errors of
+    a block are amplified by every BatchNorm in front of it), which is why whole-backbone gradients carry a loose bound.  The
+    arithmetic of each block is well-conditioned: feed the REFERENCE's dL/d(output) of a bottleneck (golden `blockgrad.*.dy`)
+    into this build's backward of that block alone and compare dL/d(input) with the reference's -- 1e-3, the north-star
+    tolerance -- for the last block, the stride-2 blocks with a downsample branch, and the first block.  Then the accumulated
+    error of dL/d(output) at every block: 1e-3 through layer3 (the six blocks next to the loss), growing towards the stem."""
+    case = CASES["tiny_resnet"]
+    g = load_golden("tiny_resnet")
+    model, d = build_model(case, DEV, torch.float32)
+    model.train()
+    backbone = model.encoder.adaptor.image_resnet.embed_images
+    io = {}
+    hooks = []
+    for lname in ("layer1", "layer2", "layer3"):
+        for bi, blk in enumerate(getattr(backbone, lname)):
+            def keep(m, i, o, key=f"{lname}.{bi}"):
+                o[0].retain_grad()
+                io[key] = (i[0][0], o[0])
+            hooks.append(blk.register_forward_hook(keep))
+    from ofasys_amd import ops
+    vals, target = case_inputs(case)
+    logits = model(make_slots(vals, DEV))[0]
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    local = {}
+    for k in case["block_grads"]:
+        x, y = io[k]
+        dy = _rows(g[f"blockgrad.{k}.dy"]).to(DEV)
+        (dx,) = torch.autograd.grad(y, x, dy, retain_graph=True)
+        want = _rows(g[f"blockgrad.{k}.dx"])
+        local[k] = rel_err(dx.cpu(), want)
+    for x, y in io.values():                   # (retain_grad also fires inside torch.autograd.grad: clear what the local runs left)
+        x.grad = None
+        y.grad = None
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    assert all(e < FP32_TOL for e in local.values()), local
+    names = [str(k) for k in g["blockgrad_keys"]]
+    acc = {k: abs(float(io[k][1].grad.double().norm()) - w) / w for k, w in zip(names, g["blockgrad_norms"])}
+    assert all(acc[k] < FP32_TOL for k in names if k.startswith("layer3.")), acc
+    assert all(e < FP32_GRAD_TOL_DEEP for e in acc.values()), acc
 
 
 def test_token_bucket_buffer_bit_exact():

@@ -274,6 +274,16 @@ int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* 
  * otherwise sched[3] = 0. */
 int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
                       float* gnorm, float clip_norm, double beta1, double beta2, void* stream);
+/* The same with a DYNAMIC LOSS SCALE (engine/optim/fp16_optimizer.py:170-204 clip_grad_norm / step, dynamic_loss_scaler.py:9-70):
+ * the arena holds loss_scale * (sum of gradients); loss_scaler: device fp64[8] = [loss_scale, iter, last_overflow_iter,
+ * last_rescale_iter, overflows_since_rescale, fatal, -, -].  sched[0] = 1 / (loss_scale * sample_size), times clip_norm / gnorm when
+ * gnorm > clip_norm > 0 (the fp16 optimizer's form: no 1e-6, no clamp); a non-finite gnorm runs check_overflow (scale /=
+ * scale_factor when overflows / iters since the last rescale >= tolerance, floor `threshold` (<= 0: none), `fatal` = 1 instead of
+ * the reference's FloatingPointError at min_loss_scale) and skips the update; otherwise update(): scale *= scale_factor every
+ * scale_window updates since the last overflow. */
+int ofa_step_schedule_scaled(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
+                             float* gnorm, double* loss_scaler, float clip_norm, double beta1, double beta2, double scale_factor,
+                             double scale_window, double tolerance, double threshold, double min_loss_scale, void* stream);
 /* Adam on fp32 master weights with grads of `dtype`; coef[0] = grad multiplier (world/sample_size and clip folded
  * in by the caller on device), writes the `dtype` model copy.  Weight decay as adam.py:209-210 (p -= wd*lr*p).
  * step >= 1: bias correction from (lr, step) on the host.  step == 0: coef is device fp32[>=4] = [grad multiplier,

@@ -345,6 +345,71 @@ __global__ void step_schedule_kernel(const float* __restrict__ gsq, const double
   sched[2] = (float)lr[0];
   gnorm[0] = gn;
 }
+
+// The scaled-loss variant of step_schedule_kernel: engine/optim/fp16_optimizer.py:170-204 + dynamic_loss_scaler.py:9-70 in one
+// device thread.  `ls` (fp64[8]) = [loss_scale, iter, last_overflow_iter, last_rescale_iter, overflows_since_rescale, fatal,
+// 0, 0]; the gradients in the arena are loss_scale * (sum of per-sample gradients).
+//   multiply_factor = 1 / (loss_scale * sample_size)                        (zero_grad :228-229, trainer.py:857-860)
+//   grad_norm       = multiply_factor * ||g||                               (:178)
+//   if grad_norm > max_norm > 0: multiply_factor *= max_norm / grad_norm    (:181-182; no "+1e-6", no clamp: the fp16 form)
+//   overflow (inf / nan norm): check_overflow (:44-70) -- last_overflow_iter = iter, ++overflows_since_rescale, and when
+//       overflows / iters_since_rescale >= tolerance: loss_scale = max(loss_scale / factor, threshold), last_rescale_iter = iter;
+//       loss_scale <= min_loss_scale restores the previous scale and sets `fatal` (the reference raises FloatingPointError);
+//       ++iter; the update is SKIPPED (trainer.py catches OverflowError and zeroes the grads)
+//   otherwise update() (:33-37): if (iter - last_overflow_iter) % scale_window == 0: loss_scale *= factor,
+//       last_rescale_iter = iter; ++iter.
+__global__ void step_schedule_scaled_kernel(const float* __restrict__ gsq, const double* __restrict__ sample_size,
+                                            double* __restrict__ step, const double* __restrict__ lr, float* __restrict__ sched,
+                                            float* __restrict__ gnorm, double* __restrict__ ls, float clip_norm, double beta1,
+                                            double beta2, double scale_factor, double scale_window, double tolerance,
+                                            double threshold, double min_loss_scale) {
+  if (threadIdx.x || blockIdx.x) return;
+  const double n = sample_size[0];
+  const double scale = ls[0];
+  double mf = n > 0.0 ? 1.0 / (scale * n) : 0.0;
+  const float gn = (float)(mf * sqrt((double)gsq[0]));
+  gnorm[0] = n > 0.0 ? gn : __builtin_nanf("");
+  if (!(n > 0.0) || !isfinite(gn)) {             // overflow: the loss scaler's check_overflow, the update is skipped
+    const double it = ls[1];
+    const double since = it - ls[3];
+    ls[2] = it;
+    ls[4] += 1.0;
+    const double pct = ls[4] / since;             // (since == 0 -> inf / nan >= tolerance is true / false as in Python's float division
+    if (since <= 0.0 || pct >= tolerance) {      //  ... which raises ZeroDivisionError there; treated as "decrease" here)
+      double dec = scale / scale_factor;
+      if (threshold > 0.0 && dec < threshold) dec = threshold;
+      ls[0] = dec;
+      ls[3] = it;
+      ls[4] = 0.0;
+    }
+    if (ls[0] <= min_loss_scale) {                // FloatingPointError in the reference: raised BEFORE its `_iter += 1`
+      ls[0] = scale;
+      ls[5] = 1.0;
+    } else {
+      ls[1] = it + 1.0;
+    }
+    sched[0] = 0.f;
+    sched[1] = 0.f;
+    sched[2] = (float)lr[0];
+    sched[3] = 1.f;
+    sched[4] += 1.f;
+    return;
+  }
+  sched[3] = 0.f;
+  if (clip_norm > 0.f && gn > clip_norm) mf *= (double)clip_norm / (double)gn;
+  const double t = step[0] + 1.0;
+  step[0] = t;
+  const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+  sched[0] = (float)mf;
+  sched[1] = (float)(lr[0] * sqrt(bc2) / bc1);
+  sched[2] = (float)lr[0];
+  const double it = ls[1];
+  if (fmod(it - ls[2], scale_window) == 0.0) {
+    ls[0] = scale * scale_factor;
+    ls[3] = it;
+  }
+  ls[1] = it + 1.0;
+}
 }  // namespace ofa
 using namespace ofa;
 
@@ -473,6 +538,18 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   else
     hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   return check_launch("adam_step");
+}
+
+extern "C" int ofa_step_schedule_scaled(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
+                                        float* gnorm, double* loss_scaler, float clip_norm, double beta1, double beta2,
+                                        double scale_factor, double scale_window, double tolerance, double threshold,
+                                        double min_loss_scale, void* stream) {
+  OFA_REQUIRE(gsq && sample_size && step && lr && sched && gnorm && loss_scaler, OFA_ERR_INVALID, "step_schedule_scaled: null pointer");
+  OFA_REQUIRE(scale_factor > 1.0 && scale_window >= 1.0 && tolerance >= 0.0 && min_loss_scale >= 0.0, OFA_ERR_INVALID,
+              "step_schedule_scaled: bad scaler configuration");
+  hipLaunchKernelGGL(step_schedule_scaled_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gsq, sample_size, step, lr, sched, gnorm,
+                     loss_scaler, clip_norm, beta1, beta2, scale_factor, scale_window, tolerance, threshold, min_loss_scale);
+  return check_launch("step_schedule_scaled");
 }
 
 extern "C" int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,

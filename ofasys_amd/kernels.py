@@ -620,6 +620,14 @@ def step_schedule(gsq, sample_size, step, lr, sched, gnorm, clip_norm, beta1, be
                float(beta1), float(beta2), stream())
 
 
+def step_schedule_scaled(gsq, sample_size, step, lr, sched, gnorm, loss_scaler, clip_norm, beta1, beta2, scale_factor=2.0,
+                         scale_window=2000, tolerance=0.0, threshold=None, min_loss_scale=1e-4):
+    """step_schedule with the reference's dynamic loss scaler (see ofa_step_schedule_scaled); loss_scaler: fp64[8] device state."""
+    lib().call("ofa_step_schedule_scaled", ptr(gsq), ptr(sample_size), ptr(step), ptr(lr), ptr(sched), ptr(gnorm), ptr(loss_scaler),
+               float(clip_norm), float(beta1), float(beta2), float(scale_factor), float(scale_window), float(tolerance),
+               float(threshold or 0.0), float(min_loss_scale), stream())
+
+
 def adam_step(master, exp_avg, exp_avg_sq, grad, model_param, coef, lr, beta1, beta2, eps, weight_decay, step):
     lib().call("ofa_adam_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), ptr(model_param), ptr(coef),
                master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),

@@ -171,7 +171,8 @@ class TrainStep:
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
                  bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2,
-                 label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0, dp_graph: str = None):
+                 label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0, dp_graph: str = None,
+                 loss_scale=None):
         self.model = model
         self.fp = FlatParams(model)
         dev = self.fp.flat.device
@@ -200,6 +201,19 @@ class TrainStep:
         self.graph_warmup = graph_warmup
         self.dp_graph = dp_graph or os.environ.get("OFA_DP_GRAPH", "full")
         assert self.dp_graph in ("full", "split"), self.dp_graph
+        # loss_scale: None, or a dict for the reference's DYNAMIC loss scaler (engine/optim/dynamic_loss_scaler.py; the fp16
+        # trainer default, default_trainer.yaml:7-9): {"init_scale": 128, "scale_factor": 2, "scale_window": 2000, "tolerance": 0,
+        # "threshold": None, "min_loss_scale": 1e-4}.  The whole state machine runs on the device (ofa_step_schedule_scaled):
+        # the loss gradient is seeded with the scale, an overflowing update is skipped and the scale halved, and it grows back
+        # every scale_window clean updates.  (The compute dtypes of this build are bf16 / fp32, whose exponent range makes the
+        # scale numerically idle; it is here so that a reference fp16 recipe runs unchanged.)
+        self.loss_scale_cfg = None
+        if loss_scale is not None:
+            cfg = {"init_scale": 2.0 ** 7, "scale_factor": 2.0, "scale_window": 2000, "tolerance": 0.0, "threshold": None,
+                   "min_loss_scale": 1e-4}
+            cfg.update(loss_scale if isinstance(loss_scale, dict) else {})
+            self.loss_scale_cfg = cfg
+            self._ls = torch.tensor([cfg["init_scale"], 0, -1, -1, 0, 0, 0, 0], dtype=torch.float64, device=dev)
         self._graphs = {}                           # batch structure -> dict(graphs, static samples, seen count)
         self._skipped_seen = 0.0
         self.last = {}
@@ -244,7 +258,10 @@ class TrainStep:
             else:
                 loss = ops.cross_entropy_sum(logits, target, self.pad)
                 n = target.ne(self.pad).sum()
-            loss.backward()
+            if self.loss_scale_cfg is None:
+                loss.backward()
+            else:                                    # FP16Optimizer.backward: loss * loss_scale (fp16_optimizer.py:92-102)
+                loss.backward(self._ls[0].to(loss.dtype))
             self._stats[0] += n
             self._stats[1] += loss.detach().double()
             self._stats[2] += n
@@ -260,8 +277,14 @@ class TrainStep:
         # batch sets the skip flag instead (ofa_step_schedule) and ofa_adam_step leaves weights and moments untouched
         self._gsq.zero_()
         K.sumsq(self.fp.grad, self._gsq)
-        K.step_schedule(self._gsq, self._stats, self._step_t, self._lr_t, self._sched, self._gnorm_t, self.clip_norm,
-                        self.betas[0], self.betas[1])       # adam.py:205-207 + the clip coefficient, one device thread
+        if self.loss_scale_cfg is None:
+            K.step_schedule(self._gsq, self._stats, self._step_t, self._lr_t, self._sched, self._gnorm_t, self.clip_norm,
+                            self.betas[0], self.betas[1])   # adam.py:205-207 + the clip coefficient, one device thread
+        else:
+            c = self.loss_scale_cfg
+            K.step_schedule_scaled(self._gsq, self._stats, self._step_t, self._lr_t, self._sched, self._gnorm_t, self._ls,
+                                   self.clip_norm, self.betas[0], self.betas[1], c["scale_factor"], c["scale_window"],
+                                   c["tolerance"], c["threshold"], c["min_loss_scale"])
         K.adam_step(self.master, self.exp_avg, self.exp_avg_sq, self.fp.grad, self.fp.flat, self._sched, 0.0,
                     self.betas[0], self.betas[1], self.eps, self.weight_decay, 0)
         self._gnorm = self._gnorm_t
@@ -269,6 +292,12 @@ class TrainStep:
     def check(self):
         """Host-side poll of the device guard (ONE sync): raises FloatingPointError as engine/trainer.py:866-876 does when an
         update since the last call saw a non-finite gradient norm or no target token (that update was skipped on the device)."""
+        if self.loss_scale_cfg is not None:          # overflows are the scaler's business (trainer.py:957-960 logs and goes on) ...
+            if float(self._ls[5]) != 0.0:            # ... until the scale hits the floor (dynamic_loss_scaler.py:58-66)
+                raise FloatingPointError(f"Minimum loss scale reached ({self.loss_scale_cfg['min_loss_scale']}). Your loss is "
+                                         "probably exploding. Try lowering the learning rate, using gradient clipping or "
+                                         "increasing the batch size.")
+            return
         skipped = float(self._sched[4])
         if skipped > self._skipped_seen:
             n = int(skipped - self._skipped_seen)
@@ -357,6 +386,8 @@ class TrainStep:
             self._update()
         self.num_updates += 1
         self.last = {"stats": self._stats, "gnorm": self._gnorm, "skipped": self._sched[3:5]}
+        if self.loss_scale_cfg is not None:
+            self.last["loss_scale"] = self._ls[0:1]
         return self.last
 
 

@@ -689,6 +689,44 @@ def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_d
     param.addcdiv_(exp_avg, denom, value=-step_size)
 
 
+def loss_scaler_step(state, raw_norm, sample_size, clip_norm, scale_factor=2.0, scale_window=2000, tolerance=0.0, threshold=None,
+                     min_loss_scale=1e-4):
+    """One update of the fp16 optimizer's scalar arithmetic around the dynamic loss scaler: engine/optim/fp16_optimizer.py:170-204,
+    228-229 + dynamic_loss_scaler.py:9-70.  state: dict(loss_scale, iter, last_overflow_iter, last_rescale_iter,
+    overflows_since_rescale), modified in place.  raw_norm: ||g|| of the loss-scaled, summed gradients.
+    -> (status "ok" | "overflow" | "fatal", multiply_factor applied to the gradients (0 when the update is skipped))"""
+    mf = 1.0 / state["loss_scale"] / sample_size
+    grad_norm = mf * raw_norm
+    if grad_norm > clip_norm > 0.0:
+        mf *= clip_norm / grad_norm
+    if grad_norm == float("inf") or grad_norm != grad_norm:              # check_overflow :44-70
+        prev = state["loss_scale"]
+        since = state["iter"] - state["last_rescale_iter"]
+        state["last_overflow_iter"] = state["iter"]
+        state["overflows_since_rescale"] += 1
+        if state["overflows_since_rescale"] / float(since) >= tolerance:
+            state["loss_scale"] /= scale_factor
+            if threshold is not None:
+                state["loss_scale"] = max(state["loss_scale"], threshold)
+            state["last_rescale_iter"] = state["iter"]
+            state["overflows_since_rescale"] = 0
+        if state["loss_scale"] <= min_loss_scale:
+            state["loss_scale"] = prev
+            return "fatal", 0.0
+        state["iter"] += 1
+        return "overflow", 0.0
+    if (state["iter"] - state["last_overflow_iter"]) % scale_window == 0:   # update :33-37
+        state["loss_scale"] *= scale_factor
+        state["last_rescale_iter"] = state["iter"]
+    state["iter"] += 1
+    return "ok", mf
+
+
+def new_loss_scaler(init_scale=2.0 ** 15):
+    """dynamic_loss_scaler.py:10-28"""
+    return {"loss_scale": float(init_scale), "iter": 0, "last_overflow_iter": -1, "last_rescale_iter": -1, "overflows_since_rescale": 0}
+
+
 # --------------------------------------------------------------------------------------------
 # the reference's fused-softmax extensions (SURVEY.md section 2a) restated
 # --------------------------------------------------------------------------------------------

@@ -93,3 +93,19 @@ def test_update_arithmetic_matches_reference_recording():
             sel = np.abs(gc) > 1e-3 * gm
             assert sel.sum() > 0
             assert np.abs(want - mine)[sel].max() <= 2e-3 * TC.HYPER["lr"], k
+
+
+def test_dynamic_loss_scaler_restatement_matches_reference_recording():
+    """oracle/restate.loss_scaler_step against tests/golden/loss_scaler.json (the reference's DynamicLossScaler run inside the
+    fp16 optimizer's clip / step arithmetic, oracle/gen_scaler_golden.py)."""
+    import json
+    import os
+    from oracle import scaler_cases as SC
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "loss_scaler.json")))
+    for name, c in SC.CASES.items():
+        st = restate.new_loss_scaler(c["init_scale"])
+        for (raw, n), want in zip(c["seq"], g[name]):
+            status, mf = restate.loss_scaler_step(st, SC.raw_value(raw), n, c["clip"], c["scale_factor"], c["scale_window"],
+                                                  c["tolerance"], c["threshold"], c["min_loss_scale"])
+            assert status == want["status"] and st["loss_scale"] == want["loss_scale"] and st["iter"] == want["iter"], (name, want)
+            assert abs(mf - want["multiply_factor"]) <= 1e-12 * abs(want["multiply_factor"])

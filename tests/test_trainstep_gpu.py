@@ -117,3 +117,78 @@ def test_adam_kernel_vs_reference_recording():
     K.sumsq(grad, out)
     i = [str(x) for x in g["param_keys"]].index("decoder.layers.3.ffn_layernorm.weight")
     assert abs(float(out) ** 0.5 - float(g["s0.grad_pre_norms"][i])) <= 1e-5 * float(g["s0.grad_pre_norms"][i])
+
+
+def test_dynamic_loss_scaler_kernel_vs_reference_recording():
+    """ofa_step_schedule_scaled (scale, overflow counters, skip flag, multiply factor, all on the device) against the reference's
+    DynamicLossScaler + fp16-optimizer arithmetic recorded in tests/golden/loss_scaler.json."""
+    import json
+    import os
+    from ofasys_amd import kernels as K
+    from oracle import scaler_cases as SC
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "loss_scaler.json")))
+    for name, c in SC.CASES.items():
+        ls = torch.tensor([c["init_scale"], 0, -1, -1, 0, 0, 0, 0], dtype=torch.float64, device=DEV)
+        step = torch.zeros(1, dtype=torch.float64, device=DEV)
+        lr = torch.tensor([1e-3], dtype=torch.float64, device=DEV)
+        sched, gnorm = torch.zeros(5, device=DEV), torch.zeros(1, device=DEV)
+        n_ok = 0
+        for (raw, n), want in zip(c["seq"], g[name]):
+            raw = SC.raw_value(raw)
+            gsq = torch.tensor([raw * raw], dtype=torch.float32, device=DEV)
+            stats = torch.tensor([float(n), 0.0, float(n)], dtype=torch.float64, device=DEV)
+            K.step_schedule_scaled(gsq, stats, step, lr, sched, gnorm, ls, c["clip"], 0.9, 0.999, c["scale_factor"], c["scale_window"],
+                                   c["tolerance"], c["threshold"], c["min_loss_scale"])
+            h = ls.tolist()
+            assert h[0] == want["loss_scale"] and h[1] == want["iter"], (name, want, h)
+            assert (h[5] == 1.0) == (want["status"] == "fatal") or any(r["status"] == "fatal" for r in g[name])
+            if want["status"] == "ok":
+                n_ok += 1
+                assert float(sched[3]) == 0.0 and abs(float(sched[0]) - want["multiply_factor"]) <= 2e-6 * want["multiply_factor"]
+                assert abs(float(gnorm) - want["grad_norm"]) <= 2e-6 * want["grad_norm"]
+            else:
+                assert float(sched[3]) == 1.0 and float(sched[0]) == 0.0 and float(sched[1]) == 0.0
+            assert float(step) == n_ok                              # Adam's update counter advances on real updates only
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_with_dynamic_loss_scale(use_graph):
+    """TrainStep(loss_scale=...): the scaled run walks the unscaled trajectory (powers of two scale gradients exactly), the scale
+    doubles every scale_window clean updates, a poisoned step is skipped on the device with the scale halved, training goes on."""
+    from ofasys_amd.trainer import TrainStep
+    from oracle.cases import CASES
+    from tests.golden_util import case_inputs
+    case = dict(CASES["tiny_text"], overrides={"dropout": 0.0})
+    vals, target = case_inputs(case)
+    runs = []
+    for scaled in (False, True):
+        model, d = build_model(case, DEV, torch.bfloat16)
+        tr = TrainStep(model, lr=1e-3, clip_norm=1.0, use_graph=use_graph, graph_warmup=1,
+                       loss_scale={"init_scale": 64.0, "scale_window": 3} if scaled else None)
+        batch = {"slots": make_slots(vals, DEV, torch.bfloat16), "target": target.to(DEV)}
+        losses = [float(tr.train_step([batch])["stats"][1]) for _ in range(7)]
+        runs.append((losses, tr, model))
+    (l0, _, _), (l1, tr, model) = runs
+    # the first update sees identical weights (2^k scaling is exact); later ones drift apart like any two bf16 runs whose clip
+    # coefficient differs in the 6th digit (clip/(gn + 1e-6) clamped vs the fp16 optimizer's clip/gn)
+    assert abs(l0[0] - l1[0]) <= 1e-6 * abs(l0[0]) and abs(l0[1] - l1[1]) <= 2e-3 * abs(l0[1])
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 5e-2 * abs(a)
+    # iters 0..6 clean, last_overflow_iter = -1: the scale doubles at iter 2 and 5 ((iter + 1) % 3 == 0)
+    assert float(tr.last["loss_scale"]) == 64.0 * 4 and float(tr._ls[1]) == 7.0
+    with torch.no_grad():
+        p = dict(model.named_parameters())["decoder.layers.0.fc1.bias"]
+        keep = p[0].clone()
+        p[0] = float("inf")
+    w, t = tr.master.clone(), float(tr._step_t)
+    out = tr.train_step([batch])
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        p[0] = keep
+        tr.master[:] = torch.where(torch.isfinite(tr.master), tr.master, w)      # (the poisoned element itself)
+    assert float(out["skipped"][0]) == 1.0 and float(out["loss_scale"]) == 128.0 and float(tr._step_t) == t
+    assert torch.equal(tr.master, w)
+    tr.check()                                                       # an overflow is not an error for the scaler
+    out = tr.train_step([batch])
+    torch.cuda.synchronize()
+    assert float(out["skipped"][0]) == 0.0 and float(tr._step_t) == t + 1

@@ -99,6 +99,9 @@ class FlatParams:
 _CAPTURE_MODE = "thread_local"
 
 
+_KEEP_ALIVE = []        # CUDAGraph objects are never destroyed: the destructor of one whose capture failed aborts the process
+
+
 class _Uncapturable(Exception):
     """A sample holds something the static-input walker does not understand: the step must stay eager."""
 
@@ -165,9 +168,13 @@ class TrainStep:
       "full"  (default) ONE graph holds forward, backward, the bucketed gradient all-reduces -- launched from inside backward
               as each bucket completes, so RCCL traffic over xGMI overlaps the remaining backward kernels -- the scalar
               all-reduce, clip and Adam.  RCCL collectives are captured like any other stream work.
-      "split" two graphs (forward+backward, clip+Adam) around an eager bucket-by-bucket all-reduce: no overlap; the fallback
-              when capturing collectives fails.
-      The chain full -> split -> eager is walked on capture failure (identically on every rank: the failure is structural)."""
+      "split" two graphs (forward+backward, clip+Adam) around an eager bucket-by-bucket all-reduce: no overlap.  Chosen
+              automatically when the process group's backend is not nccl (gloo's host-side collectives cannot be captured), or
+              with dp_graph="split" / OFA_DP_GRAPH=split.
+      A capture that fails cannot be retried in the same process (torch leaves the CUDA generator in its capturing state:
+      "Cannot register the state during capturing stage" on every later capture), so there is no full -> split retry: the step
+      engine warns, keeps the half-built graph objects alive (their destructor would abort the process) and runs eagerly from
+      then on -- identically on every rank, the failure being structural."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
                  bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2,
@@ -199,7 +206,12 @@ class TrainStep:
         self._lr = float(lr)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self.graph_warmup = graph_warmup
-        self.dp_graph = dp_graph or os.environ.get("OFA_DP_GRAPH", "full")
+        default_dp = "full"
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(process_group) != "nccl":
+                default_dp = "split"
+        self.dp_graph = dp_graph or os.environ.get("OFA_DP_GRAPH") or default_dp
         assert self.dp_graph in ("full", "split"), self.dp_graph
         # loss_scale: None, or a dict for the reference's DYNAMIC loss scaler (engine/optim/dynamic_loss_scaler.py; the fp16
         # trainer default, default_trainer.yaml:7-9): {"init_scale": 128, "scale_factor": 2, "scale_window": 2000, "tolerance": 0,
@@ -310,6 +322,7 @@ class TrainStep:
         entry = {"static": samples, "graphs": [], "mode": mode}
         if self.world == 1 or mode == "full":
             g = torch.cuda.CUDAGraph()
+            _KEEP_ALIVE.append(g)
             with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._fwd_bwd(samples, overlap_reduce=self.world > 1, structure=structure)
                 if self.world > 1:
@@ -318,6 +331,7 @@ class TrainStep:
             entry["graphs"] = [g]
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            _KEEP_ALIVE.extend((ga, gb))
             with torch.cuda.graph(ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._fwd_bwd(samples, overlap_reduce=False)
             with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
@@ -359,25 +373,22 @@ class TrainStep:
                 done = True
             elif entry["seen"] >= self.graph_warmup and (self.world == 1 or self.dp_graph != "full"
                                                          or self.reducer.knows(structure) or self.graph_warmup == 0):
-                modes = ["full", "split"] if (self.world > 1 and self.dp_graph == "full") else ["split"]
-                for mode in modes:
-                    rng_state = ops._Rng.offset
-                    try:
-                        torch.cuda.synchronize()
-                        cap = self._capture(samples, structure, mode)
-                    except Exception as e:          # anything uncapturable (a custom adaptor, a collective): next mode, loudly
-                        warnings.warn(f"ofasys_amd.TrainStep: hipGraph capture ({mode}) failed ({type(e).__name__}: {e})")
-                        ops._Rng.offset = rng_state
-                        ops.defer_reductions(False)
-                        continue
+                mode = "full" if (self.world > 1 and self.dp_graph == "full") else "split"
+                rng_state = ops._Rng.offset
+                try:
+                    torch.cuda.synchronize()
+                    cap = self._capture(samples, structure, mode)
+                except Exception as e:              # anything uncapturable (a custom adaptor, a collective): eager from now on
+                    warnings.warn(f"ofasys_amd.TrainStep: hipGraph capture ({mode}) failed ({type(e).__name__}: {e}); a failed "
+                                  "capture cannot be retried in this process -- running eagerly")
+                    ops._Rng.offset = rng_state
+                    ops.defer_reductions(False)
+                    self.use_graph = False
+                else:
                     cap["static_tensors"] = sample_tensors(cap["static"])
                     entry.update(cap)
                     self._replay(entry, samples)
                     done = True
-                    break
-                else:
-                    warnings.warn("ofasys_amd.TrainStep: running eagerly")
-                    self.use_graph = False
             else:
                 entry["seen"] += 1
         if not done:

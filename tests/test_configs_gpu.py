@@ -428,3 +428,27 @@ def test_dp_step_graph_with_captured_rccl_collectives():
         assert l0 == l1 and torch.equal(m0, m1)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The driver's multi-GPU invocation, `python bench.py --gpus 2 ...` run BARE: bench.py self-launches two ranks under
+    torch.distributed.run (127.0.0.1 rendezvous), every rank builds the model, broadcasts the weights, runs the data-parallel train
+    step and rank 0 prints ONE JSON line with the whole-job rate.  One GPU here, so both ranks sit on device 0
+    (OFA_BENCH_DEVICE=0) and the collectives go through gloo: gloo's host-side all-reduce cannot be captured into a hipGraph, so
+    the step engine picks the split mode by itself (two graphs around an eager all-reduce)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OFA_BENCH_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "4", "--steps", "4",
+                        "--warmup", "1", "--no-cpu-baseline", "--profile-gemm", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and abs(out["value"] - 2 * out["tokens_per_sec_per_gpu"]) <= 1e-6 * out["value"]
+    assert out["config"]["step_mode"] == "two hipGraphs + eager all-reduce", out["config"]["step_mode"]

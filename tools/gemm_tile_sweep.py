@@ -3,7 +3,7 @@
 import os
 import sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofasys_amd import kernels as K
 dev = 'cuda'
 torch.manual_seed(0)

@@ -421,6 +421,36 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
   }
 }
 
+// Phase-timestamp probe of tools/gemm_timeline.py (measurement build only: the Makefile never sets -DOFA_GEMM_TIMELINE; in the
+// product every macro below is empty).  Thread 0 of each workgroup stamps the shader clock into 32 slots of `ws`: 0 entry,
+// 1 first tile landed, 2 K loop done, 3 epilogue stores issued, 4 stores acknowledged, 5 HW_ID, 6 XCC_ID, 7 / 31 the 100 MHz
+// clock at entry / exit, 8..23 K-step ends.
+#ifdef OFA_GEMM_TIMELINE
+#define OFA_TL(i) do { if (threadIdx.x == 0 && (i) < 24) tl[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define OFA_TL_BEGIN                                                                                                           \
+  unsigned long long* tl = (unsigned long long*)ws + 32 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));   \
+  int tlk = 8;                                                                                                                 \
+  if (threadIdx.x == 0) {                                                                                                      \
+    tl[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                         \
+    tl[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                        \
+    tl[7] = __builtin_amdgcn_s_memrealtime();                                                                                  \
+  }                                                                                                                            \
+  OFA_TL(0)
+#define OFA_TL_STEP do { OFA_TL(tlk); ++tlk; } while (0)
+#define OFA_TL_END                                                        \
+  do {                                                                    \
+    OFA_TL(3);                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+    OFA_TL(4);                                                            \
+    if (threadIdx.x == 0) tl[31] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
+#else
+#define OFA_TL(i) do { } while (0)
+#define OFA_TL_BEGIN do { } while (0)
+#define OFA_TL_STEP do { } while (0)
+#define OFA_TL_END do { } while (0)
+#endif
+
 template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool GLDS>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
@@ -441,6 +471,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = tiles_m * tiles_n;
+  OFA_TL_BEGIN;
   int t, ks;
   tile_and_slice(ntiles, t, ks);
   // grouped order inside the XCD's run: consecutive ids walk GM tile-rows before moving to the next tile-column, so the
@@ -481,6 +512,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    OFA_TL(1);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
     FragAddr<BM, A_KMAJ> fax[2];
     FragAddr<BN, B_KMAJ> faw[2];
@@ -525,6 +557,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       OFA_MMA(x1, w1);                                                                                 \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's DMA has landed (explicit: never rely on hipcc) */ \
       __syncthreads();                 /* ... and so has everybody else's; fences the buffer swap */ \
+      OFA_TL_STEP;                                                                                     \
     }
     int kt = 0;
     int knext = kbeg + BK;
@@ -578,6 +611,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 
   // epilogue through the wave's slice of the (idle) LDS stages: see epilogue_lds
   __syncthreads();                                     // every wave is done with the fragment reads / the last DMA
+  OFA_TL(2);
   {
     const bool split = gridDim.y > 1;
     constexpr int REGION = ((GLDS ? 2 * (EA + EB) * 2 : 2 * (GA::ELEMS + GB::ELEMS) * 2) / (WM * WN)) & ~1023;
@@ -593,6 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       epilogue_lds<2, 2, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
+  OFA_TL_END;
 }
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -610,16 +645,17 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // while tile kt multiplies; the wait in front of the stage barrier is `vmcnt(2 * pieces)` -- only the OLDEST tile has to
 // have landed.  Same tile geometry, swizzle, fragment reads and epilogue as gemm_mfma_kernel (LDS-DMA path: whole K
 // tiles); the stage select is an add on the fragment address registers instead of an offset immediate.
-template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int S = 4>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN, S = 4;
+  constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+  static_assert(S == 3 || S == 4, "ring depth");
   typedef TileGeom<BM, A_KMAJ> GA;
   typedef TileGeom<BN, B_KMAJ> GB;
   constexpr int NVA = GA::NVEC / NT, NVB = GB::NVEC / NT, P = NVA + NVB;
   constexpr int EA = BM * BK, EB = BN * BK;
   constexpr uint32_t STG = (uint32_t)(EA + EB) * 2u;                  // bytes per stage: [A tile | B tile]
-  static_assert(2 * P <= 63, "vmcnt field");
+  static_assert((S - 2) * P <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -677,8 +713,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int later = issued - kt - 1;                                 // tiles issued behind tile kt (block-uniform)
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    if (S >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the bare barrier instruction: __syncthreads() is fence + barrier and hipcc materialises the fence as
     // `s_waitcnt vmcnt(0)` -- every tile in flight would be drained at every step (seen in the ISA; the ring then ran
@@ -775,13 +811,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Big-tile kernel: 4 waves, each owning a (32*TM) x (32*TN) block of accumulators (TM x TN MFMA tiles; 4 x 4 = 256 fp32
-// registers per lane, the unified VGPR/AccVGPR file of CDNA3/4 holds 512).  Why: with 64x64 per wave every K-step moves
-// 16 KiB of fragments per wave out of LDS for 16 MFMAs -- 128 B/clk/CU, exactly the LDS peak, so the 128x128 kernel
-// saturates LDS at ~40% MFMA utilisation.  A 128x128 wave tile needs 8 fragment reads per 16 MFMAs (64 B/clk/CU).
-// One workgroup per CU (128 KiB of LDS: 2 stages x (A 32 KiB + B 32 KiB)), one wave per SIMD, so the overlap is built
-// into the wave's own instruction stream: fragments of k-slice kk+1 are read while slice kk multiplies, the barrier that
-// retires an LDS stage sits in front of the LAST slice's MFMAs, and the DMA of tile t+2 is issued right behind it.
+// Big-tile kernel: a WGM x WGN grid of waves, each owning a (32*TM) x (32*TN) block of accumulators (TM x TN MFMA tiles), ONE
+// workgroup per CU (128 KiB of LDS: 2 stages x (A 32 KiB + B 32 KiB)).  Shipped form: eight waves in a 2 x 4 grid of 128 x 64
+// (or 96 x 64) blocks -- a 256 x 256 (192 x 256) tile, two waves per SIMD, 128 accumulator registers per lane.  Why the big
+// block: with 64x64 per wave every K-step moves 16 KiB of fragments per wave out of LDS for 16 MFMAs; 128 x 64 needs 24
+// fragment reads per 32 MFMAs.  Why two waves per SIMD: round 1's form of this kernel (four waves of 128 x 128, one per
+// SIMD) had nothing to run while a wave sat at the stage barrier or waited for fragments (1.47-1.74 us per K-step against
+// 1.42-1.55 with eight waves, and a 2.5 instead of 5.8 us epilogue: profiles/round2_gemm_timeline.txt section C).
+// The overlap inside a wave is built into its instruction stream: fragments of k-slice kk+1 are read while slice kk
+// multiplies, the barrier that retires an LDS stage sits in front of the LAST slice's MFMAs, and the DMA of tile t+2 is
+// issued right behind it, one piece per MFMA gap.
 
 // per-lane LDS byte addresses (relative to LDS base, buffer 0 of the operand)
 template <int R, bool KMAJ> struct BigAddr {
@@ -820,10 +859,11 @@ __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
 // which fragment read (0..nr-1, or -1) follows MFMA number t of a slice: one read behind each of the first nr MFMAs
 __host__ __device__ constexpr int big_read_after(int t, int nr) { return t < nr ? t : -1; }
 
-template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
-                                                       float* __restrict__ ws) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
+template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
+                                                                 float* __restrict__ ws) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
+  static_assert(BM <= 256 && BN <= 256, "operand stage is 256 rows");
   static_assert(A_KMAJ || BM == 256, "m-major tiles are 256 wide (swizzle)");
   static_assert(B_KMAJ || BN == 256, "m-major tiles are 256 wide (swizzle)");
   constexpr int NVA = BM * 8 / NT, NVB = BN * 8 / NT;
@@ -835,8 +875,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
   bf16_t* sB1 = sB0 + STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int ntiles = tiles_m * tiles_n;
+  OFA_TL_BEGIN;
   int t, ks;
   tile_and_slice(ntiles, t, ks);
   constexpr int GM = 8;
@@ -886,12 +927,14 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
   static_for<0, TN>([&](auto ic) { big_frag<BN, B_KMAJ, KK, decltype(ic)::value, 0>(wb[SET][decltype(ic)::value], faw); })
 #define BIG_WAITCNT "s_waitcnt lgkmcnt(0)"
 #define BIG_WAIT(SET)                                                                  \
-  if constexpr (TM == 4)                                                               \
+  if constexpr (TM == 4 && TN == 2)                                                    \
     asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]), "+v"(xa[SET][3]),   \
-                 "+v"(wb[SET][0]), "+v"(wb[SET][1]), "+v"(wb[SET][2]), "+v"(wb[SET][3]));                           \
-  else                                                                                 \
+                 "+v"(wb[SET][0]), "+v"(wb[SET][TN - 1]));                                                          \
+  else if constexpr (TM == 3 && TN == 2)                                               \
     asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]),                     \
-                 "+v"(wb[SET][0]), "+v"(wb[SET][1]), "+v"(wb[SET][2]), "+v"(wb[SET][3]))
+                 "+v"(wb[SET][0]), "+v"(wb[SET][TN - 1]));                                                          \
+  else                                                                                 \
+    static_assert(TM == 4 && TN == 2, "BIG_WAIT names every fragment register: add the shape")
   // One k-slice: TM*TN MFMAs on fragment set SET, with the NEXT slice's fragment reads (k-slice KKN into the other set)
   // woven in between them.  Issuing the 8 reads in one burst in front of the MFMAs serialises the two: all four waves
   // run in lockstep behind the stage barrier, their 32 reads queue up in the LDS pipe and the in-order wave cannot reach
@@ -912,6 +955,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
     dma(sA0, sB0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    OFA_TL(1);
     if (nk > 1) dma(sA1, sB1);
     BIG_ISSUE(0, 0);
     bf16_t* curA = sA0;                // the stage being multiplied; its buffers are refilled with tile kt+2
@@ -965,6 +1009,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
         BIG_SB;
       });
       if (more2) knext += BK;
+      OFA_TL_STEP;
       curA = (bf16_t*)((uintptr_t)curA ^ (uintptr_t)(STAGE * 2));
       curB = (bf16_t*)((uintptr_t)curB ^ (uintptr_t)(STAGE * 2));
     }
@@ -975,9 +1020,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
 #undef BIG_WAIT
 #undef BIG_ISSUE
   __syncthreads();                                     // every wave is done with the fragment reads
+  OFA_TL(2);
   {
     const bool split = gridDim.y > 1;
-    constexpr int REGION = 4 * STAGE * 2 / 4;          // 32 KiB per wave
+    constexpr int REGION = 4 * STAGE * 2 / (WGM * WGN);   // 32 KiB per wave (16 KiB with eight waves)
     unsigned char* wl = smem_raw + wave * REGION;
     const int m_w = m0 + wm * TM * 32, n_w = n0 + wn * TN * 32;
     if (split) {
@@ -990,6 +1036,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int tiles_m, 
       epilogue_lds<TM, TN, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
+  OFA_TL_END;
 }
 
 template <bool OUT_F32>
@@ -1045,12 +1092,12 @@ static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, fl
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF>
+template <int WM, int WN, bool AK, bool BKM, bool OF, int S = 4>
 static void launch_ring(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  const size_t lds = 4 * (size_t)(BM + BN) * BK * sizeof(bf16_t);
-  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF>;
+  const size_t lds = S * (size_t)(BM + BN) * BK * sizeof(bf16_t);
+  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF, S>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1088,27 +1135,27 @@ static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int split
   else launch_cfg<1, 1, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
 }
 
-template <int TM, int TN, bool AK, bool BKM, bool OF>
+template <int TM, int TN, bool AK, bool BKM, bool OF, int WGM = 2, int WGN = 2>
 static void launch_big(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const size_t lds = 4 * (size_t)256 * BK * sizeof(bf16_t);     // 2 operands x 2 stages x 32 KiB
-  auto kern = gemm_big_kernel<TM, TN, AK, BKM, OF>;
+  auto kern = gemm_big_kernel<TM, TN, AK, BKM, OF, WGM, WGN>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid(tiles_m * tiles_n, splits, batch), block(256);
+  dim3 grid(tiles_m * tiles_n, splits, batch), block(64 * WGM * WGN);
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
 template <bool AK, bool BKM, bool OF>
 static void launch_big_shape(const GemmArgs& g, int batch, int tm, int splits, int ksplit, float* ws, hipStream_t st) {
   if constexpr (AK) {
-    if (tm == 3) { launch_big<3, 4, AK, BKM, OF>(g, batch, splits, ksplit, ws, st); return; }
+    if (tm == 3) { launch_big<3, 2, AK, BKM, OF, 2, 4>(g, batch, splits, ksplit, ws, st); return; }   // 96 x 64 per wave
   }
-  launch_big<4, 4, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+  launch_big<4, 2, AK, BKM, OF, 2, 4>(g, batch, splits, ksplit, ws, st);                              // 128 x 64 per wave
 }
 
 struct GemmPlan { int wm, wn, big_tm, splits, ksplit, K; };
@@ -1138,37 +1185,45 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }
   else if (t12 * maxs >= want && g.N >= 128) { wm = 1; wn = 2; tiles = t12; }
   else { wm = 1; wn = 1; tiles = t11; }
-  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11 / 44 / 34
+  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11 / 44 (= 84) / 34 (= 83)
   if (force_tile == 22) { wm = 2; wn = 2; tiles = t22; }
   else if (force_tile == 12) { wm = 1; wn = 2; tiles = t12; }
   else if (force_tile == 11) { wm = 1; wn = 1; tiles = t11; }
-  // big tiles (one 256-thread workgroup per CU, 128x128 or 96x128 per wave): whole K tiles only.  With one workgroup per
-  // CU nothing overlaps a tile's output burst (the C write of a 14336 x 2304 x 768 product is 30% of its time, measured
-  // by removing the epilogue) -- two co-resident 128x128 workgroups hide it -- so the big tile only pays off when the K
-  // loop is long enough to amortise it (K >= 4096), or when the whole product is ONE round of <= 256 workgroups (measured,
-  // 14336 x 768 outputs as 225 tiles of 192 x 256: K = 768 25.4 vs 27.7 us, K = 3072 71.7 vs 85.7 us) -- and the grid
-  // fills the 256 CUs.
-  int big_tm = 0;
+  // Big tiles: ONE 512-thread workgroup per CU, eight waves of 128 x 64 (256 x 256 tile) or 96 x 64 (192 x 256) -- two waves per
+  // SIMD, so one wave's barrier / LDS waits are covered by the other's MFMAs: 1.42 us per K-step of 2048 MFMA-clocks against
+  // 0.87 us per 1024 for a pair of 128 x 128 workgroups (tools/gemm_timeline.py, profiles/round2_gemm_timeline.txt).  The
+  // price is per tile: first-tile flight, epilogue, store acknowledgement and re-dispatch cost 7.6 us with nothing else
+  // on the CU to hide them (4.2 us per pair of 128 x 128 workgroups), and the grid is quantised in rounds of 256 tiles.
+  // The choice is made on that model (microseconds; profiles/round2_gemm_eight_wave_sweep.txt is what it was fitted to):
+  //     time = rounds x (K-steps x step + per-tile)      128 x 128: 512 slots, step 0.90 (1.0 NT), per-tile 4.2
+  //                                                      256 x 256: 256 slots, step 1.45, per-tile 7.6
+  //                                                      192 x 256: 256 slots, step 1.13, per-tile 6.5   (k-major A only)
+  // e.g. 13312 x 768 x 3072: 95 / 77 / 61 -> 192 x 256 (measured 81 / 77-83 / 65); 13312 x 2304 x 768: 62 / 50 / 60 -> 256 x 256
+  // (62 / 54 / 61); 13312 x 3072 x 768 (NN): 75 / 75 / 80 -> stays on 128 x 128 (76 / 76 / 84).  m-major A (weight gradients)
+  // keeps the rule of round 1: one round of <= 256 tiles or K >= 4096, on the 256 x 256 tile.
+  int big_tm = 0;                                           // 3: 192 x 256, 4: 256 x 256
   const bool big_ok = (g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA) && g.N >= 256 && g.M >= 192;
   if (big_ok && force_tile != 22 && force_tile != 12 && force_tile != 11) {
-    auto fill = [&](int bm) {
-      const int64_t t = (int64_t)cdiv(g.M, bm) * cdiv(g.N, 256) * batch;
-      return (double)t / (double)(cdiv(t, 256) * 256) * ((double)g.M / (cdiv(g.M, bm) * bm)) * ((double)g.N / (cdiv(g.N, 256) * 256));
-    };
-    const double f4 = fill(256), f3 = g.transA ? 0.0 : fill(192) * 0.97;
-    if (force_tile == 44) big_tm = 4;
-    else if (force_tile == 34) big_tm = g.transA ? 4 : 3;
-    // (0.7: a packed batch of 12800 / 13312 rows x 768 columns fills 201 / 210 of the 256 CUs with 192 x 256 tiles and still beats
-    //  the two partial rounds of 128 x 128 tiles by 6-28 %, profiles/round2_gemm_tile_sweep.txt)
-    else if (f4 >= 0.7 || f3 >= 0.7) {
-      const int tm = f4 >= f3 ? 4 : 3;
-      const int64_t t = (int64_t)cdiv(g.M, tm * 64) * cdiv(g.N, 256) * batch;
-      if (g.K >= 4096 || t <= 256) big_tm = tm;
+    const int64_t t4 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256) * batch, t3 = (int64_t)cdiv(g.M, 192) * cdiv(g.N, 256) * batch;
+    if (force_tile == 44 || force_tile == 84) big_tm = 4;
+    else if (force_tile == 34 || force_tile == 83) big_tm = g.transA ? 4 : 3;
+    else if (!g.transA) {
+      const int nk = g.K / BK;
+      if (batch == 1 && nk >= 4 && t22 >= 512 && wm == 2 && wn == 2) {
+        auto est = [&](int64_t t, int slots, double step, double per_tile) { return (double)cdiv(t, slots) * (nk * step + per_tile); };
+        const double e2 = est(t22, 512, g.transB ? 1.0 : 0.90, 4.2);
+        const double e4 = t4 >= 128 ? est(t4, 256, 1.45, 7.6) : 1e30, e3 = t3 >= 128 ? est(t3, 256, 1.13, 6.5) : 1e30;
+        if (e4 <= e3 && e4 < 0.95 * e2) big_tm = 4;
+        else if (e3 < e4 && e3 < 0.95 * e2) big_tm = 3;
+      }
+    } else {
+      const double f4 = (double)t4 / (double)(cdiv(t4, 256) * 256) * ((double)g.M / (cdiv(g.M, 256) * 256)) * ((double)g.N / (cdiv(g.N, 256) * 256));
+      if (f4 >= 0.7 && (g.K >= 4096 || t4 <= 256)) big_tm = 4;
     }
-  }
-  if (big_tm) {
-    wm = wn = 0;
-    tiles = (int64_t)cdiv(g.M, big_tm * 64) * cdiv(g.N, 256) * batch;
+    if (big_tm) {
+      wm = wn = 0;
+      tiles = big_tm == 4 ? t4 : t3;
+    }
   }
   int splits = 1;
   if (!big_tm && tiles < want && maxs > 1) {

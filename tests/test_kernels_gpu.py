@@ -67,10 +67,11 @@ GEMM_SHAPES = [(64, 64, 64), (128, 128, 128), (200, 136, 72), (130, 768, 256), (
                (256, 3072, 768), (1000, 208, 264)]
 
 
-@pytest.mark.parametrize("M,N,K_", [(3584, 4096, 4096), (3320, 3848, 4160)])
+@pytest.mark.parametrize("M,N,K_", [(3584, 4096, 4096), (3320, 3848, 4160), (4032, 3072, 256), (13312, 768, 768)])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 def test_gemm_big_tile(K, M, N, K_, ta, tb):
-    """Long-K products that fill the chip take the 256x256 / 192x256 workgroup tiles (csrc/gemm_mfma.hip, gemm_big_kernel)."""
+    """Products the planner sends to the 256x256 / 192x256 eight-wave tiles (csrc/gemm_mfma.hip, gemm_big_kernel): long K, one
+    round of 192 x 256 tiles, and the packed train step's 13312-row shape."""
     torch.manual_seed(11)
     a = torch.randn((K_, M) if ta else (M, K_), device=DEV).bfloat16()
     b = torch.randn((N, K_) if tb else (K_, N), device=DEV).bfloat16()
@@ -83,6 +84,47 @@ def test_gemm_big_tile(K, M, N, K_, ta, tb):
     K.gemm(a, b, ta, tb, out=acc, accumulate=True)
     assert rel(acc.float() - 1, ref * 2 - bias.float()) < 2e-2
     assert rel(K.gemm(a, b, ta, tb, bias=bias, alpha=0.5, out_f32=True), ref) < 2e-3
+
+
+_FORCED_TILE_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from ofasys_amd import kernels as K
+torch.manual_seed(5)
+rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-9))
+for M, N, K_ in [(600, 520, 192), (1000, 768, 256), (2050, 1288, 128), (192, 256, 64), (3333, 264, 448)]:
+    for ta, tb in [(False, True), (False, False), (True, False), (True, True)]:
+        a = torch.randn((K_, M) if ta else (M, K_), device="cuda").bfloat16()
+        b = torch.randn((N, K_) if tb else (K_, N), device="cuda").bfloat16()
+        bias = torch.randn(N, device="cuda").bfloat16()
+        brow = torch.randn(M, device="cuda").bfloat16()
+        prod = (a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())
+        for _ in range(2):
+            assert rel(K.gemm(a, b, ta, tb, bias=bias, alpha=0.5), (prod + bias.float()) * 0.5) < 1e-2, (M, N, K_, ta, tb)
+        assert rel(K.gemm(a, b, ta, tb, bias=brow, bias_row=True), prod + brow.float()[:, None]) < 1e-2, (M, N, K_, ta, tb, "row")
+        assert rel(K.gemm(a, b, ta, tb, bias=bias, alpha=0.5, out_f32=True), (prod + bias.float()) * 0.5) < 2e-3, (M, N, K_, ta, tb, "f32")
+        acc = torch.ones(M, N, device="cuda", dtype=torch.bfloat16)
+        K.gemm(a, b, ta, tb, out=acc, accumulate=True)
+        assert rel(acc.float() - 1, prod) < 2e-2, (M, N, K_, ta, tb, "acc")
+        wide = torch.zeros(M, N + 24, device="cuda", dtype=torch.bfloat16)         # ldc > N: nothing outside the view is written
+        K.gemm(a, b, ta, tb, out=wide[:, :N])
+        assert rel(wide[:, :N], prod) < 1e-2 and float(wide[:, N:].abs().max()) == 0.0, (M, N, K_, ta, tb, "ldc")
+print("forced tiles ok")
+"""
+
+
+@pytest.mark.parametrize("tile", ["83", "84"])
+def test_gemm_eight_wave_tiles_forced(K, tile):
+    """Every product of the list on the eight-wave 192 x 256 / 256 x 256 kernels (gemm_big_kernel<3|4, 2, .., 2, 4>): ragged edges in M
+    and N, all four operand layouts, column / row bias, alpha, fp32 output, accumulation, ldc > N.  OFA_GEMM_TILE is read once
+    per process, hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OFA_GEMM_TILE=tile)
+    r = subprocess.run([sys.executable, "-c", _FORCED_TILE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced tiles ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -421,6 +421,13 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
   }
 }
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // Phase-timestamp probe of tools/gemm_timeline.py (measurement build only: the Makefile never sets -DOFA_GEMM_TIMELINE; in the
 // product every macro below is empty).  Thread 0 of each workgroup stamps the shader clock into 32 slots of `ws`: 0 entry,
 // 1 first tile landed, 2 K loop done, 3 epilogue stores issued, 4 stores acknowledged, 5 HW_ID, 6 XCC_ID, 7 / 31 the 100 MHz
@@ -506,13 +513,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
     glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
     const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
+    int knext = kbeg;
     if (nk > 0) {
       glds_issue<NT, NVA>(pa, stepA, sA[0], wave_u);
       glds_issue<NT, NVB>(pb, stepB, sB[0], wave_u);
+      knext += BK;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     OFA_TL(1);
+    if (nk > 1) {                      // tile 1 travels under the whole of K-step 0
+      if (!B_KMAJ && knext + BK > g.b_krows)     // zero-padded contraction tail: clamp B's k rows
+        glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
+      glds_issue<NT, NVA>(pa, stepA, sA[1], wave_u);
+      glds_issue<NT, NVB>(pb, stepB, sB[1], wave_u);
+      knext += BK;
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
     FragAddr<BM, A_KMAJ> fax[2];
     FragAddr<BN, B_KMAJ> faw[2];
@@ -523,53 +539,80 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     }
     constexpr int OA0 = 0, OA1 = EA * 2, OB0 = 2 * EA * 2, OB1 = 2 * EA * 2 + EB * 2;   // byte offsets of the 4 buffers
     static_assert(OB1 + 3 * 16 * (BM > BN ? BM : BN) * 2 + 4 * (BM > BN ? BM : BN) * 2 < 65536, "ds offset field");
-#define OFA_ISSUE(KK, X, W, OA, OB)                          \
-    frag_issue<BM, A_KMAJ, KK, OA>(X[0], fax[0]);            \
-    frag_issue<BM, A_KMAJ, KK, OA>(X[1], fax[1]);            \
-    frag_issue<BN, B_KMAJ, KK, OB>(W[0], faw[0]);            \
-    frag_issue<BN, B_KMAJ, KK, OB>(W[1], faw[1])
+    // The K-step, pinned instruction by instruction (sched_barrier): two complete fragment sets, the reads of k-slice kk+1
+    // go out one per MFMA gap of slice kk and are waited for only in front of slice kk+1's first MFMA.  Left to itself
+    // hipcc sinks the (side-effect-free) MFMAs below the asm reads so that ONE register set suffices -- every slice then
+    // issued its reads behind its own MFMAs and sat out a full LDS round trip with an empty matrix pipe (seen in the ISA;
+    // tools/gemm_timeline.py: 165-225 clocks per 4-MFMA slice instead of 128).  The stage barrier sits in front of the
+    // LAST slice's MFMAs; behind it that slice multiplies while the first fragments of the next stage are read and the
+    // DMA pieces of tile kt+2 are sent for into the stage just retired (prefetch distance: one K-step, as before).
+#define OFA_SB __builtin_amdgcn_sched_barrier(0)
 #define OFA_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
-#define OFA_MMA(X, W)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
-                                                            __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
-#define OFA_KSTEP(OA, OB, NEXT_A, NEXT_B, MORE)                                                        \
+#define OFA_MF(X, W, I, J)                                                                                     \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[J]), __builtin_bit_cast(bf16x8, X[I]), \
+                                                        acc[I][J], 0, 0, 0)
+#define OFA_SLICE(X, W, XN, WN, KKN, OA, OB)                                        \
+    OFA_MF(X, W, 0, 0); frag_issue<BM, A_KMAJ, KKN, OA>(XN[0], fax[0]); OFA_SB;     \
+    OFA_MF(X, W, 0, 1); frag_issue<BM, A_KMAJ, KKN, OA>(XN[1], fax[1]); OFA_SB;     \
+    OFA_MF(X, W, 1, 0); frag_issue<BN, B_KMAJ, KKN, OB>(WN[0], faw[0]); OFA_SB;     \
+    OFA_MF(X, W, 1, 1); frag_issue<BN, B_KMAJ, KKN, OB>(WN[1], faw[1]); OFA_SB
+#define OFA_DMA(Q, DST_A, DST_B)                                                                                        \
+    static_for<(Q) * (NVA + NVB) / 4, ((Q) + 1) * (NVA + NVB) / 4>([&](auto pc) {                                       \
+      constexpr int pi = decltype(pc)::value;                                                                           \
+      if constexpr (pi < NVA) {                                                                                         \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)pa[pi], (lvoid_t*)(DST_A + (wave_u * 64 + pi * NT) * 8), 16, 0, 0); \
+        pa[pi] += stepA;                                                                                                \
+      } else {                                                                                                          \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)pb[pi - NVA], (lvoid_t*)(DST_B + (wave_u * 64 + (pi - NVA) * NT) * 8), 16, 0, 0); \
+        pb[pi - NVA] += stepB;                                                                                          \
+      }                                                                                                                 \
+    })
+#define OFA_KSTEP(OA, OB, OAN, OBN, CUR_A, CUR_B, HAS_NEXT, MORE2)                                     \
     {                                                                                                  \
-      if (MORE) {                      /* DMA of the next tile runs under this tile's MFMAs */          \
-        if (!B_KMAJ && knext + BK > g.b_krows)   /* zero-padded contraction tail: clamp B's k rows */    \
-          glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);                \
-        glds_issue<NT, NVA>(pa, stepA, NEXT_A, wave_u);                                                \
-        glds_issue<NT, NVB>(pb, stepB, NEXT_B, wave_u);                                                \
-        knext += BK;                                                                                   \
+      OFA_WAIT(x0, w0); OFA_SB;                                                                        \
+      OFA_SLICE(x0, w0, x1, w1, 1, OA, OB);                                                            \
+      OFA_WAIT(x1, w1); OFA_SB;                                                                        \
+      OFA_SLICE(x1, w1, x0, w0, 2, OA, OB);                                                            \
+      OFA_WAIT(x0, w0); OFA_SB;                                                                        \
+      OFA_SLICE(x0, w0, x1, w1, 3, OA, OB);                                                            \
+      OFA_WAIT(x1, w1);                /* every fragment of this stage is in registers */              \
+      if (HAS_NEXT) {                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* tile kt+1 has landed (explicit: hipcc does not see the DMA) */ \
+        __syncthreads();               /* ... for every wave, and every wave is done reading this stage */ \
       }                                                                                                \
-      u64x2 x0[2], w0[2], x1[2], w1[2];                                                                \
-      OFA_ISSUE(0, x0, w0, OA, OB);                                                                    \
-      OFA_WAIT(x0, w0);                                                                                \
-      OFA_ISSUE(1, x1, w1, OA, OB);    /* next k-slice's LDS reads fly under this slice's MFMAs */      \
-      OFA_MMA(x0, w0);                                                                                 \
-      OFA_WAIT(x1, w1);                                                                                \
-      OFA_ISSUE(2, x0, w0, OA, OB);                                                                    \
-      OFA_MMA(x1, w1);                                                                                 \
-      OFA_WAIT(x0, w0);                                                                                \
-      OFA_ISSUE(3, x1, w1, OA, OB);                                                                    \
-      OFA_MMA(x0, w0);                                                                                 \
-      OFA_WAIT(x1, w1);                                                                                \
-      OFA_MMA(x1, w1);                                                                                 \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* this wave's DMA has landed (explicit: never rely on hipcc) */ \
-      __syncthreads();                 /* ... and so has everybody else's; fences the buffer swap */ \
+      const bool more2 = (MORE2);                                                                      \
+      if (more2 && !B_KMAJ && knext + BK > g.b_krows)   /* zero-padded contraction tail: clamp B's k rows */ \
+        glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);                  \
+      OFA_SB;                                                                                          \
+      /* last slice: its MFMAs cover the next stage's first fragment reads and the DMA issue of tile kt+2 (after the */ \
+      /* very last K-step the reads fetch a stale stage; they are waited for and dropped) */            \
+      OFA_MF(x1, w1, 0, 0); frag_issue<BM, A_KMAJ, 0, OAN>(x0[0], fax[0]); if (more2) { OFA_DMA(0, CUR_A, CUR_B); } OFA_SB; \
+      OFA_MF(x1, w1, 0, 1); frag_issue<BM, A_KMAJ, 0, OAN>(x0[1], fax[1]); if (more2) { OFA_DMA(1, CUR_A, CUR_B); } OFA_SB; \
+      OFA_MF(x1, w1, 1, 0); frag_issue<BN, B_KMAJ, 0, OBN>(w0[0], faw[0]); if (more2) { OFA_DMA(2, CUR_A, CUR_B); } OFA_SB; \
+      OFA_MF(x1, w1, 1, 1); frag_issue<BN, B_KMAJ, 0, OBN>(w0[1], faw[1]); if (more2) { OFA_DMA(3, CUR_A, CUR_B); } OFA_SB; \
+      if (more2) knext += BK;                                                                          \
       OFA_TL_STEP;                                                                                     \
     }
-    int kt = 0;
-    int knext = kbeg + BK;
-    for (; kt + 1 < nk; kt += 2) {
-      OFA_KSTEP(OA0, OB0, sA[1], sB[1], true);
-      OFA_KSTEP(OA1, OB1, sA[0], sB[0], (kt + 2 < nk));
+    if (nk > 0) {
+      u64x2 x0[2], w0[2], x1[2], w1[2];
+      frag_issue<BM, A_KMAJ, 0, OA0>(x0[0], fax[0]);
+      frag_issue<BM, A_KMAJ, 0, OA0>(x0[1], fax[1]);
+      frag_issue<BN, B_KMAJ, 0, OB0>(w0[0], faw[0]);
+      frag_issue<BN, B_KMAJ, 0, OB0>(w0[1], faw[1]);
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) {
+        OFA_KSTEP(OA0, OB0, OA1, OB1, sA[0], sB[0], true, (kt + 2 < nk));
+        OFA_KSTEP(OA1, OB1, OA0, OB0, sA[1], sB[1], (kt + 2 < nk), (kt + 3 < nk));
+      }
+      if (kt < nk) OFA_KSTEP(OA0, OB0, OA1, OB1, sA[0], sB[0], false, false);
+      OFA_WAIT(x0, w0);                // retire the look-ahead reads before the epilogue re-uses LDS and registers
     }
-    if (kt < nk) OFA_KSTEP(OA0, OB0, sA[1], sB[1], false);
 #undef OFA_KSTEP
-#undef OFA_ISSUE
+#undef OFA_DMA
+#undef OFA_SLICE
+#undef OFA_MF
 #undef OFA_WAIT
-#undef OFA_MMA
+#undef OFA_SB
   } else {
   uint4 ra[NVA], rb[NVB];
   if (nk > 0) {
@@ -630,12 +673,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
   OFA_TL_END;
 }
 
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Ring-staged kernel for SMALL grids (<= ~2 workgroups per CU: every decoder-side product of the model, 2048 rows).

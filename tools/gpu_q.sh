@@ -1,9 +1,6 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/r2stats -o p -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-gemm 0 > $R/gpurun_out/q_stats_run.log 2>&1
-python $R/tools/prof_summary.py /tmp/r2stats/p_results.db 24 40 > $R/gpurun_out/q_kernel_stats.txt 2>&1
-python $R/tools/prof_by_grid.py /tmp/r2stats/p_results.db > $R/gpurun_out/q_by_grid.txt 2>&1
-head -30 $R/gpurun_out/q_kernel_stats.txt | cut -c1-170
-grep -i gemm $R/gpurun_out/q_by_grid.txt | head -30 | cut -c1-200
-tail -1 $R/gpurun_out/q_stats_run.log | cut -c1-300
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/q_tests.log 2>&1; tail -5 gpurun_out/q_tests.log
+OFA_GEMM_TILE=0 timeout 300 python tools/gemm_tile_sweep.py 13312 2048 > gpurun_out/q_sweep_new.txt 2>&1; grep -v amdgpu gpurun_out/q_sweep_new.txt
+OFA_GEMM_TILE=22 OFA_GEMM_SPLIT_MIN_K=1000000 timeout 300 python tools/gemm_tile_sweep.py 13312 > gpurun_out/q_sweep_new22.txt 2>&1; grep -v amdgpu gpurun_out/q_sweep_new22.txt
+timeout 600 python bench.py --steps 30 --warmup 8 > gpurun_out/q_bench.log 2>&1; tail -1 gpurun_out/q_bench.log | cut -c1-400

@@ -286,18 +286,47 @@ __device__ __forceinline__ void rdtr(u64x2& d, uint32_t addr_lo, uint32_t addr_h
 #define ATT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), B, C, 0, 0, 0)
 #define ATT_MFMA2(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
+// Phase-timestamp probe of tools/attn_timeline.py (measurement build only: -DOFA_ATTN_TIMELINE is never set by the Makefile; in
+// the product the macros are empty).  Wave 0 of each forward workgroup records s_memtime at entry / first tiles landed / exit and,
+// inside its fifth key block, at every phase boundary of fwd_block.
+#ifdef OFA_ATTN_TIMELINE
+__device__ unsigned long long g_attn_tl[8192 * 16];
+#define ATT_FS(i, dep) do { asm volatile("" : "+v"(dep)); if (fs) fs[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATT_FS_ARG , unsigned long long* fs
+#define ATT_FS_PASS(cond) , ((cond) ? fsv : nullptr)
+#else
+#define ATT_FS(i, dep) do { } while (0)
+#define ATT_FS_ARG
+#define ATT_FS_PASS(cond)
+#endif
+
+// max / sum of a value with its partner lane in the other 32-lane half: one v_permlane32_swap (gfx950) instead of a
+// ds_bpermute round trip through the LDS crossbar (tools/attn_timeline.py: 160 + 136 clocks per key block for the two exchanges
+// of the online softmax).  swap(a, b) exchanges a's upper half with b's lower half: with a = b = v the pair (a, b) then holds
+// {v[lane], v[lane ^ 32]} in some order in EVERY lane.
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int BUF>   // BUF selects the double-buffer half at compile time (immediates)
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                           f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
-                                          uint32_t dead_now, bool has_bias, const float (&bz)[16], float sc) {
+                                          uint32_t dead_now, bool has_bias, const float (&bz)[16], float sc ATT_FS_ARG) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
+  ATT_FS(0, m_run);
   u64x2 kf[4];
   rd128<KOFF>(kf[0], ta.km[0]);
   rd128<KOFF>(kf[1], ta.km[1]);
   rd128<KOFF>(kf[2], ta.km[2]);
   rd128<KOFF>(kf[3], ta.km[3]);
   ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
+  ATT_FS(1, m_run);
   u64x2 vf[2][2];   // [j][dt]
   rdtr<VOFF, 0>(vf[0][0], ta.tr[0], trx[0]);
   rdtr<VOFF, 0>(vf[0][1], ta.tr[1], trx[1]);
@@ -310,7 +339,8 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   float s[16];
   float mx = -INFINITY;
   const bool diag = a.causal && (key0 + 31 > q0);
-  if (has_bias || dead_now || diag) {
+  const bool general = has_bias || dead_now || diag;
+  if (general) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = crowl(r, hi), key = key0 + j;
@@ -322,24 +352,34 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
       s[r] = t;
       mx = fmaxf(mx, t);
     }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = st[r] * sc;
-      mx = fmaxf(mx, s[r]);
-    }
+  } else {                                 // whole block alive: the row max is taken on the raw scores (sc > 0), the scale rides
+#pragma unroll                             // in the exponent's multiply-add
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+    mx *= sc;
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  ATT_FS(2, mx);
+  mx = xhalf_max(mx);
+  ATT_FS(3, mx);
   const float m_new = fmaxf(m_run, mx);
   const float m_use = m_new == -INFINITY ? 0.f : m_new;
   float p[16];
   float ps = 0.f;
+  if (general) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    p[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
-    ps += p[r];
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
+      ps += p[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc, -m_use));
+      ps += p[r];
+    }
   }
-  ps += __shfl_xor(ps, 32, 64);
+  ATT_FS(4, ps);
+  ps = xhalf_sum(ps);
+  ATT_FS(5, ps);
   if (__any(m_new != m_run)) {
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
     l_run *= alpha;
@@ -352,12 +392,14 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   }
   l_run += ps;
   ATT_WAIT4(vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+  ATT_FS(6, l_run);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const bf16x8 pf = pack8f(p + 8 * j);
     ot[0] = ATT_MFMA(vf[j][0], pf, ot[0]);
     ot[1] = ATT_MFMA(vf[j][1], pf, ot[1]);
   }
+  ATT_FS(7, l_run);
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
@@ -373,6 +415,15 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
     seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.out, a.ldo, nullptr, 0, tid);
     return;
   }
+#ifdef OFA_ATTN_TIMELINE
+  unsigned long long fsv[16];
+  for (int z = 0; z < 16; ++z) fsv[z] = 0;
+  fsv[8] = __builtin_amdgcn_s_memtime();
+  fsv[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  fsv[13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  fsv[14] = __builtin_amdgcn_s_memrealtime();
+  const int tl_wg = blockIdx.y * gridDim.x + blockIdx.x;
+#endif
   if (!seg_enter(a, b, bh, h, qb0, true)) return;        // (workgroup-uniform)
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
@@ -406,6 +457,9 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
+#ifdef OFA_ATTN_TIMELINE
+  fsv[9] = __builtin_amdgcn_s_memtime();
+#endif
   const bool live_wave = q0 < a.T;
   float bz[16];
   for (int kb = 0; kb < nkb; kb += 2) {
@@ -421,9 +475,12 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
         bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
-        fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc);
+        fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
       }
       ATT_SYNC();
+#ifdef OFA_ATTN_TIMELINE
+      if (kb == 4) fsv[10] = __builtin_amdgcn_s_memtime();
+#endif
     }
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
@@ -437,7 +494,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
         bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc);
+        fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc ATT_FS_PASS(false));
       }
       ATT_SYNC();
     }
@@ -454,6 +511,12 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
             ot[dt][4 * qq + 3] * c);
     if (hi == 0 && a.lse) a.lse[(int64_t)bh * a.Tpad + qi] = (m_run == -INFINITY ? 0.f : m_run) + log2f(l_run > 0.f ? l_run : 1.f);
   }
+#ifdef OFA_ATTN_TIMELINE
+  fsv[11] = __builtin_amdgcn_s_memtime();
+  fsv[15] = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && tl_wg < 8192)
+    for (int z = 0; z < 16; ++z) g_attn_tl[tl_wg * 16 + z] = fsv[z];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
@@ -634,17 +697,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int BUF>
-__device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&kf)[4],
-                                          const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0, int key0,
-                                          int ki, int hi, bool key_dead, float live, bool has_bias, const float (&bz)[16], float sc, float c,
-                                          const float4 (&l4)[4], const float4 (&d4)[4]) {
-  constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES;
+// Register budget.  Round 1's form of this kernel held 400 registers (one wave per SIMD: nothing ran while a wave waited for
+// fragments, the stage barrier or its own softmax arithmetic).  Now: the additive bias is a template parameter (its 16 + 2 x 16
+// staging registers exist only in the biased instantiation); the per-row softmax statistics (lse, delta) of a query block travel
+// with the block's Q / dO tiles through LDS (256 bytes per stage, one 4-byte LDS-DMA per lane of wave 0) instead of two
+// prefetched register sets of 32; and the transposed Q / dO fragments are read AFTER the S / dP MFMAs have been issued, into the
+// registers of the row-major fragments those MFMAs have consumed.
+constexpr int STAT_BYTES = 256;                            // per stage: lse[32] | delta[32] of the query block (fp32)
+__device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const float* __restrict__ delta_bh, int q0,
+                                         unsigned char* __restrict__ lds_stat, int lane, int wave_u) {
+  if (wave_u == 0) {                                       // lanes 0..31: lse[q0 + lane], lanes 32..63: delta[q0 + lane - 32]
+    const float* src = (lane < 32 ? lse_bh : delta_bh - 32) + q0 + lane;
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)lds_stat, 4, 0, 0);
+  }
+}
+
+template <int BUF, bool BIAS>
+__device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, uint32_t stat_addr,
+                                          const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0,
+                                          int key0, int ki, int hi, bool key_dead, float live, const float (&bz)[16], float sc,
+                                          float c) {
+  constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES, SOFF = BUF * STAT_BYTES;
   u64x2 qf[4], dof[4];
   rd128<QOFF>(qf[0], ta.km[0]); rd128<QOFF>(qf[1], ta.km[1]); rd128<QOFF>(qf[2], ta.km[2]); rd128<QOFF>(qf[3], ta.km[3]);
   rd128<DOOFF>(dof[0], ta.km[0]); rd128<DOOFF>(dof[1], ta.km[1]); rd128<DOOFF>(dof[2], ta.km[2]); rd128<DOOFF>(dof[3], ta.km[3]);
+  // lse / delta of this lane's 16 query rows (rows 8g + 4hi + 0..3): four 16-byte reads each, the 32 lanes of a half read the
+  // same address (broadcast)
+  u64x2 l2[4], d2[4];
+  rd128<SOFF>(l2[0], stat_addr); rd128<SOFF + 32>(l2[1], stat_addr); rd128<SOFF + 64>(l2[2], stat_addr); rd128<SOFF + 96>(l2[3], stat_addr);
+  rd128<SOFF + 128>(d2[0], stat_addr); rd128<SOFF + 160>(d2[1], stat_addr); rd128<SOFF + 192>(d2[2], stat_addr); rd128<SOFF + 224>(d2[3], stat_addr);
   ATT_WAIT4(qf[0], qf[1], qf[2], qf[3]);
   ATT_WAIT4(dof[0], dof[1], dof[2], dof[3]);
+  ATT_WAIT4(l2[0], l2[1], l2[2], l2[3]);
+  ATT_WAIT4(d2[0], d2[1], d2[2], d2[3]);
+  f32x16 st, dp;
+  zero16f(st);
+  zero16f(dp);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    st = ATT_MFMA(qf[kk], kf[kk], st);     // S[q][key]
+    dp = ATT_MFMA(dof[kk], vf[kk], dp);    // dP[q][key]
+  }
+  __builtin_amdgcn_sched_barrier(0);       // the transposed reads go out behind the MFMAs (hipcc would hoist them: +32 registers)
   u64x2 qtf[2][2], dotf[2][2];
   rdtr<QOFF, 0>(qtf[0][0], ta.tr[0], trx[0]);
   rdtr<QOFF, 0>(qtf[0][1], ta.tr[1], trx[1]);
@@ -654,28 +748,21 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   rdtr<DOOFF, 0>(dotf[0][1], ta.tr[1], trx[1]);
   rdtr<DOOFF, 1>(dotf[1][0], ta.tr[0], trx[0]);
   rdtr<DOOFF, 1>(dotf[1][1], ta.tr[1], trx[1]);
-  f32x16 st, dp;
-  zero16f(st);
-  zero16f(dp);
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    st = ATT_MFMA(qf[kk], kf[kk], st);     // S[q][key]
-    dp = ATT_MFMA(dof[kk], vf[kk], dp);    // dP[q][key]
-  }
   float lv[16], dv16[16];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
-    lv[4 * g4] = l4[g4].x; lv[4 * g4 + 1] = l4[g4].y; lv[4 * g4 + 2] = l4[g4].z; lv[4 * g4 + 3] = l4[g4].w;
-    dv16[4 * g4] = d4[g4].x; dv16[4 * g4 + 1] = d4[g4].y; dv16[4 * g4 + 2] = d4[g4].z; dv16[4 * g4 + 3] = d4[g4].w;
+    const float4 l4 = __builtin_bit_cast(float4, l2[g4]), d4 = __builtin_bit_cast(float4, d2[g4]);
+    lv[4 * g4] = l4.x; lv[4 * g4 + 1] = l4.y; lv[4 * g4 + 2] = l4.z; lv[4 * g4 + 3] = l4.w;
+    dv16[4 * g4] = d4.x; dv16[4 * g4 + 1] = d4.y; dv16[4 * g4 + 2] = d4.z; dv16[4 * g4 + 3] = d4.w;
   }
   float p[16], ds[16];
-  const bool general = has_bias || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
+  const bool general = BIAS || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
   if (general) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = q0 + crowl(r, hi);
       float t = st[r] * sc;
-      if (has_bias) t += bz[r];
+      if (BIAS) t += bz[r];
       bool dead = key_dead || q >= a.T;
       if (a.causal) dead |= ki > q;
       const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[r]);
@@ -703,9 +790,11 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
+template <bool BIAS>
+__device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][Q tile | dO tile], then [2][lse | delta]
+  unsigned char* lds_stat = smem + 4 * TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
@@ -733,62 +822,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
   const float c = head_scale(a, h);
   const bf16_t* qbase = a.q + (int64_t)b * a.T * a.ldq;
   const bf16_t* dobase = a.dout + (int64_t)b * a.T * a.ldo;
-  const float* lse_b = a.lse + (int64_t)bh * a.Tpad + 4 * hi;
-  const float* delta_b = a.delta + (int64_t)bh * a.Tpad + 4 * hi;
-  const bf16_t* bcol = a.bias ? a.bias + (int64_t)bh * a.T * a.S + krow : nullptr;
+  const float* lse_bh = a.lse + (int64_t)bh * a.Tpad;
+  const float* delta_bh = a.delta + (int64_t)bh * a.Tpad;
+  const bf16_t* bcol = BIAS ? a.bias + (int64_t)bh * a.T * a.S + krow : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
   ta.init((uint32_t)(uintptr_t)smem, lane);
   const uint32_t* trx = ta.trx;
+  const uint32_t stat_addr = (uint32_t)(uintptr_t)lds_stat + 16 * hi;
 
   f32x16 dvt[2], dkt[2];
   zero16f(dvt[0]); zero16f(dvt[1]); zero16f(dkt[0]); zero16f(dkt[1]);
   const int nqb = (a.T + 31) / 32;
   const int qb_first = a.causal ? kb0 / 32 : 0;          // the workgroup starts where its FIRST wave needs
   const bool live_wave = key0 < a.S;
-  float4 l4[4], d4[4], l4n[4], d4n[4];
-  auto load_stats = [&](int q0, float4 (&L)[4], float4 (&Dd)[4]) {
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      L[g4] = *reinterpret_cast<const float4*>(lse_b + q0 + 8 * g4);
-      Dd[g4] = *reinterpret_cast<const float4*>(delta_b + q0 + 8 * g4);
-    }
-  };
-  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight
+  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (BIAS only)
   float bz[16];
   if (qb_first < nqb) {
-    load_stats(qb_first * 32, l4, d4);
-    bA.issue(bcol, qb_first * 32, a.T, a.S, hi);
+    if constexpr (BIAS) bA.issue(bcol, qb_first * 32, a.T, a.S, hi);
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
+    stat_dma(lse_bh, delta_bh, qb_first * 32, lds_stat, lane, wave_u);
   }
   ATT_SYNC();
   for (int qb = qb_first; qb < nqb; qb += 2) {
     {
       if (qb + 1 < nqb) {
-        load_stats((qb + 1) * 32, l4n, d4n);            // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
-        bB.issue(bcol, (qb + 1) * 32, a.T, a.S, hi);
+        if constexpr (BIAS) bB.issue(bcol, (qb + 1) * 32, a.T, a.S, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
         tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 1) * 32, lds_stat + STAT_BYTES, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
-        bA.take(bcol, bz);
-        dkv_block<0>(a, ta, trx, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bcol != nullptr, bz, sc, c, l4, d4);
+        if constexpr (BIAS) bA.take(bcol, bz);
+        dkv_block<0, BIAS>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
     if (qb + 1 < nqb) {
       if (qb + 2 < nqb) {
-        load_stats((qb + 2) * 32, l4, d4);
-        bA.issue(bcol, (qb + 2) * 32, a.T, a.S, hi);
+        if constexpr (BIAS) bA.issue(bcol, (qb + 2) * 32, a.T, a.S, hi);
         tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 2) * 32, lds_stat, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {
-        bB.take(bcol, bz);
-        dkv_block<1>(a, ta, trx, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bcol != nullptr, bz, sc, c, l4n, d4n);
+        if constexpr (BIAS) bB.take(bcol, bz);
+        dkv_block<1, BIAS>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
@@ -808,6 +890,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnL a) {
   }
 }
 
+// two waves per SIMD for the bias-free form (fits 256 registers); the biased one keeps one (it would spill)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<true>(a); }
+
 static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int dtype) {
   OFA_REQUIRE(dtype == OFA_BF16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 only (dtype %d); use the unfused path", dtype);
   OFA_REQUIRE(B > 0 && heads > 0 && T > 0 && S > 0, OFA_ERR_INVALID, "attention: bad shape B=%d heads=%d T=%d S=%d", B, heads, T, S);
@@ -825,6 +911,7 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
                             int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(q && k && v && out, OFA_ERR_INVALID, "attn_fwd: null pointer");
+  OFA_REQUIRE(scale > 0.f, OFA_ERR_INVALID, "attn_fwd: the score scale must be positive (row maxima are taken on the raw scores), got %g", (double)scale);
   OFA_REQUIRE(!seg || (!bias && !kpm && lse && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
               "attn_fwd: the ragged (seg) mode takes no bias / key-padding mask, needs lse and a 16-byte aligned table");
   OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_fwd: bad c_attn dtype %d", c_attn_dtype);
@@ -858,6 +945,14 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(cdiv(T, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, dim3(cdiv(S, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
+  const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);
+  if (bias) hipLaunchKernelGGL(attn_bwd_dkv_bias_lds_kernel, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
   return check_launch("attn_bwd_dkv");
 }
+
+#ifdef OFA_ATTN_TIMELINE
+extern "C" int ofa_debug_attn_timeline(void* dst_host, int64_t bytes) {   // measurement build only (tools/attn_timeline.py)
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_attn_tl), (size_t)bytes);
+}
+#endif

@@ -314,11 +314,12 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int BUF>   // BUF selects the double-buffer half at compile time (immediates)
+template <int BUF, bool BIAS>   // BUF selects the double-buffer half at compile time (immediates)
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                           f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
-                                          uint32_t dead_now, bool has_bias, const float (&bz)[16], float sc ATT_FS_ARG) {
+                                          uint32_t dead_now, const float (&bz)[16], float sc ATT_FS_ARG) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
+  constexpr bool has_bias = BIAS;
   ATT_FS(0, m_run);
   u64x2 kf[4];
   rd128<KOFF>(kf[0], ta.km[0]);
@@ -402,7 +403,8 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   ATT_FS(7, l_run);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
+template <bool BIAS>
+__device__ __forceinline__ void attn_fwd_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile], 4 KiB each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   for (int kk = 0; kk < 4; ++kk) qf[kk] = ld16(qp + kk * 16);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* brow = a.bias ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
+  const bf16_t* brow = BIAS ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  bpre.issue(brow, 0, a.S, hi);
+  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
@@ -468,14 +470,14 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       const BiasRow bcur = bpre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        bpre.issue(brow, (kb + 1) * 32, a.S, hi);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
-        fwd_block<0>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
+        if constexpr (BIAS) bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
+        fwd_block<0, BIAS>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
       }
       ATT_SYNC();
 #ifdef OFA_ATTN_TIMELINE
@@ -487,14 +489,14 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
       const BiasRow bcur = bpre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        bpre.issue(brow, (kb + 2) * 32, a.S, hi);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        fwd_block<1>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, sc ATT_FS_PASS(false));
+        if constexpr (BIAS) bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        fwd_block<1, BIAS>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(false));
       }
       ATT_SYNC();
     }
@@ -519,23 +521,23 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(AttnL a) {
 #endif
 }
 
+// three waves per SIMD for the bias-free form (its registers fit 168); the biased one keeps two
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<false>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<true>(a); }
+
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int BUF>
+template <int BUF, bool BIAS>
 __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                          const bf16x8 (&dof)[4], f32x16 (&dqt)[2], int key0, int q0, int qi, int hi,
-                                         uint32_t dead_now, bool has_bias, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
+                                         uint32_t dead_now, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
                                          float delta_q, float c) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
+  constexpr bool has_bias = BIAS;
   u64x2 kf[4], vf[4];
   rd128<KOFF>(kf[0], ta.km[0]); rd128<KOFF>(kf[1], ta.km[1]); rd128<KOFF>(kf[2], ta.km[2]); rd128<KOFF>(kf[3], ta.km[3]);
   rd128<VOFF>(vf[0], ta.km[0]); rd128<VOFF>(vf[1], ta.km[1]); rd128<VOFF>(vf[2], ta.km[2]); rd128<VOFF>(vf[3], ta.km[3]);
   ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
   ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
-  u64x2 ktf[2][2];
-  rdtr<KOFF, 0>(ktf[0][0], ta.tr[0], trx[0]);
-  rdtr<KOFF, 0>(ktf[0][1], ta.tr[1], trx[1]);
-  rdtr<KOFF, 1>(ktf[1][0], ta.tr[0], trx[0]);
-  rdtr<KOFF, 1>(ktf[1][1], ta.tr[1], trx[1]);
   f32x16 st, dp;
   zero16f(st);
   zero16f(dp);
@@ -544,6 +546,12 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
     st = ATT_MFMA(kf[kk], qf[kk], st);
     dp = ATT_MFMA(vf[kk], dof[kk], dp);
   }
+  __builtin_amdgcn_sched_barrier(0);       // the transposed K reads go out behind the MFMAs, into the registers those have consumed
+  u64x2 ktf[2][2];
+  rdtr<KOFF, 0>(ktf[0][0], ta.tr[0], trx[0]);
+  rdtr<KOFF, 0>(ktf[0][1], ta.tr[1], trx[1]);
+  rdtr<KOFF, 1>(ktf[1][0], ta.tr[0], trx[0]);
+  rdtr<KOFF, 1>(ktf[1][1], ta.tr[1], trx[1]);
   float ds[16];
   const bool diag = a.causal && (key0 + 31 > q0);
   if (has_bias || dead_now || diag) {
@@ -564,7 +572,7 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
       ds[r] = p * (dp[r] * c - delta_q);
     }
   }
-  if (dbrow && qi < a.T) {
+  if (BIAS && dbrow && qi < a.T) {
     if ((a.S & 3) == 0 && key0 + 32 <= a.S) {             // 4 consecutive keys per register quad: 8-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
@@ -586,7 +594,8 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
+template <bool BIAS>
+__device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -616,8 +625,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   const float c = head_scale(a, h);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* brow = a.bias ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
-  bf16_t* dbrow = a.dbias ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
+  const bf16_t* brow = BIAS ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
+  bf16_t* dbrow = (BIAS && a.dbias) ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  bpre.issue(brow, 0, a.S, hi);
+  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
@@ -649,14 +658,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
       const BiasRow bcur = bpre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        bpre.issue(brow, (kb + 1) * 32, a.S, hi);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
-        dq_block<0>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, brow != nullptr, bz, dbrow, sc, lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
+        dq_block<0, BIAS>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
       ATT_SYNC();
@@ -666,14 +675,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
       const BiasRow bcur = bpre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        bpre.issue(brow, (kb + 2) * 32, a.S, hi);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        dq_block<1>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, brow != nullptr, bz, dbrow, sc, lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        dq_block<1, BIAS>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
       ATT_SYNC();
@@ -695,6 +704,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnL a) {
             dqt[dt][4 * qq + 2] * a.scale, dqt[dt][4 * qq + 3] * a.scale);
   }
 }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Register budget.  Round 1's form of this kernel held 400 registers (one wave per SIMD: nothing ran while a wave waited for
@@ -920,7 +932,9 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
   a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_fwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
-  hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(cdiv(T, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  const dim3 grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
+  if (bias) hipLaunchKernelGGL(attn_fwd_bias_lds_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_lds_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_fwd");
 }
 
@@ -942,7 +956,9 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   a.rows_q = rows_q; a.rows_k = rows_k;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_bwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(cdiv(T, 128) + (seg ? 1 : 0), B * heads), dim3(256), 4 * TILE_BYTES, st, a);
+  const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
+  if (bias) hipLaunchKernelGGL(attn_bwd_dq_bias_lds_kernel, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
   const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);

@@ -14,7 +14,15 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/r2write -o p -- python $R/benc
 python $R/tools/pmc_traffic.py /tmp/r2fetch/p_results.db /tmp/r2write/p_results.db $O/round2_pmc_traffic.json 4 > $O/round2_pmc_traffic.txt 2>&1
 # MFMA busy / LDS activity / bank conflicts per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/r2mfma -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/mfma_run.log 2>&1
-python $R/tools/pmc_dump.py /tmp/r2mfma/p_results.db > $O/round2_pmc_mfma_lds_raw.txt 2>&1
+(echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
+ echo "#   -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph   (MI355X, round 2, packed cfg-2 step; tools/pmc_dump.py)"
+ echo "# Averages per launch, grouped by (kernel, grid x).  MFMA utilisation = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs);"
+ echo "# LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.  Appended per line as [mfma xx% | lds-conflict yy%]."
+ python $R/tools/pmc_dump.py /tmp/r2mfma/p_results.db) > $O/round2_pmc_mfma_lds.txt 2>&1
 cd $R
 python bench.py > $O/round2_bench.json 2> $O/bench_run.log
 tail -c 800 $O/round2_bench.json
+python bench.py --workload cfg2b --steps 20 --warmup 5 --no-cpu-baseline > $O/round2_bench_cfg2b.json 2> $O/bench_cfg2b_run.log
+python bench.py --workload cfg4 --steps 20 --warmup 5 --no-cpu-baseline > $O/round2_bench_cfg4.json 2> $O/bench_cfg4_run.log
+python tools/attn_bench.py > $O/round2_attn_bench.txt 2>&1
+OFA_GEMM_TILE=0 python tools/gemm_tile_sweep.py 13312 12800 2048 > $O/round2_gemm_plan_sweep.txt 2>&1

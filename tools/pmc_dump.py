@@ -22,4 +22,10 @@ for did, cs in per.items():
     a = agg[k]; a[0] += 1; a[1] += meta[did][2]
     for n, v in cs.items(): a[2][n] += v
 for (name, g), (n, us, cs) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{name} grid {g} calls {n} avg {us/n:.1f} us  " + "  ".join(f"{k}={v/n:.3g}" for k, v in sorted(cs.items())))
+    extra = ""
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cs.get("GRBM_GUI_ACTIVE", 0) > 0:      # (1024 SIMDs, 8 XCDs: MI355X)
+        extra += f"  [mfma {100.0 * (cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024) / (cs['GRBM_GUI_ACTIVE'] / 8):4.1f}%"
+        if cs.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            extra += f" | lds-conflict {100.0 * cs.get('SQ_LDS_BANK_CONFLICT', 0.0) / cs['SQ_LDS_IDX_ACTIVE']:4.1f}%"
+        extra += "]"
+    print(f"{name} grid {g} calls {n} avg {us/n:.1f} us  " + "  ".join(f"{k}={v/n:.3g}" for k, v in sorted(cs.items())) + extra)

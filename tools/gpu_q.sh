@@ -1,9 +1,7 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-export OFA_SWEEP_SHAPES="TN,2304,768,13312;TN,768,768,13312;TN,3072,768,13312;TN,768,3072,13312;TN,2304,768,2048;TN,3072,768,2048"
-for bs in 0 1; do
-OFA_GEMM_BIGSPLIT=$bs rocprofv3 --kernel-trace --stats -d /tmp/bs$bs -o p -- python $R/tools/gemm_tile_sweep.py 1 > $R/gpurun_out/q_bs$bs.log 2>&1
-echo "== BIGSPLIT=$bs"; grep -v amdgpu $R/gpurun_out/q_bs$bs.log | grep tile
-python $R/tools/prof_by_grid.py /tmp/bs$bs/p_results.db | grep -i "gemm\|splitk" | head -14 | cut -c1-170
-done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+export OFASYS_AMD_LIB=$GRAFT_REPO_ROOT/tools/experiments/_build/libofasys_amd_deep.so
+(
+for t in 33 35 22; do OFA_GEMM_TILE=$t OFA_SWEEP_CHECK=1 timeout 300 python tools/gemm_tile_sweep.py 13312; done
+) > gpurun_out/q_sweep_deep.txt 2>&1
+grep -v amdgpu gpurun_out/q_sweep_deep.txt

@@ -136,7 +136,8 @@ int ofa_attn_softmax_fwd(const void* x, const void* bias, const uint8_t* kpm, vo
  * q: [B, T, heads*64] rows (ld = ldq elements); k, v: [B, S, heads*64] rows (both with ld = ldk);
  * bias: optional dense [B*heads, T, S] additive bias (same dtype); kpm: optional uint8 [B,S]; c_attn: optional
  * [heads] per-head output scale (:342-345), fp32 or bf16 as c_attn_dtype says (the parameter itself, no cast kernel). out: [B, T, heads*64] (ld = ldo); lse: fp32 [B*heads, Tpad].  scale
- * multiplies q.k (the reference pre-scales q, :218).  Tpad: a multiple of 32 covering T.
+ * multiplies q.k (the reference pre-scales q, :218) and must be positive (the kernel takes row maxima on the raw scores; a
+ * non-positive scale is refused).  Tpad: a multiple of 32 covering T.
  * Attention dropout is not supported here (the reference default is attention_dropout = 0.0).
  * Ragged ("packed rows") mode, seg != NULL: the reference pads every sample to the longest and masks the padding
  * (multihead_attention.py:319-326); here the batch may arrive packed instead.  seg: device int32 [B][4] = {q_off, q_len, k_off,

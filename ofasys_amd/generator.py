@@ -30,7 +30,8 @@ class StepDecoder:
         """Encode the sources (eagerly), optionally expand to beams (`beam_order`: row index per output row), and point the
         static buffers at the new batch."""
         m = self.model
-        m.eval()
+        m.eval()                                          # decoding is an inference-mode activity: the model STAYS in eval mode (call
+        #                                                   model.train() before the next train step, as with the reference's generator)
         for mod in m.decoder.modules():                   # packed decode projections follow the current parameters
             if getattr(mod, "_decode_pack_cache", None) is not None:
                 mod._decode_pack()
@@ -39,7 +40,10 @@ class StepDecoder:
             if beam_order is not None:
                 enc = m.encoder.reorder_encoder_out(enc, beam_order)
         out = enc["encoder_out"][0]
-        shape = (out.shape[1], out.shape[0], out.dtype)
+        # captured step graphs bake in parameter ADDRESSES: a TrainStep built afterwards (its arenas re-point p.data) or a
+        # model.to(...) must drop them, so the storage of one parameter is part of the cache key
+        fingerprint = next(m.decoder.parameters()).data_ptr()
+        shape = (out.shape[1], out.shape[0], out.dtype, fingerprint)
         if shape != self._shape:                          # another batch shape: new buffers, new graphs
             self._shape, self._graphs, self._pool, self._seq = shape, {}, None, 0
             self.enc = {k: [t.clone() for t in v] if isinstance(v, list) else v for k, v in enc.items()}

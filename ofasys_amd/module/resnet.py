@@ -125,13 +125,14 @@ class ResNet(nn.Module):
         """x: [B, 3, H, W] image -> (rows [B*h*w, 1024] in (b, h, w) order, h, w); the reference returns [B,1024,h,w] and
         its caller immediately flattens to [B, h*w, 1024] (adaptor/image_resnet.py:159) -- the same rows."""
         B, _, H, W = x.shape
-        out, H, W = _conv(x, self.conv1, B, H, W, nchw=True)
-        out = ops.batch_norm(out, self.bn1, relu=True)
-        out, H, W = ops.max_pool(out, B, H, W, self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding)
-        fm = (out, B, H, W)
-        for layer in (self.layer1, self.layer2, self.layer3):
-            for blk in layer:
-                fm = blk(fm)
+        with ops.bn_scope():
+            out, H, W = _conv(x, self.conv1, B, H, W, nchw=True)
+            out = ops.batch_norm(out, self.bn1, relu=True)
+            out, H, W = ops.max_pool(out, B, H, W, self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding)
+            fm = (out, B, H, W)
+            for layer in (self.layer1, self.layer2, self.layer3):
+                for blk in layer:
+                    fm = blk(fm)
         out, B, H, W = fm
         return out, H, W
 

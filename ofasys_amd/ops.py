@@ -1040,11 +1040,17 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and not nchw:
             dcol = K.gemm(dy, w2, False, False)
             dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
-        dw2 = K.gemm(dy, col, True, False)                                        # [Cout, Kpad]
-        if direct:
-            dw = dw2.view(weight.shape)
+        gw = _sink(weight) if direct else None
+        if gw is not None:                                                        # 1x1 convolution: dW += dY^T X straight into the arena,
+            K.gemm(dy, col, True, False, out=gw.view(Cout, Cin), accumulate=True, fold=_fold())   # split-K slabs folded in the batch
+            _sink_done(weight)
+            dw = None
         else:
-            dw = dw2[:, :kh * kw * Cin].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+            dw2 = K.gemm(dy, col, True, False)                                    # [Cout, Kpad]
+            if direct:
+                dw = dw2.view(weight.shape)
+            else:
+                dw = dw2[:, :kh * kw * Cin].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
         db = K.colsum(dy, out_dtype=weight.dtype) if bias is not None else None
         return dx, dw, db, None
 
@@ -1054,6 +1060,26 @@ def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, nchw=False):
     kh, kw = weight.shape[2], weight.shape[3]
     y = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw))
     return y, K.conv_out_size(H, kh, stride, pad), K.conv_out_size(W, kw, stride, pad)
+
+
+class _BnScope:
+    pending = None
+
+
+class bn_scope:
+    """`with ops.bn_scope():` around a backbone's forward: the `num_batches_tracked += 1` of every BatchNorm inside becomes ONE
+    batched launch at exit instead of one 4 us launch per layer (94 per step in a ResNet-101 backbone)."""
+
+    def __enter__(self):
+        self.outer = _BnScope.pending
+        _BnScope.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        counters, _BnScope.pending = _BnScope.pending, self.outer
+        if counters and exc[0] is None:
+            torch._foreach_add_(counters, 1)
+        return False
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -1087,7 +1113,10 @@ def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None):
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _BnScope.pending is not None:
+            _BnScope.pending.append(bn.num_batches_tracked)        # one batched increment when the backbone's forward ends
+        else:
+            bn.num_batches_tracked.add_(1)
     rm, rv = bn.running_mean, bn.running_var
     cast = rm is not None and rm.dtype != torch.float32       # model.bfloat16() casts the buffers too: keep the update in fp32
     if cast:

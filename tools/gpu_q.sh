@@ -1,7 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-export OFASYS_AMD_LIB=$GRAFT_REPO_ROOT/tools/experiments/_build/libofasys_amd_deep.so
-(
-for t in 33 35 22; do OFA_GEMM_TILE=$t OFA_SWEEP_CHECK=1 timeout 300 python tools/gemm_tile_sweep.py 13312; done
-) > gpurun_out/q_sweep_deep.txt 2>&1
-grep -v amdgpu gpurun_out/q_sweep_deep.txt
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_configs_gpu.py tests/test_trainstep_gpu.py -x -q -m gpu > gpurun_out/q_tests.log 2>&1; tail -3 gpurun_out/q_tests.log
+timeout 600 python bench.py --workload cfg2b --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/q_bench2b.log 2>&1; tail -1 gpurun_out/q_bench2b.log | cut -c1-200

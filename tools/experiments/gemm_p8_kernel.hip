@@ -6,6 +6,9 @@
 // acknowledgement and the re-dispatch (5 us per tile) are gone, but the epilogue grew from 2.5 to ~4 us (four passes through a 4 KiB
 // bounce slice, 20-68 bytes of spills whose reloads wait vmcnt(0)) and all eight waves of the CU sit in it together.  What it would
 // take: the bounce in the retired stage (delay the next tile's step-1 DMA behind the epilogue), DMA pointers as 32-bit offsets.
+// (A second version did move the bounce into the retired stage -- two 64-row epilogue passes, the refill sent for behind a barrier
+//  after the epilogue: correct, but hipcc then spilled 168-216 bytes per lane INTO the K loop and it ran 2x slower (150 vs 76 us).
+//  The register budget, not the schedule, is what a persistent form of this kernel has to be designed around.)
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent eight-wave kernel: the 256 x 256 tile of gemm_big_kernel<4, 2, .., 2, 4> (eight waves, 128 x 64 each, two per
 // SIMD), but ONE workgroup per CU walks a list of tiles and the operand stream never stops at a tile boundary.

@@ -21,6 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HALF = {"bf16": torch.bfloat16, "fp16": torch.float16}
+_HALF_NOW = [torch.bfloat16]       # the 16-bit dtype of this run (--dtype)
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2:1 sparsity excluded)
 PEAK_HBM_GBPS = 8000.0        # HBM3E, same guide
 V_TEXT = 50260                # 4 specials + 50260 <text>_i + <mask> + 1000 <bin>_i = 51265
@@ -63,7 +65,7 @@ def build(args, device):
             a.entangle_position_embedding = True
         m.cfg.adaptor.image_patch_embed.embed_dim = m.cfg.encoder_embed_dim      # the adaptor's own default is 768 (base)
     m.initialize(d)
-    m = m.to(device).to(torch.bfloat16)
+    m = m.to(device).to(HALF[getattr(args, 'dtype', 'bf16')])
     return m, d
 
 
@@ -79,10 +81,10 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2", pack=False):
         for b in range(B):
             if zero[b]:
                 img[b, :, int(torch.randint(0, 8, (1,), generator=g))] = 0.0
-        img = img.to(torch.bfloat16)
+        img = img.to(_HALF_NOW[0])
         nvis = B * 8 * 196 - int(zero.sum()) * 196
     else:
-        img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16)
+        img = torch.randn(B, 3, 224, 224, generator=g).to(_HALF_NOW[0])
     src = torch.randint(4, V, (B, Ts_text), generator=g)
     slen = torch.randint(Ts_text // 2, Ts_text + 1, (B,), generator=g)
     slen[0] = Ts_text
@@ -256,9 +258,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL, the product path); gloo only to smoke-test the N > 1 code path "
                          "on a one-GPU box together with OFA_BENCH_DEVICE=0 (all ranks on one device)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="compute dtype: bf16 (the BASELINE configuration) or fp16 with the reference's dynamic loss scaler "
+                         "(its own default trainer precision)")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher plumbing only: init the process group, one all-reduce, print the JSON skeleton (runs without a GPU)")
     args = ap.parse_args()
+    _HALF_NOW[0] = HALF[args.dtype]
     if args.batch is None:
         args.batch = 4 if args.workload == "cfg4" else 32
 
@@ -300,7 +306,8 @@ def main():
             dist.broadcast(p.data, 0)
     from ofasys_amd import ops
     ops.manual_seed(1 + rank)                                      # dropout streams differ per rank (fairseq: seed + rank)
-    trainer = TrainStep(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph, dp_graph=args.dp_graph)
+    trainer = TrainStep(model, lr=1e-4, clip_norm=1.0, use_graph=not args.no_graph, dp_graph=args.dp_graph,
+                        loss_scale={"init_scale": 128.0} if args.dtype == "fp16" else None)
     Ts_text, Tt, nvis, desc = WORKLOADS[args.workload]
     # a few distinct batches of the same structure: replays copy each new batch into the graph's static inputs
     packed = args.workload == "cfg2" and not args.no_pack
@@ -373,7 +380,7 @@ def main():
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
         traffic, step_bytes, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (bf16 v_mfma_f32_32x32x16_bf16, all instantiations)",
+                "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (" + ("bf16 v_mfma_f32_32x32x16_bf16" if args.dtype == "bf16" else "fp16 v_mfma_f32_32x32x16_f16") + ", all instantiations)",
                 "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS, "step_flops": step_flops,
                 "step_flops_padded_shape": step_flops_padded,
                 "step_flops_basis": ("non-pad positions only (ragged row packing: each sample at its own lengths)" if packed else
@@ -398,7 +405,7 @@ def main():
         out = {
             "metric": "multimodal tokens/sec (enc+dec train step)", "value": total_tokens * args.steps / dt,
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tokens_per_sec_per_gpu": total_tokens * args.steps / dt / world,
             "config": {"workload": desc + ", OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,

@@ -25,8 +25,11 @@
 extern "C" {
 #endif
 
-/* OFA_F16 is accepted by the fused-softmax entry points (the dtype the reference routes to them, multihead_attention.py:83-91,
- * scaled_masked_softmax.cpp:45-47); every other entry point computes in fp32 or bf16 and returns OFA_ERR_INVALID for it. */
+/* Element types.  Every entry point takes fp32, bf16 or fp16 storage (`dtype`), accumulates in fp32 and -- for the 16-bit types --
+ * multiplies on the matrix cores (v_mfma_f32_32x32x16_bf16 / _f16).  fp16 is the reference trainer's default precision
+ * (config/default_trainer.yaml:7-25) and the only dtype it routes to its fused-softmax extensions (multihead_attention.py:83-91);
+ * the fused attention kernels (ofa_attn_fwd / _bwd / _bwd_prep) are 16-bit only.  "bf16" in a comment below means "the 16-bit
+ * dtype of the call" unless it says otherwise. */
 typedef enum { OFA_F32 = 0, OFA_BF16 = 1, OFA_F16 = 2 } ofa_dtype;
 
 enum {

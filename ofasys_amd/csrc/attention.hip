@@ -45,7 +45,7 @@ constexpr int TILE_BYTES = 32 * HD * 2;   // 4 KiB: 32 rows x 64 bf16
 
 struct AttnL {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout; const bf16_t* bias; const uint8_t* kpm;
-  const void* c_attn; int c_bf16; bf16_t* out; float* lse; const float* delta;   // c_attn: fp32 or (c_bf16) bf16 [heads]
+  const void* c_attn; int c_dt; bf16_t* out; float* lse; const float* delta;   // c_attn: [heads] in the dtype code c_dt
   bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dbias;
   int B, heads, T, S, Tpad;
   int64_t ldq, ldk, ldo;
@@ -111,15 +111,38 @@ __device__ __forceinline__ bool seg_enter(AttnL& a, int& b, int& bh, int h, int 
 
 __device__ __forceinline__ float head_scale(const AttnL& a, int h) {
   if (!a.c_attn) return 1.0f;
-  return a.c_bf16 ? bf2f(((const bf16_t*)a.c_attn)[h]) : ((const float*)a.c_attn)[h];
+  return a.c_dt == OFA_BF16 ? bf2f(((const bf16_t*)a.c_attn)[h]) : a.c_dt == OFA_F16 ? (float)((const f16_t*)a.c_attn)[h] : ((const float*)a.c_attn)[h];
+}
+// The 16-bit storage type is a template flag (F16): bf16 (v_mfma_f32_32x32x16_bf16) or fp16 (v_mfma_f32_32x32x16_f16); tiles, swizzles and
+// fragment reads are the same for both (bf16_t stands for "16-bit element" in the pointer types below).
+template <bool F16> __device__ __forceinline__ uint32_t enc2(float lo, float hi) {
+  if constexpr (F16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ float lo16(uint32_t w) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2_t, w)[0];
+  else return __uint_as_float(w << 16);
+}
+template <bool F16> __device__ __forceinline__ float hi16(uint32_t w) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2_t, w)[1];
+  else return __uint_as_float(w & 0xffff0000u);
+}
+template <bool F16> __device__ __forceinline__ float dec1(uint16_t u) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16_t, u);
+  else return bf2f(u);
+}
+template <bool F16> __device__ __forceinline__ uint16_t enc1(float v) {
+  if constexpr (F16) return __builtin_bit_cast(uint16_t, (f16_t)v);
+  else return f2bf(v);
 }
 __device__ __forceinline__ bf16x8 ld16(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+template <bool F16>
 __device__ __forceinline__ bf16x8 pack8f(const float* f) {
   union { uint4 u; bf16x8 v; } r;
-  r.u.x = pack_bf16x2(f[0], f[1]);
-  r.u.y = pack_bf16x2(f[2], f[3]);
-  r.u.z = pack_bf16x2(f[4], f[5]);
-  r.u.w = pack_bf16x2(f[6], f[7]);
+  r.u.x = enc2<F16>(f[0], f[1]);
+  r.u.y = enc2<F16>(f[2], f[3]);
+  r.u.z = enc2<F16>(f[4], f[5]);
+  r.u.w = enc2<F16>(f[6], f[7]);
   return r.v;
 }
 __device__ __forceinline__ void zero16f(f32x16& a) {
@@ -127,10 +150,11 @@ __device__ __forceinline__ void zero16f(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 __device__ __forceinline__ int crowl(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+template <bool F16>
 __device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
   uint2 o;
-  o.x = pack_bf16x2(a, b);
-  o.y = pack_bf16x2(c, d);
+  o.x = enc2<F16>(a, b);
+  o.y = enc2<F16>(c, d);
   *reinterpret_cast<uint2*>(p) = o;
 }
 // "dead key" flag of this lane's key in a 32-key block (out of range or padded).  The byte load is issued one block
@@ -159,19 +183,20 @@ struct BiasRow {
     }
   }
 };
-__device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]);
+template <bool F16> __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]);
+template <bool F16>
 __device__ __forceinline__ void bias_row_take(const BiasRow& p, const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
   if (!brow) return;
   if (p.vec) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      b[4 * g4] = __uint_as_float(p.raw[g4].x << 16) * LOG2E;
-      b[4 * g4 + 1] = __uint_as_float(p.raw[g4].x & 0xffff0000u) * LOG2E;
-      b[4 * g4 + 2] = __uint_as_float(p.raw[g4].y << 16) * LOG2E;
-      b[4 * g4 + 3] = __uint_as_float(p.raw[g4].y & 0xffff0000u) * LOG2E;
+      b[4 * g4] = lo16<F16>(p.raw[g4].x) * LOG2E;
+      b[4 * g4 + 1] = hi16<F16>(p.raw[g4].x) * LOG2E;
+      b[4 * g4 + 2] = lo16<F16>(p.raw[g4].y) * LOG2E;
+      b[4 * g4 + 3] = hi16<F16>(p.raw[g4].y) * LOG2E;
     }
   } else {
-    bias16(brow, key0, S, hi, b);          // ragged tail block / unaligned rows: in place
+    bias16<F16>(brow, key0, S, hi, b);     // ragged tail block / unaligned rows: in place
   }
 }
 struct BiasCol {
@@ -184,29 +209,30 @@ struct BiasCol {
       raw[r] = q < T ? bcol[(int64_t)q * S] : (unsigned short)0;
     }
   }
-  __device__ __forceinline__ void take(const bf16_t* bcol, float (&b)[16]) const {
+  template <bool F16> __device__ __forceinline__ void take(const bf16_t* bcol, float (&b)[16]) const {
     if (!bcol) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) b[r] = __uint_as_float((uint32_t)raw[r] << 16) * LOG2E;
+    for (int r = 0; r < 16; ++r) b[r] = dec1<F16>(raw[r]) * LOG2E;
   }
 };
 
 // additive bias of the 16 scores a lane holds for a 32-key block (keys key0 + crowl(r, hi)), pre-multiplied by log2(e)
+template <bool F16>
 __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
   if ((S & 3) == 0 && key0 + 32 <= S) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const uint2 u = *reinterpret_cast<const uint2*>(brow + key0 + 8 * g4 + 4 * hi);
-      b[4 * g4] = __uint_as_float(u.x << 16) * LOG2E;
-      b[4 * g4 + 1] = __uint_as_float(u.x & 0xffff0000u) * LOG2E;
-      b[4 * g4 + 2] = __uint_as_float(u.y << 16) * LOG2E;
-      b[4 * g4 + 3] = __uint_as_float(u.y & 0xffff0000u) * LOG2E;
+      b[4 * g4] = lo16<F16>(u.x) * LOG2E;
+      b[4 * g4 + 1] = hi16<F16>(u.x) * LOG2E;
+      b[4 * g4 + 2] = lo16<F16>(u.y) * LOG2E;
+      b[4 * g4 + 3] = hi16<F16>(u.y) * LOG2E;
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + crowl(r, hi);
-      b[r] = key < S ? bf2f(brow[key]) * LOG2E : 0.f;
+      b[r] = key < S ? dec1<F16>(brow[key]) * LOG2E : 0.f;
     }
   }
 }
@@ -283,8 +309,12 @@ __device__ __forceinline__ void rdtr(u64x2& d, uint32_t addr_lo, uint32_t addr_h
     __syncthreads();                                   \
   } while (0)
 #define ATT_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#define ATT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), B, C, 0, 0, 0)
-#define ATT_MFMA2(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+template <bool F16, typename A, typename B, typename C>
+__device__ __forceinline__ C att_mfma(const A& a, const B& b, const C& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#define ATT_MFMA(A, B, C) att_mfma<F16>(A, B, C)
 
 // Phase-timestamp probe of tools/attn_timeline.py (measurement build only: -DOFA_ATTN_TIMELINE is never set by the Makefile; in
 // the product the macros are empty).  Wave 0 of each forward workgroup records s_memtime at entry / first tiles landed / exit and,
@@ -314,7 +344,7 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int BUF, bool BIAS>   // BUF selects the double-buffer half at compile time (immediates)
+template <int BUF, bool BIAS, bool F16>   // BUF selects the double-buffer half at compile time (immediates)
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                           f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
                                           uint32_t dead_now, const float (&bz)[16], float sc ATT_FS_ARG) {
@@ -396,14 +426,14 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   ATT_FS(6, l_run);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const bf16x8 pf = pack8f(p + 8 * j);
+    const bf16x8 pf = pack8f<F16>(p + 8 * j);
     ot[0] = ATT_MFMA(vf[j][0], pf, ot[0]);
     ot[1] = ATT_MFMA(vf[j][1], pf, ot[1]);
   }
   ATT_FS(7, l_run);
 }
 
-template <bool BIAS>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile], 4 KiB each
@@ -476,8 +506,8 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
-        fwd_block<0, BIAS>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        fwd_block<0, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
       }
       ATT_SYNC();
 #ifdef OFA_ATTN_TIMELINE
@@ -495,8 +525,8 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        fwd_block<1, BIAS>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(false));
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        fwd_block<1, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(false));
       }
       ATT_SYNC();
     }
@@ -509,7 +539,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
-        st4(op + dt * 32 + 8 * qq + 4 * hi, ot[dt][4 * qq] * c, ot[dt][4 * qq + 1] * c, ot[dt][4 * qq + 2] * c,
+        st4<F16>(op + dt * 32 + 8 * qq + 4 * hi, ot[dt][4 * qq] * c, ot[dt][4 * qq + 1] * c, ot[dt][4 * qq + 2] * c,
             ot[dt][4 * qq + 3] * c);
     if (hi == 0 && a.lse) a.lse[(int64_t)bh * a.Tpad + qi] = (m_run == -INFINITY ? 0.f : m_run) + log2f(l_run > 0.f ? l_run : 1.f);
   }
@@ -522,11 +552,13 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
 }
 
 // three waves per SIMD for the bias-free form (its registers fit 168); the biased one keeps two
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<false>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<false, false>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_f16_lds_kernel(AttnL a) { attn_fwd_body<false, true>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_f16_lds_kernel(AttnL a) { attn_fwd_body<true, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int BUF, bool BIAS>
+template <int BUF, bool BIAS, bool F16>
 __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                          const bf16x8 (&dof)[4], f32x16 (&dqt)[2], int key0, int q0, int qi, int hi,
                                          uint32_t dead_now, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
@@ -576,25 +608,25 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
     if ((a.S & 3) == 0 && key0 + 32 <= a.S) {             // 4 consecutive keys per register quad: 8-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
-        st4(dbrow + key0 + 8 * g4 + 4 * hi, ds[4 * g4], ds[4 * g4 + 1], ds[4 * g4 + 2], ds[4 * g4 + 3]);
+        st4<F16>(dbrow + key0 + 8 * g4 + 4 * hi, ds[4 * g4], ds[4 * g4 + 1], ds[4 * g4 + 2], ds[4 * g4 + 3]);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = key0 + crowl(r, hi);
-        if (key < a.S) dbrow[key] = f2bf(ds[r]);
+        if (key < a.S) dbrow[key] = enc1<F16>(ds[r]);
       }
     }
   }
   ATT_WAIT4(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const bf16x8 dsf = pack8f(ds + 8 * j);
+    const bf16x8 dsf = pack8f<F16>(ds + 8 * j);
     dqt[0] = ATT_MFMA(ktf[j][0], dsf, dqt[0]);
     dqt[1] = ATT_MFMA(ktf[j][1], dsf, dqt[1]);
   }
 }
 
-template <bool BIAS>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
@@ -664,8 +696,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take(bcur, brow, kb * 32, a.S, hi, bz);
-        dq_block<0, BIAS>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        dq_block<0, BIAS, F16>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
       ATT_SYNC();
@@ -681,8 +713,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        dq_block<1, BIAS>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        dq_block<1, BIAS, F16>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
       ATT_SYNC();
@@ -700,13 +732,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
-        st4(op + dt * 32 + 8 * qq + 4 * hi, dqt[dt][4 * qq] * a.scale, dqt[dt][4 * qq + 1] * a.scale,
+        st4<F16>(op + dt * 32 + 8 * qq + 4 * hi, dqt[dt][4 * qq] * a.scale, dqt[dt][4 * qq + 1] * a.scale,
             dqt[dt][4 * qq + 2] * a.scale, dqt[dt][4 * qq + 3] * a.scale);
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<false>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<false, false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<false, true>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<true, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Register budget.  Round 1's form of this kernel held 400 registers (one wave per SIMD: nothing ran while a wave waited for
@@ -724,7 +758,7 @@ __device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const
   }
 }
 
-template <int BUF, bool BIAS>
+template <int BUF, bool BIAS, bool F16>
 __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, uint32_t stat_addr,
                                           const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0,
                                           int key0, int ki, int hi, bool key_dead, float live, const float (&bz)[16], float sc,
@@ -793,8 +827,8 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   ATT_WAIT4(dotf[0][0], dotf[0][1], dotf[1][0], dotf[1][1]);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const bf16x8 pf = pack8f(p + 8 * j);
-    const bf16x8 dsf = pack8f(ds + 8 * j);
+    const bf16x8 pf = pack8f<F16>(p + 8 * j);
+    const bf16x8 dsf = pack8f<F16>(ds + 8 * j);
     dvt[0] = ATT_MFMA(dotf[j][0], pf, dvt[0]);
     dvt[1] = ATT_MFMA(dotf[j][1], pf, dvt[1]);
     dkt[0] = ATT_MFMA(qtf[j][0], dsf, dkt[0]);
@@ -802,7 +836,7 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   }
 }
 
-template <bool BIAS>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][Q tile | dO tile], then [2][lse | delta]
@@ -867,8 +901,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
-        if constexpr (BIAS) bA.take(bcol, bz);
-        dkv_block<0, BIAS>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c);
+        if constexpr (BIAS) bA.template take<F16>(bcol, bz);
+        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
@@ -881,8 +915,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {
-        if constexpr (BIAS) bB.take(bcol, bz);
-        dkv_block<1, BIAS>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c);
+        if constexpr (BIAS) bB.template take<F16>(bcol, bz);
+        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
@@ -895,20 +929,22 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int d = dt * 32 + 8 * qq + 4 * hi;
-        st4(dkp + d, dkt[dt][4 * qq] * a.scale, dkt[dt][4 * qq + 1] * a.scale, dkt[dt][4 * qq + 2] * a.scale,
+        st4<F16>(dkp + d, dkt[dt][4 * qq] * a.scale, dkt[dt][4 * qq + 1] * a.scale, dkt[dt][4 * qq + 2] * a.scale,
             dkt[dt][4 * qq + 3] * a.scale);
-        st4(dvp + d, dvt[dt][4 * qq] * c, dvt[dt][4 * qq + 1] * c, dvt[dt][4 * qq + 2] * c, dvt[dt][4 * qq + 3] * c);
+        st4<F16>(dvp + d, dvt[dt][4 * qq] * c, dvt[dt][4 * qq + 1] * c, dvt[dt][4 * qq + 2] * c, dvt[dt][4 * qq + 3] * c);
       }
   }
 }
 
 // two waves per SIMD for both forms: the bias-free one fits 256 registers; the biased one spills 16 and is still 16 % faster that way
 // (tools/attn_bias_bench.py, 448 x 448: backward 409 -> 343 us)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, true>(a); }
 
 static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int dtype) {
-  OFA_REQUIRE(dtype == OFA_BF16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 only (dtype %d); use the unfused path", dtype);
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 / fp16 only (dtype %d); use the unfused path", dtype);
   OFA_REQUIRE(B > 0 && heads > 0 && T > 0 && S > 0, OFA_ERR_INVALID, "attention: bad shape B=%d heads=%d T=%d S=%d", B, heads, T, S);
   OFA_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (ldo % 8) == 0, OFA_ERR_INVALID, "attention: leading dims must be multiples of 8");
   OFA_REQUIRE(Tpad % 32 == 0 && Tpad >= T, OFA_ERR_INVALID, "attention: Tpad must be a multiple of 32 covering T (T=%d Tpad=%d)", T, Tpad);
@@ -927,15 +963,15 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
   OFA_REQUIRE(scale > 0.f, OFA_ERR_INVALID, "attn_fwd: the score scale must be positive (row maxima are taken on the raw scores), got %g", (double)scale);
   OFA_REQUIRE(!seg || (!bias && !kpm && lse && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
               "attn_fwd: the ragged (seg) mode takes no bias / key-padding mask, needs lse and a 16-byte aligned table");
-  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_fwd: bad c_attn dtype %d", c_attn_dtype);
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_fwd: bad c_attn dtype %d", c_attn_dtype);
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
-  a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
+  a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_fwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   const dim3 grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  if (bias) hipLaunchKernelGGL(attn_fwd_bias_lds_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_lds_kernel, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  auto kern = dtype == OFA_F16 ? (bias ? attn_fwd_bias_f16_lds_kernel : attn_fwd_f16_lds_kernel) : (bias ? attn_fwd_bias_lds_kernel : attn_fwd_lds_kernel);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_fwd");
 }
 
@@ -947,24 +983,24 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(!seg || (!bias && !kpm && !dbias && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
               "attn_bwd: the ragged (seg) mode takes no bias / key-padding mask / dbias and a 16-byte aligned table");
-  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_bwd: bad c_attn dtype %d", c_attn_dtype);
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_bwd: bad c_attn dtype %d", c_attn_dtype);
   OFA_REQUIRE(q && k && v && dout && lse && delta && dq && dk && dv, OFA_ERR_INVALID, "attn_bwd: null pointer");
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
-  a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   a.rows_q = rows_q; a.rows_k = rows_k;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_bwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  if (bias) hipLaunchKernelGGL(attn_bwd_dq_bias_lds_kernel, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
-  else hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
+  auto dq_kern = dtype == OFA_F16 ? (bias ? attn_bwd_dq_bias_f16_lds_kernel : attn_bwd_dq_f16_lds_kernel) : (bias ? attn_bwd_dq_bias_lds_kernel : attn_bwd_dq_lds_kernel);
+  hipLaunchKernelGGL(dq_kern, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_bwd_dq");
   if (rc) return rc;
   const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);
-  if (bias) hipLaunchKernelGGL(attn_bwd_dkv_bias_lds_kernel, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
-  else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
+  auto kv_kern = dtype == OFA_F16 ? (bias ? attn_bwd_dkv_bias_f16_lds_kernel : attn_bwd_dkv_f16_lds_kernel) : (bias ? attn_bwd_dkv_bias_lds_kernel : attn_bwd_dkv_lds_kernel);
+  hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
   return check_launch("attn_bwd_dkv");
 }
 

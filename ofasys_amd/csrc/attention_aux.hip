@@ -6,7 +6,8 @@ constexpr int HD = 64;
 
 // ------------------------------------------------------------------------------------------------ backward: delta
 // delta[bh, q] = sum_d dout[q,h,d] * out[q,h,d]   (row-sum of dO*O; invariant under the c_attn output scale)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+template <typename E>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const E* __restrict__ dout, const E* __restrict__ out,
                                                          float* __restrict__ delta, int B, int heads, int T, int Tpad,
                                                          int64_t ldo) {
   // 8 lanes per (row, head): each lane 8 elements
@@ -21,8 +22,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     row = item / heads;
     h = (int)(item % heads);
     float x[8], y[8];
-    load_vec<bf16_t>(dout + row * ldo + h * HD + sub * 8, x);
-    load_vec<bf16_t>(out + row * ldo + h * HD + sub * 8, y);
+    load_vec<E>(dout + row * ldo + h * HD + sub * 8, x);
+    load_vec<E>(out + row * ldo + h * HD + sub * 8, y);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += x[j] * y[j];
   }
@@ -86,11 +87,15 @@ using namespace ofa;
 
 extern "C" int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad,
                                  int64_t ldo, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_BF16, OFA_ERR_UNSUPPORTED, "attn_bwd_prep: bf16 only");
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "attn_bwd_prep: bf16 / fp16 only");
   OFA_REQUIRE(dout && out && delta && (ldo % 8) == 0 && Tpad >= T, OFA_ERR_INVALID, "attn_bwd_prep: bad argument");
   const int64_t threads = (int64_t)B * T * heads * 8;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
-                     (const bf16_t*)out, delta, B, heads, T, Tpad, ldo);
+  if (dtype == OFA_BF16)
+    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                       (const bf16_t*)out, delta, B, heads, T, Tpad, ldo);
+  else
+    hipLaunchKernelGGL(attn_delta_kernel<f16_t>, dim3(cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dout,
+                       (const f16_t*)out, delta, B, heads, T, Tpad, ldo);
   return check_launch("attn_bwd_prep");
 }
 
@@ -110,13 +115,15 @@ __global__ __launch_bounds__(256) void mean_heads_kernel(const T* __restrict__ p
 
 extern "C" int ofa_mean_heads(const void* p, void* out, int B, int heads, int64_t n, int dtype, void* stream) {
   OFA_REQUIRE(p && out && B > 0 && heads > 0 && n > 0, OFA_ERR_INVALID, "mean_heads: bad argument");
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "mean_heads: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "mean_heads: bad dtype %d", dtype);
   int64_t gx = (n + 255) / 256;
   dim3 grid((unsigned)(gx > 1024 ? 1024 : gx), B), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((mean_heads_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)p, (float*)out, heads, n);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((mean_heads_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)p, (bf16_t*)out, heads, n);
+  else
+    hipLaunchKernelGGL((mean_heads_kernel<f16_t>), grid, block, 0, (hipStream_t)stream, (const f16_t*)p, (f16_t*)out, heads, n);
   return check_launch("mean_heads");
 }
 
@@ -124,7 +131,7 @@ extern "C" int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C,
                                    void* stream) {
   OFA_REQUIRE(x && xt && B > 0 && T > 0 && C > 0 && Tpad >= T && ld >= C, OFA_ERR_INVALID, "transpose_heads: bad argument");
   dim3 grid(cdiv(Tpad, 64), cdiv(C, 64), B), block(256);
-  if (dtype == OFA_BF16)
+  if (dtype != OFA_F32)                                      // (a pure 16-bit move: bf16 and fp16 alike)
     hipLaunchKernelGGL((transpose_heads_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)xt,
                        T, C, Tpad, ld);
   else
@@ -136,13 +143,16 @@ extern "C" int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C,
 extern "C" int ofa_c_attn_grad(const float* delta, const void* c_attn, void* dc, int B, int heads, int T, int64_t ld,
                                int accumulate, int c_attn_dtype, void* stream) {
   OFA_REQUIRE(delta && c_attn && dc && B > 0 && heads > 0 && T > 0 && ld >= T, OFA_ERR_INVALID, "c_attn_grad: bad argument");
-  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "c_attn_grad: bad dtype %d", c_attn_dtype);
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "c_attn_grad: bad dtype %d", c_attn_dtype);
   hipStream_t st = (hipStream_t)stream;
   if (c_attn_dtype == OFA_F32)
     hipLaunchKernelGGL((c_attn_grad_kernel<float>), dim3(heads), dim3(1024), 0, st, delta, (const float*)c_attn, (float*)dc, B, heads,
                        T, ld, accumulate);
-  else
+  else if (c_attn_dtype == OFA_BF16)
     hipLaunchKernelGGL((c_attn_grad_kernel<bf16_t>), dim3(heads), dim3(1024), 0, st, delta, (const bf16_t*)c_attn, (bf16_t*)dc, B,
+                       heads, T, ld, accumulate);
+  else
+    hipLaunchKernelGGL((c_attn_grad_kernel<f16_t>), dim3(heads), dim3(1024), 0, st, delta, (const f16_t*)c_attn, (f16_t*)dc, B,
                        heads, T, ld, accumulate);
   return check_launch("c_attn_grad");
 }

@@ -14,7 +14,7 @@
 namespace ofa {
 
 struct DecodeArgs {
-  const void* q; const void* k; const void* v; const void* bias; const uint8_t* kpm; const void* c_attn; int c_bf16;
+  const void* q; const void* k; const void* v; const void* bias; const uint8_t* kpm; const void* c_attn; int c_dt;
   void* out; void* probs;
   int B, heads, S;
   int64_t ldk, bsk, kpm_ld;
@@ -24,6 +24,7 @@ struct DecodeArgs {
 template <typename T> __device__ __forceinline__ float exp_t(float x);
 template <> __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float exp_t<f16_t>(float x) { return __expf(x); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
 #pragma unroll 4
     for (int r = 0; r < KPI; ++r) o += red[r * HD + tid];
     float c = 1.0f;
-    if (a.c_attn) c = a.c_bf16 ? bf2f(((const bf16_t*)a.c_attn)[h]) : ((const float*)a.c_attn)[h];
+    if (a.c_attn) c = a.c_dt == OFA_BF16 ? bf2f(((const bf16_t*)a.c_attn)[h]) : a.c_dt == OFA_F16 ? (float)((const f16_t*)a.c_attn)[h] : ((const float*)a.c_attn)[h];
     st1<T>((T*)a.out + ((int64_t)b * a.heads + h) * HD + tid, o * inv_l * c);
   }
   if (a.probs) {
@@ -118,8 +119,8 @@ extern "C" int ofa_attn_decode(const void* q, const void* k, const void* v, cons
                                const void* c_attn, int c_attn_dtype, void* out, void* probs, int B, int heads, int head_dim,
                                int S, int64_t ldk, int64_t k_batch_stride, int64_t kpm_ld, float scale, int dtype,
                                void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "attn_decode: bad dtype %d", dtype);
-  OFA_REQUIRE(c_attn_dtype == OFA_F32 || c_attn_dtype == OFA_BF16, OFA_ERR_INVALID, "attn_decode: bad c_attn dtype %d", c_attn_dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "attn_decode: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_decode: bad c_attn dtype %d", c_attn_dtype);
   OFA_REQUIRE(head_dim == 64, OFA_ERR_UNSUPPORTED, "attn_decode: head_dim=%d (only 64: every OFA size)", head_dim);
   OFA_REQUIRE(B > 0 && heads > 0 && S > 0, OFA_ERR_INVALID, "attn_decode: bad shape B=%d heads=%d S=%d", B, heads, S);
   OFA_REQUIRE(S <= 32768, OFA_ERR_UNSUPPORTED, "attn_decode: S=%d exceeds the LDS score buffer (32768)", S);
@@ -130,7 +131,7 @@ extern "C" int ofa_attn_decode(const void* q, const void* k, const void* v, cons
               (long long)k_batch_stride);
   OFA_REQUIRE(!kpm || kpm_ld >= S, OFA_ERR_INVALID, "attn_decode: key padding mask row shorter than S");
   DecodeArgs a{};
-  a.q = q; a.k = k; a.v = v; a.bias = bias; a.kpm = kpm; a.c_attn = c_attn; a.c_bf16 = c_attn_dtype == OFA_BF16;
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.kpm = kpm; a.c_attn = c_attn; a.c_dt = c_attn_dtype;
   a.out = out; a.probs = probs; a.B = B; a.heads = heads; a.S = S; a.ldk = ldk; a.bsk = k_batch_stride; a.kpm_ld = kpm_ld;
   a.scale = scale;
   const int kpi = 256 / (64 / n);
@@ -140,8 +141,13 @@ extern "C" int ofa_attn_decode(const void* q, const void* k, const void* v, cons
     auto kern = attn_decode_kernel<float>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, st, a);
-  } else {
+  } else if (dtype == OFA_BF16) {
     auto kern = attn_decode_kernel<bf16_t>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, st, a);
+  }
+  else {
+    auto kern = attn_decode_kernel<f16_t>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, st, a);
   }

@@ -46,30 +46,36 @@ static inline int bias_grid(int64_t work) {
 
 extern "C" int ofa_bias_block_add(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype,
                                   void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "bias_block_add: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "bias_block_add: bad dtype %d", dtype);
   OFA_REQUIRE(bias && values && B > 0 && A > 0 && n > 0 && start >= 0 && start + n <= T, OFA_ERR_INVALID,
               "bias_block_add: bad argument (T=%d start=%d n=%d)", T, start, n);
   const int64_t total = (int64_t)B * A * n * n;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((bias_block_add_kernel<float>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (float*)bias, (const float*)values, B, A, T, start, n);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((bias_block_add_kernel<bf16_t>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)bias, (const bf16_t*)values, B, A, T, start, n);
+  else
+    hipLaunchKernelGGL((bias_block_add_kernel<f16_t>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (f16_t*)bias, (const f16_t*)values, B, A, T, start, n);
   return check_launch("bias_block_add");
 }
 
 extern "C" int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype,
                                    void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "bias_block_grad: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "bias_block_grad: bad dtype %d", dtype);
   OFA_REQUIRE(dbias && dvalues && B > 0 && A > 0 && n > 0 && start >= 0 && start + n <= T, OFA_ERR_INVALID,
               "bias_block_grad: bad argument (T=%d start=%d n=%d)", T, start, n);
   const int64_t total = (int64_t)A * n * n;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((bias_block_grad_kernel<float>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)dbias, (float*)dvalues, B, A, T, start, n);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((bias_block_grad_kernel<bf16_t>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dbias, (bf16_t*)dvalues, B, A, T, start, n);
+  else
+    hipLaunchKernelGGL((bias_block_grad_kernel<f16_t>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16_t*)dbias, (f16_t*)dvalues, B, A, T, start, n);
   return check_launch("bias_block_grad");
 }

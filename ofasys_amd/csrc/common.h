@@ -43,6 +43,36 @@ typedef _Float16 f16_t;
 template <typename T> struct Vec;  // 16-byte vector of T
 template <> struct Vec<float> { static constexpr int N = 4; typedef float4 type; };
 template <> struct Vec<bf16_t> { static constexpr int N = 8; typedef uint4 type; };
+template <> struct Vec<f16_t> { static constexpr int N = 8; typedef uint4 type; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+// the 8 (4) storage elements of a 16-byte register quad as floats -- kernels that load raw uint4 use this instead of load_vec
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* out) {
+  out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, float* out) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& r, float* out) {
+  const f32x8_t f = __builtin_convertvector(__builtin_bit_cast(f16x8_t, r), f32x8_t);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = f[i];
+}
+// two floats -> one 32-bit pair of storage elements (16-bit types only)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
 
 // load/store N consecutive elements (16-byte aligned) as floats
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
@@ -59,7 +89,16 @@ template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, fl
     out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void load_vec<f16_t>(const f16_t* p, float* out) {
+  unpack16<f16_t>(*reinterpret_cast<const uint4*>(p), out);
+}
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
+template <> __device__ __forceinline__ void store_vec<f16_t>(f16_t* p, const float* in) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_f16x2(in[2 * i], in[2 * i + 1]);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
 template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
@@ -78,6 +117,10 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v);
 template <> __device__ __forceinline__ void st1<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---------------------------------------------------------------- element-type dispatch of the C-ABI entry points
+#define OFA_DT_OK(dt) ((dt) == OFA_F32 || (dt) == OFA_BF16 || (dt) == OFA_F16)
+__host__ __device__ inline int dt_vecn(int dt) { return dt == OFA_F32 ? 4 : 8; }   // elements per 16-byte vector
 
 // ---------------------------------------------------------------- wave64 reductions
 // DPP data sharing instead of __shfl_xor: a shuffle compiles to ds_bpermute_b32 -- an LDS-pipe instruction with ~100+

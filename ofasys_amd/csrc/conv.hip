@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void relu_kernel(const T* __restrict__ x, cons
 }  // namespace ofa
 using namespace ofa;
 
-#define OFA_DT(name) OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, name ": bad dtype %d", dtype)
+#define OFA_DT(name) OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, name ": bad dtype %d", dtype)
 extern "C" int ofa_conv_out_size(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 extern "C" int ofa_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Kpad,
@@ -370,9 +370,13 @@ extern "C" int ofa_im2col(const void* x, void* col, int B, int H, int W, int C, 
   if (dtype == OFA_F32) {
     if (x_nchw) hipLaunchKernelGGL((im2col_kernel<float, true>), grid, block, 0, st, (const float*)x, (float*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
     else hipLaunchKernelGGL((im2col_kernel<float, false>), grid, block, 0, st, (const float*)x, (float*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
-  } else {
+  } else if (dtype == OFA_BF16) {
     if (x_nchw) hipLaunchKernelGGL((im2col_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
     else hipLaunchKernelGGL((im2col_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  }
+  else {
+    if (x_nchw) hipLaunchKernelGGL((im2col_kernel<f16_t, true>), grid, block, 0, st, (const f16_t*)x, (f16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+    else hipLaunchKernelGGL((im2col_kernel<f16_t, false>), grid, block, 0, st, (const f16_t*)x, (f16_t*)col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
   }
   return check_launch("im2col");
 }
@@ -388,8 +392,10 @@ extern "C" int ofa_col2im(const void* dcol, void* dx, int B, int H, int W, int C
   dim3 grid(grid_1d((int64_t)B * H * W * (C / n))), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((col2im_kernel<float>), grid, block, 0, st, (const float*)dcol, (float*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((col2im_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
+  else
+    hipLaunchKernelGGL((col2im_kernel<f16_t>), grid, block, 0, st, (const f16_t*)dcol, (f16_t*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad);
   return check_launch("col2im");
 }
 
@@ -416,8 +422,10 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
     dim3 grid(cdiv(C / n, 32), groups), block(256);
     if (dtype == OFA_F32)
       hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
-    else
+    else if (dtype == OFA_BF16)
       hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+    else
+      hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
@@ -425,8 +433,10 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
   dim3 grid(grid_1d(rows * (C / n))), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (const float*)residual, (float*)y, rows, C, relu);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)mean, (const float*)rstd, (const bf16_t*)residual, (bf16_t*)y, rows, C, relu);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (const float*)mean, (const float*)rstd, (const f16_t*)residual, (f16_t*)y, rows, C, relu);
   return check_launch("batchnorm_apply");
 }
 
@@ -445,17 +455,23 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   if (dtype == OFA_F32) {
     hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
-  } else {
+  } else if (dtype == OFA_BF16) {
     hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
+  }
+  else {
+    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");
   if (rc) return rc;
   dim3 g2(grid_1d(rows * (C / n)));
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats);
+  else
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<f16_t>), g2, block, 0, st, (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, (const f16_t*)gamma, mean, rstd, (const float*)sums, (f16_t*)dx, (f16_t*)dres, rows, C, relu, batch_stats);
   return check_launch("batchnorm_bwd_dx");
 }
 
@@ -467,7 +483,8 @@ extern "C" int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(grid_1d((int64_t)B * Ho * Wo * C)), block(256);
   if (dtype == OFA_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (float*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
-  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, (f16_t*)y, arg, B, H, W, C, K, stride, pad, Ho, Wo);
   return check_launch("maxpool_fwd");
 }
 
@@ -479,7 +496,8 @@ extern "C" int ofa_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(grid_1d((int64_t)B * H * W * C)), block(256);
   if (dtype == OFA_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), grid, block, 0, st, (const float*)dy, arg, (float*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, arg, (bf16_t*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dy, arg, (bf16_t*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<f16_t>), grid, block, 0, st, (const f16_t*)dy, arg, (f16_t*)dx, B, H, W, C, K, stride, pad, Ho, Wo);
   return check_launch("maxpool_bwd");
 }
 
@@ -490,6 +508,7 @@ extern "C" int ofa_relu(const void* x, const void* gate, void* y, int64_t n, int
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32) hipLaunchKernelGGL((relu_kernel<float>), dim3(grid_1d(n)), dim3(256), 0, st, (const float*)x, (const float*)gate, (float*)y, n);
-  else hipLaunchKernelGGL((relu_kernel<bf16_t>), dim3(grid_1d(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)gate, (bf16_t*)y, n);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((relu_kernel<bf16_t>), dim3(grid_1d(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)gate, (bf16_t*)y, n);
+  else hipLaunchKernelGGL((relu_kernel<f16_t>), dim3(grid_1d(n)), dim3(256), 0, st, (const f16_t*)x, (const f16_t*)gate, (f16_t*)y, n);
   return check_launch("relu");
 }

@@ -351,7 +351,7 @@ static inline int grid_for(int64_t work) {
 }  // namespace ofa
 using namespace ofa;
 
-#define OFA_DT_CHECK(name) OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, name ": bad dtype %d", dtype)
+#define OFA_DT_CHECK(name) OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, name ": bad dtype %d", dtype)
 
 extern "C" int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
   OFA_DT_CHECK("gelu_fwd");
@@ -361,9 +361,12 @@ extern "C" int ofa_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* 
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((gelu_kernel<float, false>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)nullptr,
                        (const float*)x, (float*)y, n / 4, n);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)nullptr,
                        (const bf16_t*)x, (bf16_t*)y, n / 8, n);
+  else
+    hipLaunchKernelGGL((gelu_kernel<f16_t, false>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const f16_t*)nullptr,
+                       (const f16_t*)x, (f16_t*)y, n / 8, n);
   return check_launch("gelu_fwd");
 }
 
@@ -375,9 +378,12 @@ extern "C" int ofa_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, 
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((gelu_kernel<float, true>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy,
                        (const float*)x, (float*)dx, n / 4, n);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy,
                        (const bf16_t*)x, (bf16_t*)dx, n / 8, n);
+  else
+    hipLaunchKernelGGL((gelu_kernel<f16_t, true>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const f16_t*)dy,
+                       (const f16_t*)x, (f16_t*)dx, n / 8, n);
   return check_launch("gelu_bwd");
 }
 
@@ -391,9 +397,13 @@ extern "C" int ofa_dropout_add_fwd(const void* x, const void* residual, void* y,
   if (dtype == OFA_F32) {
     if (residual) hipLaunchKernelGGL((dropout_kernel<float, true>), grid, block, 0, st, (const float*)x, (const float*)residual, (float*)y, n, p, seed, offset, offset_base);
     else hipLaunchKernelGGL((dropout_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (float*)y, n, p, seed, offset, offset_base);
-  } else {
+  } else if (dtype == OFA_BF16) {
     if (residual) hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, p, seed, offset, offset_base);
     else hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n, p, seed, offset, offset_base);
+  }
+  else {
+    if (residual) hipLaunchKernelGGL((dropout_kernel<f16_t, true>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)residual, (f16_t*)y, n, p, seed, offset, offset_base);
+    else hipLaunchKernelGGL((dropout_kernel<f16_t, false>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (f16_t*)y, n, p, seed, offset, offset_base);
   }
   return check_launch("dropout_add_fwd");
 }
@@ -413,9 +423,12 @@ extern "C" int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((add_rowvec_mask_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)a,
                        (const float*)b, (const float*)vec, rowmask, (float*)y, rows, cols);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((add_rowvec_mask_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st,
                        (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)vec, rowmask, (bf16_t*)y, rows, cols);
+  else
+    hipLaunchKernelGGL((add_rowvec_mask_kernel<f16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st,
+                       (const f16_t*)a, (const f16_t*)b, (const f16_t*)vec, rowmask, (f16_t*)y, rows, cols);
   return check_launch("add_rowvec_mask");
 }
 
@@ -429,17 +442,23 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
     if (dtype == OFA_F32)
       hipLaunchKernelGGL((embedding_fwd_scalar_kernel<float>), dim3(grid_for(n * D)), dim3(256), 0, st, (const float*)weight,
                          ids, (float*)out, n, D, V);
-    else
+    else if (dtype == OFA_BF16)
       hipLaunchKernelGGL((embedding_fwd_scalar_kernel<bf16_t>), dim3(grid_for(n * D)), dim3(256), 0, st,
                          (const bf16_t*)weight, ids, (bf16_t*)out, n, D, V);
+    else
+      hipLaunchKernelGGL((embedding_fwd_scalar_kernel<f16_t>), dim3(grid_for(n * D)), dim3(256), 0, st,
+                         (const f16_t*)weight, ids, (f16_t*)out, n, D, V);
     return check_launch("embedding_fwd_scalar");
   }
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((embedding_fwd_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)weight, ids,
                        (float*)out, n, D, V);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)weight,
                        ids, (bf16_t*)out, n, D, V);
+  else
+    hipLaunchKernelGGL((embedding_fwd_kernel<f16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const f16_t*)weight,
+                       ids, (f16_t*)out, n, D, V);
   return check_launch("embedding_fwd");
 }
 
@@ -453,9 +472,12 @@ extern "C" int ofa_gather_rows(const void* src, const int64_t* index, void* out,
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)src, index,
                        (float*)out, n, D, src_rows);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)src, index,
                        (bf16_t*)out, n, D, src_rows);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<f16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const f16_t*)src, index,
+                       (f16_t*)out, n, D, src_rows);
   return check_launch("gather_rows");
 }
 
@@ -497,11 +519,15 @@ extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dwe
     if (dtype == OFA_F32)
       hipLaunchKernelGGL((embedding_bwd_scalar_kernel<float>), grid, block, 0, st, (const float*)dout, ids, (float*)dweight,
                          slice_ws, n, D, V, padding_idx, (const uint8_t*)present_ws, S);
-    else
+    else if (dtype == OFA_BF16)
       hipLaunchKernelGGL((embedding_bwd_scalar_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dout, ids,
                          (bf16_t*)dweight, slice_ws, n, D, V, padding_idx, (const uint8_t*)present_ws, S);
+    else
+      hipLaunchKernelGGL((embedding_bwd_scalar_kernel<f16_t>), grid, block, 0, st, (const f16_t*)dout, ids,
+                         (f16_t*)dweight, slice_ws, n, D, V, padding_idx, (const uint8_t*)present_ws, S);
   } else if (dtype == OFA_F32) EMB_CASE(float);
-  else EMB_CASE(bf16_t);
+  else if (dtype == OFA_BF16) EMB_CASE(bf16_t);
+         else EMB_CASE(f16_t);
 #undef EMB_CASE
 #undef EMB_LAUNCH
   int rc = check_launch("embedding_bwd");
@@ -509,8 +535,11 @@ extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dwe
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((embedding_fold_kernel<float>), dim3((unsigned)V), dim3(256), 0, st, slice_ws, (float*)dweight, D, V,
                        padding_idx, (const uint8_t*)present_ws, S);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((embedding_fold_kernel<bf16_t>), dim3((unsigned)V), dim3(256), 0, st, slice_ws, (bf16_t*)dweight, D, V,
+                       padding_idx, (const uint8_t*)present_ws, S);
+  else
+    hipLaunchKernelGGL((embedding_fold_kernel<f16_t>), dim3((unsigned)V), dim3(256), 0, st, slice_ws, (f16_t*)dweight, D, V,
                        padding_idx, (const uint8_t*)present_ws, S);
   return check_launch("embedding_fold");
 }
@@ -525,9 +554,12 @@ extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H,
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)img, (float*)col,
                        B, C, H, W, p, Kpad);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img,
                        (bf16_t*)col, B, C, H, W, p, Kpad);
+  else
+    hipLaunchKernelGGL((im2col_patch_kernel<f16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const f16_t*)img,
+                       (f16_t*)col, B, C, H, W, p, Kpad);
   return check_launch("im2col_patch");
 }
 
@@ -541,7 +573,7 @@ extern "C" int ofa_colsum_slots(int64_t rows) {
 extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha,
                           int accumulate, int dtype, int out_dtype, void* stream) {
   OFA_DT_CHECK("colsum");
-  OFA_REQUIRE(out_dtype == OFA_F32 || out_dtype == OFA_BF16, OFA_ERR_INVALID, "colsum: bad out dtype %d", out_dtype);
+  OFA_REQUIRE(OFA_DT_OK(out_dtype), OFA_ERR_INVALID, "colsum: bad out dtype %d", out_dtype);
   OFA_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && x && (out || accumulate == OFA_DEFER_FOLD) && ws, OFA_ERR_INVALID,
               "colsum: bad argument");
   const int n = dtype == OFA_F32 ? 4 : 8;
@@ -551,16 +583,21 @@ extern "C" int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int
   dim3 grid(cdiv(cols / n, 32), groups), block(256);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, ws, rows, cols, ld);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, ws, rows, cols, ld);
+  else
+    hipLaunchKernelGGL((colsum_partial_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, ws, rows, cols, ld);
   int rc = check_launch("colsum_partial");
   if (rc || accumulate == OFA_DEFER_FOLD) return rc;          // deferred: the caller folds ws (ofa_fold_batched)
   if (out_dtype == OFA_F32)
     hipLaunchKernelGGL((colsum_final_kernel<float>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws, (float*)out,
                        cols, groups, alpha, accumulate);
-  else
+  else if (out_dtype == OFA_BF16)
     hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws,
                        (bf16_t*)out, cols, groups, alpha, accumulate);
+  else
+    hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3(cdiv(cols, 64)), dim3(1024), 0, st, (const float*)ws,
+                       (f16_t*)out, cols, groups, alpha, accumulate);
   return check_launch("colsum_final");
 }
 
@@ -634,8 +671,10 @@ extern "C" int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((mul_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, rows, cols, b_rowvec);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((mul_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, cols, b_rowvec);
+  else
+    hipLaunchKernelGGL((mul_kernel<f16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)y, rows, cols, b_rowvec);
   return check_launch("mul");
 }
 
@@ -648,8 +687,10 @@ extern "C" int ofa_scale_row_groups(const void* x, const float* scale, void* y, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((scale_row_groups_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)x, scale, (float*)y, rows, cols, group);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((scale_row_groups_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const bf16_t*)x, scale, (bf16_t*)y, rows, cols, group);
+  else
+    hipLaunchKernelGGL((scale_row_groups_kernel<f16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st, (const f16_t*)x, scale, (f16_t*)y, rows, cols, group);
   return check_launch("scale_row_groups");
 }
 

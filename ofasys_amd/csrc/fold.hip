@@ -27,13 +27,25 @@ struct FoldJobs {
 
 __device__ __forceinline__ void fold_store(const FoldJobs& J, int j, int64_t c, int64_t cols, const float (&t)[4]) {
   const float alpha = J.alpha[j];
-  const bool acc = J.flags[j] & 1, f32 = J.flags[j] & 2;
+  const bool acc = J.flags[j] & 1, f32 = J.flags[j] & 2, f16 = J.flags[j] & 8;
   if (c + 4 <= cols && (cols & 3) == 0) {                       // whole quad, aligned (out + c is 8 / 16-byte aligned)
     if (f32) {
       float4* o = reinterpret_cast<float4*>((float*)J.out[j] + c);
       float4 v = make_float4(t[0] * alpha, t[1] * alpha, t[2] * alpha, t[3] * alpha);
       if (acc) { const float4 u = *o; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
       *o = v;
+    } else if (f16) {
+      uint2* o = reinterpret_cast<uint2*>((f16_t*)J.out[j] + c);
+      float v[4] = {t[0] * alpha, t[1] * alpha, t[2] * alpha, t[3] * alpha};
+      if (acc) {
+        const uint2 u = *o;
+        const f16x2_t a = __builtin_bit_cast(f16x2_t, u.x), b = __builtin_bit_cast(f16x2_t, u.y);
+        v[0] += (float)a[0]; v[1] += (float)a[1]; v[2] += (float)b[0]; v[3] += (float)b[1];
+      }
+      uint2 w;
+      w.x = pack_f16x2(v[0], v[1]);
+      w.y = pack_f16x2(v[2], v[3]);
+      *o = w;
     } else {
       uint2* o = reinterpret_cast<uint2*>((bf16_t*)J.out[j] + c);
       float v[4] = {t[0] * alpha, t[1] * alpha, t[2] * alpha, t[3] * alpha};
@@ -56,6 +68,9 @@ __device__ __forceinline__ void fold_store(const FoldJobs& J, int j, int64_t c, 
     if (f32) {
       float* o = (float*)J.out[j] + c + e;
       *o = acc ? *o + v : v;
+    } else if (f16) {
+      f16_t* o = (f16_t*)J.out[j] + c + e;
+      *o = (f16_t)(acc ? (float)*o + v : v);
     } else {
       bf16_t* o = (bf16_t*)J.out[j] + c + e;
       *o = f2bf(acc ? bf2f(*o) + v : v);
@@ -162,11 +177,11 @@ extern "C" int ofa_fold_batched(const ofa_fold_job* jobs, int njobs, void* strea
     for (int i = 0; i < n; ++i) {
       const ofa_fold_job& b = jobs[base + i];
       OFA_REQUIRE(b.part && b.out && b.cols > 0 && b.nslots > 0 && b.stride >= b.cols, OFA_ERR_INVALID, "fold_batched: bad job %d", base + i);
-      OFA_REQUIRE(b.out_dtype == OFA_F32 || b.out_dtype == OFA_BF16, OFA_ERR_INVALID, "fold_batched: bad out dtype %d", b.out_dtype);
+      OFA_REQUIRE(OFA_DT_OK(b.out_dtype), OFA_ERR_INVALID, "fold_batched: bad out dtype %d", b.out_dtype);
       J.part[i] = b.part; J.out[i] = b.out; J.cols[i] = b.cols; J.stride[i] = b.stride; J.alpha[i] = b.alpha;
       J.nslots[i] = b.nslots;
       const bool wide = b.nslots <= 16;
-      J.flags[i] = (unsigned char)((b.accumulate ? 1 : 0) | (b.out_dtype == OFA_F32 ? 2 : 0) | (wide ? 4 : 0));
+      J.flags[i] = (unsigned char)((b.accumulate ? 1 : 0) | (b.out_dtype == OFA_F32 ? 2 : 0) | (wide ? 4 : 0) | (b.out_dtype == OFA_F16 ? 8 : 0));
       J.block0[i] = blocks;
       blocks += (unsigned)(wide ? (b.cols + 1023) / 1024 : (b.cols + 127) / 128);
     }

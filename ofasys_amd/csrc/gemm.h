@@ -16,7 +16,7 @@ __host__ __device__ inline int64_t batch_off(int z, int inner, int64_t s_in, int
   return (int64_t)(z / inner) * s_out + (int64_t)(z % inner) * s_in;
 }
 int gemm_simple_launch(const GemmArgs& g, int batch, int dtype, hipStream_t st);
-int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st);
+int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool f16 = false);
 bool gemm_mfma_supported(const GemmArgs& g);
 int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes);
 }  // namespace ofa

@@ -29,6 +29,29 @@
 namespace ofa {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+// The 16-bit element type is a template flag (F16): bf16 (default, v_mfma_f32_32x32x16_bf16) or fp16 (v_mfma_f32_32x32x16_f16).  Data
+// movement (LDS-DMA, fragment reads, swizzles) is the same for both; only the MFMA and the epilogue's conversions differ.
+template <bool F16> __device__ __forceinline__ float lo16(uint32_t w) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2_t, w)[0];
+  else return __uint_as_float(w << 16);
+}
+template <bool F16> __device__ __forceinline__ float hi16(uint32_t w) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16x2_t, w)[1];
+  else return __uint_as_float(w & 0xffff0000u);
+}
+template <bool F16> __device__ __forceinline__ uint32_t enc2(float lo, float hi) {
+  if constexpr (F16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ float dec1(uint16_t u) {
+  if constexpr (F16) return (float)__builtin_bit_cast(f16_t, u);
+  else return bf2f(u);
+}
+template <bool F16, typename A, typename B, typename C>
+__device__ __forceinline__ C mfma16(const A& a, const B& b, const C& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -245,17 +268,17 @@ __device__ __forceinline__ void tile_and_slice(int ntiles, int& t, int& ks) {
 }
 
 // epilogue on 4 consecutive columns n..n+3 of row m
-template <bool OUT_F32>
+template <bool OUT_F32, bool F16 = false>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int m, int n, float v0, float v1, float v2,
                                                float v3) {
   float v[4] = {v0, v1, v2, v3};
   if (g.flags & OFA_GEMM_BIAS_COL) {
     const uint2 b = *reinterpret_cast<const uint2*>((const bf16_t*)g.bias + n);
-    v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
-    v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
+    v[0] += lo16<F16>(b.x); v[1] += hi16<F16>(b.x);
+    v[2] += lo16<F16>(b.y); v[3] += hi16<F16>(b.y);
   }
   if (g.flags & OFA_GEMM_BIAS_ROW) {
-    const float b = bf2f(((const bf16_t*)g.bias)[m]);
+    const float b = dec1<F16>(((const bf16_t*)g.bias)[m]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += b;
   }
@@ -272,12 +295,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int 
     bf16_t* p = (bf16_t*)Cb + (int64_t)m * g.ldc + n;
     if (g.flags & OFA_GEMM_ACCUM) {
       const uint2 o = *reinterpret_cast<const uint2*>(p);
-      v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-      v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
+      v[0] += lo16<F16>(o.x); v[1] += hi16<F16>(o.x);
+      v[2] += lo16<F16>(o.y); v[3] += hi16<F16>(o.y);
     }
     uint2 o;
-    o.x = pack_bf16x2(v[0], v[1]);
-    o.y = pack_bf16x2(v[2], v[3]);
+    o.x = enc2<F16>(v[0], v[1]);
+    o.y = enc2<F16>(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = o;
   }
 }
@@ -288,7 +311,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, void* Cb, int 
 // wave bounces its block through its private slice of the (now idle) LDS stages: quads go in with an XOR swizzle on the
 // 16-byte chunk index, come back out as whole 16-byte row segments, and one store instruction writes 2-8 full rows.
 // Bias / alpha are applied on the way in, C-accumulation on the way out.  RAW: split-K partials (fp32, no bias/alpha).
-template <int TM, int TN, bool F32, bool RAW>
+template <int TM, int TN, bool F32, bool RAW, bool F16 = false>
 __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&acc)[TM][TN], unsigned char* __restrict__ wl,
                                              int region_bytes, void* __restrict__ Cb, int64_t ldc, int m_w, int n_w,
                                              int lane) {
@@ -318,8 +341,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bcol[j][q][0] = __uint_as_float(braw[j][q].x << 16); bcol[j][q][1] = __uint_as_float(braw[j][q].x & 0xffff0000u);
-        bcol[j][q][2] = __uint_as_float(braw[j][q].y << 16); bcol[j][q][3] = __uint_as_float(braw[j][q].y & 0xffff0000u);
+        bcol[j][q][0] = lo16<F16>(braw[j][q].x); bcol[j][q][1] = hi16<F16>(braw[j][q].x);
+        bcol[j][q][2] = lo16<F16>(braw[j][q].y); bcol[j][q][3] = hi16<F16>(braw[j][q].y);
       }
   } else {
 #pragma unroll
@@ -339,7 +362,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
       float brow = 0.f;
       if (!RAW && (g.flags & OFA_GEMM_BIAS_ROW)) {
         const int m = m_w + i * 32 + ml;
-        brow = bf2f(((const bf16_t*)g.bias)[m < g.M ? m : g.M - 1]);
+        brow = dec1<F16>(((const bf16_t*)g.bias)[m < g.M ? m : g.M - 1]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -353,8 +376,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
             *reinterpret_cast<float4*>(wl + mloc * ROWB + (((nloc >> 2) ^ sw) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = enc2<F16>(v[0], v[1]);
+            o.y = enc2<F16>(v[2], v[3]);
             *reinterpret_cast<uint2*>(wl + mloc * ROWB + (((nloc >> 3) ^ sw) << 4) + ((nloc >> 2) & 1) * 8) = o;
           }
         }
@@ -406,10 +429,10 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
             old.x = a.x; old.y = a.y;
             if (second) { const uint2 b = *reinterpret_cast<const uint2*>(p + 4); old.z = b.x; old.w = b.y; }
           }
-          o.x = pack_bf16x2(__uint_as_float(u.x << 16) + __uint_as_float(old.x << 16), __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(old.x & 0xffff0000u));
-          o.y = pack_bf16x2(__uint_as_float(u.y << 16) + __uint_as_float(old.y << 16), __uint_as_float(u.y & 0xffff0000u) + __uint_as_float(old.y & 0xffff0000u));
-          o.z = pack_bf16x2(__uint_as_float(u.z << 16) + __uint_as_float(old.z << 16), __uint_as_float(u.z & 0xffff0000u) + __uint_as_float(old.z & 0xffff0000u));
-          o.w = pack_bf16x2(__uint_as_float(u.w << 16) + __uint_as_float(old.w << 16), __uint_as_float(u.w & 0xffff0000u) + __uint_as_float(old.w & 0xffff0000u));
+          o.x = enc2<F16>(lo16<F16>(u.x) + lo16<F16>(old.x), hi16<F16>(u.x) + hi16<F16>(old.x));
+          o.y = enc2<F16>(lo16<F16>(u.y) + lo16<F16>(old.y), hi16<F16>(u.y) + hi16<F16>(old.y));
+          o.z = enc2<F16>(lo16<F16>(u.z) + lo16<F16>(old.z), hi16<F16>(u.z) + hi16<F16>(old.z));
+          o.w = enc2<F16>(lo16<F16>(u.w) + lo16<F16>(old.w), hi16<F16>(u.w) + hi16<F16>(old.w));
         }
         if (vec16 && second) *reinterpret_cast<uint4*>(p) = o;
         else {
@@ -458,7 +481,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #define OFA_TL_END do { } while (0)
 #endif
 
-template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool GLDS>
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool GLDS, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
   constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
@@ -549,8 +572,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 #define OFA_SB __builtin_amdgcn_sched_barrier(0)
 #define OFA_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
 #define OFA_MF(X, W, I, J)                                                                                     \
-    acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[J]), __builtin_bit_cast(bf16x8, X[I]), \
-                                                        acc[I][J], 0, 0, 0)
+    acc[I][J] = mfma16<F16>(W[J], X[I], acc[I][J])
 #define OFA_SLICE(X, W, XN, WN, KKN, OA, OB)                                        \
     OFA_MF(X, W, 0, 0); frag_issue<BM, A_KMAJ, KKN, OA>(XN[0], fax[0]); OFA_SB;     \
     OFA_MF(X, W, 0, 1); frag_issue<BM, A_KMAJ, KKN, OA>(XN[1], fax[1]); OFA_SB;     \
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);  // D[n][m]
+          acc[i][j] = mfma16<F16>(fw[j], fx[i], acc[i][j]);  // D[n][m]
     }
     if (more) {
       stage_store<BM, A_KMAJ, NT, NVA>(ra, sA[cur ^ 1], tid);
@@ -663,11 +685,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
-      epilogue_lds<2, 2, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+      epilogue_lds<2, 2, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
       void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
-      epilogue_lds<2, 2, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+      epilogue_lds<2, 2, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
   OFA_TL_END;
@@ -682,7 +704,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 // while tile kt multiplies; the wait in front of the stage barrier is `vmcnt(2 * pieces)` -- only the OLDEST tile has to
 // have landed.  Same tile geometry, swizzle, fragment reads and epilogue as gemm_mfma_kernel (LDS-DMA path: whole K
 // tiles); the stage select is an add on the fragment address registers instead of an offset immediate.
-template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int S = 4>
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int S = 4, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
   constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
@@ -776,8 +798,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
 #define RING_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
 #define RING_MMA(X, W)                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W[j]),                          \
-                                                            __builtin_bit_cast(bf16x8, X[i]), acc[i][j], 0, 0, 0)
+        acc[i][j] = mfma16<F16>(W[j], X[i], acc[i][j])
 #define RING_DMA(Q)                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     if (refill) {                                                                                                      \
@@ -838,11 +859,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
-      epilogue_lds<2, 2, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+      epilogue_lds<2, 2, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
       void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
-      epilogue_lds<2, 2, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+      epilogue_lds<2, 2, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
 }
@@ -896,7 +917,7 @@ __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
 // which fragment read (0..nr-1, or -1) follows MFMA number t of a slice: one read behind each of the first nr MFMAs
 __host__ __device__ constexpr int big_read_after(int t, int nr) { return t < nr ? t : -1; }
 
-template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM = 2, int WGN = 2>
+template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM = 2, int WGN = 2, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                  float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
@@ -981,8 +1002,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
 #define BIG_SLICE(SET, KKN)                                                                                         \
   static_for<0, TM * TN>([&](auto tc) {                                                                             \
     constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;                                                  \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[SET][j]),                     \
-                                                        __builtin_bit_cast(bf16x8, xa[SET][i]), acc[i][j], 0, 0, 0); \
+    acc[i][j] = mfma16<F16>(wb[SET][j], xa[SET][i], acc[i][j]); \
     constexpr int r = big_read_after(t, TM + TN);                                                                   \
     if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, KKN, (r < TM ? r : 0), 0>(xa[1 - (SET)][r < TM ? r : 0], fax); \
     if constexpr (r >= TM) big_frag<BN, B_KMAJ, KKN, (r >= TM ? r - TM : 0), 0>(wb[1 - (SET)][r >= TM ? r - TM : 0], faw); \
@@ -1025,8 +1045,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
       // (after the last K-step the reads below fetch a stale stage; they are waited for and dropped)
       static_for<0, TM * TN>([&](auto tc) {
         constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[1][j]),
-                                                            __builtin_bit_cast(bf16x8, xa[1][i]), acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<F16>(wb[1][j], xa[1][i], acc[i][j]);
         constexpr int r = big_read_after(t, TM + TN);
         if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, 0, (r < TM ? r : 0), 0>(xa[0][r < TM ? r : 0], fax);
         if constexpr (r >= TM) big_frag<BN, B_KMAJ, 0, (r >= TM ? r - TM : 0), 0>(wb[0][r >= TM ? r - TM : 0], faw);
@@ -1066,17 +1085,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
-      epilogue_lds<TM, TN, true, true>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+      epilogue_lds<TM, TN, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
       void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
-      epilogue_lds<TM, TN, OUT_F32, false>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+      epilogue_lds<TM, TN, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
   OFA_TL_END;
 }
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool F16 = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const float* __restrict__ ws, int splits) {
   const int64_t quads = (int64_t)g.M * ((g.N + 3) / 4);
   const int bz = blockIdx.y;
@@ -1089,7 +1108,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const fl
       const float4 p = *reinterpret_cast<const float4*>(ws + (((int64_t)bz * splits + k) * g.M + m) * ((g.N + 3) & ~3) + n);
       s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    epilogue_store<OUT_F32>(g, Cb, m, n, s.x, s.y, s.z, s.w);
+    epilogue_store<OUT_F32, F16>(g, Cb, m, n, s.x, s.y, s.z, s.w);
   }
 }
 
@@ -1113,13 +1132,13 @@ bool gemm_mfma_supported(const GemmArgs& g) {
   return true;
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF, bool GL>
+template <int WM, int WN, bool AK, bool BKM, bool OF, bool GL, bool F16 = false>
 static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const size_t lds = GL ? 2 * (size_t)(BM + BN) * BK * sizeof(bf16_t)
                         : 2 * (size_t)(TileGeom<BM, AK>::ELEMS + TileGeom<BN, BKM>::ELEMS) * sizeof(bf16_t);
-  auto kern = gemm_mfma_kernel<WM, WN, AK, BKM, OF, GL>;
+  auto kern = gemm_mfma_kernel<WM, WN, AK, BKM, OF, GL, F16>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1129,12 +1148,12 @@ static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, fl
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF, int S = 4>
+template <int WM, int WN, bool AK, bool BKM, bool OF, int S = 4, bool F16 = false>
 static void launch_ring(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const size_t lds = S * (size_t)(BM + BN) * BK * sizeof(bf16_t);
-  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF, S>;
+  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF, S, F16>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1153,31 +1172,31 @@ static bool use_ring(const GemmArgs& g, int wm, int wn, int64_t blocks, int kspl
   return blocks <= cap && ksplit >= 4 * BK;
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF>
+template <int WM, int WN, bool AK, bool BKM, bool OF, bool F16 = false>
 static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   if (use_ring(g, WM, WN, (int64_t)cdiv(g.M, 64 * WM) * cdiv(g.N, 64 * WN) * splits * batch, ksplit)) {
-    launch_ring<WM, WN, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+    launch_ring<WM, WN, AK, BKM, OF, 4, F16>(g, batch, splits, ksplit, ws, st);
     return;
   }
   // LDS-DMA staging needs full K tiles (no zero fill); anything else takes the register-staged loop
-  if ((g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA)) launch_cfg2<WM, WN, AK, BKM, OF, true>(g, batch, splits, ksplit, ws, st);
-  else launch_cfg2<WM, WN, AK, BKM, OF, false>(g, batch, splits, ksplit, ws, st);
+  if ((g.K % BK) == 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA)) launch_cfg2<WM, WN, AK, BKM, OF, true, F16>(g, batch, splits, ksplit, ws, st);
+  else launch_cfg2<WM, WN, AK, BKM, OF, false, F16>(g, batch, splits, ksplit, ws, st);
 }
 
-template <bool AK, bool BKM, bool OF>
+template <bool AK, bool BKM, bool OF, bool F16 = false>
 static void launch_shape(const GemmArgs& g, int batch, int wm, int wn, int splits, int ksplit, float* ws,
                          hipStream_t st) {
-  if (wm == 2 && wn == 2) launch_cfg<2, 2, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
-  else if (wm == 1 && wn == 2) launch_cfg<1, 2, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
-  else launch_cfg<1, 1, AK, BKM, OF>(g, batch, splits, ksplit, ws, st);
+  if (wm == 2 && wn == 2) launch_cfg<2, 2, AK, BKM, OF, F16>(g, batch, splits, ksplit, ws, st);
+  else if (wm == 1 && wn == 2) launch_cfg<1, 2, AK, BKM, OF, F16>(g, batch, splits, ksplit, ws, st);
+  else launch_cfg<1, 1, AK, BKM, OF, F16>(g, batch, splits, ksplit, ws, st);
 }
 
-template <int TM, int TN, bool AK, bool BKM, bool OF, int WGM = 2, int WGN = 2>
+template <int TM, int TN, bool AK, bool BKM, bool OF, int WGM = 2, int WGN = 2, bool F16 = false>
 static void launch_big(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const size_t lds = 4 * (size_t)256 * BK * sizeof(bf16_t);     // 2 operands x 2 stages x 32 KiB
-  auto kern = gemm_big_kernel<TM, TN, AK, BKM, OF, WGM, WGN>;
+  auto kern = gemm_big_kernel<TM, TN, AK, BKM, OF, WGM, WGN, F16>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1187,12 +1206,12 @@ static void launch_big(const GemmArgs& g, int batch, int splits, int ksplit, flo
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-template <bool AK, bool BKM, bool OF>
+template <bool AK, bool BKM, bool OF, bool F16 = false>
 static void launch_big_shape(const GemmArgs& g, int batch, int tm, int splits, int ksplit, float* ws, hipStream_t st) {
   if constexpr (AK) {
-    if (tm == 3) { launch_big<3, 2, AK, BKM, OF, 2, 4>(g, batch, splits, ksplit, ws, st); return; }   // 96 x 64 per wave
+    if (tm == 3) { launch_big<3, 2, AK, BKM, OF, 2, 4, F16>(g, batch, splits, ksplit, ws, st); return; }   // 96 x 64 per wave
   }
-  launch_big<4, 2, AK, BKM, OF, 2, 4>(g, batch, splits, ksplit, ws, st);                              // 128 x 64 per wave
+  launch_big<4, 2, AK, BKM, OF, 2, 4, F16>(g, batch, splits, ksplit, ws, st);                              // 128 x 64 per wave
 }
 
 struct GemmPlan { int wm, wn, big_tm, splits, ksplit, K; };
@@ -1278,7 +1297,7 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
 
 int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes) { return gemm_plan(g, batch, ws_bytes > 0, ws_bytes).splits; }
 
-int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool f16) {
   GemmArgs g = g_in;
   g.b_krows = g.K;
   const GemmPlan pl = gemm_plan(g, batch, ws != nullptr, ws_bytes);
@@ -1287,7 +1306,10 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
   const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
 #define GEMM_DISPATCH(AK, BKM, OF)                                                                      \
   do {                                                                                                  \
-    if (big_tm) launch_big_shape<AK, BKM, OF>(g, batch, big_tm, splits, ksplit, (float*)ws, st);        \
+    if (f16) {                                                                                          \
+      if (big_tm) launch_big_shape<AK, BKM, OF, true>(g, batch, big_tm, splits, ksplit, (float*)ws, st);  \
+      else launch_shape<AK, BKM, OF, true>(g, batch, wm, wn, splits, ksplit, (float*)ws, st);           \
+    } else if (big_tm) launch_big_shape<AK, BKM, OF>(g, batch, big_tm, splits, ksplit, (float*)ws, st); \
     else launch_shape<AK, BKM, OF>(g, batch, wm, wn, splits, ksplit, (float*)ws, st);                   \
   } while (0)
   if (ak && bk) { if (of) GEMM_DISPATCH(true, true, true); else GEMM_DISPATCH(true, true, false); }
@@ -1300,7 +1322,9 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
   if (splits > 1 && !(g.flags & OFA_GEMM_DEFER_REDUCE)) {
     const int64_t quads = (int64_t)g.M * ((g.N + 3) / 4);
     dim3 grid((unsigned)((quads + 255) / 256 > 2048 ? 2048 : (quads + 255) / 256), batch), block(256);
-    if (of) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, block, 0, st, g, (const float*)ws, splits);
+    if (of && f16) hipLaunchKernelGGL((splitk_reduce_kernel<true, true>), grid, block, 0, st, g, (const float*)ws, splits);
+    else if (of) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, block, 0, st, g, (const float*)ws, splits);
+    else if (f16) hipLaunchKernelGGL((splitk_reduce_kernel<false, true>), grid, block, 0, st, g, (const float*)ws, splits);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, block, 0, st, g, (const float*)ws, splits);
     rc = check_launch("gemm_splitk_reduce");
   }
@@ -1312,7 +1336,7 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
 using namespace ofa;
 
 extern "C" int ofa_gemm_splits(int M, int N, int K, int transA, int transB, int batch, int flags, int dtype, int64_t ws_bytes) {
-  if (dtype != OFA_BF16 || (flags & OFA_GEMM_FORCE_SIMPLE) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 1;
+  if ((dtype != OFA_BF16 && dtype != OFA_F16) || (flags & OFA_GEMM_FORCE_SIMPLE) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 1;
   GemmArgs g{};
   g.M = M; g.N = N; g.K = K; g.transA = transA; g.transB = transB; g.flags = flags;
   g.lda = transA ? M : K; g.ldb = transB ? K : N; g.ldc = N;
@@ -1323,7 +1347,7 @@ extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias,
                         int transB, int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t strideA, int64_t strideB,
                         int64_t strideC, int batch_inner, int64_t strideA2, int64_t strideB2, int64_t strideC2,
                         float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "gemm: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "gemm: bad dtype %d", dtype);
   OFA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, OFA_ERR_INVALID, "gemm: negative size");
   if (M == 0 || N == 0 || batch == 0) return 0;
   OFA_REQUIRE(A && B && C, OFA_ERR_INVALID, "gemm: null pointer");
@@ -1331,12 +1355,12 @@ extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias,
   OFA_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, OFA_ERR_INVALID,
               "gemm: leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda, (long long)ldb,
               (long long)ldc);
-  OFA_REQUIRE(!(dtype == OFA_F32 && (flags & OFA_GEMM_OUT_F32)), OFA_ERR_INVALID, "gemm: OUT_F32 is for bf16 inputs");
+  OFA_REQUIRE(!(dtype == OFA_F32 && (flags & OFA_GEMM_OUT_F32)), OFA_ERR_INVALID, "gemm: OUT_F32 is for 16-bit inputs");
   if (batch_inner <= 0 || batch_inner >= batch) { batch_inner = batch; strideA2 = strideB2 = strideC2 = 0; }
   GemmArgs g{A, B, C, bias, M, N, K, transA, transB, lda, ldb, ldc, strideA, strideB, strideC, alpha, flags,
              batch_inner, strideA2, strideB2, strideC2};
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == OFA_BF16 && !(flags & OFA_GEMM_FORCE_SIMPLE) && K > 0 && gemm_mfma_supported(g))
-    return gemm_mfma_launch(g, batch, ws, ws_bytes, st);
+  if (dtype != OFA_F32 && !(flags & OFA_GEMM_FORCE_SIMPLE) && K > 0 && gemm_mfma_supported(g))
+    return gemm_mfma_launch(g, batch, ws, ws_bytes, st, dtype == OFA_F16);
   return gemm_simple_launch(g, batch, dtype, st);
 }

@@ -78,12 +78,12 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(GemmArgs g) {
 
 int gemm_simple_launch(const GemmArgs& g, int batch, int dtype, hipStream_t st) {
   dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), batch), block(256);
-  if (dtype == OFA_F32)
-    hipLaunchKernelGGL((gemm_simple_kernel<float, float>), grid, block, 0, st, g);
-  else if (g.flags & OFA_GEMM_OUT_F32)
-    hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float>), grid, block, 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, bf16_t>), grid, block, 0, st, g);
+  const bool of = (g.flags & OFA_GEMM_OUT_F32) != 0;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((gemm_simple_kernel<float, float>), grid, block, 0, st, g);
+  else if (dtype == OFA_BF16 && of) hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float>), grid, block, 0, st, g);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, bf16_t>), grid, block, 0, st, g);
+  else if (of) hipLaunchKernelGGL((gemm_simple_kernel<f16_t, float>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_simple_kernel<f16_t, f16_t>), grid, block, 0, st, g);
   return check_launch("gemm_simple");
 }
 

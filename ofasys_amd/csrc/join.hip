@@ -14,6 +14,7 @@ namespace ofa {
 template <typename T> __device__ __forceinline__ float rnd(float v);
 template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
 template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float rnd<f16_t>(float v) { return (float)(f16_t)v; }
 
 // keep / drop decisions of the N (4 or 8) elements starting at element index e0 (e0 % N == 0): dropout_kernel's rule
 // (element e <- Philox counter offset + e/8, halfword e%8)
@@ -38,6 +39,7 @@ template <typename T> __device__ __forceinline__ void jn_unpack(const uint4& r, 
 template <> __device__ __forceinline__ void jn_unpack<float>(const uint4& r, float* out) {
   out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
 }
+template <> __device__ __forceinline__ void jn_unpack<f16_t>(const uint4& r, float* out) { unpack16<f16_t>(r, out); }
 template <> __device__ __forceinline__ void jn_unpack<bf16_t>(const uint4& r, float* out) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -332,7 +334,7 @@ static int join_wpr(int cols, int n) {
   return wpr;
 }
 static int join_check(int64_t rows, int cols, int dtype, const char* what) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "%s: bad dtype %d", what, dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "%s: bad dtype %d", what, dtype);
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(rows >= 0 && cols > 0 && cols % n == 0 && cols <= 64 * n * 8, OFA_ERR_UNSUPPORTED,
               "%s: cols=%d must be a multiple of %d and <= %d", what, cols, n, 64 * n * 8);
@@ -367,7 +369,8 @@ extern "C" int ofa_join_fwd(const void* x, const void* residual, const void* gam
     else JOIN_FWD(T, 8);              \
   } while (0)
   if (dtype == OFA_F32) JOIN_FWD_T(float);
-  else JOIN_FWD_T(bf16_t);
+  else if (dtype == OFA_BF16) JOIN_FWD_T(bf16_t);
+  else JOIN_FWD_T(f16_t);
 #undef JOIN_FWD_T
 #undef JOIN_FWD
   return check_launch("join_fwd");
@@ -407,7 +410,8 @@ extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const
     else JOIN_BWD(T, 8);               \
   } while (0)
   if (dtype == OFA_F32) JOIN_BWD_T(float);
-  else JOIN_BWD_T(bf16_t);
+  else if (dtype == OFA_BF16) JOIN_BWD_T(bf16_t);
+  else JOIN_BWD_T(f16_t);
 #undef JOIN_BWD_T
 #undef JOIN_BWD
   return check_launch("join_bwd");

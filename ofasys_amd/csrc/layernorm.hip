@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       for (int j = 0; j < N; ++j) {
         if (GELU) {
           float cdf, e;
-          gauss_cdf<sizeof(T) == 4>(v[i][j], cdf, e);
+          gauss_cdf<!__is_same(T, bf16_t)>(v[i][j], cdf, e);
           v[i][j] *= cdf;
         }
         s += v[i][j];
@@ -106,6 +106,7 @@ template <typename T> __device__ __forceinline__ void unpack_vec(const uint4& r,
 template <> __device__ __forceinline__ void unpack_vec<float>(const uint4& r, float* out) {
   out[0] = __uint_as_float(r.x); out[1] = __uint_as_float(r.y); out[2] = __uint_as_float(r.z); out[3] = __uint_as_float(r.w);
 }
+template <> __device__ __forceinline__ void unpack_vec<f16_t>(const uint4& r, float* out) { unpack16<f16_t>(r, out); }
 template <> __device__ __forceinline__ void unpack_vec<bf16_t>(const uint4& r, float* out) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
             if (GELU) {
               const float h = xv[i][j];
               float cdf, e;
-              gauss_cdf<sizeof(T) == 4>(h, cdf, e);
+              gauss_cdf<!__is_same(T, bf16_t)>(h, cdf, e);
               gp[i][j] = cdf + h * 0.39894228040143267794f * e;
               xv[i][j] = h * cdf;
             }
@@ -398,7 +399,7 @@ static int ln_bwd_dispatch(const void* dy, const void* x, const void* g, const f
 
 static int ln_check(int64_t rows, int cols, int dtype, bool bwd) {
   OFA_REQUIRE(rows >= 0 && cols > 0, OFA_ERR_INVALID, "layernorm: bad shape rows=%lld cols=%d", (long long)rows, cols);
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "layernorm: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "layernorm: bad dtype %d", dtype);
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(cols % n == 0, OFA_ERR_UNSUPPORTED, "layernorm: cols=%d must be a multiple of %d", cols, n);
   if (bwd) {                                      // the same row split the dispatcher makes; <= 8 vectors per lane
@@ -430,8 +431,9 @@ extern "C" int ofa_layernorm_fwd(const void* x, const void* gamma, const void* b
   OFA_REQUIRE(x && gamma && beta && y, OFA_ERR_INVALID, "layernorm_fwd: null pointer");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == OFA_F32 ? ln_fwd_dispatch<float, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st)
-                          : ln_fwd_dispatch<bf16_t, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+  return dtype == OFA_F32    ? ln_fwd_dispatch<float, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+         : dtype == OFA_BF16 ? ln_fwd_dispatch<bf16_t, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+                             : ln_fwd_dispatch<f16_t, false>(x, gamma, beta, y, mean, rstd, rows, cols, eps, st);
 }
 
 extern "C" int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const void* beta, void* y, float* mean,
@@ -440,8 +442,9 @@ extern "C" int ofa_gelu_layernorm_fwd(const void* h, const void* gamma, const vo
   OFA_REQUIRE(h && gamma && beta && y, OFA_ERR_INVALID, "gelu_layernorm_fwd: null pointer");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == OFA_F32 ? ln_fwd_dispatch<float, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st)
-                          : ln_fwd_dispatch<bf16_t, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st);
+  return dtype == OFA_F32    ? ln_fwd_dispatch<float, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+         : dtype == OFA_BF16 ? ln_fwd_dispatch<bf16_t, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st)
+                             : ln_fwd_dispatch<f16_t, true>(h, gamma, beta, y, mean, rstd, rows, cols, eps, st);
 }
 
 extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
@@ -453,7 +456,9 @@ extern "C" int ofa_layernorm_bwd(const void* dy, const void* x, const void* gamm
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
              ? ln_bwd_dispatch<float, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st);
+         : dtype == OFA_BF16
+             ? ln_bwd_dispatch<bf16_t, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<f16_t, false>(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, ws, rows, cols, accumulate, st);
 }
 
 extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, const float* mean,
@@ -465,5 +470,7 @@ extern "C" int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void*
   hipStream_t st = (hipStream_t)stream;
   return dtype == OFA_F32
              ? ln_bwd_dispatch<float, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st)
-             : ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st);
+         : dtype == OFA_BF16
+             ? ln_bwd_dispatch<bf16_t, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st)
+             : ln_bwd_dispatch<f16_t, true>(dy, h, gamma, mean, rstd, nullptr, dh, dgamma, dbeta, dbias, ws, rows, cols, accumulate, st);
 }

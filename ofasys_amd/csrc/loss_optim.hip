@@ -281,8 +281,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
       g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
     } else {
       const uint2 gr = *reinterpret_cast<const uint2*>(grad + i);
-      g[0] = __uint_as_float(gr.x << 16); g[1] = __uint_as_float(gr.x & 0xffff0000u);
-      g[2] = __uint_as_float(gr.y << 16); g[3] = __uint_as_float(gr.y & 0xffff0000u);
+      if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {        // fp16
+        const f16x2_t a = __builtin_bit_cast(f16x2_t, gr.x), b = __builtin_bit_cast(f16x2_t, gr.y);
+        g[0] = (float)a[0]; g[1] = (float)a[1]; g[2] = (float)b[0]; g[3] = (float)b[1];
+      } else {
+        g[0] = __uint_as_float(gr.x << 16); g[1] = __uint_as_float(gr.x & 0xffff0000u);
+        g[2] = __uint_as_float(gr.y << 16); g[3] = __uint_as_float(gr.y & 0xffff0000u);
+      }
     }
     upd(g[0], p4.x, m4.x, v4.x);
     upd(g[1], p4.y, m4.y, v4.y);
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
       *reinterpret_cast<float4*>(model + i) = p4;
     } else {
       uint2 o;
-      o.x = pack_bf16x2(p4.x, p4.y);
-      o.y = pack_bf16x2(p4.z, p4.w);
+      o.x = pack2<T>(p4.x, p4.y);
+      o.y = pack2<T>(p4.z, p4.w);
       *reinterpret_cast<uint2*>(model + i) = o;
     }
   }
@@ -415,37 +420,41 @@ using namespace ofa;
 
 extern "C" int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, int64_t rows,
                                      int64_t V, int64_t ld, int64_t ignore_index, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "cross_entropy_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "cross_entropy_fwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && target && lse && row_loss, OFA_ERR_INVALID, "cross_entropy_fwd: bad argument");
   OFA_REQUIRE(ld % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_INVALID, "cross_entropy_fwd: ld=%lld must be a multiple of the 16-byte vector width", (long long)ld);
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((ce_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_loss, V, ld, ignore_index);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_loss, V, ld, ignore_index);
+  else
+    hipLaunchKernelGGL((ce_fwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, target, lse, row_loss, V, ld, ignore_index);
   return check_launch("cross_entropy_fwd");
 }
 
 extern "C" int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,
                                      void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,
                                      void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "cross_entropy_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "cross_entropy_bwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && target && lse && dlogits, OFA_ERR_INVALID, "cross_entropy_bwd: bad argument");
   OFA_REQUIRE(ld % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_INVALID, "cross_entropy_bwd: ld must be a multiple of the 16-byte vector width");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, grad_scale, (float*)dlogits, V, ld, ignore_index);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index);
+  else
+    hipLaunchKernelGGL((ce_bwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, target, lse, grad_scale, (f16_t*)dlogits, V, ld, ignore_index);
   return check_launch("cross_entropy_bwd");
 }
 
 extern "C" int ofa_ls_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, float* row_nll,
                                         float* row_cnt, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, float eps,
                                         int64_t cstart, int64_t cend, const uint8_t* cmask, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "ls_cross_entropy_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "ls_cross_entropy_fwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 1 && ld >= V && logits && target && lse && row_loss && row_nll && row_cnt, OFA_ERR_INVALID,
               "ls_cross_entropy_fwd: bad argument");
   OFA_REQUIRE(eps >= 0.f && eps < 1.f && (cstart < 0 || (cstart >= 4 && cend > cstart && cend <= V)), OFA_ERR_INVALID,
@@ -455,8 +464,10 @@ extern "C" int ofa_ls_cross_entropy_fwd(const void* logits, const int64_t* targe
   const LsCfg cfg{eps, cstart, cend, cmask};
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((lsce_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_loss, row_nll, row_cnt, V, ld, ignore_index, cfg);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((lsce_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_loss, row_nll, row_cnt, V, ld, ignore_index, cfg);
+  else
+    hipLaunchKernelGGL((lsce_fwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, target, lse, row_loss, row_nll, row_cnt, V, ld, ignore_index, cfg);
   return check_launch("ls_cross_entropy_fwd");
 }
 
@@ -464,7 +475,7 @@ extern "C" int ofa_ls_cross_entropy_bwd(const void* logits, const int64_t* targe
                                         const float* row_w, const float* grad_scale, void* dlogits, int64_t rows, int64_t V,
                                         int64_t ld, int64_t ignore_index, float eps, int64_t cstart, int64_t cend,
                                         const uint8_t* cmask, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "ls_cross_entropy_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "ls_cross_entropy_bwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 1 && ld >= V && logits && target && lse && row_cnt && dlogits, OFA_ERR_INVALID,
               "ls_cross_entropy_bwd: bad argument");
   if (rows == 0) return 0;
@@ -472,37 +483,41 @@ extern "C" int ofa_ls_cross_entropy_bwd(const void* logits, const int64_t* targe
   const LsCfg cfg{eps, cstart, cend, cmask};
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((lsce_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, lse, row_cnt, row_w, grad_scale, (float*)dlogits, V, ld, ignore_index, cfg);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((lsce_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, target, lse, row_cnt, row_w, grad_scale, (bf16_t*)dlogits, V, ld, ignore_index, cfg);
+  else
+    hipLaunchKernelGGL((lsce_bwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, target, lse, row_cnt, row_w, grad_scale, (f16_t*)dlogits, V, ld, ignore_index, cfg);
   return check_launch("ls_cross_entropy_bwd");
 }
 
 extern "C" int ofa_probs_fwd(const void* logits, float* out, int64_t rows, int64_t V, int64_t ld, int log_probs, int dtype,
                              void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "probs_fwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "probs_fwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && out, OFA_ERR_INVALID, "probs_fwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32) hipLaunchKernelGGL((probs_fwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, out, V, ld, log_probs);
-  else hipLaunchKernelGGL((probs_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, out, V, ld, log_probs);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((probs_fwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)logits, out, V, ld, log_probs);
+  else hipLaunchKernelGGL((probs_fwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, out, V, ld, log_probs);
   return check_launch("probs_fwd");
 }
 
 extern "C" int ofa_probs_bwd(const float* dy, const float* y, void* dlogits, int64_t rows, int64_t V, int64_t ld,
                              int log_probs, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "probs_bwd: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "probs_bwd: bad dtype %d", dtype);
   OFA_REQUIRE(rows >= 0 && V > 0 && ld >= V && dy && y && dlogits, OFA_ERR_INVALID, "probs_bwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32) hipLaunchKernelGGL((probs_bwd_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (float*)dlogits, V, ld, log_probs);
-  else hipLaunchKernelGGL((probs_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (bf16_t*)dlogits, V, ld, log_probs);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((probs_bwd_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (bf16_t*)dlogits, V, ld, log_probs);
+  else hipLaunchKernelGGL((probs_bwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, dy, y, (f16_t*)dlogits, V, ld, log_probs);
   return check_launch("probs_bwd");
 }
 
 extern "C" int ofa_sumsq_ws_floats(void) { return 1024; }
 
 extern "C" int ofa_sumsq(const void* x, float* out, float* ws, int64_t n, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "sumsq: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "sumsq: bad dtype %d", dtype);
   OFA_REQUIRE(n >= 0 && out && ws && (n == 0 || x), OFA_ERR_INVALID, "sumsq: bad argument");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -510,7 +525,8 @@ extern "C" int ofa_sumsq(const void* x, float* out, float* ws, int64_t n, int dt
   int64_t nbl = (n / vecw + 255) / 256;
   const int nb = (int)(nbl < 1 ? 1 : (nbl > 1024 ? 1024 : nbl));
   if (dtype == OFA_F32) hipLaunchKernelGGL((sumsq_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, ws, n);
-  else hipLaunchKernelGGL((sumsq_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, ws, n);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((sumsq_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, ws, n);
+  else hipLaunchKernelGGL((sumsq_kernel<f16_t>), dim3(nb), dim3(256), 0, st, (const f16_t*)x, ws, n);
   int rc = check_launch("sumsq");
   if (rc) return rc;
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, nb);
@@ -520,7 +536,7 @@ extern "C" int ofa_sumsq(const void* x, float* out, float* ws, int64_t n, int dt
 extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* model_param,
                              const float* coef, int64_t n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int step, int dtype, void* stream) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16, OFA_ERR_INVALID, "adam_step: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "adam_step: bad dtype %d", dtype);
   OFA_REQUIRE(n >= 0 && step >= 0 && master && exp_avg && exp_avg_sq && grad && model_param, OFA_ERR_INVALID, "adam_step: bad argument");
   OFA_REQUIRE(step >= 1 || coef, OFA_ERR_INVALID, "adam_step: step == 0 takes the step size and lr from coef[1], coef[2]");
   if (n == 0) return 0;
@@ -535,8 +551,10 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   const int nb = (int)(nbl > 4096 ? 4096 : nbl);
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((adam_kernel<float>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const float*)grad, (float*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
-  else
+  else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const bf16_t*)grad, (bf16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
+  else
+    hipLaunchKernelGGL((adam_kernel<f16_t>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const f16_t*)grad, (f16_t*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   return check_launch("adam_step");
 }
 

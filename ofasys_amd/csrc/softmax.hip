@@ -108,8 +108,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* dy, const T* 
 template <int MODE>
 static int softmax_launch(const void* x, const void* bias, const uint8_t* mask, void* y, float scale, int64_t rows,
                           int sq, int sk, int np, int mask_b, int causal, int dtype, hipStream_t st) {
-  OFA_REQUIRE(dtype == OFA_F32 || dtype == OFA_BF16 || (dtype == OFA_F16 && MODE != SM_ATTN), OFA_ERR_INVALID,
-              "softmax: bad dtype %d", dtype);
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "softmax: bad dtype %d", dtype);
   OFA_REQUIRE(sk > 0 && sk <= 64 * SM_MAX_PER_LANE, OFA_ERR_UNSUPPORTED, "softmax: sk=%d must be in [1,4096]", sk);
   OFA_REQUIRE(x && y, OFA_ERR_INVALID, "softmax: null pointer");
   if (rows == 0) return 0;

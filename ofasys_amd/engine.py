@@ -27,8 +27,14 @@ logger = logging.getLogger("ofasys_amd")
 @dataclass
 class CommonConfig:
     seed: int = 1
-    bf16: bool = True              # the reference defaults to fp16 + dynamic loss scaling (default_trainer.yaml:7-8); the MI355X
-    fp32: bool = False             # build computes in bf16 (same 8-bit exponent as fp32: no loss scaler needed) or fp32
+    bf16: bool = True              # the MI355X build defaults to bf16 (same 8-bit exponent as fp32: no loss scaler needed);
+    fp32: bool = False             # fp32 on request;
+    fp16: bool = False             # fp16 + the reference's dynamic loss scaler: its own default (default_trainer.yaml:7-25)
+    fp16_init_scale: int = 128     # (default_trainer.yaml:9-13, engine/optim/dynamic_loss_scaler.py)
+    fp16_scale_window: Optional[int] = None
+    fp16_scale_tolerance: float = 0.0
+    min_loss_scale: float = 1e-4
+    threshold_loss_scale: Optional[float] = None
     log_interval: int = 10
     use_graph: bool = True
 
@@ -106,8 +112,9 @@ class Trainer:
         Task.upgrade_model_adaptor_cfg(tasks, model.cfg)
         model.initialize(self.global_dict)
         model.to(device)
+        half = torch.float16 if cfg.common.fp16 else torch.bfloat16
         if not cfg.common.fp32:
-            model.to(torch.bfloat16)
+            model.to(half)
         if world > 1:
             import torch.distributed as dist
             for t in list(model.parameters()) + list(model.buffers()):
@@ -118,12 +125,22 @@ class Trainer:
         self.step_engine = TrainStep(model, lr=cfg.optimization.lr[0], betas=tuple(cfg.optimizer.adam_betas), eps=cfg.optimizer.adam_eps,
                                      weight_decay=cfg.optimizer.weight_decay, clip_norm=cfg.optimization.clip_norm,
                                      use_graph=cfg.common.use_graph, label_smoothing=crit.label_smoothing,
-                                     drop_worst_ratio=crit.drop_worst_ratio)
+                                     drop_worst_ratio=crit.drop_worst_ratio, loss_scale=self._loss_scale_cfg(world))
         for task in tasks:
             task.init_data_iterator("train", rank, world)
         self._device, self._rank, self._world = device, rank, world
-        self._float_dtype = torch.float32 if cfg.common.fp32 else torch.bfloat16
+        self._float_dtype = torch.float32 if cfg.common.fp32 else half
         return self.step_engine
+
+    def _loss_scale_cfg(self, world):
+        """fp16: the reference builds its FP16Optimizer with a DynamicLossScaler (fp16_optimizer.py:262-285): scale_window defaults
+        to 2**14 / world / update_freq; fp32 / bf16 train unscaled."""
+        c = self.cfg.common
+        if not c.fp16 or c.fp32:
+            return None
+        window = c.fp16_scale_window if c.fp16_scale_window is not None else max(1, int(2 ** 14 / world))
+        return {"init_scale": float(c.fp16_init_scale), "scale_factor": 2.0, "scale_window": window,
+                "tolerance": c.fp16_scale_tolerance, "threshold": c.threshold_loss_scale, "min_loss_scale": c.min_loss_scale}
 
     def _micro_batches(self, tasks):
         """samples[task][i] of engine/trainer.py:747-766, flattened: update_freq micro-batches of every task, on the device."""

@@ -166,7 +166,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
         flags |= GEMM_ACCUM
     if force_simple:
         flags |= GEMM_FORCE_SIMPLE
-    if dt == BF16 and out.dtype == torch.float32:
+    if dt != F32 and out.dtype == torch.float32:
         flags |= GEMM_OUT_F32
     if a_kpad_zero:
         flags |= 32   # OFA_GEMM_A_KPAD_ZERO
@@ -232,7 +232,7 @@ def gemm_heads(a, b, out, M, N, K, trans_a, trans_b, lda, ldb, ldc, B, heads, sa
     starts at X + b*sX2 + h*sX."""
     dt = dtype_code(a)
     flags = GEMM_ACCUM if accumulate else 0
-    if dt == BF16 and out.dtype == torch.float32:
+    if dt != F32 and out.dtype == torch.float32:
         flags |= GEMM_OUT_F32
     ws = workspace(256 << 20, a.device, "gemm")
     lib().call("ofa_gemm", ptr(a), ptr(b), ptr(out), None, M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, B * heads,
@@ -247,7 +247,7 @@ def scaled_softmax(x, scale):
     x = x.contiguous()
     b, np_, sq, sk = x.shape
     y = torch.empty_like(x)
-    lib().call("ofa_scaled_softmax_fwd", ptr(x), ptr(y), float(scale), b, np_, sq, sk, dtype_code(x, True), stream())
+    lib().call("ofa_scaled_softmax_fwd", ptr(x), ptr(y), float(scale), b, np_, sq, sk, dtype_code(x), stream())
     return y
 
 
@@ -256,7 +256,7 @@ def scaled_softmax_bwd(dy, y, scale, inplace=False):
     y = y.contiguous()
     rows = y.numel() // y.shape[-1]
     dx = dy if inplace else torch.empty_like(dy)
-    lib().call("ofa_scaled_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), 1, 1, rows, y.shape[-1], dtype_code(y, True),
+    lib().call("ofa_scaled_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), 1, 1, rows, y.shape[-1], dtype_code(y),
                stream())
     return dx
 
@@ -267,7 +267,7 @@ def scaled_masked_softmax(x, mask, scale):
     b, np_, sq, sk = x.shape
     y = torch.empty_like(x)
     lib().call("ofa_scaled_masked_softmax_fwd", ptr(x), ptr(mask), ptr(y), float(scale), b, np_, sq, sk, mask.shape[0],
-               dtype_code(x, True), stream())
+               dtype_code(x), stream())
     return y
 
 
@@ -276,7 +276,7 @@ def scaled_masked_softmax_bwd(dy, y, scale, inplace=True):
     assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and y.dim() == 4
     b, np_, sq, sk = y.shape
     dx = dy if inplace else torch.empty_like(dy)
-    lib().call("ofa_scaled_masked_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), b, np_, sq, sk, dtype_code(y, True),
+    lib().call("ofa_scaled_masked_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), b, np_, sq, sk, dtype_code(y),
                stream())
     return dx
 
@@ -286,7 +286,7 @@ def scaled_upper_triang_masked_softmax(x, scale):
     ab, sq, sk = x.shape
     assert sq == sk
     y = torch.empty_like(x)
-    lib().call("ofa_scaled_upper_triang_masked_softmax_fwd", ptr(x), ptr(y), float(scale), ab, sq, dtype_code(x, True), stream())
+    lib().call("ofa_scaled_upper_triang_masked_softmax_fwd", ptr(x), ptr(y), float(scale), ab, sq, dtype_code(x), stream())
     return y
 
 
@@ -295,7 +295,7 @@ def scaled_upper_triang_masked_softmax_bwd(dy, y, scale, inplace=True):
     assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape and y.dim() == 3 and y.shape[1] == y.shape[2]
     dx = dy if inplace else torch.empty_like(dy)
     lib().call("ofa_scaled_upper_triang_masked_softmax_bwd", ptr(dy), ptr(y), ptr(dx), float(scale), y.shape[0], y.shape[1],
-               dtype_code(y, True), stream())
+               dtype_code(y), stream())
     return dx
 
 

@@ -79,15 +79,15 @@ def lib():
     return _lib
 
 
-def dtype_code(t, allow_f16=False):
-    """ofa_dtype of a tensor.  fp16 is accepted only where the C ABI declares it (the fused-softmax entry points)."""
+def dtype_code(t, allow_f16=True):
+    """ofa_dtype of a tensor: fp32, bf16 or fp16 (every entry point of the C ABI takes the three)."""
     if t.dtype == torch.float32:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
     if allow_f16 and t.dtype == torch.float16:
         return F16
-    raise OfaError(f"ofasys_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+    raise OfaError(f"ofasys_amd kernels take float32, bfloat16 or float16 tensors, got {t.dtype}")
 
 
 def ptr(t):

@@ -103,7 +103,7 @@ class MultiheadAttention(nn.Module):
         if torch.is_tensor(key_padding_mask) and key_padding_mask.dim() == 0:
             key_padding_mask = None
         p_drop = self.dropout_module.p if (self.training or self.dropout_module.apply_during_inference) else 0.0
-        fused = (xq.dtype == torch.bfloat16 and self.head_dim == 64 and p_drop == 0.0 and not need_weights
+        fused = (xq.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 64 and p_drop == 0.0 and not need_weights
                  and self.q_proj.bias is not None)
         if bias is not None and bias.dtype != xq.dtype:
             bias = bias.to(xq.dtype)
@@ -249,7 +249,7 @@ class MultiheadAttention(nn.Module):
         c = self._cache(incremental_state)
         kvq = None
         if (not static_kv and self.self_attention and not torch.is_grad_enabled() and self.q_proj.bias is not None
-                and xq.dtype == torch.bfloat16):
+                and xq.dtype in (torch.bfloat16, torch.float16)):
             # ONE packed k|v|q projection per step instead of three 10-us launches (the step is launch-bound)
             W, Bv = self._decode_pack()
             kvq = K.gemm(xq.contiguous(), W, False, True, bias=Bv)            # [B, 3D]

@@ -735,7 +735,7 @@ def _scale_heads(x, c_attn, heads):
 def attention(q, k, v, heads, scale, bias=None, key_padding_mask=None, c_attn=None, causal=False, dropout_p=0.0,
               need_weights=False):
     """Attention core on [B,T,D] rows.  Returns (out [B,T,D], probs [B*heads,T,S] or None)."""
-    fused_ok = (q.dtype == torch.bfloat16 and q.shape[-1] // heads == 64 and dropout_p == 0.0 and not need_weights)
+    fused_ok = (q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] // heads == 64 and dropout_p == 0.0 and not need_weights)
     if bias is not None and bias.dtype != q.dtype:
         bias = bias.to(q.dtype)
     if fused_ok:

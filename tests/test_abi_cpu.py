@@ -44,8 +44,8 @@ def test_status_codes_not_asserts():
         h.call("ofa_scaled_masked_softmax_bwd", 1, 1, 1, 1.0, 1, 1, 4, 5000, L.F16, None)
     with pytest.raises(L.OfaError, match="dtype"):
         h.call("ofa_scaled_upper_triang_masked_softmax_bwd", 1, 1, 1, 1.0, 1, 8, 7, None)
-    with pytest.raises(L.OfaError, match="dtype"):                                                     # fp16: softmax entry points only
-        h.call("ofa_layernorm_fwd", 1, 1, 1, 1, 1, 1, 4, 8, 1e-5, L.F16, None)
+    with pytest.raises(L.OfaError, match="dtype"):                                                     # an unknown dtype code
+        h.call("ofa_layernorm_fwd", 1, 1, 1, 1, 1, 1, 4, 8, 1e-5, 7, None)
     with pytest.raises(L.OfaError, match="bf16"):
         h.call("ofa_attn_fwd", 1, 1, 1, None, None, None, L.F32, 1, None, 1, 1, 32, 32, 32, 64, 64, 64, 1.0, 0, None, 0, 0, L.F32, None)
 

@@ -77,7 +77,14 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 break
         assert cnt == len(slots), cnt
         output = self.concat(modality_outputs)
-        return output.embed, output.masks, output.pos_embed, output.self_attn_bias, None
+        modal_mask = None
+        if getattr(self.cfg, "modal_ffn", False):                       # general.py:143-146, 156-157: [B, T] int64, value = modality - 1
+            parts = [torch.full_like(o.masks, int(slot.modality.value) - 1, dtype=torch.int64)
+                     for o, slot in zip(modality_outputs, slots)]
+            modal_mask = torch.cat(parts, dim=-1)
+            # every column belongs to one slot: the layers route on this host-side layout (module/transformer_layer.py, _modal_plan)
+            modal_mask._ofa_cols = tuple((int(slot.modality.value) - 1, int(o.masks.shape[-1])) for o, slot in zip(modality_outputs, slots))
+        return output.embed, output.masks, output.pos_embed, output.self_attn_bias, modal_mask
 
     def forward_output(self, x: Tensor, extra: Dict[str, Any], slots: List[Slot], **kwargs):
         output_slot = None

@@ -8,8 +8,10 @@ Fusions relative to the reference's op-by-op graph (same arithmetic, fewer HBM r
   * [attn_ln] + dropout + residual add + the NEXT LayerNorm (this layer's final_layer_norm, or the next layer's first
     pre-LN handed in through a LayerChain) -> one "residual join" kernel each way (csrc/join.hip); pre-LN stacks only
 Only the configuration space of OFASys' GeneralistModel is implemented: pre- or post-LN, scale_attn / scale_fc /
-scale_heads / scale_resids; modal_ffn (single-device MoE) and cross_self_attention are refused loudly.
+scale_heads / scale_resids, modal_ffn (one FFN expert per modality, routed by the adaptor's modality mask);
+cross_self_attention is refused loudly.
 """
+import copy
 from typing import Dict, List, Optional
 
 import torch
@@ -17,6 +19,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import ops
+from ..preprocessor.instruction import ModalityType
 from .layers import Dropout, DropPath, LayerNorm, OfaLinear
 from .multihead_attention import MultiheadAttention
 
@@ -45,7 +48,7 @@ def _act_name(cfg):
 class _FFNMixin:
     def _joinable(self):
         """The fused residual joins cover the pre-LN layer without scale_resids / DropPath (OFASys' defaults)."""
-        return (self.normalize_before and self.w_resid is None
+        return (self.normalize_before and self.w_resid is None and not self.modal_ffn
                 and (self.drop_path.drop_prob == 0.0 or not self.training))
 
     def _join(self, x, residual, ln_a, ln_b, x_bias=None):
@@ -61,7 +64,95 @@ class _FFNMixin:
         ps = [bias] + [q for ln in (ln_a, ln_b) if ln is not None for q in (ln.weight, ln.bias)]
         return self.training and ops.join_takes_bias_grad(*ps)
 
-    def _ffn(self, x, normed=None, chain=None):
+    # ---- modal_ffn (transformer_layer.py:50-54, 116-130 / 300-304, 335-349; sparse_dispatcher.py:44-110): one copy of fc1 / fc2 per
+    # ModalityType, every row multiplied by the expert of its modality.  The reference builds one-hot gates from the adaptor's
+    # [B, T] modality mask FLATTENED BATCH-MAJOR and applies them to the rows of x flattened TIME-MAJOR ([T, B, D]): row
+    # r = t*B + b takes the modality of mask.view(-1)[r] = mask[r // T, r % T].  That pairing is reproduced as it is (it is what
+    # a reference checkpoint was trained with; tests/golden/tiny_modal_ffn.npz is a reference run).  Every column of the mask
+    # belongs to one slot, so the routing is a function of (B, T, slot modalities and widths) alone: the row permutation that
+    # groups the rows by expert is built on the host once per batch structure -- no nonzero() / tolist() sync as in the
+    # dispatcher, hipGraph-safe -- and each expert is one GEMM over a contiguous row range.  The reference's trailing x.half()
+    # (:129) is a no-op in an fp16 model, the only one it runs in; other dtypes are kept here.
+    def _init_experts(self):
+        self.modal_ffn = bool(getattr(self.cfg, "modal_ffn", False))
+        if self.modal_ffn:
+            self.experts_num = len(ModalityType)
+            self.experts_fc1 = nn.ModuleList([copy.deepcopy(self.fc1) for _ in range(self.experts_num)])
+            self.experts_fc2 = nn.ModuleList([copy.deepcopy(self.fc2) for _ in range(self.experts_num)])
+
+    _MODAL_PLANS = {}
+
+    @classmethod
+    def _modal_plan(cls, cols, B, T, device):
+        """cols: ((expert, width), ...) of the mask's columns -> (perm, inverse, [(expert, start, end)]) for [T*B] rows."""
+        key = (cols, B, T, str(device))
+        plan = cls._MODAL_PLANS.get(key)
+        if plan is None:
+            col_expert = [e for e, w in cols for _ in range(w)][:T]
+            assert len(col_expert) == T, (cols, T)
+            row_expert = [col_expert[r % T] for r in range(T * B)]          # (sic) see above
+            order = sorted(range(T * B), key=lambda r: (row_expert[r], r))
+            inverse = [0] * (T * B)
+            for pos, r in enumerate(order):
+                inverse[r] = pos
+            ranges, start = [], 0
+            for e in sorted(set(row_expert)):
+                n = row_expert.count(e)
+                ranges.append((e, start, start + n))
+                start += n
+            # the same permutation for rows stored batch-major (the [T, B, D] VIEW of [B, T, D] memory the stacks pass around):
+            # logical row r = t*B + b lives at b*T + t
+            bm = lambda r: (r % B) * T + r // B
+            order_b = [bm(r) for r in order]
+            inverse_b = [0] * (T * B)
+            for r in range(T * B):
+                inverse_b[bm(r)] = inverse[r]
+            dev = lambda v: torch.tensor(v, dtype=torch.long, device=device)
+            plan = (dev(order), dev(inverse), ranges, dev(order_b), dev(inverse_b))
+            cls._MODAL_PLANS[key] = plan
+        return plan
+
+    def _modal_linear(self, modal_mask, x, experts):
+        T, B, D = x.shape
+        cols = getattr(modal_mask, "_ofa_cols", None)
+        if cols is None:
+            raise ValueError("modal_ffn: the modality mask must come from OFAGeneralAdaptor (it carries the slot layout)")
+        perm, inverse, ranges, perm_b, inverse_b = self._modal_plan(cols, B, T, x.device)
+        batch_major = x.transpose(0, 1).is_contiguous()                     # keep the memory layout of the input: the row kernels
+        if batch_major:                                                     # downstream add tensors element by element in memory order
+            xs = ops.PackRowsFn.apply(x.transpose(0, 1).reshape(B * T, D), perm_b, inverse_b)
+        else:
+            xs = ops.PackRowsFn.apply(x.contiguous().view(T * B, D), perm, inverse)   # rows grouped by expert
+        ys = [experts[e](xs[a:b]) for e, a, b in ranges]
+        y = ys[0] if len(ys) == 1 else torch.cat(ys, 0)
+        if batch_major:
+            return ops.PackRowsFn.apply(y, inverse_b, perm_b).view(B, T, -1).transpose(0, 1)
+        return ops.PackRowsFn.apply(y, inverse, perm).view(T, B, -1)
+
+    def _decoder_modal_mask(self, modal_mask, x):
+        """The decoder hands `modal_mask[:x.shape[1], :x.shape[0]]` to the experts (transformer_layer.py:477, 486)."""
+        if not self.modal_ffn or modal_mask is None:
+            return modal_mask
+        m = modal_mask[:x.shape[1], :x.shape[0]]
+        m._ofa_cols = modal_mask._ofa_cols                                  # (_modal_plan keeps the first T columns)
+        return m
+
+    def _upgrade_experts(self, state_dict, name):
+        """Keys of this layer that a checkpoint lacks are filled from the module: an expert from the module's current fc1 / fc2
+        (transformer_layer.py:105-114)."""
+        if not self.modal_ffn:
+            return
+        prefix = name + "." if name != "" else ""
+        own = self.state_dict()
+        for k in own:
+            if prefix + k in state_dict:
+                continue
+            src = k
+            for i in range(self.experts_num):
+                src = src.replace(f"experts_fc1.{i}.", "fc1.").replace(f"experts_fc2.{i}.", "fc2.")
+            state_dict[prefix + k] = own[src]
+
+    def _ffn(self, x, normed=None, chain=None, modal_mask=None):
         """residual + dropout(fc2(ffn_ln(act_dropout(act(fc1(LN(x)))))))   -- :186-208 / :471-494.
         normed: final_layer_norm(x) when the preceding join already produced it; chain: see LayerChain."""
         if normed is not None:
@@ -71,7 +162,14 @@ class _FFNMixin:
         else:
             residual = x
         act_p = self.activation_dropout_module.p if self.training else 0.0
-        if self.ffn_layernorm is not None and act_p == 0.0 and self._gelu and self.fc1.bias is not None:
+        if self.modal_ffn:
+            if not self._gelu:
+                raise NotImplementedError("only activation_fn='gelu' (OFASys default) is implemented")
+            x = ops.gelu(self._modal_linear(modal_mask, x, self.experts_fc1))
+            x = self.activation_dropout_module(x)
+            if self.ffn_layernorm is not None:
+                x = self.ffn_layernorm(x)
+        elif self.ffn_layernorm is not None and act_p == 0.0 and self._gelu and self.fc1.bias is not None:
             x = ops.linear_gelu_layer_norm(x, self.fc1.weight, self.fc1.bias, self.ffn_layernorm.weight,
                                            self.ffn_layernorm.bias, self.ffn_layernorm.eps)
         else:
@@ -90,7 +188,7 @@ class _FFNMixin:
             if chain is not None:
                 chain.normed = z
             return x
-        x = self.fc2(x)
+        x = self._modal_linear(modal_mask, x, self.experts_fc2) if self.modal_ffn else self.fc2(x)
         if self.w_resid is not None:
             residual = ops.mul_rowvec(residual, self.w_resid)                   # :204-205
         x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
@@ -104,8 +202,6 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         super().__init__()
         cfg = args
         self.cfg = cfg
-        if getattr(cfg, "modal_ffn", False):
-            raise NotImplementedError("modal_ffn is not implemented in ofasys_amd")
         self.embed_dim = cfg.encoder.embed_dim
         self.self_attn = self.build_self_attention(self.embed_dim, cfg)
         self.self_attn_layer_norm = LayerNorm(self.embed_dim)
@@ -118,6 +214,7 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         self.normalize_before = cfg.encoder.normalize_before
         self.fc1 = OfaLinear(self.embed_dim, cfg.encoder.ffn_embed_dim)
         self.fc2 = OfaLinear(cfg.encoder.ffn_embed_dim, self.embed_dim)
+        self._init_experts()
         self.attn_ln = LayerNorm(self.embed_dim) if cfg.scale_attn else None
         self.nh = self.self_attn.num_heads
         self.head_dim = self.self_attn.head_dim
@@ -155,13 +252,13 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         if join:
             x, h = self._join(x, residual, self.attn_ln, self.final_layer_norm,
                               x_bias=self.self_attn.out_proj.bias if own else None)
-            return self._ffn(x, normed=h, chain=chain), self_attn_weights
+            return self._ffn(x, normed=h, chain=chain, modal_mask=modal_mask), self_attn_weights
         if self.attn_ln is not None:
             x = self.attn_ln(x)
         x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)   # :181-182
         if not self.normalize_before:
             x = self.self_attn_layer_norm(x)
-        x = self._ffn(x)
+        x = self._ffn(x, modal_mask=modal_mask)
         return x, self_attn_weights
 
     def upgrade_state_dict_named(self, state_dict, name):
@@ -171,6 +268,7 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
                 k = "{}.layer_norms.{}.{}".format(name, old, m)
                 if k in state_dict:
                     state_dict["{}.{}.{}".format(name, new, m)] = state_dict.pop(k)
+        self._upgrade_experts(state_dict, name)
 
 
 class TransformerDecoderLayer(nn.Module, _FFNMixin):
@@ -178,8 +276,6 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         super().__init__()
         cfg = args
         self.cfg = cfg
-        if getattr(cfg, "modal_ffn", False):
-            raise NotImplementedError("modal_ffn is not implemented in ofasys_amd")
         if cfg.cross_self_attention:
             raise NotImplementedError("cross_self_attention is not used by OFASys' GeneralistModel")
         self.embed_dim = cfg.decoder.embed_dim
@@ -207,6 +303,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         self.w_resid = nn.Parameter(torch.ones(self.embed_dim), requires_grad=True) if cfg.scale_resids else None
         self.fc1 = OfaLinear(self.embed_dim, cfg.decoder.ffn_embed_dim)
         self.fc2 = OfaLinear(cfg.decoder.ffn_embed_dim, self.embed_dim)
+        self._init_experts()
         self.final_layer_norm = LayerNorm(self.embed_dim)
         self.need_attn = True
         self.drop_path = DropPath(float(drop_path_rate), batch_axis=1)
@@ -286,7 +383,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 x = ops.dropout_add(self.drop_path(x), residual, self.dropout_module.p, self.training)
                 if not self.normalize_before:
                     x = self.encoder_attn_layer_norm(x)
-        x = self._ffn(x, normed=h, chain=chain)
+        x = self._ffn(x, normed=h, chain=chain, modal_mask=self._decoder_modal_mask(modal_mask, x))
         return x, cross_attn_weights, self_attn_weights       # (sic) the reference returns them in this order, :495
 
     def make_generation_fast_(self, need_attn: bool = False, **kwargs):
@@ -299,3 +396,4 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 k = "{}.layer_norms.{}.{}".format(name, old, m)
                 if k in state_dict:
                     state_dict["{}.{}.{}".format(name, new, m)] = state_dict.pop(k)
+        self._upgrade_experts(state_dict, name)

@@ -29,6 +29,21 @@ def rows_view(x):
     return xc.view(-1, C), lambda y: y.view(*lead, y.shape[-1])
 
 
+def like_layout(x, ref):
+    """x in the memory order of `ref` (same shape): rows_view() flattens each operand in ITS OWN storage order, so an element-wise
+    row kernel over two operands needs both in one order -- a [T,B,C] tensor against a [T,B,C] view of [B,T,C] storage would
+    otherwise pair row t*B+b with row b*T+t."""
+    if x.dim() != 3 or x.shape != ref.shape:
+        return x
+    ref_bm = ref.transpose(0, 1).is_contiguous() and not ref.is_contiguous()
+    x_bm = x.transpose(0, 1).is_contiguous() and not x.is_contiguous()
+    if ref_bm == x_bm and (x_bm or x.is_contiguous() == ref.is_contiguous()):
+        return x
+    if ref_bm:
+        return x.transpose(0, 1).contiguous().transpose(0, 1)
+    return x.contiguous()
+
+
 def batch_major(x):
     """[T,B,C] (any strides) -> contiguous [B,T,C] (a view when x is already a transposed batch-major buffer)."""
     xt = x.transpose(0, 1)
@@ -404,6 +419,8 @@ class AddFn(torch.autograd.Function):
 
 def dropout_add(x, residual, p, training):
     """residual + dropout(x) (transformer_layer.py:181-182); plain add when not training / p == 0."""
+    if residual is not None:
+        x = like_layout(x, residual)
     x2d, restore = rows_view(x)
     r2d = None
     if residual is not None:
@@ -418,6 +435,8 @@ def dropout_add(x, residual, p, training):
 
 
 def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+    if b is not None:
+        b = like_layout(b, a)
     a2d, restore = rows_view(a)
     b2d = rows_view(b)[0] if b is not None else None
     m = rowmask.reshape(-1) if rowmask is not None else None
@@ -876,7 +895,13 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
         V = logits.shape[-1]
-        l2d = logits.reshape(-1, V) if logits.is_contiguous() else logits.view(-1, V)
+        if logits.is_contiguous():
+            l2d = logits.reshape(-1, V)
+        else:
+            try:
+                l2d = logits.view(-1, V)                       # a padded-stride view of row storage: no copy
+            except RuntimeError:
+                l2d = logits.contiguous().view(-1, V)          # a transposed [T, B, V] layout (op-by-op layer stacks)
         if l2d.stride(1) != 1 or l2d.stride(0) % (4 if l2d.dtype == torch.float32 else 8) != 0:
             pad = (-V) % 8
             store = torch.zeros(l2d.shape[0], V + pad, dtype=l2d.dtype, device=l2d.device)

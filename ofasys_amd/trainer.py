@@ -171,6 +171,9 @@ class TrainStep:
       "split" two graphs (forward+backward, clip+Adam) around an eager bucket-by-bucket all-reduce: no overlap.  Chosen
               automatically when the process group's backend is not nccl (gloo's host-side collectives cannot be captured), or
               with dp_graph="split" / OFA_DP_GRAPH=split.
+      Do not keep an autograd graph of this model alive from BEFORE the capture (outputs of an earlier forward on another
+      stream): it pins the parameters' AccumulateGrad nodes to that stream and torch routes the captured backward through
+      it, which invalidates the capture (ROCm: a crash in hipStreamEndCapture).  `del` such outputs first.
       A capture that fails cannot be retried in the same process (torch leaves the CUDA generator in its capturing state:
       "Cannot register the state during capturing stage" on every later capture), so there is no full -> split retry: the step
       engine warns, keeps the half-built graph objects alive (their destructor would abort the process) and runs eagerly from
@@ -318,6 +321,8 @@ class TrainStep:
 
     # ------------------------------------------------------------------ graph plumbing
     def _capture(self, samples, structure, mode):
+        import gc
+        gc.collect()                      # drop unreachable autograd graphs (see the class docstring) before recording
         pool = torch.cuda.graph_pool_handle()
         entry = {"static": samples, "graphs": [], "mode": mode}
         if self.world == 1 or mode == "full":

@@ -31,6 +31,18 @@ CASES = {
         full_grads=["encoder.adaptor.text.token_rel_pos_table_list.0.weight", "decoder.layers.0.encoder_attn.c_attn",
                     "encoder.adaptor.text.type_embedding.weight"],
     ),
+    # modal_ffn (one FFN expert per modality).  The reference's modal_for_ffn ends in x.half() (transformer_layer.py:129), so it
+    # only runs in an fp16 model: the fixture is a HALF-precision reference run on CPU ("half": True)
+    "tiny_modal_ffn": dict(
+        arch="tiny", active={"text"}, overrides={"modal_ffn": True}, adaptor_overrides={}, half=True,
+        slots=[("BOX", True, ("tok", "box", (3, 4), None), None),
+               ("TEXT", True, ("tok", "srcA", (3, 7), [7, 5, 3]), None),
+               ("STRUCT", True, ("tok", "srcB", (3, 5), None), None),
+               ("TEXT", False, ("tok", "prev", (3, 6), [6, 4, 6]), None)],
+        full_grads=["encoder.layers.0.experts_fc1.0.weight", "encoder.layers.1.experts_fc2.2.weight",
+                    "encoder.layers.0.experts_fc1.7.bias", "decoder.layers.0.experts_fc1.0.weight",
+                    "decoder.layers.1.experts_fc2.0.bias", "encoder.layers.0.fc1.weight"],
+    ),
     # cfg-2 family: image_patch_embed + text -> text, base, the adaptor's only working corner
     "base_patch": dict(
         arch="base", active={"text", "image_patch_embed"},

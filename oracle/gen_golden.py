@@ -33,6 +33,8 @@ def run_case(name, case):
 
     model, d = build_reference_model(case["arch"], VOCAB_EXTRA, case["active"], case["overrides"], case["adaptor_overrides"])
     recipe.fill_state(model.state_dict())
+    if case.get("half"):               # (modal_ffn: the reference forces fp16 activations; the whole run is in half, on CPU)
+        model.half()
     model.eval()
     if case.get("train"):          # dropout is 0 in such cases: train mode only switches BatchNorm to batch statistics
         model.train()
@@ -109,7 +111,8 @@ def run_case(name, case):
     out["grad_norms"] = np.array([gn[k] for k in sorted(gn.keys())], dtype=np.float64)
     params = dict(model.named_parameters())
     for k in case["full_grads"]:
-        out["grad." + k] = params[k].grad.detach()
+        if params[k].grad is not None:     # (an unused parameter -- e.g. the shared fc1 of a modal_ffn layer -- has no gradient: norm -1 above)
+            out["grad." + k] = params[k].grad.detach()
     for k in case.get("buffers", []):
         out["buffer." + k] = model.state_dict()[k].detach().clone()
     if blk_io:
@@ -126,6 +129,7 @@ def run_case(name, case):
         out["image_rp_bucket_crc"] = np.array([zlib_crc(model.state_dict()["encoder.adaptor.image_resnet.image_rp_bucket"])])
     out["token_rp_bucket_crc"] = np.array([zlib_crc(model.state_dict()["encoder.adaptor.text.token_rp_bucket"])])
     out["token_rp_bucket_corner"] = model.state_dict()["encoder.adaptor.text.token_rp_bucket"][:300:7, :300:7].clone()
+    out = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.float16 else v) for k, v in out.items()}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
     print(name, "loss", float(loss), "logits", tuple(logits.shape), "file KB",
           os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024)

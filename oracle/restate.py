@@ -74,6 +74,7 @@ class OConfig:
     resnet_layers: tuple = (3, 8, 36)       # adaptor/image_resnet.py:44-47 (default resnet152), module/resnet.py:249-261
     image_bucket_size: int = 42             # adaptor/image_resnet.py:62-65
     training: bool = False                  # BatchNorm batch statistics (dropout must be 0 for a deterministic oracle)
+    modal_ffn: bool = False                 # ofa.py:119-121: one FFN expert per ModalityType
 
 
 # --------------------------------------------------------------------------------------------
@@ -355,6 +356,10 @@ def general_adaptor(state, cfg, side, slots):
                     b[:, :, s0:s0 + n, s0:s0 + n] = b[:, :, s0:s0 + n, s0:s0 + n] + o[3][l]
                 s0 += n
             bias.append(b)
+    if cfg.modal_ffn:
+        general_adaptor.modal_mask = modal_mask_of([(s.modality, o[1].shape[0], o[1].shape[1]) for s, o in zip(slots, outs)])
+    else:
+        general_adaptor.modal_mask = None
     return embed, masks, pos_embed, bias
 
 
@@ -417,18 +422,46 @@ def mha_fast(state, prefix, cfg, x, key_padding_mask):
 # --------------------------------------------------------------------------------------------
 # layers (a12, a14) -- module/transformer_layer.py
 # --------------------------------------------------------------------------------------------
-def _ffn(state, p, cfg, x):
+def modal_mask_of(slots):
+    """adaptor/general.py:143-146, 156-157: [B, T] int64, modality value - 1 over the columns of each slot (slot order).
+    A token slot contributes its own width; callers pass the per-slot widths."""
+    return torch.cat([torch.full((b, t), MODALITY_ORDER_VALUE[mod] - 1, dtype=torch.int64) for mod, b, t in slots], dim=1)
+
+
+# ModalityType values (preprocessor/instruction.py:21-31)
+MODALITY_ORDER_VALUE = {"TEXT": 1, "IMAGE": 2, "BOX": 3, "AUDIO": 4, "MOTION": 5, "PHONE": 6, "VIDEO": 7, "STRUCT": 8, "CATEGORY": 9}
+
+
+def modal_for_ffn(state, p, modal_mask, x):
+    """transformer_layer.py:116-130 + sparse_dispatcher.py:44-110 with one-hot gates: every row goes through the expert its gate
+    selects.  The gates are indexed by the mask flattened BATCH-major (`modal_mask.view(bs * seq_len)`, :118-121) while the rows
+    of x are flattened TIME-major (`x.view(seq_len * bs, dim)`, :124-125): row r takes the modality of mask.view(-1)[r].  (The
+    reference's trailing x.half() is what restricts it to fp16 models; the oracle computes in fp32.)"""
+    T, B, D = x.shape
+    flat = modal_mask.reshape(-1)
+    x2 = x.reshape(T * B, D)
+    out = None
+    for e in sorted(set(flat.tolist())):
+        idx = (flat == e).nonzero().squeeze(1)
+        y = linear(state, f"{p}.{e}", x2[idx])
+        if out is None:
+            out = torch.zeros(T * B, y.shape[1], dtype=y.dtype)
+        out = out.index_add(0, idx, y)                                    # dispatcher.combine: zeros.index_add (:102-104)
+    return out.view(T, B, -1)
+
+
+def _ffn(state, p, cfg, x, modal_mask=None):
     """transformer_layer.py:186-208 / :471-494 (pre-LN, scale_fc LayerNorm over F inside the FFN)."""
     r = x
     x = layer_norm(state, p + ".final_layer_norm", x, cfg.eps)
-    x = gelu(linear(state, p + ".fc1", x))
+    x = gelu(modal_for_ffn(state, p + ".experts_fc1", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc1", x))
     if (p + ".ffn_layernorm.weight") in state:
         x = layer_norm(state, p + ".ffn_layernorm", x, cfg.eps)
-    x = linear(state, p + ".fc2", x)
+    x = modal_for_ffn(state, p + ".experts_fc2", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc2", x)
     return r + x
 
 
-def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias):
+def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias, modal_mask=None):
     """transformer_layer.py:132-209 (normalize_before=True, dropout/droppath identity in eval)."""
     r = x
     h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
@@ -439,11 +472,11 @@ def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias):
     if (p + ".attn_ln.weight") in state:
         h = layer_norm(state, p + ".attn_ln", h, cfg.eps)                 # :179-180
     x = r + h
-    return _ffn(state, p, cfg, x)
+    return _ffn(state, p, cfg, x, modal_mask)
 
 
 def decoder_layer(state, p, cfg, x, enc, enc_padding_mask, self_attn_mask, self_attn_padding_mask,
-                  self_attn_bias, cross_attn_bias, need_head_weights):
+                  self_attn_bias, cross_attn_bias, need_head_weights, modal_mask=None):
     """transformer_layer.py:351-495."""
     r = x
     h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
@@ -458,7 +491,9 @@ def decoder_layer(state, p, cfg, x, enc, enc_padding_mask, self_attn_mask, self_
     if (p + ".cross_attn_ln.weight") in state:
         h = layer_norm(state, p + ".cross_attn_ln", h, cfg.eps)           # :464-465
     x = r + h
-    return _ffn(state, p, cfg, x), cross_w
+    if modal_mask is not None:
+        modal_mask = modal_mask[:x.shape[1], :x.shape[0]]                 # :477, 486
+    return _ffn(state, p, cfg, x, modal_mask), cross_w
 
 
 # --------------------------------------------------------------------------------------------
@@ -467,6 +502,7 @@ def decoder_layer(state, p, cfg, x, enc, enc_padding_mask, self_attn_mask, self_
 def encoder_forward(state, cfg, slots, record=None):
     """model/transformer.py:78-156."""
     embed, masks, pos_embed, bias = general_adaptor(state, cfg, "encoder", slots)
+    modal_mask = general_adaptor.modal_mask
     if record is not None:
         record["enc_embed"] = embed                                       # adaptor output, before pad zeroing
     has_pad = bool(masks.any())                                           # :110
@@ -483,7 +519,7 @@ def encoder_forward(state, cfg, slots, record=None):
         b = None
         if cfg.use_self_attn_bias:                                        # :121-126
             b = bias[0 if cfg.share_attn_bias else l].view(-1, T, T)
-        x = encoder_layer(state, f"encoder.layers.{l}", cfg, x, masks if has_pad else None, b)
+        x = encoder_layer(state, f"encoder.layers.{l}", cfg, x, masks if has_pad else None, b, modal_mask)
         if record is not None:
             record[f"enc_layer{l}"] = x
     x = layer_norm(state, "encoder.layer_norm", x, cfg.eps)               # :142-143
@@ -493,6 +529,7 @@ def encoder_forward(state, cfg, slots, record=None):
 def decoder_forward(state, cfg, slots, enc_out, record=None):
     """model/transformer.py:365-522 + forward :349-363 (tied output projection adaptor/text.py:94-96,142)."""
     embed, masks, pos_embed, bias = general_adaptor(state, cfg, "decoder", slots)
+    modal_mask = general_adaptor.modal_mask
     B, Tt, D = embed.shape
     A = cfg.heads
     enc = enc_out["encoder_out"]
@@ -514,7 +551,7 @@ def decoder_forward(state, cfg, slots, enc_out, record=None):
             sb = False                                                    # :477 (forces the slow path)
         last = l == cfg.dec_layers - 1                                    # alignment_layer default, :421-422
         x, cw = decoder_layer(state, f"decoder.layers.{l}", cfg, x, enc, enc_out["encoder_padding_mask"],
-                              future, masks, sb, cross_bias, need_head_weights=last)
+                              future, masks, sb, cross_bias, need_head_weights=last, modal_mask=modal_mask)
         if record is not None:
             record[f"dec_layer{l}"] = x
         if last:

@@ -57,7 +57,7 @@ def oracle_cfg(case):
         case["adaptor_overrides"].get("image_resnet", {}).get("resnet_type", "resnet152")]
     return OConfig(**ARCH[case["arch"]], use_self_attn_bias=ov.get("use_self_attn_bias", True),
                    entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent,
-                   resnet_layers=layers, training=bool(case.get("train", False)))
+                   resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)))
 
 
 def case_inputs(case):

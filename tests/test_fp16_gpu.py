@@ -212,3 +212,61 @@ def test_model_fp16_against_golden_and_train_step_under_the_loss_scaler():
     torch.cuda.synchronize()
     assert float(step._sched[4]) == skipped0 + 1 and float(step._ls[0]) < 2.0 ** 40
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_modal_ffn_matches_the_reference_fp16_run():
+    """modal_ffn (one FFN expert per modality, transformer_layer.py:116-130): the model in fp16 against tests/golden/tiny_modal_ffn.npz,
+    a HALF-precision run of the reference itself (its modal_for_ffn only runs in fp16) -- logits, loss, cross-attention map,
+    every parameter's gradient norm (unused experts: zero) and five expert gradients in full; then the same step through
+    TrainStep's hipGraph (the routing is built on the host from the slot layout: nothing in it syncs)."""
+    from oracle.cases import CASES
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import TrainStep
+    from tests.golden_util import case_inputs, load_golden, rel_err
+    from tests.model_util import build_model, make_slots
+    name = "tiny_modal_ffn"
+    case, g = CASES[name], load_golden(name)
+    model, d = build_model(case, DEV, H)
+    model.eval()
+    vals, target = case_inputs(case)
+    slots = make_slots(vals, DEV, H)
+    logits, extra, enc = model(slots, return_encoder_out=True)
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    model.zero_grad()
+    loss.backward()
+    assert rel_err(logits.detach().float().cpu(), g["logits"]) < 6e-3
+    assert rel_err(loss.detach().float().cpu(), g["loss"][0]) < 3e-3
+    assert rel_err(extra["attn"][0].float().cpu(), g["attn"]) < 6e-3
+    params = dict(model.named_parameters())
+    gn = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norms"]))
+    scale = max(gn.values())
+    for k, want in gn.items():
+        if k == "decoder.adaptor.embed_tokens.weight":
+            continue
+        p = params[k]
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        if want <= 0:                                  # unused: the shared fc1 / fc2 (no gradient), experts of absent modalities (zero)
+            assert got == 0.0, k
+        else:
+            assert abs(got - want) <= 3e-2 * want + 1e-3 * scale, (k, got, want)
+    for k in g:
+        if k.startswith("grad."):
+            got, want = params[k[5:]].grad.float().cpu().double(), torch.from_numpy(g[k]).double()
+            assert float((got - want).abs().max()) <= 3e-2 * float(want.abs().max()) + 1e-4 * scale, k
+    # state-dict schema: the experts are there under the reference's names
+    keys = set(model.state_dict().keys())
+    want_keys = {str(x).split("|")[0] for x in g["state_keys"]}
+    assert {k for k in want_keys if "experts_fc" in k} <= keys
+    # graph-captured train step.  (The autograd graph of the forward above must be gone first: a live graph keeps the parameters'
+    # AccumulateGrad nodes bound to the stream it ran on, and torch would route the captured backward through that stream.)
+    del logits, extra, enc, loss
+    model.zero_grad(set_to_none=True)
+    model.train()
+    step = TrainStep(model, lr=1e-3, clip_norm=1.0, use_graph=True, graph_warmup=1, loss_scale={"init_scale": 128.0})
+    sample = {"slots": slots, "target": target.to(DEV)}
+    losses = []
+    for _ in range(6):
+        st = step.train_step([sample])["stats"].tolist()
+        losses.append(st[1] / max(st[0], 1.0))
+    assert any("graphs" in e for e in step._graphs.values()), "the modal_ffn step was not captured"
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0]

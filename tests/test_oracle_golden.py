@@ -15,6 +15,8 @@ TOL = 2e-5   # fp32 vs fp32, different op order only (reference noise floor 2e-6
 def test_forward_backward_matches_reference(name):
     torch.set_num_threads(8)
     case = CASES[name]
+    # a "half" case is a reference run in fp16 (modal_ffn only exists there): the fp32 oracle meets it at fp16's rounding
+    TOL, GTOL = (4e-3, 2e-2) if case.get("half") else (globals()["TOL"], 1e-4)
     g = load_golden(name)
     state = state_from_golden(g)
     params = {k: v.requires_grad_(True) for k, v in state.items()
@@ -50,7 +52,7 @@ def test_forward_backward_matches_reference(name):
             assert p.grad is None or float(p.grad.norm()) == 0.0, k
             continue
         got = float(p.grad.double().norm()) if p.grad is not None else 0.0
-        assert abs(got - want) <= 1e-4 * want + 1e-5, (k, got, want)  # k_proj.bias grads are exactly 0 in maths
+        assert abs(got - want) <= GTOL * want + (1e-2 if case.get("half") else 1e-5), (k, got, want)  # k_proj.bias grads are exactly 0 in maths
     for k in g:
         if k.startswith("grad."):
             assert rel_err(state[k[5:]].grad, g[k]) < 5 * TOL, k

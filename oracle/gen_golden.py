@@ -251,15 +251,17 @@ if __name__ == "__main__":
     if len(sys.argv) == 3 and sys.argv[1] == "--case":
         run_case(sys.argv[2], CASES[sys.argv[2]])
         sys.exit(0)
+    manifest_only = len(sys.argv) == 2 and sys.argv[1] == "--manifest"     # rewrite MANIFEST.json after single --case runs
     # one fresh process per case: the reference's dataclass defaults are shared mutable instances, so adaptor
     # configs (embed_dim, layers, ...) leak from one model to the next inside a process
     import subprocess
-    for name in CASES:
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
-    softmax_vectors()
-    softmax_bwd_vectors()
-    ls_ce_vectors()
-    box_vectors()
+    if not manifest_only:
+        for name in CASES:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
+        softmax_vectors()
+        softmax_bwd_vectors()
+        ls_ce_vectors()
+        box_vectors()
     manifest = {
         "generator": "oracle/gen_golden.py",
         "torch": torch.__version__, "numpy": np.__version__,

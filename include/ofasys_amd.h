@@ -105,6 +105,24 @@ int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int
              int batch_inner, int64_t strideA2, int64_t strideB2, int64_t strideC2,
              float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- grouped weight-gradient products: up to 8 independent  slabs_p[s][m][n] = sum over K-slice s of a_p^T b_p  in ONE
+ * launch (256 x 256 eight-wave tiles).  The nn.Linear weight gradients of one Transformer layer (dW = dY^T X, what autograd
+ * computes for transformer_layer.py:194,202 and multihead_attention.py:199-217,346) are 9-36 such tiles each: launched alone
+ * each has to be cut into 3-7 short K-slices to occupy the chip; together they fill it with ~2 long slices each.
+ * The slabs are finished by ofa_fold_batched (out (+)= alpha * sum_s slabs[s]).  16-bit operands; k % 64 == 0, m, n, lda,
+ * ldb % 8 == 0, 16-byte aligned pointers.  `items` is a HOST array. */
+typedef struct ofa_gemm_group_item {
+  const void* a;     /* [k, m] rows (lda >= m): output-gradient rows dY */
+  const void* b;     /* [k, n] rows (ldb >= n): layer-input rows X */
+  float* slabs;      /* [splits][m][n] fp32, written (not accumulated) */
+  int64_t lda, ldb;
+  int32_t m, n, k;
+  int32_t splits;    /* filled by ofa_gemm_group_plan */
+} ofa_gemm_group_item;
+/* host only: validates the items and fills `splits` (one K-slice length for the group: <= 256 workgroups in total) */
+int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype);
+int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dtype, void* stream);
+
 /* ---- the reference's fused softmax extensions, wave64 re-derivations.
  * x,y: [b, np, sq, sk]; softmax over sk of scale*x, fp32 accumulate.  sk <= 4096 (scaled_masked_softmax_cuda.cu:47-52). */
 int ofa_scaled_softmax_fwd(const void* x, void* y, float scale, int b, int np, int sq, int sk, int dtype, void* stream);

@@ -917,9 +917,11 @@ __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
 // which fragment read (0..nr-1, or -1) follows MFMA number t of a slice: one read behind each of the first nr MFMAs
 __host__ __device__ constexpr int big_read_after(int t, int nr) { return t < nr ? t : -1; }
 
-template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM = 2, int WGN = 2, bool F16 = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
-                                                                 float* __restrict__ ws) {
+// (t, ks, bz): output tile, K-slice and batch index of this workgroup; nsplit > 1 or to_ws: the raw fp32 tile goes to
+// slab ks of ws ([nsplit][M][(N+3)&~3] per batch) instead of C
+template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM, int WGN, bool F16>
+__device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, int tiles_n, int ksplit,
+                                              float* __restrict__ ws, int t, int ks, int bz, int nsplit, bool to_ws) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
   static_assert(BM <= 256 && BN <= 256, "operand stage is 256 rows");
   static_assert(A_KMAJ || BM == 256, "m-major tiles are 256 wide (swizzle)");
@@ -934,17 +936,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int ntiles = tiles_m * tiles_n;
   OFA_TL_BEGIN;
-  int t, ks;
-  tile_and_slice(ntiles, t, ks);
   constexpr int GM = 8;
   const int gsz = GM * tiles_n;
   const int gid = t / gsz, first_m = gid * GM;
   const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
   const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int bz = blockIdx.z;
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
@@ -1078,13 +1076,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
   __syncthreads();                                     // every wave is done with the fragment reads
   OFA_TL(2);
   {
-    const bool split = gridDim.y > 1;
+    const bool split = to_ws || nsplit > 1;
     constexpr int REGION = 4 * STAGE * 2 / (WGM * WGN);   // 32 KiB per wave (16 KiB with eight waves)
     unsigned char* wl = smem_raw + wave * REGION;
     const int m_w = m0 + wm * TM * 32, n_w = n0 + wn * TN * 32;
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
-      float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
+      float* wsb = ws + ((int64_t)bz * nsplit + ks) * g.M * n4;
       epilogue_lds<TM, TN, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
@@ -1093,6 +1091,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
     }
   }
   OFA_TL_END;
+}
+
+template <int TM, int TN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int WGM = 2, int WGN = 2, bool F16 = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
+                                                                 float* __restrict__ ws) {
+  int t, ks;
+  tile_and_slice(tiles_m * tiles_n, t, ks);
+  gemm_big_body<TM, TN, A_KMAJ, B_KMAJ, OUT_F32, WGM, WGN, F16>(g, tiles_m, tiles_n, ksplit, ws, t, ks, (int)blockIdx.z,
+                                                                (int)gridDim.y, false);
+}
+
+// Grouped weight-gradient products (ofa_gemm_group_tn): up to GROUP_MAX independent  slabs_p[s] = A_p^T B_p over K-slice s
+// in ONE launch of 256 x 256 eight-wave tiles.  A layer's weight gradients are each 9-36 such tiles: alone, a product has
+// to be cut into 3-7 K-slices of 128 x 128 tiles to occupy the chip (short K loops, per-tile overheads every ~30 K-steps,
+// a 3-7 slab reduce); together they fill the 256 CUs with ~2 slices each and K loops of ~100 steps.
+constexpr int GROUP_MAX = 8;
+struct GroupItem {
+  const void* A; const void* B; float* ws;
+  int64_t lda, ldb;
+  int M, N, K, ksplit, splits, tiles_m, tiles_n, first;   // first: index of the item's first workgroup
+};
+struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total; };
+
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
+  // XCD chunks over the flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2
+  const int id = xcd_remap((int)blockIdx.x, ga.total);
+  int p = 0;
+  for (int q = 1; q < ga.n; ++q)
+    if (id >= ga.it[q].first) p = q;
+  const GroupItem& it = ga.it[p];
+  GemmArgs g;
+  g.A = it.A; g.B = it.B; g.C = nullptr; g.bias = nullptr;
+  g.M = it.M; g.N = it.N; g.K = it.K; g.transA = 1; g.transB = 0;
+  g.lda = it.lda; g.ldb = it.ldb; g.ldc = 0; g.strideA = g.strideB = g.strideC = 0;
+  g.alpha = 1.f; g.flags = 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.b_krows = it.K;
+  const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
+  const int ks = local / ntiles, t = local - ks * ntiles;
+  gemm_big_body<4, 2, false, false, true, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, true);
 }
 
 template <bool OUT_F32, bool F16 = false>
@@ -1341,6 +1378,80 @@ extern "C" int ofa_gemm_splits(int M, int N, int K, int transA, int transB, int 
   g.M = M; g.N = N; g.K = K; g.transA = transA; g.transB = transB; g.flags = flags;
   g.lda = transA ? M : K; g.ldb = transB ? K : N; g.ldc = N;
   return gemm_mfma_splits(g, batch, ws_bytes);
+}
+
+// ---- grouped weight-gradient products
+static bool group_item_ok(const ofa_gemm_group_item& it) {
+  if (it.m <= 0 || it.n <= 0 || it.k <= 0 || !it.a || !it.b) return false;
+  if ((it.k % BK) || (it.m & 7) || (it.n & 7)) return false;          // whole LDS-DMA K tiles; 16-byte vectors along m and n
+  if (it.lda < it.m || it.ldb < it.n || (it.lda & 7) || (it.ldb & 7)) return false;
+  if (((uintptr_t)it.a & 15) || ((uintptr_t)it.b & 15)) return false;
+  return true;
+}
+
+// K-slice length shared by the group: the shortest (in K tiles) for which the whole group is at most one round of 256
+// workgroups; every product is then cut into ceil(k / length) slices, so workgroups of long and short contractions run
+// about equally long.  A slice keeps >= 4 K tiles.
+static void group_plan(ofa_gemm_group_item* items, int n) {
+  int kmax = 0;
+  for (int p = 0; p < n; ++p) kmax = items[p].k > kmax ? items[p].k : kmax;
+  int len = kmax;
+  for (int l = 4 * BK; l < kmax; l += BK) {
+    int64_t wgs = 0;
+    for (int p = 0; p < n; ++p) wgs += (int64_t)cdiv(items[p].m, 256) * cdiv(items[p].n, 256) * cdiv(items[p].k, l);
+    if (wgs <= 256) { len = l; break; }
+  }
+  for (int p = 0; p < n; ++p) {
+    int sp = cdiv(items[p].k, len);
+    sp = sp > 32 ? 32 : sp;
+    const int ksplit = cdiv(cdiv(items[p].k, BK), sp) * BK;
+    items[p].splits = cdiv(items[p].k, ksplit);
+  }
+}
+
+extern "C" int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype) {
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_INVALID, "gemm_group: 16-bit operands only (dtype %d)", dtype);
+  OFA_REQUIRE(items && n >= 1 && n <= GROUP_MAX, OFA_ERR_INVALID, "gemm_group: 1..%d products per launch (got %d)", GROUP_MAX, n);
+  for (int p = 0; p < n; ++p)
+    OFA_REQUIRE(group_item_ok(items[p]), OFA_ERR_INVALID,
+                "gemm_group: product %d (m=%d n=%d k=%d lda=%lld ldb=%lld) needs k %% 64 == 0, m, n, lda, ldb %% 8 == 0 and 16-byte aligned operands",
+                p, items[p].m, items[p].n, items[p].k, (long long)items[p].lda, (long long)items[p].ldb);
+  group_plan(items, n);
+  return 0;
+}
+
+extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_INVALID, "gemm_group: 16-bit operands only (dtype %d)", dtype);
+  OFA_REQUIRE(items && n >= 1 && n <= GROUP_MAX, OFA_ERR_INVALID, "gemm_group: 1..%d products per launch (got %d)", GROUP_MAX, n);
+  GroupArgs ga;
+  int first = 0;
+  for (int p = 0; p < n; ++p) {
+    const ofa_gemm_group_item& it = items[p];
+    OFA_REQUIRE(group_item_ok(it) && it.slabs && !((uintptr_t)it.slabs & 15), OFA_ERR_INVALID, "gemm_group: product %d is not eligible", p);
+    OFA_REQUIRE(it.splits >= 1 && it.splits <= 32, OFA_ERR_INVALID, "gemm_group: product %d: splits %d (run ofa_gemm_group_plan)", p, it.splits);
+    GroupItem& d = ga.it[p];
+    d.A = it.a; d.B = it.b; d.ws = it.slabs; d.lda = it.lda; d.ldb = it.ldb;
+    d.M = it.m; d.N = it.n; d.K = it.k;
+    d.ksplit = cdiv(cdiv(it.k, BK), it.splits) * BK;
+    d.splits = it.splits;
+    OFA_REQUIRE(cdiv(it.k, d.ksplit) == it.splits, OFA_ERR_INVALID, "gemm_group: product %d: %d slices leave an empty one", p, it.splits);
+    d.tiles_m = cdiv(it.m, 256); d.tiles_n = cdiv(it.n, 256);
+    d.first = first;
+    first += d.tiles_m * d.tiles_n * d.splits;
+  }
+  for (int p = n; p < GROUP_MAX; ++p) ga.it[p] = ga.it[0];
+  ga.n = n; ga.total = first;
+  const size_t lds = 4 * (size_t)256 * BK * sizeof(bf16_t);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_group_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_group_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F16) hipLaunchKernelGGL(gemm_group_tn_kernel<true>, dim3(ga.total), dim3(512), lds, st, ga);
+  else hipLaunchKernelGGL(gemm_group_tn_kernel<false>, dim3(ga.total), dim3(512), lds, st, ga);
+  return check_launch("gemm_group_tn");
 }
 
 extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA,

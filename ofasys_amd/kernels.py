@@ -208,6 +208,42 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
     return out
 
 
+class _GroupItem(ctypes.Structure):     # ofa_gemm_group_item
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("lda", ctypes.c_int64),
+                ("ldb", ctypes.c_int64), ("m", ctypes.c_int32), ("n", ctypes.c_int32), ("k", ctypes.c_int32),
+                ("splits", ctypes.c_int32)]
+
+
+GROUP_MAX = 8
+
+
+def gemm_group_ok(dy, x, out):
+    """Can out[M,N] (+)= dy[K,M]^T x[K,N] ride in a grouped launch (ofa_gemm_group_tn)?"""
+    return (dy.dim() == 2 and x.dim() == 2 and dy.dtype in (torch.bfloat16, torch.float16) and x.dtype == dy.dtype
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0] and dy.shape[0] % 64 == 0
+            and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.is_contiguous() and _prof is None)
+
+
+def gemm_group_tn(products, fold):
+    """products: [(dy [K,M], x [K,N], out [M,N], alpha)], each passing gemm_group_ok: out += alpha * dy^T x for all of them in
+    ONE launch of 256 x 256 tiles (fp32 K-slice slabs) + the FoldQueue's batched reduce (`fold`: the queue to register the
+    slabs with; the caller flushes it)."""
+    assert 1 <= len(products) <= GROUP_MAX
+    arr = (_GroupItem * len(products))()
+    for it, (dy, x, out, alpha) in zip(arr, products):
+        it.a, it.b, it.lda, it.ldb = dy.data_ptr(), x.data_ptr(), dy.stride(0), x.stride(0)
+        it.m, it.n, it.k = dy.shape[1], x.shape[1], dy.shape[0]
+    dt = dtype_code(products[0][0])
+    lib().call("ofa_gemm_group_plan", ctypes.addressof(arr), len(products), dt)
+    slabs = [torch.empty(it.splits * it.m * it.n, dtype=torch.float32, device=products[0][0].device) for it in arr]
+    for it, sl in zip(arr, slabs):
+        it.slabs = sl.data_ptr()
+    lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
+    for it, sl, (dy, x, out, alpha) in zip(arr, slabs, products):   # (registered after the launch: add() may flush the queue)
+        fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
+
+
 # ---- optional per-launch timing of the GEMM kernel family (bench.py roofline): HIP events on the launch stream
 _prof = None
 _PROF_REPS = 5

@@ -238,6 +238,8 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         if attn_mask is not None:
             attn_mask = attn_mask.masked_fill(attn_mask.to(torch.bool), -1e8 if x.dtype == torch.float32 else -1e4)
         join = self._joinable()
+        # (the earliest node of the layer: autograd runs it last, and it launches the layer's weight gradients as one group)
+        x = ops.wgrad_boundary(x)
         normed = chain.take() if chain is not None else None
         if normed is not None and self.normalize_before:
             residual, x = x, normed
@@ -339,6 +341,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 attn_mod._set_input_buffer(incremental_state, saved)
         join = self._joinable()
         cross = self.encoder_attn is not None and encoder_out is not None
+        x = ops.wgrad_boundary(x)                     # (see the encoder layer)
         normed = chain.take() if chain is not None else None
         if normed is not None and self.normalize_before:
             residual, x = x, normed

@@ -5,6 +5,7 @@ activation is a dense [rows, C] matrix in batch-major order ([B,T,C] storage); f
 boundary are transposed *views* of that storage, so no layout copies happen between ops.
 """
 import math
+import os
 
 import torch
 
@@ -119,6 +120,7 @@ def defer_reductions(flag):
 
 
 def flush_folds():
+    flush_wgrads()
     _Fold.queued = False
     if _Fold.queue is not None:
         _Fold.queue.flush()
@@ -134,6 +136,84 @@ def _fold():
         except RuntimeError:
             return None                             # not inside a backward pass: reduce immediately
     return q
+
+
+# Grouped weight gradients: the nn.Linear weight gradients of one Transformer layer (dW += dY^T X into the arena) are
+# collected while the layer's backward runs and launched together when its input gradient is produced (wgrad_boundary) --
+# one launch of 256 x 256 tiles with ~2 long K-slices per product instead of one launch of 3-7 short slices each
+# (kernels.gemm_group_tn).  The queue holds dY and X until then.
+class _Wgrads:
+    enabled = os.environ.get("OFA_WGRAD_GROUP", "1") != "0"
+    items = []           # (dy, x2d, out, alpha, weight)
+    queued = False       # an end-of-backward flush is registered with the autograd engine
+
+
+def _wgrad(dy, x2d, gw, alpha, *weights):
+    """gw += alpha * dy^T x2d (gw: the arena gradient of `weights` -- one weight, or several packed row-wise), then tell the
+    reducer."""
+    if _Wgrads.enabled and K.gemm_group_ok(dy, x2d, gw) and _flush_at_end_of_backward():
+        _Wgrads.items.append((dy, x2d, gw, float(alpha), weights))
+        if len(_Wgrads.items) == K.GROUP_MAX:
+            flush_wgrads()
+        return
+    K.gemm(dy, x2d, True, False, alpha=alpha, out=gw, accumulate=True, fold=_fold())
+    for w in weights:
+        _sink_done(w)
+
+
+def _flush_at_end_of_backward():
+    """Makes sure whatever is still queued when the running backward pass ends is launched; False outside a backward pass."""
+    if not _Wgrads.queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _Wgrads.queued = True
+        except RuntimeError:
+            return False
+    return True
+
+
+def _end_of_backward():
+    _Wgrads.queued = False
+    flush_wgrads()
+
+
+def flush_wgrads():
+    items, _Wgrads.items = _Wgrads.items, []
+    if not items:
+        return
+    if len(items) == 1:
+        dy, x2d, gw, alpha, _ = items[0]
+        K.gemm(dy, x2d, True, False, alpha=alpha, out=gw, accumulate=True, fold=_fold())
+    else:
+        fold = _fold()
+        q = fold if fold is not None else K.FoldQueue()
+        K.gemm_group_tn([it[:4] for it in items], q)
+        if fold is None:
+            q.flush()                                # gradients are consumed from inside backward (bucket all-reduces): reduce now
+        else:
+            q.flush_if_large()
+    for it in items:
+        for w in it[4]:
+            _sink_done(w)
+
+
+class _WgradBoundaryFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        flush_wgrads()
+        return dy
+
+
+def wgrad_boundary(x):
+    """Identity on a layer's input; in backward (when the layer's last gradient has been produced) the layer's queued weight
+    gradients are launched as one group."""
+    if _Wgrads.enabled and torch.is_grad_enabled() and x.requires_grad:
+        return _WgradBoundaryFn.apply(x)
+    return x
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
@@ -304,8 +384,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _sink(weight)
             if gw is not None:                                                       # dW += dY^T X, in the arena
-                K.gemm(dy, x2d, True, False, alpha=ctx.alpha, out=gw, accumulate=True, fold=_fold())
-                _sink_done(weight)
+                _wgrad(dy, x2d, gw, ctx.alpha, weight)
             else:
                 dw = K.gemm(dy, x2d, True, False, alpha=ctx.alpha)                   # dW = dY^T X
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -353,8 +432,7 @@ class LinearGeluLayerNormFn(torch.autograd.Function):
         gw = _sink(weight)
         dw = None
         if gw is not None:
-            K.gemm(dh, x2d, True, False, out=gw, accumulate=True, fold=_fold())
-            _sink_done(weight)
+            _wgrad(dh, x2d, gw, 1.0, weight)
         else:
             dw = K.gemm(dh, x2d, True, False)
         return dx, dw, dbias, dg, db, None
@@ -568,6 +646,15 @@ def _packed(ws, arena_view):
     return arena_view if arena_view is not None else torch.cat([w.reshape(w.shape[0], -1) if w.dim() > 1 else w for w in ws])
 
 
+def _packed_wgrads(ws, gview, dy2, x2):
+    """Weight gradients dy2^T x2 of row-wise packed weights `ws`: into their packed arena view (through the layer's grouped
+    launch) when there is one, else fresh slices for autograd."""
+    if gview is not None:
+        _wgrad(dy2, x2, gview, 1.0, *ws)
+        return [None] * len(ws)
+    return _packed_grads(ws, None, lambda o, acc, f: K.gemm(dy2, x2, True, False, out=o, accumulate=acc, fold=f))
+
+
 def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
     """Run `grad_packed_fn(out, accumulate)` into the packed arena gradient when there is one (and notify the sinks); otherwise compute a fresh packed gradient and return its per-parameter slices for autograd."""
     if gview is not None:
@@ -621,8 +708,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
                                            outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
-        gws = _packed_grads((wk, wv, wq), pack.get("gw"),
-                            lambda o, acc, f: K.gemm(d2, x2d, True, False, out=o, accumulate=acc, fold=f), (d2, x2d))
+        gws = _packed_wgrads((wk, wv, wq), pack.get("gw"), d2, x2d)
         gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
                             lambda o, acc, f: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype, fold=f), (d2,))
         dc = None
@@ -671,11 +757,10 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
-        gq = _packed_grads((wq,), _sink(wq), lambda o, acc, f: K.gemm(dq2, xq2, True, False, out=o, accumulate=acc, fold=f), (dq2, xq2))
+        gq = _packed_wgrads((wq,), _sink(wq), dq2, xq2)
         gbq = _packed_grads((bq,), _sink(bq), lambda o, acc, f: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype, fold=f),
                             (dq2,))
-        gws = _packed_grads((wk, wv), pack.get("gw"),
-                            lambda o, acc, f: K.gemm(dkv2, xkv2, True, False, out=o, accumulate=acc, fold=f), (dkv2, xkv2))
+        gws = _packed_wgrads((wk, wv), pack.get("gw"), dkv2, xkv2)
         gbs = _packed_grads((bk, bv), pack.get("gb"),
                             lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
         dc = None

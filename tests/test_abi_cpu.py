@@ -33,6 +33,33 @@ def test_host_only_entry_points():
     assert h.cdll.ofa_layernorm_bwd_ws_rows() > 0
 
 
+def test_gemm_group_plan_is_host_only():
+    """ofa_gemm_group_plan: one K-slice length for the group, at most 256 workgroups of 256 x 256 tiles in total."""
+    import ctypes as C
+    from ofasys_amd import kernels as K
+    h = L.lib()
+
+    def plan(shapes, dt=L.BF16):
+        arr = (K._GroupItem * len(shapes))()
+        for it, (m, n, k) in zip(arr, shapes):
+            it.a, it.b, it.lda, it.ldb, it.m, it.n, it.k = 4096, 8192, m, n, m, n, k
+        h.call("ofa_gemm_group_plan", C.addressof(arr), len(shapes), dt)
+        return [it.splits for it in arr]
+
+    assert plan([(768, 3072, 13312), (3072, 768, 13312), (2304, 768, 13312), (768, 768, 13312)]) == [2, 2, 2, 2]
+    sp = plan([(2304, 768, 3072), (768, 768, 3072), (1536, 768, 13312), (768, 3072, 3072), (3072, 768, 3072)])
+    tiles = [27, 9, 18, 36, 36]
+    assert sum(t * s for t, s in zip(tiles, sp)) <= 256 and sp[2] > sp[0] >= 1        # the long contraction gets more slices
+    assert plan([(256, 256, 64)]) == [1]
+    assert plan([(4096, 4096, 1024), (4096, 4096, 512)]) == [1, 1]                     # more than one round already: no slicing
+    with pytest.raises(L.OfaError, match="gemm_group"):
+        plan([(768, 768, 100)])                                                        # k % 64
+    with pytest.raises(L.OfaError, match="gemm_group"):
+        plan([(768, 768, 128)], L.F32)
+    with pytest.raises(L.OfaError, match="gemm_group"):
+        plan([(256, 256, 64)] * 9)
+
+
 def test_status_codes_not_asserts():
     h = L.lib()
     # argument validation happens before any launch, so it is observable without a GPU

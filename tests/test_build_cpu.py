@@ -40,6 +40,7 @@ def _kernel_meta(src, tmp_path):
     ("attention.hip", r"attn_bwd_dq(_f16)?_lds_kernel", 4),
     ("gemm_mfma.hip", r"gemm_mfma_kernelILi2ELi2ELb[01]ELb[01]ELb0ELb1E", 0),   # 128x128 LDS-DMA kernels, bf16 out
     ("gemm_mfma.hip", r"gemm_ring_kernelILi[12]ELi[12]ELb[01]ELb[01]ELb0E", 0),  # 4-stage ring kernels, bf16 out
+    ("gemm_mfma.hip", r"gemm_group_tn_kernel", 0),                               # grouped weight gradients (256 accumulator registers live)
 ])
 def test_hot_kernels_do_not_spill(tmp_path, src, pattern, max_spill):
     meta = _kernel_meta(src, tmp_path)

@@ -152,6 +152,40 @@ def test_gemm(K, dtype, M, N, K_, ta, tb):
         assert rel(acc, ref2) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shapes", [
+    [(768, 3072, 1024), (3072, 768, 1024), (2304, 768, 1024), (768, 768, 1024)],          # one encoder layer's four products
+    [(768, 768, 512), (1536, 768, 2048), (200, 776, 512), (8, 8, 64), (264, 256, 1088)],   # unequal K, ragged M / N, a tiny one
+    [(256, 256, 64)] * 8,                                                                  # the most one launch takes
+])
+def test_gemm_group_tn(K, dtype, shapes):
+    """ofa_gemm_group_tn + ofa_fold_batched: out_p += alpha_p * dy_p^T x_p for a group of weight-gradient products, against fp32
+    matmuls of the same 16-bit data (K-slices are fp32 partial sums: summation order is the only difference)."""
+    torch.manual_seed(5)
+    prods, refs = [], []
+    for i, (M, N, Kk) in enumerate(shapes):
+        dy = torch.randn(Kk, M + 8 * (i % 2), device=DEV).to(dtype)[:, :M]      # every other operand with lda > m
+        x = torch.randn(Kk, N, device=DEV).to(dtype)
+        out = torch.randn(M, N, device=DEV)
+        alpha = 0.5 + 0.25 * i
+        refs.append(out + alpha * (dy.float().t() @ x.float()))
+        assert K.gemm_group_ok(dy, x, out)
+        prods.append((dy, x, out, alpha))
+    q = K.FoldQueue()
+    K.gemm_group_tn(prods, q)
+    q.flush()
+    for (dy, x, out, alpha), ref in zip(prods, refs):
+        assert rel(out, ref) < 2e-5 * max(1.0, math.sqrt(dy.shape[0] / 64)), (tuple(out.shape), rel(out, ref))
+    # the same group again lands on top (accumulate): twice the product
+    K.gemm_group_tn(prods, q)
+    q.flush()
+    dy, x, out, alpha = prods[0]
+    assert rel(out, refs[0] + alpha * (dy.float().t() @ x.float())) < 1e-4
+    # not eligible: ragged contraction, fp32 operands
+    assert not K.gemm_group_ok(dy[:40], x[:40], out)
+    assert not K.gemm_group_ok(dy.float(), x.float(), out)
+
+
 def test_gemm_splitk_and_batched(K):
     torch.manual_seed(2)
     # wgrad shape: skinny output, long contraction -> split-K path

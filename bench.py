@@ -399,7 +399,8 @@ def main():
                          "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
                          "how": f"instrumented eager step(s) right after the timed region: every MFMA-GEMM call of the step "
                                 f"is re-launched {prof['reps']}x back to back between two HIP events on its launch stream "
-                                f"(duration = elapsed/{prof['reps']}; includes the split-K reduce kernel where one is used)"})
+                                f"(duration = elapsed/{prof['reps']}; includes the split-K reduce kernel where one is used; a layer's grouped "
+                                f"weight-gradient launch counts as one launch, timed with the fold of its K-slice slabs)"})
         else:
             roof.update({"achieved": step_tflops, "frac": step_tflops / PEAK_BF16_TFLOPS})
         out = {

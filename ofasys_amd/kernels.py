@@ -222,7 +222,7 @@ def gemm_group_ok(dy, x, out):
     return (dy.dim() == 2 and x.dim() == 2 and dy.dtype in (torch.bfloat16, torch.float16) and x.dtype == dy.dtype
             and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0] and dy.shape[0] % 64 == 0
             and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
-            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.is_contiguous() and _prof is None)
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.is_contiguous())
 
 
 def gemm_group_tn(products, fold):
@@ -240,6 +240,23 @@ def gemm_group_tn(products, fold):
     for it, sl in zip(arr, slabs):
         it.slabs = sl.data_ptr()
     lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
+    if _prof is not None:
+        # roofline timing (see gemm): the launch again, back to back, each time with the reduce of its slabs (into scratch
+        # outputs) -- the other products' timings include their split-K reduce too
+        scratch = [torch.empty_like(out) for (_, _, out, _) in products]
+        jobs = (_FoldJob * len(products))(*[
+            _FoldJob(sl.data_ptr(), sc.data_ptr(), it.m * it.n, it.m * it.n, it.splits, 0, 1.0, dtype_code(sc))
+            for it, sl, sc in zip(arr, slabs, scratch)])
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(_PROF_REPS):
+            lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
+            lib().call("ofa_fold_batched", ctypes.addressof(jobs), len(products), stream())
+        e1.record()
+        es = products[0][0].element_size()
+        _prof.append((sum(2.0 * it.m * it.n * it.k for it in arr), e0, e1,
+                      sum((it.m + it.n) * it.k * es + it.splits * it.m * it.n * 4 for it in arr)))
     for it, sl, (dy, x, out, alpha) in zip(arr, slabs, products):   # (registered after the launch: add() may flush the queue)
         fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
 

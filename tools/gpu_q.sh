@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.log; tail -c 1500 gpurun_out/bench_final.json
+timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "rc=$?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -5

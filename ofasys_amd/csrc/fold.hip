@@ -109,9 +109,16 @@ __global__ __launch_bounds__(256) void fold_batched_kernel(FoldJobs J) {
         t[2] = (((t[2] + v0.z) + v1.z) + v2.z) + v3.z;
         t[3] = (((t[3] + v0.w) + v1.w) + v2.w) + v3.w;
       }
-      for (; s < ns; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
-        t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
+      // the 1..3 remaining slots (ALL of them for the 2-3 K-slice slabs of a grouped weight-gradient launch): loads issued
+      // together (clamped to the last slot, dropped when beyond it), additions in slot order
+      if (s < ns) {
+        const int rem = ns - s;
+        const float4 v0 = *reinterpret_cast<const float4*>(r + (int64_t)s * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(r + (int64_t)(rem > 1 ? s + 1 : s) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(r + (int64_t)(rem > 2 ? s + 2 : s) * stride);
+        t[0] += v0.x; t[1] += v0.y; t[2] += v0.z; t[3] += v0.w;
+        if (rem > 1) { t[0] += v1.x; t[1] += v1.y; t[2] += v1.z; t[3] += v1.w; }
+        if (rem > 2) { t[0] += v2.x; t[1] += v2.y; t[2] += v2.z; t[3] += v2.w; }
       }
     } else {
       for (int s = 0; s < ns; ++s)

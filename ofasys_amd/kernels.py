@@ -4,6 +4,7 @@ Each wrapper allocates outputs with torch (plumbing: device memory + streams), c
 kernel on torch's current stream.  Everything here requires GPU tensors; nothing falls back to torch math.
 """
 import ctypes
+import os
 
 import torch
 
@@ -41,10 +42,10 @@ class FoldQueue:
 
     # partial rows are folded while they still sit in the 256 MiB Infinity Cache: deferring a whole backward pass worth
     # of split-K slabs (3.6 GB on cfg-2) sends them to HBM and back and costs more than the saved launches
-    MAX_PENDING_BYTES = 96 << 20
+    MAX_PENDING_BYTES = 48 << 20        # (one layer's grouped weight-gradient slabs: 12.20 ms/step; 96 MiB 12.25, 200 MiB 12.35, 16 MiB 12.29)
 
     def __init__(self):
-        self.jobs, self.keep, self.bytes, self.outs = [], [], 0, set()
+        self.jobs, self.keep, self.bytes, self.outs, self.want_flush = [], [], 0, set(), False
 
     def add(self, part, part_off, out, cols, stride, nslots, alpha=1.0, accumulate=True, flush_ok=True):
         assert part.dtype == torch.float32 and out.is_contiguous()

@@ -119,6 +119,14 @@ def defer_reductions(flag):
         _Fold.queue = None
 
 
+def drop_pending():
+    """Forget queued weight gradients and folds without launching them: the start of a step, so that what a backward pass that
+    raised left behind is not added to the next step's gradients."""
+    _Wgrads.items, _Wgrads.queued, _Fold.queued = [], False, False
+    if _Fold.queue is not None:
+        _Fold.queue.__init__()
+
+
 def flush_folds():
     flush_wgrads()
     _Fold.queued = False

@@ -247,6 +247,7 @@ class TrainStep:
     def _fwd_bwd(self, samples, overlap_reduce, structure=None):
         model = self.model
         model.train()
+        ops.drop_pending()
         self.fp.zero_grad()
         self._stats.zero_()
         self.reducer.overlap = overlap_reduce

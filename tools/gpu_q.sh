@@ -1,3 +1,3 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "rc=$?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -5
+R=$GRAFT_REPO_ROOT; cd $R
+for mb in 96 40 16 200; do echo "== pending $mb MB"; OFA_FOLD_PENDING_MB=$mb timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-gemm 0 2>&1 | tail -1 | cut -c80-200; done

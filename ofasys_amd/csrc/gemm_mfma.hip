@@ -978,6 +978,13 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
   faw.init(lds0 + 2 * STAGE * 2, wn * TN * 32, lane);
 
   u64x2 xa[2][TM], wb[2][TN];
+#ifndef OFA_BIG_RPG_TN
+#define OFA_BIG_RPG_TN 1
+#endif
+  // fragment reads woven behind each MFMA.  For the all-m-major (weight-gradient) form, whose fragments are two transposing
+  // reads each, issuing them earlier (2 or 3 fragments per gap) is slower: 216 / 221 / 230 us for the encoder layer's group
+  // (tools/gemm_group_bench.py) -- the LDS pipe wants them spread out
+  constexpr int RPG = (!A_KMAJ && !B_KMAJ) ? OFA_BIG_RPG_TN : 1;
 #define BIG_ISSUE(KK, SET)                                                                                        \
   static_for<0, TM>([&](auto ic) { big_frag<BM, A_KMAJ, KK, decltype(ic)::value, 0>(xa[SET][decltype(ic)::value], fax); }); \
   static_for<0, TN>([&](auto ic) { big_frag<BN, B_KMAJ, KK, decltype(ic)::value, 0>(wb[SET][decltype(ic)::value], faw); })
@@ -1001,9 +1008,11 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
   static_for<0, TM * TN>([&](auto tc) {                                                                             \
     constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;                                                  \
     acc[i][j] = mfma16<F16>(wb[SET][j], xa[SET][i], acc[i][j]); \
-    constexpr int r = big_read_after(t, TM + TN);                                                                   \
-    if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, KKN, (r < TM ? r : 0), 0>(xa[1 - (SET)][r < TM ? r : 0], fax); \
-    if constexpr (r >= TM) big_frag<BN, B_KMAJ, KKN, (r >= TM ? r - TM : 0), 0>(wb[1 - (SET)][r >= TM ? r - TM : 0], faw); \
+    static_for<0, RPG>([&](auto qc) {                                                                               \
+      constexpr int r = big_read_after(t * RPG + decltype(qc)::value, TM + TN);                                     \
+      if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, KKN, (r < TM ? r : 0), 0>(xa[1 - (SET)][r < TM ? r : 0], fax); \
+      if constexpr (r >= TM) big_frag<BN, B_KMAJ, KKN, (r >= TM ? r - TM : 0), 0>(wb[1 - (SET)][r >= TM ? r - TM : 0], faw); \
+    });                                                                                                             \
     BIG_SB;                                                                                                         \
   })
   if (nk > 0) {
@@ -1044,9 +1053,11 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
       static_for<0, TM * TN>([&](auto tc) {
         constexpr int t = decltype(tc)::value, i = t / TN, j = t % TN;
         acc[i][j] = mfma16<F16>(wb[1][j], xa[1][i], acc[i][j]);
-        constexpr int r = big_read_after(t, TM + TN);
-        if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, 0, (r < TM ? r : 0), 0>(xa[0][r < TM ? r : 0], fax);
-        if constexpr (r >= TM) big_frag<BN, B_KMAJ, 0, (r >= TM ? r - TM : 0), 0>(wb[0][r >= TM ? r - TM : 0], faw);
+        static_for<0, RPG>([&](auto qc) {
+          constexpr int r = big_read_after(t * RPG + decltype(qc)::value, TM + TN);
+          if constexpr (r >= 0 && r < TM) big_frag<BM, A_KMAJ, 0, (r < TM ? r : 0), 0>(xa[0][r < TM ? r : 0], fax);
+          if constexpr (r >= TM) big_frag<BN, B_KMAJ, 0, (r >= TM ? r - TM : 0), 0>(wb[0][r >= TM ? r - TM : 0], faw);
+        });
         if (more2) {
           constexpr int NP = NVA + NVB, NM = TM * TN;
           static_for<t * NP / NM, (t + 1) * NP / NM>([&](auto pc) {

@@ -1,3 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for mb in 96 40 16 200; do echo "== pending $mb MB"; OFA_FOLD_PENDING_MB=$mb timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-gemm 0 2>&1 | tail -1 | cut -c80-200; done
+for v in "" rpg2 rpg3; do
+  if [ -z "$v" ]; then echo "== product (1 read per gap)"; unset OFASYS_AMD_LIB; else echo "== $v"; export OFASYS_AMD_LIB=$R/tools/experiments/_build/libofasys_amd_$v.so; fi
+  timeout 300 python tools/gemm_group_bench.py 2>&1 | tail -2
+done

@@ -1160,8 +1160,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
         gw = _sink(weight) if direct else None
         if gw is not None:                                                        # 1x1 convolution: dW += dY^T X straight into the arena,
-            K.gemm(dy, col, True, False, out=gw.view(Cout, Cin), accumulate=True, fold=_fold())   # split-K slabs folded in the batch
-            _sink_done(weight)
+            _wgrad(dy, col, gw.view(Cout, Cin), 1.0, weight)                      # in groups of up to 8 products (flush_wgrads)
             dw = None
         else:
             dw2 = K.gemm(dy, col, True, False)                                    # [Cout, Kpad]

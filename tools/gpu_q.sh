@@ -1,6 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for v in "" rpg2 rpg3; do
-  if [ -z "$v" ]; then echo "== product (1 read per gap)"; unset OFASYS_AMD_LIB; else echo "== $v"; export OFASYS_AMD_LIB=$R/tools/experiments/_build/libofasys_amd_$v.so; fi
-  timeout 300 python tools/gemm_group_bench.py 2>&1 | tail -2
-done
+timeout 900 python -m pytest tests/test_model_gpu.py tests/test_configs_gpu.py -x -q -m gpu -k "resnet or video or cfg4 or cfg3" 2>&1 | tail -2
+echo "== cfg2b grouped"; timeout 600 python bench.py --workload cfg2b --steps 20 --warmup 5 --no-cpu-baseline --profile-gemm 0 2>&1 | tail -1 | cut -c80-200
+echo "== cfg2b ungrouped"; OFA_WGRAD_GROUP=0 timeout 600 python bench.py --workload cfg2b --steps 20 --warmup 5 --no-cpu-baseline --profile-gemm 0 2>&1 | tail -1 | cut -c80-200

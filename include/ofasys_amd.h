@@ -171,7 +171,10 @@ int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, 
                  int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k,
                  int dtype, void* stream);
 /* Backward.  lse: fp32 [B*heads, Tpad] as written by ofa_attn_fwd (base-2 log-sum-exp of the scaled, biased, masked
- * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O) from ofa_attn_bwd_prep; dout: [B,T,heads*64] rows (ld = ldo).
+ * scores); delta: fp32 [B*heads, Tpad] = rowsum(dO*O); dout: [B,T,heads*64] rows (ld = ldo).
+ * out != NULL (the forward output O, rows like dout): the dQ kernel computes delta from dO and O on its way in and WRITES it
+ * (rows t < T; in ragged mode also zeros in the filler rows) -- for the dK/dV kernel and ofa_c_attn_grad; no separate pass.
+ * out == NULL: delta is an input, filled by ofa_attn_bwd_prep beforehand.
  * Writes dq [B,T,D] (ld = ldq), dk, dv [B,S,D] (ld = ldk); dbias (optional, [B*heads,T,S]) receives dS.
  * No transposed operand copies are needed: the kernels transpose tiles on the LDS read (ds_read_b64_tr_b16).
  * seg != NULL: ragged mode as in ofa_attn_fwd (delta from ofa_attn_bwd_prep(B = 1, T = rows_q): [heads, Tpad] by packed row;
@@ -179,9 +182,9 @@ int ofa_attn_fwd(const void* q, const void* k, const void* v, const void* bias, 
 int ofa_attn_bwd_prep(const void* dout, const void* out, float* delta, int B, int heads, int T, int Tpad, int64_t ldo,
                       int dtype, void* stream);
 int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
-                 const void* c_attn, int c_attn_dtype, const float* lse, const float* delta, void* dq, void* dk, void* dv,
-                 void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
-                 int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
+                 const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out, void* dq, void* dk,
+                 void* dv, void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo,
+                 float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */

@@ -45,7 +45,7 @@ constexpr int TILE_BYTES = 32 * HD * 2;   // 4 KiB: 32 rows x 64 bf16
 
 struct AttnL {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dout; const bf16_t* bias; const uint8_t* kpm;
-  const void* c_attn; int c_dt; bf16_t* out; float* lse; const float* delta;   // c_attn: [heads] in the dtype code c_dt
+  const void* c_attn; int c_dt; bf16_t* out; float* lse; float* delta;   // c_attn: [heads] in the dtype code c_dt
   bf16_t* dq; bf16_t* dk; bf16_t* dv; bf16_t* dbias;
   int B, heads, T, S, Tpad;
   int64_t ldq, ldk, ldo;
@@ -59,7 +59,7 @@ struct AttnL {
 // downstream, where 0 * NaN would poison the weight gradients -- so the workgroups of ONE extra grid column zero them: 64
 // columns (head h) of rows [off + len, next_off) of up to two outputs.  Replaces a memset of the whole output per call.
 __device__ __forceinline__ void seg_zero_fill(const int* seg, int B, int b, int h, bool k_side, int rows, bf16_t* o1, int64_t ld1,
-                                              bf16_t* o2, int64_t ld2, int tid) {
+                                              bf16_t* o2, int64_t ld2, int tid, float* stat_h = nullptr) {
   const int4 s = reinterpret_cast<const int4*>(seg)[b];
   const int lo = k_side ? s.z + s.w : s.x + s.y;
   int hi = rows;
@@ -72,6 +72,11 @@ __device__ __forceinline__ void seg_zero_fill(const int* seg, int B, int b, int 
     const int r = lo + (i >> 3), c = (i & 7) * 8;
     if (o1) *reinterpret_cast<uint4*>(o1 + (int64_t)r * ld1 + h * HD + c) = z;
     if (o2) *reinterpret_cast<uint4*>(o2 + (int64_t)r * ld2 + h * HD + c) = z;
+  }
+  if (stat_h) {                                                     // a per-row fp32 statistic of head h (delta): same filler rows
+    for (int r = lo + tid; r < hi; r += 256) stat_h[r] = 0.f;
+    if (b == 0)
+      for (int r = tid; r < (k_side ? s.z : s.x); r += 256) stat_h[r] = 0.f;
   }
   if (b == 0) {                                                     // rows in front of the first segment (normally none)
     const int first = k_side ? s.z : s.x;
@@ -637,7 +642,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
   if (a.seg && blockIdx.x == gridDim.x - 1) {
-    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, nullptr, 0, tid);
+    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, nullptr, 0, tid, a.out ? a.delta + (int64_t)h * a.Tpad : nullptr);
     return;
   }
   if (!seg_enter(a, b, bh, h, qb0, true)) return;
@@ -653,7 +658,26 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     dof[kk] = ld16(dop + kk * 16);
   }
   const float lse_q = a.lse[(int64_t)bh * a.Tpad + qrow];
-  const float delta_q = a.delta[(int64_t)bh * a.Tpad + qrow];
+  float delta_q;
+  if (a.out) {
+    // delta = rowsum(dO * O) of this lane's query row, from the dO fragments already in registers and the matching 32 values
+    // of O (the other 32 live in the partner lane); written out for the dK/dV kernel and the c_attn gradient
+    const bf16_t* outp = a.out + ((int64_t)b * a.T + qrow) * a.ldo + h * HD + hi * 8;
+    float sdo = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 of = ld16(outp + kk * 16);
+      const uint4 ow = __builtin_bit_cast(uint4, of), dw = __builtin_bit_cast(uint4, dof[kk]);
+      sdo += lo16<F16>(ow.x) * lo16<F16>(dw.x) + hi16<F16>(ow.x) * hi16<F16>(dw.x);
+      sdo += lo16<F16>(ow.y) * lo16<F16>(dw.y) + hi16<F16>(ow.y) * hi16<F16>(dw.y);
+      sdo += lo16<F16>(ow.z) * lo16<F16>(dw.z) + hi16<F16>(ow.z) * hi16<F16>(dw.z);
+      sdo += lo16<F16>(ow.w) * lo16<F16>(dw.w) + hi16<F16>(ow.w) * hi16<F16>(dw.w);
+    }
+    delta_q = xhalf_sum(sdo);
+    if (hi == 0 && qi < a.T) a.delta[(int64_t)bh * a.Tpad + qi] = delta_q;
+  } else {
+    delta_q = a.delta[(int64_t)bh * a.Tpad + qrow];
+  }
   const float c = head_scale(a, h);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
@@ -976,8 +1000,8 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
 }
 
 extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
-                            const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, const float* delta,
-                            void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
+                            const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                            const void* out, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
                             int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
                             int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
@@ -988,6 +1012,7 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
   a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.out = (bf16_t*)const_cast<void*>(out);   // != NULL: the dQ kernel computes delta itself (and writes it)
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   a.rows_q = rows_q; a.rows_k = rows_k;

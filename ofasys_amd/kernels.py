@@ -461,8 +461,7 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     B, T, D = q.shape
     S = k.shape[1]
     Tpad = pad32(T)
-    delta = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
-    lib().call("ofa_attn_bwd_prep", ptr(dout), ptr(out), ptr(delta), B, heads, T, Tpad, ldo, dtype_code(q), stream())
+    delta = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)   # rowsum(dO*O): written by the dQ kernel
     dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if need_dbias else None
     if bias is not None:
         bias = bias.contiguous()
@@ -485,11 +484,11 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
         lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
-                   ptr(delta), ptr(dq), ptr(dk), ptr(dv), None, seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo,
+                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), None, seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo,
                    float(scale), int(causal), ptr(seg.table), T, S, dtype_code(q), stream())
         return dq, dk, dv, None, delta
     lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
-               ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
+               ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
                int(causal), None, 0, 0, dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
 

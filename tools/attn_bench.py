@@ -23,7 +23,7 @@ for (B, A, T, S, causal) in [(32, 12, 448, 448, False), (32, 12, 64, 64, True), 
     from ofasys_amd.lib import lib, ptr, stream
     def bwd():
         lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, ptr(kpm.view(torch.uint8)),
-                   ptr(c), 0, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), None, B, A, T, S, Tp, D, D, D, 0.125, int(causal), None, 0, 0, 1, stream())
+                   ptr(c), 0, ptr(lse), ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), None, B, A, T, S, Tp, D, D, D, 0.125, int(causal), None, 0, 0, 1, stream())
     tb = bench(bwd)
     fl = 4.0 * B * A * T * S * 64 * (0.5 if causal else 1)
     print(f"B{B} A{A} T{T} S{S} causal={causal}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF | bwd(dq+dkv) {tb:7.1f} us {2.5*fl/tb/1e6:6.1f} TF")

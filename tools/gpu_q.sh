@@ -1,7 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/q; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/r2b -o p -- python $R/bench.py --workload cfg2b --steps 6 --warmup 2 --no-cpu-baseline --profile-gemm 0 > $O/stats2b_run.log 2>&1
-grep -c . $O/stats2b_run.log; tail -1 $O/stats2b_run.log | cut -c1-200
-python $R/tools/prof_summary.py /tmp/r2b/p_results.db 20 60 > $O/cfg2b_kernel_stats.txt 2>&1
-head -50 $O/cfg2b_kernel_stats.txt | cut -c1-160
+R=$GRAFT_REPO_ROOT; cd $R
+timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_fp16_gpu.py tests/test_packing_gpu.py -x -q -m gpu -k "attn or attention or pack or ragged or c_attn" > gpurun_out/attn_tests.log 2>&1; grep -E "passed|failed" gpurun_out/attn_tests.log | tail -2; grep -E "^FAILED|Error" gpurun_out/attn_tests.log | head -5
+timeout 300 python tools/attn_bench.py 2>&1 | tail -4
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-gemm 0 2>&1 | tail -1 | cut -c80-200

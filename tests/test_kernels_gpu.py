@@ -367,6 +367,21 @@ def test_fused_attention(K, B, heads, T, S, causal, use_bias, use_kpm):
     # dc_attn[h] = sum(delta[:, h, :T]) / c[h]
     dc = delta.view(B, heads, -1)[:, :, :T].sum((0, 2)) / c
     assert rel(dc, cr.grad) < 3e-2
+    # delta = rowsum(dO * O): written by the dQ kernel; the two-call form (ofa_attn_bwd_prep, then ofa_attn_bwd with out == NULL)
+    # gives the same rows and the same gradients
+    want = (dout.float() * out.float()).view(B, T, heads, 64).sum(-1).permute(0, 2, 1)
+    assert rel(delta.view(B, heads, -1)[:, :, :T], want) < 1e-5
+    if not use_bias:
+        from ofasys_amd.lib import lib, ptr, stream
+        Tp = K.pad32(T)
+        d2 = torch.empty(B * heads, Tp, device=DEV)
+        lib().call("ofa_attn_bwd_prep", ptr(dout), ptr(out), ptr(d2), B, heads, T, Tp, D, 1, stream())
+        assert rel(d2.view(B, heads, -1)[:, :, :T], want) < 1e-5
+        dq2, dk2, dv2 = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, ptr(kpm.view(torch.uint8)) if use_kpm else None, ptr(c), 0,
+                   ptr(lse), ptr(d2), None, ptr(dq2), ptr(dk2), ptr(dv2), None, B, heads, T, S, Tp, D, D, D, scale, int(causal), None, 0,
+                   0, 1, stream())
+        assert rel(dq2, dq) < 1e-3 and rel(dk2, dk) < 1e-3 and rel(dv2, dv) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

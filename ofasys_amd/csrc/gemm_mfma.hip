@@ -1211,11 +1211,9 @@ static void launch_ring(const GemmArgs& g, int batch, int splits, int ksplit, fl
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-// small grids take the 4-stage ring (see gemm_ring_kernel); OFA_GEMM_RING=0 disables, =2 forces it wherever legal
+// small grids take the 4-stage ring (see gemm_ring_kernel)
 static bool use_ring(const GemmArgs& g, int wm, int wn, int64_t blocks, int ksplit) {
-  static const int mode = getenv("OFA_GEMM_RING") ? atoi(getenv("OFA_GEMM_RING")) : 1;
-  if (mode == 0 || (g.K % BK) != 0 || (ksplit % BK) != 0 || (g.flags & OFA_GEMM_NO_LDS_DMA)) return false;
-  if (mode == 2) return true;
+  if ((g.K % BK) != 0 || (ksplit % BK) != 0 || (g.flags & OFA_GEMM_NO_LDS_DMA)) return false;
   const int64_t cap = (wm == 1 && wn == 1) ? 512 : 256;              // 64 KiB of LDS: two per CU; 96 / 128 KiB: one
   return blocks <= cap && ksplit >= 4 * BK;
 }
@@ -1278,12 +1276,11 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   const int64_t t11 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) * batch;
   int maxs = has_ws ? g.K / 256 : 1;                 // every split keeps >= 4 K-tiles
   maxs = maxs < 1 ? 1 : (maxs > 32 ? 32 : maxs);
-  static const int64_t want_env = getenv("OFA_GEMM_WANT") ? atoi(getenv("OFA_GEMM_WANT")) : 0;     // experiments
   // short contractions are not split: at K = 768 a split saves a few K-steps but costs a second (reduce) launch --
   // 2048 x 2304 x 768: 28.9 us split in two + reduce vs 16.2 us unsplit; from K = 2304 up the split wins (21.5 vs 24.7 us)
-  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 1024;
+  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 1024;   // (tools/gemm_timeline.py)
   if (g.K < split_min_k) maxs = 1;
-  const int64_t want = want_env ? want_env : 384;
+  const int64_t want = 384;
   int wm, wn;
   int64_t tiles;
   if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }

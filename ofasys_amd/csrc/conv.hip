@@ -107,11 +107,14 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, double* __restrict__ partial,
-                                                         int64_t rows, int C, int relu) {
+                                                         int64_t rows, int C, int relu, int cw_log2) {
   constexpr int N = Vec<T>::N;
-  __shared__ double red[2][8][32][N];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = (blockIdx.x * 32 + cx) * N;
+  // a block is cw column vectors (32, or C/N when the layer is narrower: 64 channels are 8 bf16 vectors -- with a fixed
+  // 32 x 8 shape three quarters of the threads of those layers had no column) x 256/cw row lanes
+  __shared__ double red[2][256][N];
+  const int cw = 1 << cw_log2, rl = 256 >> cw_log2;
+  const int cx = threadIdx.x & (cw - 1), ry = threadIdx.x >> cw_log2;
+  const int c = (blockIdx.x * cw + cx) * N;
   // double accumulators: BatchNorm over few values per channel (B*h*w = 32 on a 64x64 image) makes the backward chain
   // ill-conditioned; fp64 VALU is full rate on this part and the kernel is HBM-bound anyway
   double s0[N], s1[N];
@@ -123,35 +126,59 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
 #pragma unroll
       for (int j = 0; j < N; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
     }
-    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < rows; r += (int64_t)gridDim.y * 8) {
-      float a[N], b[N];
-      load_vec<T>(x + r * C + c, b);
+    const int64_t step = (int64_t)gridDim.y * rl;
+    auto add = [&](const float (&a)[N], const float (&b)[N], const float (&yy)[N]) {
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < N; ++j) { s0[j] += (double)b[j]; s1[j] += (double)b[j] * (double)b[j]; }
       } else {
-        load_vec<T>(dy + r * C + c, a);
-        if (relu) {
-          float yy[N];
-          load_vec<T>(y + r * C + c, yy);
 #pragma unroll
-          for (int j = 0; j < N; ++j) a[j] = yy[j] > 0.f ? a[j] : 0.f;
+        for (int j = 0; j < N; ++j) {
+          const float g = (relu && !(yy[j] > 0.f)) ? 0.f : a[j];
+          s0[j] += (double)g;
+          s1[j] += (double)g * (double)((b[j] - mu[j]) * rs[j]);
         }
-#pragma unroll
-        for (int j = 0; j < N; ++j) { s0[j] += (double)a[j]; s1[j] += (double)a[j] * (double)((b[j] - mu[j]) * rs[j]); }
       }
+    };
+    int64_t r = (int64_t)blockIdx.y * rl + ry;
+    for (; r + step < rows; r += 2 * step) {            // two rows per trip: every load of both is in flight before the adds
+      float a0[N], b0[N], y0[N], a1[N], b1[N], y1[N];
+      load_vec<T>(x + r * C + c, b0);
+      load_vec<T>(x + (r + step) * C + c, b1);
+      if (MODE == 1) {
+        load_vec<T>(dy + r * C + c, a0);
+        load_vec<T>(dy + (r + step) * C + c, a1);
+        if (relu) {
+          load_vec<T>(y + r * C + c, y0);
+          load_vec<T>(y + (r + step) * C + c, y1);
+        }
+      }
+      add(a0, b0, y0);
+      add(a1, b1, y1);
+    }
+    if (r < rows) {
+      float a0[N], b0[N], y0[N];
+      load_vec<T>(x + r * C + c, b0);
+      if (MODE == 1) {
+        load_vec<T>(dy + r * C + c, a0);
+        if (relu) load_vec<T>(y + r * C + c, y0);
+      }
+      add(a0, b0, y0);
     }
   }
 #pragma unroll
-  for (int j = 0; j < N; ++j) { red[0][ry][cx][j] = s0[j]; red[1][ry][cx][j] = s1[j]; }
+  for (int j = 0; j < N; ++j) { red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j]; }
   __syncthreads();
-  if (ry < 2 && c < C) {
+  if ((int)threadIdx.x < 2 * cw) {
+    const int q = threadIdx.x >> cw_log2, col = threadIdx.x & (cw - 1);
+    const int cc = (blockIdx.x * cw + col) * N;
+    if (cc < C) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      double t = 0.0;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) t += red[ry][r][cx][j];
-      partial[((int64_t)blockIdx.y * 2 + ry) * C + c + j] = t;
+      for (int j = 0; j < N; ++j) {
+        double t = 0.0;
+        for (int l = 0; l < rl; ++l) t += red[q][l * cw + col][j];          // fixed order
+        partial[((int64_t)blockIdx.y * 2 + q) * C + cc + j] = t;
+      }
     }
   }
 }
@@ -248,6 +275,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// N consecutive fp32 values (N = 4 or 8; p is 16-byte aligned: channel offsets are multiples of N)
+template <int N> __device__ __forceinline__ void ldf(const float* __restrict__ p, float (&o)[N]) {
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) {
+    const float4 v = reinterpret_cast<const float4*>(p)[q];
+    o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+  }
+}
+
 // g = dy*[y>0];  dx = gamma*rstd*(g - [batch_stats] (sum_g + xhat*sum_gx)/rows);  dres = g (optional)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ y,
@@ -262,10 +298,16 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
   const float inv = 1.0f / (float)rows;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     const int c = (int)(v % vpr) * N;
-    float g[N], xx[N], gm[N], o[N];
+    float g[N], xx[N], gm[N], o[N], mu[N], rs[N], sg[N], sx[N];
     load_vec<T>(dy + v * N, g);
     load_vec<T>(x + v * N, xx);
     load_vec<T>(gamma + c, gm);
+    // the per-channel statistics as 16-byte loads, all issued here: read one by one inside the loop below (behind the
+    // batch_stats branch) they were 4 dependent round trips per element -- 1.5 TB/s where bn_apply runs 6.8
+    ldf<N>(mean + c, mu);
+    ldf<N>(rstd + c, rs);
+    ldf<N>(sums + c, sg);
+    ldf<N>(sums + C + c, sx);
     if (relu) {
       float yy[N];
       load_vec<T>(y + v * N, yy);
@@ -274,10 +316,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const float xh = (xx[j] - mean[c + j]) * rstd[c + j];
-      float t = g[j];
-      if (batch_stats) t -= (sums[c + j] + xh * sums[C + c + j]) * inv;
-      o[j] = gm[j] * rstd[c + j] * t;
+      const float xh = (xx[j] - mu[j]) * rs[j];
+      const float t = batch_stats ? g[j] - (sg[j] + xh * sx[j]) * inv : g[j];
+      o[j] = gm[j] * rs[j] * t;
     }
     store_vec<T>(dx + v * N, o);
     if (dres) store_vec<T>(dres + v * N, g);
@@ -399,6 +440,13 @@ extern "C" int ofa_col2im(const void* dcol, void* dx, int B, int H, int W, int C
   return check_launch("col2im");
 }
 
+// column vectors per statistics block, as a power of two: 32, or fewer when the layer has fewer than 32 vectors of channels
+// (narrower blocks for launches of few blocks were tried: [25088 x 512] 30 -> 40 us, nothing gained elsewhere)
+static int bn_cw_log2(int vec_cols) {
+  int l = 5;
+  while (l > 0 && (1 << l) > vec_cols) --l;
+  return l;
+}
 static int bn_groups(int64_t rows) {
   int64_t g = (rows + 127) / 128;
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
@@ -419,13 +467,14 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, eps, C, mean, rstd);
   } else {
     const int groups = bn_groups(rows);
-    dim3 grid(cdiv(C / n, 32), groups), block(256);
+    const int cwl = bn_cw_log2(C / n);
+    dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
     if (dtype == OFA_F32)
-      hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+      hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
     else if (dtype == OFA_BF16)
-      hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+      hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
     else
-      hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0);
+      hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
@@ -450,17 +499,18 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
   hipStream_t st = (hipStream_t)stream;
   const int groups = bn_groups(rows);
+  const int cwl = bn_cw_log2(C / n);
   float* sums = ws + (int64_t)4 * 256 * C;
-  dim3 grid(cdiv(C / n, 32), groups), block(256);
+  dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
   if (dtype == OFA_F32) {
-    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else if (dtype == OFA_BF16) {
-    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
   }
   else {
-    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu);
+    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");

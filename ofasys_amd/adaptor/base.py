@@ -100,15 +100,15 @@ class BaseAdaptor(torch.nn.Module):
     def forward_hook_fn(self, inputs, output: AdaptorOutput):
         """adaptor/base.py:152-191."""
         slot: Slot = inputs[0]
-        if self.embed_scale != 1.0:
-            raise NotImplementedError("no_scale_embedding=False is not used by OFASys' default configs")
-        if self.cfg.scale_embedding_gradient != 1.0:
-            raise NotImplementedError("scale_embedding_gradient != 1 is not implemented")
-        embed = output.embed
+        embed = ops.scale(output.embed, self.embed_scale)                    # :168 (sqrt(D) unless no_scale_embedding)
         pos = output.pos_embed if (self.cfg.entangle_position_embedding and output.pos_embed is not None) else None
         typ = self.type_embedding.weight.view(-1) if (slot.is_src and self.type_embedding is not None) else None
         if pos is not None or typ is not None:
             embed = ops.add_rowvec_mask(embed, pos, typ)                     # :170-173 in one pass
+        if self.cfg.scale_embedding_gradient != 1.0:
+            # :174-176 `embed * a + embed.detach() * (1 - a)`: the value is unchanged, the gradient flowing back into the
+            # embedding / position / type tables is multiplied by a
+            embed = ops.scale(embed, 1.0, float(self.cfg.scale_embedding_gradient))
         if self.layernorm_embedding is not None:
             embed = self.layernorm_embedding(embed)
         if self.layernorm_position is not None and output.pos_embed is not None:

@@ -13,7 +13,8 @@ from ..module import Embedding, OfaLinear
 from ..preprocessor import ModalityType, Slot
 from .base import AdaptorOutput, BaseAdaptor
 
-OFAAdaptorConfig = ConfigStore().make_dataclass("ofasys.adaptor", "OFAAdaptorConfig", __name__)
+OFAAdaptorConfig = ConfigStore().make_dataclass("ofasys.adaptor", "OFAAdaptorConfig", __name__,
+                                                ["text", "image_resnet", "image_patch_embed", "image_vqgan", "box"])   # general.py:30-35
 
 default_adaptor = {   # adaptor/general.py:36-46
     ModalityType.TEXT: "text",

@@ -71,12 +71,17 @@ class ConfigStore:
     def names(self, group):
         return list(self.repo.get(group, {}).keys())
 
-    def make_dataclass(self, group, cls_name, module):
+    def make_dataclass(self, group, cls_name, module, prefix_names=()):
         """Synthesise a dataclass with one field per registered plugin of `group` (config_store.py:207-230).
         Unlike the reference, every instance gets FRESH sub-configs (default_factory), so adaptor settings do not
         leak between models built in one process (SURVEY.md section 5, config gotcha)."""
         flds = []
-        for name, node in self.repo.get(group, {}).items():
+        # field order as in the reference (config_store.py:210-218): `prefix_names` first, in that order, then the rest sorted by
+        # name.  The general adaptor builds its adaptors in THIS order, which fixes both the state-dict order and the RNG stream
+        # of the initial weights (tests/test_init_cpu.py: bit-identical initial state for the same seed).
+        prefix_names = list(prefix_names)
+        order = lambda kv: (prefix_names.index(kv[0]), "") if kv[0] in prefix_names else (len(prefix_names), kv[0])   # noqa: E731
+        for name, node in sorted(self.repo.get(group, {}).items(), key=order):
             flds.append((name, node.config, field(default_factory=node.config)))
         dc = dataclasses.make_dataclass(cls_name, flds, bases=(BaseDataclass,))
         dc.__module__ = module

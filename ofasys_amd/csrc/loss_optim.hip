@@ -374,7 +374,15 @@ __global__ void step_schedule_scaled_kernel(const float* __restrict__ gsq, const
   double mf = n > 0.0 ? 1.0 / (scale * n) : 0.0;
   const float gn = (float)(mf * sqrt((double)gsq[0]));
   gnorm[0] = n > 0.0 ? gn : __builtin_nanf("");
-  if (!(n > 0.0) || !isfinite(gn)) {             // overflow: the loss scaler's check_overflow, the update is skipped
+  if (!(n > 0.0)) {                              // an EMPTY batch is not an overflow: skip the update, leave the scaler's state alone
+    sched[0] = 0.f;                              // (the reference's scaler only reacts to an inf / nan norm, dynamic_loss_scaler.py:44-70)
+    sched[1] = 0.f;
+    sched[2] = (float)lr[0];
+    sched[3] = 1.f;
+    sched[4] += 1.f;
+    return;
+  }
+  if (!isfinite(gn)) {                           // overflow: the loss scaler's check_overflow, the update is skipped
     const double it = ls[1];
     const double since = it - ls[3];
     ls[2] = it;

@@ -7,7 +7,10 @@ slice of it -- no gather/scatter copies.  Buckets are cut in reverse parameter o
 them).  Every gradient contribution -- whether a HIP kernel accumulated it straight into the arena (ops._sink) or
 autograd's AccumulateGrad did -- calls `notify(i)`; once a parameter has received as many contributions as it did in
 the learning step of the SAME step structure its bucket counts down, and a full bucket fires `all_reduce(async_op=True)` on
-its slice, so RCCL traffic over xGMI overlaps the remaining backward kernels.  Counts are keyed on the step's full structure
+its slice, so RCCL traffic over xGMI overlaps the remaining backward kernels.  Buckets are launched STRICTLY IN INDEX ORDER (bucket b
+only once 0..b-1 are in flight): under DP every rank pads its own batch, so ranks can be in different modes in the same step
+(learning: everything at finish(); armed: from inside backward; replaying a graph) and completion order is rank-local -- index
+order is the one sequence of collectives every rank issues in every mode.  Counts are keyed on the step's full structure
 (trainer.sample_structure: slot modalities / attributes, every tensor shape) -- two steps with the same key run the same
 autograd graph, so the counts are exact; a contribution that still arrives for a bucket already in flight raises instead of
 racing the collective.  Whatever is left (unused parameters, the learning step itself) is reduced at `finish()`.
@@ -42,12 +45,18 @@ class GradBucketReducer:
             for i in members:
                 self.param_bucket[i] = b
         self.overlap = True                       # False: never launch from inside backward (captured steps)
+        self.profile = False                      # bench.py: time the post-backward wait of eager steps (exposed_events)
+        self.exposed_events = []
+        self.last_launch_order, self.last_early = [], 0
         self.expected = None                      # contributions per parameter per step for the current signature
         self._learned = {}                        # step signature -> learned contribution counts
         self._sig = None
         self._count = [0] * len(params)
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self.launch_order = []
         self._handles = []
         self._hooks = []
         for i, p in enumerate(params):
@@ -82,12 +91,21 @@ class GradBucketReducer:
         if self._count[i] == self.expected[i]:
             b = self.param_bucket[i]
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._launched[b]:
-                self._launch(b)
+            if self._pending[b] == 0:
+                self._ready[b] = True
+                self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch the longest prefix of complete buckets: the order of collectives is the bucket index on every rank."""
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
+        assert b == self._next, (b, self._next)
         self._launched[b] = True
+        self._next = b + 1
+        self.launch_order.append(b)
         self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _reset(self):
@@ -100,19 +118,53 @@ class GradBucketReducer:
                 if self._pending[b] == 0:
                     self._pending[b] = -1                   # nothing will ever notify: left for finish()
             self._launched[b] = False
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self.launch_order = []                              # (tests: the sequence of collectives of the last step)
         self._handles = []
 
     def finish(self):
         """Reduce whatever backward did not trigger (unused parameters, learning step), then wait for every bucket."""
         if self.world > 1:
-            for b in range(len(self.buckets)):
-                if not self._launched[b]:
-                    self._launch(b)
+            early = self._next                                  # buckets that went out from inside backward
+            for b in range(self._next, len(self.buckets)):
+                self._launch(b)
+            ev = None
+            if self.profile and self.flat_grad.is_cuda:         # how long the compute stream stalls for the exchange after backward
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self._handles:
                 h.wait()
+            if ev is not None:
+                ev[1].record()
+                self.exposed_events.append(ev)
+            self.last_early = early
+        self.last_launch_order = list(self.launch_order)
         if self.expected is None and self.overlap and self._sig is not None:
             self._learned[self._sig] = list(self._count)
         self._reset()
+
+
+    def bucket_sizes(self):
+        return [(hi - lo) * self.flat_grad.element_size() for lo, hi, _ in self.buckets]
+
+    def time_buckets_alone(self, reps=3):
+        """ms per bucket of a blocking all-reduce of that slice with nothing else running (bench.py: the un-overlapped price of the
+        exchange; run on every rank, outside any step -- the gradient arena is scratch between steps)."""
+        out = []
+        if self.world == 1 or not self.flat_grad.is_cuda:
+            return out
+        for lo, hi, _ in self.buckets:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)      # warm
+            e0.record()
+            for _ in range(reps):
+                dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / reps)
+        return out
 
 
 def all_reduce_scalars(t: torch.Tensor, group=None):

@@ -37,6 +37,9 @@ class CommonConfig:
     threshold_loss_scale: Optional[float] = None
     log_interval: int = 10
     use_graph: bool = True
+    graph_pad_to_multiple: int = 16    # with use_graph: text batches are padded to a multiple of this (collate_tokens' own
+                                       # pad_to_multiple, preprocessor/utils.py:75-113) so that a few hipGraphs cover the length
+                                       # distribution and every DP rank meets the same few structures; 1 = the reference's padding
 
 
 @dataclass
@@ -63,14 +66,23 @@ class TrainerConfig:
     optimizer: OptimizerConfig = field(default_factory=OptimizerConfig)
 
 
-def polynomial_decay_lr(step, base_lr, max_update, warmup_ratio, end_lr=0.0, power=1.0):
-    """Linear warm-up over warmup_ratio*max_update updates, then polynomial decay to end_lr at max_update."""
-    warm = int(warmup_ratio * max_update)
-    if warm > 0 and step <= warm:
-        return base_lr * step / warm
-    if step >= max_update:
+def polynomial_decay_lr(num_updates, base_lr, max_update, warmup_ratio, end_lr=0.0, power=1.0):
+    """The learning rate the NEXT update runs with after `num_updates` completed ones (engine/lr/polynomial_decay_schedule.py):
+    warmup_updates = max(int(total * ratio), 1) (`reinit`, :96-101); before the first update the rate is lr / warmup_updates
+    (:104-106); then `step_update(num_updates)` (:81-93): linear warm-up while num_updates <= warmup_updates, polynomial decay to
+    end_lr at total.  The trainer calls step_update AFTER an update (engine/trainer.py:932, 1091-1094), so update u uses
+    step_update(u - 1) -- and a skipped update (overflow) does not advance num_updates."""
+    if warmup_ratio > 0:
+        warm = max(int(max_update * warmup_ratio), 1)
+    else:
+        warm = 0
+    if num_updates <= 0:
+        return base_lr / warm if warm > 0 else base_lr
+    if warm > 0 and num_updates <= warm:
+        return base_lr * num_updates / float(warm)
+    if num_updates >= max_update:
         return end_lr
-    frac = 1.0 - (step - warm) / max(1, max_update - warm)
+    frac = 1.0 - (num_updates - warm) / (max_update - warm)
     return (base_lr - end_lr) * frac ** power + end_lr
 
 
@@ -121,7 +133,19 @@ class Trainer:
                 dist.broadcast(t.data, 0)
         from . import ops
         ops.manual_seed(cfg.common.seed + rank)                     # dropout streams differ per rank (fairseq: seed + rank)
+        if cfg.common.use_graph and cfg.common.graph_pad_to_multiple > 1:
+            for task in tasks:
+                if task.cfg.text.pad_to_multiple == 1:
+                    task.cfg.text.pad_to_multiple = cfg.common.graph_pad_to_multiple
         crit = tasks[0].cfg.criterion
+        for task in tasks[1:]:
+            # the reference builds one criterion per task (task/base.py:213-216); the step engine holds one: refuse a mix it would
+            # silently flatten
+            c = task.cfg.criterion
+            if (c.label_smoothing, c.drop_worst_ratio) != (crit.label_smoothing, crit.drop_worst_ratio):
+                raise NotImplementedError("tasks with different criterion settings (label_smoothing / drop_worst_ratio) in one "
+                                          "Trainer are not supported: the step engine applies one criterion to every micro-batch")
+        self._update_freq = max(int(t.cfg.dataset.update_freq) for t in tasks)
         self.step_engine = TrainStep(model, lr=cfg.optimization.lr[0], betas=tuple(cfg.optimizer.adam_betas), eps=cfg.optimizer.adam_eps,
                                      weight_decay=cfg.optimizer.weight_decay, clip_norm=cfg.optimization.clip_norm,
                                      use_graph=cfg.common.use_graph, label_smoothing=crit.label_smoothing,
@@ -138,7 +162,8 @@ class Trainer:
         c = self.cfg.common
         if not c.fp16 or c.fp32:
             return None
-        window = c.fp16_scale_window if c.fp16_scale_window is not None else max(1, int(2 ** 14 / world))
+        window = c.fp16_scale_window if c.fp16_scale_window is not None else \
+            max(1, int(2 ** 14 / world / getattr(self, "_update_freq", 1)))
         return {"init_scale": float(c.fp16_init_scale), "scale_factor": 2.0, "scale_window": window,
                 "tolerance": c.fp16_scale_tolerance, "threshold": c.threshold_loss_scale, "min_loss_scale": c.min_loss_scale}
 
@@ -159,11 +184,13 @@ class Trainer:
         cfg = self.cfg
         engine = self.setup(model, tasks)
         base_lr = cfg.optimization.lr[0]
+        skipped = 0                                                  # updates the device skipped (overflow): polled at log time
         for update in range(1, cfg.optimization.max_update + 1):
-            engine.lr = polynomial_decay_lr(update, base_lr, cfg.optimization.max_update, cfg.optimization.warmup_ratio,
+            engine.lr = polynomial_decay_lr(update - 1 - skipped, base_lr, cfg.optimization.max_update, cfg.optimization.warmup_ratio,
                                             cfg.optimization.end_learning_rate, cfg.optimization.power)
             out = engine.train_step(self._micro_batches(tasks))
             if update % cfg.common.log_interval == 0 or update == cfg.optimization.max_update:
+                skipped = int(float(out["skipped"][1]))              # (one sync, with the log line's own)
                 engine.check()                                       # FloatingPointError on Nan/Inf gradients (trainer.py:866-876)
                 n, loss = float(out["stats"][0]), float(out["stats"][1])
                 rec = {"update": update, "loss": loss / max(n, 1.0) / 0.6931471805599453, "sample_size": n,

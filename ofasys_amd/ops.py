@@ -943,6 +943,43 @@ def mul_rowvec(a, vec):
     return restore(MulRowvecFn.apply(a2d, vec))
 
 
+class ScaleFn(torch.autograd.Function):
+    """y = fwd * x, dx = bwd * dy (constants): `embed_scale * embed` and the gradient-only rescale
+    `embed * a + embed.detach() * (1 - a)` of the adaptor post-hook (adaptor/base.py:168, 174-176) on the row-vector multiply kernel."""
+    _vecs = {}
+
+    @classmethod
+    def _vec(cls, value, cols, like):
+        key = (float(value), cols, like.dtype, like.device)
+        v = cls._vecs.get(key)
+        if v is None:
+            v = cls._vecs[key] = torch.full((cols,), float(value), dtype=like.dtype, device=like.device)
+        return v
+
+    @staticmethod
+    def forward(ctx, x2d, fwd, bwd):
+        ctx.bwd = bwd
+        if fwd == 1.0:
+            return x2d.view_as(x2d)
+        return K.mul_rowvec(x2d, ScaleFn._vec(fwd, x2d.shape[1], x2d))
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.bwd == 1.0:
+            return dy, None, None
+        dy = dy.contiguous()
+        return K.mul_rowvec(dy, ScaleFn._vec(ctx.bwd, dy.shape[1], dy)), None, None
+
+
+def scale(x, fwd=1.0, bwd=None):
+    """fwd * x with gradient bwd * dy (bwd defaults to fwd: a plain scalar multiply)."""
+    bwd = fwd if bwd is None else bwd
+    if fwd == 1.0 and bwd == 1.0:
+        return x
+    x2d, restore = rows_view(x)
+    return restore(ScaleFn.apply(x2d, float(fwd), float(bwd)))
+
+
 # ---------------------------------------------------------------------------------------------- patch embedding
 class PatchEmbedFn(torch.autograd.Function):
     """Conv2d(C, D, kernel=stride=p) as im2col + MFMA GEMM (adaptor/image_patch_embed.py:59-73).  img [B,C,H,W],

@@ -182,7 +182,7 @@ class TrainStep:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_norm=1.0, process_group=None,
                  bucket_bytes: int = 64 << 20, use_graph: bool = False, graph_warmup: int = 2,
                  label_smoothing: float = 0.0, constraint_range=None, drop_worst_ratio: float = 0.0, dp_graph: str = None,
-                 loss_scale=None):
+                 loss_scale=None, max_graphs: int = 16):
         self.model = model
         self.fp = FlatParams(model)
         dev = self.fp.flat.device
@@ -230,6 +230,12 @@ class TrainStep:
             self.loss_scale_cfg = cfg
             self._ls = torch.tensor([cfg["init_scale"], 0, -1, -1, 0, 0, 0, 0], dtype=torch.float64, device=dev)
         self._graphs = {}                           # batch structure -> dict(graphs, static samples, seen count)
+        # Every captured structure pins its activations: the captures share ONE memory pool (step graphs replay one at a time and
+        # consume nothing of each other, so the pool's blocks are reused across them) and at most `max_graphs` structures are
+        # captured -- the rest run eagerly.  Variable-length data should arrive bucketed (pad_to_multiple / packing buckets).
+        self.max_graphs = int(max_graphs)
+        self._pool = None
+        self._warned_cap = False
         self._skipped_seen = 0.0
         self.last = {}
 
@@ -321,10 +327,15 @@ class TrainStep:
             raise FloatingPointError(f"gradients are Nan/Inf (or sample_size == 0) in {n} update(s): skipped on the device")
 
     # ------------------------------------------------------------------ graph plumbing
+    def captured_graphs(self):
+        return sum(1 for e in self._graphs.values() if "graphs" in e)
+
     def _capture(self, samples, structure, mode):
         import gc
         gc.collect()                      # drop unreachable autograd graphs (see the class docstring) before recording
-        pool = torch.cuda.graph_pool_handle()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        pool = self._pool
         entry = {"static": samples, "graphs": [], "mode": mode}
         if self.world == 1 or mode == "full":
             g = torch.cuda.CUDAGraph()
@@ -373,8 +384,15 @@ class TrainStep:
         if self.use_graph and not eager and structure is not None:
             entry = self._graphs.get(structure)
             if entry is None:
+                if len(self._graphs) >= 64 * max(self.max_graphs, 1):       # bound the bookkeeping of never-captured structures too
+                    self._graphs = {k: e for k, e in self._graphs.items() if "graphs" in e}
                 entry = self._graphs[structure] = {"seen": 0}
-            if "graphs" in entry:
+            if "graphs" not in entry and entry["seen"] >= self.graph_warmup and self.captured_graphs() >= self.max_graphs:
+                if not self._warned_cap:
+                    warnings.warn(f"ofasys_amd.TrainStep: {self.max_graphs} batch structures are captured already; further ones run "
+                                  "eagerly (bucket the padded lengths -- pad_to_multiple / packing buckets -- or raise max_graphs)")
+                    self._warned_cap = True
+            elif "graphs" in entry:
                 self._replay(entry, samples)
                 done = True
             elif entry["seen"] >= self.graph_warmup and (self.world == 1 or self.dp_graph != "full"

@@ -21,6 +21,16 @@ CASES = {
                     "decoder.layers.3.ffn_layernorm.weight", "encoder.layers.2.self_attn.q_proj.weight",
                     "decoder.adaptor.text.embed_positions.weight", "encoder.adaptor.embed_tokens.weight"],
     ),
+    # the two non-default switches of the adaptor post-hook (adaptor/base.py:168, 174-176): embed_scale = sqrt(D)
+    # (no_scale_embedding=False) and scale_embedding_gradient = 0.5 (the gradient into the embedding / type tables is halved)
+    "tiny_text_embscale": dict(
+        arch="tiny", active={"text"}, overrides={},
+        adaptor_overrides={"text": {"no_scale_embedding": False, "scale_embedding_gradient": 0.5}},
+        slots=[("TEXT", True, ("tok", "src", (2, 16), [16, 11]), None),
+               ("TEXT", False, ("tok", "prev", (2, 12), [9, 12]), None)],
+        full_grads=["encoder.adaptor.embed_tokens.weight", "encoder.adaptor.text.type_embedding.weight",
+                    "encoder.adaptor.text.layernorm_embedding.weight", "encoder.layers.0.self_attn.q_proj.weight"],
+    ),
     # three source slots incl. BOX-as-tokens: slot order != ModalityType order, block-diagonal rel-pos bias
     "tiny_multislot": dict(
         arch="tiny", active={"text"}, overrides={}, adaptor_overrides={},

@@ -70,6 +70,8 @@ class OConfig:
     eps: float = 1e-5                       # module/layer_norm.py:27
     # per-adaptor flags (adaptor/base.py:56-81); NOT inherited from the model cfg (base.py:97-101)
     adaptor_entangle: Dict[str, bool] = field(default_factory=dict)
+    adaptor_embed_scale: Dict[str, float] = field(default_factory=dict)       # sqrt(D) where no_scale_embedding=False (base.py:144)
+    adaptor_grad_scale: Dict[str, float] = field(default_factory=dict)        # scale_embedding_gradient (base.py:174-176)
     patch: int = 14                         # adaptor/image_patch_embed.py:24-29
     resnet_layers: tuple = (3, 8, 36)       # adaptor/image_resnet.py:44-47 (default resnet152), module/resnet.py:249-261
     image_bucket_size: int = 42             # adaptor/image_resnet.py:62-65
@@ -136,12 +138,16 @@ def box_to_bins(coords, max_image_size, num_bins):
 # adaptors (a3, a4, a6)
 # --------------------------------------------------------------------------------------------
 def _post_hook(state, cfg, side, name, slot, embed, pos_embed):
-    """adaptor/base.py:152-181 (embed_scale == 1 since no_scale_embedding, base.py:69,144)."""
+    """adaptor/base.py:152-181 (embed_scale == 1 by default: no_scale_embedding, base.py:69,144)."""
     p = f"{side}.adaptor.{name}"
+    embed = cfg.adaptor_embed_scale.get(name, 1.0) * embed                # base.py:168
     if cfg.adaptor_entangle.get(name, False) and pos_embed is not None:   # base.py:170-171
         embed = embed + pos_embed
     if slot.is_src and (p + ".type_embedding.weight") in state:          # base.py:172-173
         embed = embed + state[p + ".type_embedding.weight"].squeeze()
+    alpha = cfg.adaptor_grad_scale.get(name, 1.0)
+    if alpha != 1.0:                                                      # base.py:174-176
+        embed = embed * alpha + embed.detach() * (1 - alpha)
     embed = layer_norm(state, p + ".layernorm_embedding", embed, cfg.eps)  # base.py:177-178
     if pos_embed is not None:
         pos_embed = layer_norm(state, p + ".layernorm_position", pos_embed, cfg.eps)  # base.py:179-180

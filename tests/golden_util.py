@@ -53,10 +53,14 @@ def state_from_golden(g, dtype=torch.float32):
 def oracle_cfg(case):
     ov = case["overrides"]
     ent = {k: v.get("entangle_position_embedding", False) for k, v in case["adaptor_overrides"].items()}
+    D = ARCH[case["arch"]]["embed_dim"]
+    esc = {k: float(D) ** 0.5 for k, v in case["adaptor_overrides"].items() if v.get("no_scale_embedding", True) is False}
+    gsc = {k: float(v["scale_embedding_gradient"]) for k, v in case["adaptor_overrides"].items() if "scale_embedding_gradient" in v}
     layers = {"resnet50": (3, 4, 6), "resnet101": (3, 4, 23), "resnet152": (3, 8, 36)}[
         case["adaptor_overrides"].get("image_resnet", {}).get("resnet_type", "resnet152")]
     return OConfig(**ARCH[case["arch"]], use_self_attn_bias=ov.get("use_self_attn_bias", True),
                    entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent,
+                   adaptor_embed_scale=esc, adaptor_grad_scale=gsc,
                    resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)))
 
 

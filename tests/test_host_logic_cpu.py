@@ -125,6 +125,66 @@ def test_dp_bucket_reducer_gloo_world2():
     assert torch.allclose(got[: want.numel()], want, atol=1e-5) and float(got[want.numel():].abs().sum()) == 0.0
 
 
+def _dp_mixed_mode_worker(rank, world, port, q):
+    """Rank 0 runs its second step ARMED (counts learned for its structure key), rank 1 sees a NEW key in that step (learning:
+    everything goes out at finish()) -- what per-rank padding does to sample_structure under DP.  The module registered last is
+    used first, so its bucket (index 0) completes LAST in backward: completion order != index order."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd.distributed import GradBucketReducer
+    from ofasys_amd.trainer import FlatParams
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16)
+    model = torch.nn.ModuleList([a, b, c])
+    fp = FlatParams(model)
+    red = GradBucketReducer(fp.params, fp.grad, fp.offsets, None, bucket_bytes=512)
+    assert len(red.buckets) >= 3
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(4, 16, generator=g)
+    orders = []
+    for step in range(2):
+        fp.zero_grad()
+        red.begin_step("same" if rank == 0 else f"padded-to-{step}")
+        b(a(c(x))).sum().backward()
+        if step == 1:
+            assert (red.expected is not None) == (rank == 0)
+            if rank == 0:
+                assert 0 < red._next or not any(red._ready), "armed rank"
+                assert red.launch_order == sorted(red.launch_order)
+        red.finish()
+        orders.append(list(red.last_launch_order))
+    q.put((rank, fp.grad.clone().numpy(), orders))
+    dist.destroy_process_group()
+
+
+def test_dp_collective_order_is_rank_invariant_across_modes():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp_mixed_mode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, g1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert torch.equal(g0, g1)
+    for _, _, orders in res:
+        for o in orders:
+            assert o == list(range(len(o))) and len(o) >= 3          # every step, every mode: bucket 0, 1, 2, ...
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(16, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 16)
+    for rank in range(2):
+        x = torch.randn(4, 16, generator=torch.Generator().manual_seed(7 + rank))
+        b(a(c(x))).sum().backward()
+    want = torch.cat([p.grad.reshape(-1) for m in (a, b, c) for p in m.parameters()])
+    assert torch.allclose(g0[: want.numel()], want, atol=1e-5)
+
+
 def test_tool_scripts_compile():
     """tools/*.py (profiling / analysis helpers referenced by DESIGN.md) must at least parse."""
     import glob

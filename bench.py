@@ -64,6 +64,8 @@ def build(args, device):
             a.is_active = True
             a.entangle_position_embedding = True
         m.cfg.adaptor.image_patch_embed.embed_dim = m.cfg.encoder_embed_dim      # the adaptor's own default is 768 (base)
+    if getattr(args, "dropout", None) is not None:        # (parity tests: the CPU oracle has no dropout; the bench keeps the default 0.1)
+        m.cfg.dropout = float(args.dropout)
     m.initialize(d)
     m = m.to(device).to(HALF[getattr(args, 'dtype', 'bf16')])
     return m, d
@@ -112,63 +114,39 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2", pack=False):
     return sample, ntok, (slen.tolist(), tlen.tolist())
 
 
-def cpu_baseline(args):
-    """The CPU oracle (plain torch fp32 restatement, verified against the reference's golden vectors) timed on this
-    host: same model/config, bounded batch."""
+CPU_SAMPLE = {"cfg2": (8, 6), "cfg2b": (4, 4), "cfg4": (1, 4)}      # workload -> (batch, timed steps) of the CPU leg: 10-30 s of host work
+
+
+def cpu_baseline(args, model, d):
+    """The CPU oracle (oracle/restate.py: plain torch fp32 restatement, verified against the reference's golden vectors) timed on
+    this host for the SAME workload: the GPU model's own weights (held in fp32), a batch drawn by the same make_batch at a
+    bounded size, forward + CE + backward."""
     from oracle import restate
     from oracle.restate import OConfig, OSlot
-    torch.manual_seed(0)
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    D, A, F, L = 768, 12, 3072, 6
-    V = 4 + V_TEXT + 1 + 1000
-    B, Ts_text, Tt = args.cpu_batch, 191, 64
-    cfg = OConfig(embed_dim=D, ffn_dim=F, heads=A, enc_layers=L, dec_layers=L, use_self_attn_bias=False,
-                  entangle_position_embedding=True, adaptor_entangle={"text": True, "image_patch_embed": True})
+    cfgm = model.cfg
+    dims = dict(embed_dim=cfgm.encoder.embed_dim, ffn_dim=cfgm.encoder.ffn_embed_dim, heads=cfgm.encoder.attention_heads,
+                enc_layers=cfgm.encoder.layers, dec_layers=cfgm.decoder.layers)
+    if args.workload == "cfg2":
+        cfg = OConfig(**dims, use_self_attn_bias=False, entangle_position_embedding=True,
+                      adaptor_entangle={"text": True, "image_patch_embed": True})
+    else:
+        cfg = OConfig(**dims, resnet_layers=(3, 4, 23), training=True)      # resnet101, BatchNorm on batch statistics
     st = {}
-
-    def lin(p, o, i):
-        st[p + ".weight"] = (torch.randn(o, i) * 0.02).requires_grad_(True)
-        st[p + ".bias"] = torch.zeros(o, requires_grad=True)
-
-    def ln(p, n):
-        st[p + ".weight"] = torch.ones(n, requires_grad=True)
-        st[p + ".bias"] = torch.zeros(n, requires_grad=True)
-    emb = (torch.randn(V, D) * 0.02).requires_grad_(True)
-    for side in ("encoder", "decoder"):
-        st[f"{side}.adaptor.embed_tokens.weight"] = emb
-        a = f"{side}.adaptor.text"
-        ln(a + ".layernorm_embedding", D); ln(a + ".layernorm_position", D)
-        st[a + ".embed_positions.weight"] = (torch.randn(1026, D) * 0.02).requires_grad_(True)
-        if side == "encoder":
-            st[a + ".type_embedding.weight"] = torch.zeros(1, D, requires_grad=True)
-            p = f"{side}.adaptor.image_patch_embed"
-            ln(p + ".layernorm_embedding", D); ln(p + ".layernorm_position", D)
-            st[p + ".type_embedding.weight"] = torch.zeros(1, D, requires_grad=True)
-            st[p + ".embed_image_positions.weight"] = (torch.randn(257, D) * 0.02).requires_grad_(True)
-            st[p + ".cls_token"] = torch.zeros(1, 1, D, requires_grad=True)
-            st[p + ".proj.weight"] = (torch.randn(D, 3, 14, 14) * 0.02).requires_grad_(True)
-            st[p + ".proj.bias"] = torch.zeros(D, requires_grad=True)
-        for l in range(L):
-            q = f"{side}.layers.{l}"
-            attns = ["self_attn"] + (["encoder_attn"] if side == "decoder" else [])
-            for at in attns:
-                for w in ("q_proj", "k_proj", "v_proj", "out_proj"):
-                    lin(f"{q}.{at}.{w}", D, D)
-                st[f"{q}.{at}.c_attn"] = torch.ones(A, requires_grad=True)
-            ln(q + ".self_attn_layer_norm", D); ln(q + ".final_layer_norm", D); ln(q + ".ffn_layernorm", F)
-            lin(q + ".fc1", F, D); lin(q + ".fc2", D, F)
-            if side == "encoder":
-                ln(q + ".attn_ln", D)
-            else:
-                ln(q + ".self_attn_ln", D); ln(q + ".cross_attn_ln", D); ln(q + ".encoder_attn_layer_norm", D)
-        ln(f"{side}.layer_norm", D)
-    g = torch.Generator().manual_seed(1234)
-    img = torch.randn(B, 3, 224, 224, generator=g)
-    src = torch.randint(4, V, (B, Ts_text), generator=g)
-    prev = torch.randint(4, V, (B, Tt), generator=g)
-    target = torch.randint(4, V, (B, Tt), generator=g)
-    slots = [OSlot("IMAGE", True, img, ["adaptor=image_patch_embed"]), OSlot("TEXT", True, src), OSlot("TEXT", False, prev)]
+    for k, v in model.state_dict().items():
+        v = v.detach().cpu()
+        st[k] = v.float().requires_grad_(True) if (v.is_floating_point() and not k.endswith(("version", "running_mean", "running_var"))) \
+            else (v.float() if v.is_floating_point() else v.clone())
+    st["decoder.adaptor.embed_tokens.weight"] = st["encoder.adaptor.embed_tokens.weight"]
+    B, steps = CPU_SAMPLE[args.workload]
+    B = args.cpu_batch or B
+    steps = args.cpu_steps or steps
+    Ts_text, Tt, nvis, _ = WORKLOADS[args.workload]
+    sample, ntok, _ = make_batch(d, B, Ts_text, Tt, 0, torch.device("cpu"), args.workload)
+    slots = [OSlot(sl.modality.name, sl.is_src, sl.value.float() if sl.value.is_floating_point() else sl.value, sl.attributes)
+             for sl in sample["slots"]]
+    target = sample["target"]
     params = [v for v in st.values() if v.requires_grad]
 
     def step():
@@ -179,15 +157,13 @@ def cpu_baseline(args):
         loss.backward()
     step()
     t0 = time.time()
-    n = 0
-    while n < args.cpu_steps:
+    for _ in range(steps):
         step()
-        n += 1
-    dt = (time.time() - t0) / n
-    toks = B * (257 + Ts_text + Tt)
-    return {"value": toks / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/restate.py fp32, OFA-base cfg-2, batch {B} (unpadded 448+64 positions), fwd+CE+bwd, "
-                      f"{n} timed steps after 1 warm-up, torch.set_num_threads({cores})", "s_per_step": dt}
+    dt = (time.time() - t0) / steps
+    return {"value": ntok / dt, "unit": "tokens/s", "cores": cores, "kind": "port", "batch": B, "gpu_batch": args.batch,
+            "sample": f"oracle/restate.py fp32, {args.workload}, batch {B} (the GPU line runs batch {args.batch}), the padded shape "
+                      f"{nvis}+{Ts_text} -> {Tt} computed in full as the reference does, non-pad tokens counted like `value`; "
+                      f"fwd+CE+bwd, {steps} timed steps after 1 warm-up, torch.set_num_threads({cores})", "s_per_step": dt}
 
 
 def pmc_traffic():
@@ -195,7 +171,7 @@ def pmc_traffic():
     passes (profiles/, produced by tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on
     gfx950, tools/pmc_traffic.py)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         try:
             rows = json.load(open(os.path.join(here, "profiles", name)))
         except (OSError, ValueError):
@@ -210,6 +186,23 @@ def pmc_traffic():
             return tot / n, meta.get("bytes_per_step"), (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA "
                                                          "GEMM instantiations of the eager cfg-2 step)")
     return None, None, None
+
+
+def rocprof_gemm_ms(workload):
+    """(ms per step of the MFMA GEMM kernel family incl. split-K reduces and slab folds, ms per step of ALL kernels, file) from the
+    committed rocprofv3 kernel trace of this very command -- the REPLAYED hipGraph's kernels, timed by the profiler, not by HIP
+    events around relaunches (tools/collect_profiles.sh -> tools/prof_summary.py --json)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = {"cfg2": "round3_rocprof_kernel_stats.json", "cfg2b": "round3_rocprof_cfg2b_kernel_stats.json",
+            "cfg4": "round3_rocprof_cfg4_kernel_stats.json"}[workload]
+    try:
+        rows = json.load(open(os.path.join(here, "profiles", name)))
+    except (OSError, ValueError):
+        return None, None, None
+    meta = rows.pop("__meta__", {})
+    fam = sum(r["ms_per_step"] for k, r in rows.items()
+              if ("gemm_" in k and "simple" not in k) or "splitk_reduce" in k or "fold_batched" in k)
+    return fam, meta.get("total_ms_per_step"), f"profiles/{name}"
 
 
 WORKLOADS = {   # name -> (source text length, target length, visual tokens per sample, description)
@@ -242,9 +235,11 @@ def main():
     ap.add_argument("--arch", default="base")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 4 for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="CPU-leg batch (0: per workload, CPU_SAMPLE)")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-leg timed steps (0: per workload)")
     ap.add_argument("--profile-gemm", type=int, default=1, help="instrumented steps after the timed region")
+    ap.add_argument("--profile-park-cycles", type=float, default=1.5e8,
+                    help="spin-kernel cycles in front of the instrumented step (the host must finish enqueueing before the GPU starts)")
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS),
                     help="cfg2 (headline: image_patch_embed, bias-free), cfg2b (image_resnet101 + biased attention, 196+252 -> 64) "
                          "or cfg4 (video 8x224x224 -> 1568 tokens + 32 text -> 32, micro-batch 4)")
@@ -352,11 +347,44 @@ def main():
             graph_mode = {1: "one hipGraph (collectives captured)" if world > 1 else "one hipGraph", 2: "two hipGraphs + eager all-reduce"}[len(e["graphs"])]
     trainer.check()
 
+    # data-parallel exchange, measured on every rank (the collectives need all of them): each bucket's all-reduce ALONE, and how
+    # long the compute stream still waits for the exchange once backward has been enqueued in overlapped eager steps
+    dp = None
+    if world > 1:
+        red = trainer.reducer
+        alone = red.time_buckets_alone()
+        red.profile, red.exposed_events = True, []
+        for _ in range(3):
+            trainer.train_step([batches[0][0]], eager=True)
+        torch.cuda.synchronize()
+        exposed = [a.elapsed_time(b) for a, b in red.exposed_events]
+        red.profile = False
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                                      # (gloo smoke runs)
+            rccl = f"n/a ({type(e).__name__})"
+        tot_alone = sum(alone)
+        exp_ms = sum(exposed[1:]) / max(len(exposed) - 1, 1) if exposed else None
+        dp = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+              "dp_graph": trainer.dp_graph, "buckets": len(red.buckets), "bucket_bytes": red.bucket_sizes(),
+              "bucket_allreduce_ms_alone": alone, "allreduce_ms_alone_total": tot_alone,
+              "buckets_launched_inside_backward": red.last_early, "launch_order": red.last_launch_order,
+              "exposed_wait_ms_per_step": exp_ms,
+              "overlap_frac": (1.0 - exp_ms / tot_alone) if (exp_ms is not None and tot_alone > 0) else None,
+              "how": "bucket_allreduce_ms_alone: blocking all-reduce of each gradient-arena bucket with nothing else running (HIP "
+                     "events, 3 reps); exposed_wait_ms_per_step: HIP events on the compute stream around the bucket waits at the end "
+                     "of backward in overlapped EAGER steps (the timed region replays the same launches from one hipGraph); "
+                     "overlap_frac = 1 - exposed / alone"}
+
     # dominant kernel: every MFMA GEMM launch of one step bracketed by HIP events on the launch stream
     prof = None
     if args.profile_gemm > 0:
         K.gemm_profile_begin()
         for _ in range(args.profile_gemm):
+            # an eager step is host-bound (~600 launches): park the stream behind a spin kernel first so that every launch and its
+            # two events are QUEUED when the GPU reaches them -- the kernels then run back to back exactly as in the replayed graph
+            # and each event pair brackets one kernel, not the host's dispatch gap
+            torch.cuda._sleep(int(args.profile_park_cycles))
             trainer.train_step([batches[0][0]], eager=True)        # HIP events around each launch: not inside a graph
         torch.cuda.synchronize()
         prof = K.gemm_profile_end()
@@ -397,10 +425,19 @@ def main():
                          "gemm_ms_per_step": prof["time_ms"] / args.profile_gemm,
                          "gemm_flops_per_step": prof["flops"] / args.profile_gemm,
                          "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
-                         "how": f"instrumented eager step(s) right after the timed region: every MFMA-GEMM call of the step "
-                                f"is re-launched {prof['reps']}x back to back between two HIP events on its launch stream "
-                                f"(duration = elapsed/{prof['reps']}; includes the split-K reduce kernel where one is used; a layer's grouped "
-                                f"weight-gradient launch counts as one launch, timed with the fold of its K-slice slabs)"})
+                         "how": "instrumented eager step right after the timed region, the stream parked behind a spin kernel "
+                                "until the host has enqueued the whole step: every MFMA-GEMM launch of the step is bracketed IN SITU "
+                                "by two HIP events on its launch stream (one launch each, no relaunch, caches as the step leaves "
+                                "them; includes the split-K reduce where ofa_gemm runs one; a layer's grouped weight-gradient "
+                                "launch is one launch, its slab fold is a FoldQueue kernel outside this family time -- see "
+                                "roofline.rocprof for the profiler's figure incl. reduces and folds)"})
+            fam_ms, all_ms, src = rocprof_gemm_ms(args.workload)
+            if fam_ms:
+                f = prof["flops"] / args.profile_gemm / (fam_ms * 1e-3) / 1e12
+                roof["rocprof"] = {"gemm_family_ms_per_step": fam_ms, "all_kernels_ms_per_step": all_ms, "achieved": f,
+                                   "frac": f / PEAK_BF16_TFLOPS, "source": src,
+                                   "how": "rocprofv3 --kernel-trace --stats of this command (committed): durations of the replayed "
+                                          "graph's gemm_* + splitk_reduce + fold_batched kernels; flops = this run's GEMM flops"}
         else:
             roof.update({"achieved": step_tflops, "frac": step_tflops / PEAK_BF16_TFLOPS})
         out = {
@@ -415,8 +452,10 @@ def main():
                        "distinct_batches": len(batches)},
             "roofline": roof,
         }
+        if dp is not None:
+            out["dp"] = dp
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, model, d)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

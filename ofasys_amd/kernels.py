@@ -190,22 +190,20 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
         ws_bytes = ws.numel() * 4
     args = ("ofa_gemm", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, K, int(trans_a), int(trans_b), lda, ldb, ldc, batch,
             sa, sb, sc, 0, 0, 0, 0, float(alpha), flags, dt, ptr(ws), ws_bytes, stream())
-    lib().call(*args)
-    if flags & GEMM_DEFER_REDUCE:
-        fold.flush_if_large()
     if _prof is not None:
-        # roofline timing: the same launch again, _PROF_REPS times back to back between two HIP events (back-to-back so
-        # the host dispatch gap of an eager launch is not billed to the kernel); an accumulating call is replayed into a
-        # scratch output so the real gradient is not touched
-        scratch = torch.empty_like(out) if accumulate else out
-        rargs = args[:3] + (ptr(scratch),) + args[4:]
+        # roofline timing, IN SITU: two HIP events on the launch stream around THIS launch, inside the running step -- operands
+        # as cold / warm as the step leaves them, no re-launch (an eager step is host-bound, so the stream is idle when the kernel
+        # starts and the events bracket the kernel alone, + ~1 us of event overhead billed to it)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(_PROF_REPS):
-            lib().call(*rargs)
+        lib().call(*args)
         e1.record()
         _prof.append((2.0 * M * N * K * batch, e0, e1, batch * ((M * K + K * N) * a.element_size() + M * N * out.element_size())))
+    else:
+        lib().call(*args)
+    if flags & GEMM_DEFER_REDUCE:
+        fold.flush_if_large()
     return out
 
 
@@ -240,31 +238,26 @@ def gemm_group_tn(products, fold):
     slabs = [torch.empty(it.splits * it.m * it.n, dtype=torch.float32, device=products[0][0].device) for it in arr]
     for it, sl in zip(arr, slabs):
         it.slabs = sl.data_ptr()
-    lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
     if _prof is not None:
-        # roofline timing (see gemm): the launch again, back to back, each time with the reduce of its slabs (into scratch
-        # outputs) -- the other products' timings include their split-K reduce too
-        scratch = [torch.empty_like(out) for (_, _, out, _) in products]
-        jobs = (_FoldJob * len(products))(*[
-            _FoldJob(sl.data_ptr(), sc.data_ptr(), it.m * it.n, it.m * it.n, it.splits, 0, 1.0, dtype_code(sc))
-            for it, sl, sc in zip(arr, slabs, scratch)])
+        # roofline timing in situ (see gemm): the grouped launch alone; the fold of its K-slice slabs is a FoldQueue launch later on
+        # and is accounted for in bench.py from the fold kernel's own share (rocprof), not here
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(_PROF_REPS):
-            lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
-            lib().call("ofa_fold_batched", ctypes.addressof(jobs), len(products), stream())
+        lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
         e1.record()
         es = products[0][0].element_size()
         _prof.append((sum(2.0 * it.m * it.n * it.k for it in arr), e0, e1,
                       sum((it.m + it.n) * it.k * es + it.splits * it.m * it.n * 4 for it in arr)))
+    else:
+        lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
     for it, sl, (dy, x, out, alpha) in zip(arr, slabs, products):   # (registered after the launch: add() may flush the queue)
         fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
 
 
 # ---- optional per-launch timing of the GEMM kernel family (bench.py roofline): HIP events on the launch stream
 _prof = None
-_PROF_REPS = 5
+_PROF_REPS = 1            # (round 1-2 re-launched every call 5x back to back with warm caches; since round 3 the launch itself is timed)
 
 
 def gemm_profile_begin():

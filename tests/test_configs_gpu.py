@@ -452,3 +452,28 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and abs(out["value"] - 2 * out["tokens_per_sec_per_gpu"]) <= 1e-6 * out["value"]
     assert out["config"]["step_mode"] == "two hipGraphs + eager all-reduce", out["config"]["step_mode"]
+    dp = out["dp"]                                                   # the exchange describes itself
+    assert dp["world_size"] == 2 and dp["backend"] == "gloo" and dp["buckets"] == len(dp["bucket_bytes"]) == len(dp["bucket_allreduce_ms_alone"])
+    assert dp["launch_order"] == list(range(dp["buckets"])) and dp["exposed_wait_ms_per_step"] is not None
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the one-GPU lease runs the gloo variant above")
+def test_bench_two_ranks_rccl_full_graph():
+    """The product path of `bench.py --gpus 2`: one rank per GPU, backend nccl (= RCCL), the bucketed all-reduces captured inside the
+    step graph.  Runs wherever two devices are visible."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--profile-gemm", "0"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["step_mode"] == "one hipGraph (collectives captured)"
+    dp = out["dp"]
+    assert dp["world_size"] == 2 and dp["backend"] == "nccl" and dp["rccl_version"][0].isdigit()
+    assert dp["launch_order"] == list(range(dp["buckets"])) and dp["buckets_launched_inside_backward"] >= 1
+    assert all(t > 0 for t in dp["bucket_allreduce_ms_alone"])

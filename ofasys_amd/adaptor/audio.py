@@ -125,6 +125,12 @@ class AudioFbankAdaptor(BaseAdaptor):
         self.mask_prob = cfg.mask_prob
         self.mask_channel_prob = cfg.mask_channel_prob
 
+    def rel_pos_planes(self, seq_length, **kwargs):
+        if seq_length > self.audio_rp_bucket.size(0):
+            return None
+        return (("audio", id(self), seq_length),
+                lambda: [(self.audio_rp_bucket[:seq_length, :seq_length], self.audio_rel_pos_table_list)])
+
     def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
         if seq_length > self.audio_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.audio_rp_bucket.size(0)} positions of audio_rp_bucket")

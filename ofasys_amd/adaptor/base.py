@@ -119,9 +119,22 @@ class BaseAdaptor(torch.nn.Module):
             batch_size, seq_length = output.embed.size()[:2]
             num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
             for idx in range(num_rel_pos_tables):
-                values = self.get_rel_pos_bias(batch_size, seq_length, idx)
-                output.self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
+                output.self_attn_bias.append(self.lazy_rel_pos_bias(batch_size, seq_length, idx))
         return output
+
+    # ---- the rel-pos bias, deferred.  The reference materialises `expand_rel_pos_bias(get_rel_pos_bias(...))` -- [B,A,T,T] per layer
+    # -- right here (adaptor/base.py:183-189).  This build hands over an ops.LazyBias instead: `.expand()` IS that tensor (computed on
+    # demand: fp32 tier, attention-weight outputs, custom consumers), and `.planes` is what it is made of -- integer bucket ids +
+    # the per-layer tables -- which the general adaptor turns into the in-kernel form (ops.PosBias, csrc/attention.hip MODE 2).
+    def rel_pos_planes(self, seq_length, **kwargs):
+        """(key, fn) or None.  fn() -> [(bucket ids LongTensor [n, n], per-layer tables nn.ModuleList), ...] such that
+        get_rel_pos_bias(.., idx) == sum_p tables_p[idx].weight[ids_p]; key: hashable, identifies the ids (they are cached per slot
+        layout, fn only runs on a miss).  None (the default, a custom adaptor): the bias is taken dense from get_rel_pos_bias."""
+        return None
+
+    def lazy_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
+        return ops.LazyBias(lambda: self.get_rel_pos_bias(batch_size, seq_length, idx, **kwargs), batch_size,
+                            self.rel_pos_planes(seq_length, **kwargs), idx)
 
     @abstractmethod
     def forward(self, inputs: Union[Slot, List[Slot]], **kwargs) -> AdaptorOutput:

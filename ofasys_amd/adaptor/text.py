@@ -72,6 +72,12 @@ class TextAdaptor(BaseAdaptor):
         rp_bucket = self.token_rp_bucket[:seq_length, :seq_length].contiguous()
         return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight)
 
+    def rel_pos_planes(self, seq_length, **kwargs):
+        if seq_length > self.token_rp_bucket.size(0):
+            return None                                                 # (get_rel_pos_bias raises the reference's error)
+        return (("text", id(self), seq_length),
+                lambda: [(self.token_rp_bucket[:seq_length, :seq_length], self.token_rel_pos_table_list)])
+
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         src_tokens = slot.value
         if self.dictionary.pad() is not None:

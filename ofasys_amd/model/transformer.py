@@ -19,14 +19,25 @@ from ..preprocessor import Dictionary, Slot
 
 
 def _check_packable(cfg, wants_unsupported):
-    """Packed rows run on the bias-free attention configuration only (the dense [B,A,T,T] position bias of the default
-    configuration is laid out by padded position) and produce no per-layer extras."""
-    if cfg.use_self_attn_bias or not cfg.entangle_position_embedding:
-        raise NotImplementedError("row packing needs use_self_attn_bias=False and entangle_position_embedding=True "
-                                  "(the image_patch_embed / cfg-2 corner); run padded otherwise")
+    """Packed rows produce no per-layer extras (no [B,A,T,S] attention map exists in this mode)."""
     if wants_unsupported:
         raise NotImplementedError("row packing: hidden-state / attention-weight outputs, incremental decoding and full-context "
                                   "alignment are only available on padded batches")
+
+
+def _packed_bias(bias_list, q_index, q_inverse, k_index, k_inverse, prefix_ok, what):
+    """The per-layer ops.PosBias list over packed rows (pos_q / pos_k gathered ONCE: the layers share them)."""
+    if not bias_list:
+        return None
+    first = bias_list[0]
+    if not isinstance(first, ops.PosBias):
+        raise NotImplementedError(f"row packing: the {what} position bias is a dense [B,A,T,T] tensor (a custom adaptor produced it); "
+                                  "run such batches padded")
+    if first.rel is not None and not prefix_ok:
+        raise NotImplementedError(f"row packing with a rel-pos bias needs every sample's valid {what} positions to be a prefix of its "
+                                  "padded row (one ragged slot, at the end); run this batch padded")
+    base = first.packed(q_index, q_inverse, k_index, k_inverse)
+    return [ops.PosBias(base.pos_q, base.pos_k, b.heads, b.attn_scaling, b.rel, b.tables, ()) for b in bias_list]
 
 
 class TransformerEncoder(nn.Module):
@@ -53,10 +64,14 @@ class TransformerEncoder(nn.Module):
         if len(slots) == 0:
             return None
         adaptor_output = AdaptorOutput(*self.adaptor(slots))
+        layer_bias = adaptor_output.self_attn_bias if self.cfg.use_self_attn_bias else None
         if pack is not None:
             _check_packable(self.cfg, return_all_hiddens or return_all_attention_weights)
             x = ops.pack_rows(adaptor_output.embed, pack.enc_index, pack.enc_inverse).transpose(0, 1)   # [rows, 1, C] view
             layer_mask = pack.enc_self                               # padded rows are simply absent: nothing to zero or mask
+            if layer_bias is not None:
+                layer_bias = _packed_bias(layer_bias, pack.enc_index, pack.enc_inverse, pack.enc_index, pack.enc_inverse,
+                                          pack.enc_prefix, "encoder")
         else:
             # zero the padded positions (transformer.py:110-112); unconditional, no host sync
             adaptor_output.embed = ops.add_rowvec_mask(adaptor_output.embed, None, None, adaptor_output.masks)
@@ -67,9 +82,9 @@ class TransformerEncoder(nn.Module):
         encoder_attention_states = []
         chain = LayerChain()
         for idx, layer in enumerate(self.layers):
-            if self.cfg.use_self_attn_bias:
-                b = adaptor_output.self_attn_bias[0 if self.cfg.share_attn_bias else idx]
-                self_attn_bias = b.view(-1, T, T)
+            if layer_bias is not None:
+                b = layer_bias[0 if self.cfg.share_attn_bias else idx]
+                self_attn_bias = b if isinstance(b, ops.PosBias) else b.view(-1, T, T)     # (PosBias: the same tensor, un-materialised)
             else:
                 self_attn_bias = None
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
@@ -142,10 +157,12 @@ class TransformerDecoder(nn.Module):
         return TransformerDecoderLayer(cfg, no_encoder_attn, drop_path_rate=drop_path_rate)
 
     def get_cross_pos_info(self, embed, tgt_pos_embed, src_pos_embed):
-        """abs position bias for cross attention -> [B,A,Tt,Ts] (model/transformer.py:280-299)."""
-        pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling)
+        """abs position bias for cross attention (model/transformer.py:280-299): the reference's [B,A,Tt,Ts] tensor as an
+        un-materialised ops.PosBias (`.dense()` is the tensor)."""
+        scaling = self.adaptor.attn_scaling()
+        pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling / scaling)     # (= 1 for every OFA architecture)
         pos_k = self.cross_pos_k_linear(src_pos_embed)
-        return ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
+        return ops.PosBias(pos_q, pos_k, self.num_attention_heads, scaling)
 
     def forward(self, slots: List[Slot], encoder_out: Optional[Dict[str, List[Tensor]]] = None,
                 incremental_state=None, features_only: bool = False, full_context_alignment: bool = False,
@@ -183,7 +200,9 @@ class TransformerDecoder(nn.Module):
         all_self_attn_bias = adaptor_output.self_attn_bias
         if not self.cfg.entangle_position_embedding:
             cross_abs_pos_bias = self.get_cross_pos_info(tgt_embed, tgt_pos_embed, src_pos_embed=src_pos_embed)
-            cross_abs_pos_bias = cross_abs_pos_bias.reshape(-1, *cross_abs_pos_bias.size()[-2:])
+            if incremental_state is not None:                        # (a decoding step slices the bias: the tensor form)
+                cross_abs_pos_bias = cross_abs_pos_bias.dense()
+                cross_abs_pos_bias = cross_abs_pos_bias.reshape(-1, *cross_abs_pos_bias.size()[-2:])
         else:
             cross_abs_pos_bias = None
         if incremental_state is not None:                            # one step: the last target position only (:447-450)
@@ -201,7 +220,11 @@ class TransformerDecoder(nn.Module):
                               else None)
             if self.cfg.use_self_attn_bias:
                 b = all_self_attn_bias[0 if self.cfg.share_attn_bias else idx]
-                self_attn_bias = b.view(-1, *b.size()[-2:])
+                if isinstance(b, ops.PosBias) and incremental_state is None:
+                    self_attn_bias = b                                # un-materialised: the fused kernels compute it
+                else:
+                    b = b.dense() if isinstance(b, ops.PosBias) else b
+                    self_attn_bias = b.view(-1, *b.size()[-2:])
                 if incremental_state is not None:
                     self_attn_bias = self_attn_bias[:, -1:, :]        # the new position's row against every cached key
             else:
@@ -246,11 +269,20 @@ class TransformerDecoder(nn.Module):
         enc = encoder_out["encoder_out"][0]                           # [enc rows, 1, C]
         x = ops.pack_rows(adaptor_output.embed, pack.dec_index, pack.dec_inverse).transpose(0, 1)       # [dec rows, 1, C]
         tag = causal_tag(x.device)
+        self_bias = cross_bias = None
+        if self.cfg.use_self_attn_bias:
+            self_bias = _packed_bias(adaptor_output.self_attn_bias, pack.dec_index, pack.dec_inverse, pack.dec_index, pack.dec_inverse,
+                                     pack.dec_prefix, "decoder")
+        if not self.cfg.entangle_position_embedding:
+            src_pos = encoder_out["position_embeddings"][0]           # [B, Ts, C] padded, like the target's: packed here
+            cross_bias = self.get_cross_pos_info(None, adaptor_output.pos_embed, src_pos_embed=src_pos).packed(
+                pack.dec_index, pack.dec_inverse, pack.enc_index, pack.enc_inverse)
         chain = LayerChain()
         for idx, layer in enumerate(self.layers):
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
+            sb = self_bias[0 if self.cfg.share_attn_bias else idx] if self_bias is not None else False
             x, _, _ = layer(x, enc, pack.cross, None, self_attn_mask=tag, self_attn_padding_mask=pack.dec_self, need_attn=False,
-                            need_head_weights=False, self_attn_bias=False, cross_attn_bias=None,
+                            need_head_weights=False, self_attn_bias=sb, cross_attn_bias=cross_bias,
                             modal_mask=adaptor_output.modal_mask, chain=chain)
         normed = chain.take()
         if normed is not None:

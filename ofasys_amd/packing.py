@@ -10,8 +10,10 @@ The reference pads every sample of a micro-batch to the longest one, computes al
     every row-wise kernel (LayerNorm, GEMMs, GELU, residual joins, criterion) simply sees fewer rows;
     attention takes the segment table {q_off, q_len, k_off, k_len} per sample (csrc/attention.hip, ragged mode).
 
-Only the bias-free attention configuration (use_self_attn_bias = False: the image_patch_embed corner, cfg-2) is packed -- the dense
-[B,A,T,T] position bias of the default configuration is laid out by padded position.  R is rounded up to `bucket` rows so that a
+The default (biased-attention) configuration packs too since round 3: the position bias is no longer a dense [B,A,T,T] tensor laid
+out by padded position but computed inside the attention kernels from packed pos_q / pos_k rows and position-indexed bucket ids
+(ops.PosBias); the ids need packed row r of a sample to BE padded position r, i.e. each sample's valid positions must be a prefix of
+its padded row (one ragged slot, at the end -- image + text, video + text, text alone; `enc_prefix` / `dec_prefix`).  R is rounded up to `bucket` rows so that a
 handful of hipGraphs cover all batches of a length distribution.  Host side: the plan is built from HOST masks / lengths (no device
 sync), shipped with the batch, and is part of the step's static inputs.
 """
@@ -50,11 +52,14 @@ class PackPlan:
     cross: Segments
     enc_tokens: int            # non-pad positions (the metric's numerator)
     dec_tokens: int
+    enc_prefix: bool = True    # every sample's valid positions are the PREFIX 0 .. len-1 of its padded row (one ragged slot, at the
+    dec_prefix: bool = True    # end): packed row r of a sample is then padded position r, which the rel-pos ids are indexed by
 
     def to(self, device):
         mv = lambda t: t.to(device, non_blocking=True)                       # noqa: E731
         return PackPlan(mv(self.enc_index), mv(self.dec_index), mv(self.enc_inverse), mv(self.dec_inverse),
-                        self.enc_self.to(device), self.dec_self.to(device), self.cross.to(device), self.enc_tokens, self.dec_tokens)
+                        self.enc_self.to(device), self.dec_self.to(device), self.cross.to(device), self.enc_tokens, self.dec_tokens,
+                        self.enc_prefix, self.dec_prefix)
 
     def tensors(self):
         return [self.enc_index, self.dec_index, self.enc_inverse, self.dec_inverse, self.enc_self.table, self.dec_self.table,
@@ -81,7 +86,8 @@ def _layout(mask: torch.Tensor, bucket: int):
     inverse = torch.full((B * T,), -1, dtype=torch.int64)
     valid = index >= 0
     inverse[index[valid]] = torch.nonzero(valid).squeeze(1)
-    return index, inverse, offs, lengths, R
+    prefix = all(bool(keep[b, :lengths[b]].all()) for b in range(B))
+    return index, inverse, offs, lengths, R, prefix
 
 
 def build_pack_plan(enc_pad_mask: torch.Tensor, dec_pad_mask: torch.Tensor, bucket: int = 256,
@@ -91,8 +97,8 @@ def build_pack_plan(enc_pad_mask: torch.Tensor, dec_pad_mask: torch.Tensor, buck
     slots concatenated): they are packed in order."""
     assert enc_pad_mask.device.type == "cpu" and dec_pad_mask.device.type == "cpu" and enc_pad_mask.shape[0] == dec_pad_mask.shape[0]
     B = enc_pad_mask.shape[0]
-    ei, einv, eo, el, Re = _layout(enc_pad_mask.bool(), bucket)
-    di, dinv, do_, dl, Rd = _layout(dec_pad_mask.bool(), dec_bucket or bucket)
+    ei, einv, eo, el, Re, epre = _layout(enc_pad_mask.bool(), bucket)
+    di, dinv, do_, dl, Rd, dpre = _layout(dec_pad_mask.bool(), dec_bucket or bucket)
 
     def table(qo, ql, ko, kl):
         return torch.tensor([[qo[b], ql[b], ko[b], kl[b]] for b in range(B)], dtype=torch.int32)
@@ -102,7 +108,7 @@ def build_pack_plan(enc_pad_mask: torch.Tensor, dec_pad_mask: torch.Tensor, buck
                     Segments(table(eo, el, eo, el), B, Re, Re, mq_e, mq_e),
                     Segments(table(do_, dl, do_, dl), B, Rd, Rd, mq_d, mq_d),
                     Segments(table(do_, dl, eo, el), B, Rd, Re, mq_d, mq_e),
-                    int(sum(el)), int(sum(dl)))
+                    int(sum(el)), int(sum(dl)), epre, dpre)
 
 
 def causal_tag(device):

@@ -127,6 +127,20 @@ CASES = {
 }
 
 
+# Cases WITHOUT a stored golden file: the GPU test compares with the oracle directly (tests/test_bench_parity_gpu.py); listed here so
+# that oracle/ref_bf16_gap.py can measure the REFERENCE's own bf16-vs-fp32 gap on exactly these inputs (the bf16 tolerance's basis).
+EXTRA_CASES = {
+    # OFA-large + one IMAGE slot through the default adaptor with the reference's default trunk (resnet152), train-mode BatchNorm
+    "large_image": dict(
+        arch="large", active={"text", "image_resnet"}, overrides={"dropout": 0.0}, adaptor_overrides={}, train=True,
+        slots=[("IMAGE", True, ("img", "large.image", (2, 3, 224, 224)), None),
+               ("TEXT", True, ("tok", "large.src", (2, 20), [20, 13]), None),
+               ("TEXT", False, ("tok", "prev", (2, 16), [16, 9]), None)],
+        full_grads=[],
+    ),
+}
+
+
 def make_value(spec, vocab):
     if spec[0] == "tok":
         _, key, shape, lengths = spec

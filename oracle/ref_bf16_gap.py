@@ -5,9 +5,9 @@ import sys, torch
 sys.path.insert(0, '/root/repo')
 from oracle import recipe
 from oracle.ref_import import build_reference_model, install
-from oracle.cases import CASES, VOCAB_EXTRA, make_value, make_target
+from oracle.cases import CASES, EXTRA_CASES, VOCAB_EXTRA, make_value, make_target
 name = sys.argv[1]
-case = CASES[name]
+case = CASES.get(name) or EXTRA_CASES[name]
 install()
 import ofasys
 from ofasys import ModalityType

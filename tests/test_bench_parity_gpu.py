@@ -153,21 +153,22 @@ def test_cfg4_video_real_shape_vs_oracle(dtype):
         assert 0.3 < float(got[stem].double().norm()) / float(want[stem].double().norm()) < 3.0
 
 
-LARGE_IMG = {"arch": "large", "active": {"text", "image_resnet"}, "overrides": {"dropout": 0.0}, "adaptor_overrides": {}}
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_large_with_default_image_adaptor_vs_oracle(dtype):
     """OFA-large (D = 1024, 16 heads, 12 + 12 layers) with an IMAGE slot through the default adaptor (image_resnet, the reference's
-    default trunk resnet152, adaptor/image_resnet.py:45-47; 224 x 224 -> 196 positions, 2-D rel-pos bias per layer) + ragged text."""
+    default trunk resnet152, adaptor/image_resnet.py:45-47; 224 x 224 -> 196 positions, 2-D rel-pos bias per layer) + ragged text
+    (oracle/cases.py EXTRA_CASES["large_image"]).  fp32 holds the north-star 1e-3 on logits / loss / every gradient outside the
+    trunk; inside the 152-layer train-mode BatchNorm trunk at batch 2 the gradient norms get 5e-2 (50 layers: 2e-2, see
+    tests/test_model_gpu.py on the conditioning).  bf16: the REFERENCE ITSELF differs from its own fp32 run by 27.6 % of max |logit|
+    on these inputs (oracle/ref_bf16_gap.py large_image) -- the bound is 2x that, i.e. this leg only shows the MFMA path of the
+    large architecture runs an image slot end to end without blowing up; the arithmetic is pinned by the fp32 leg."""
     from ofasys_amd import ops
-    model, d = build_model(LARGE_IMG, DEV, dtype)
+    from oracle.cases import EXTRA_CASES
+    from tests.golden_util import case_inputs
+    case = EXTRA_CASES["large_image"]
+    model, d = build_model(case, DEV, dtype)
     model.train()
-    img = recipe.floats("bench.large.image", (2, 3, 224, 224))
-    src = _tok("bench.large.src", (2, 20), [20, 13])
-    prev = _tok("bench.large.prev", (2, 16), [16, 9], bos=True)
-    target = make_target(prev)
-    vals = [("IMAGE", True, img, None), ("TEXT", True, src, None), ("TEXT", False, prev, None)]
+    vals, target = case_inputs(case)
     cfg = OConfig(**ARCH["large"], resnet_layers=(3, 8, 36), training=True)
     loss, n, want = _oracle_step(oracle_state_for(model), cfg, [(vals, target)])
     with torch.no_grad():
@@ -181,12 +182,14 @@ def test_large_with_default_image_adaptor_vs_oracle(dtype):
     if dtype == torch.float32:
         assert rel_err(logits.detach().cpu(), ref_logits) < 1e-3
         assert abs(float(got_loss) - loss) <= 1e-3 * loss
-        _check_grads(got, want)
+        _check_grads(got, want, backbone_tol=5e-2)
     else:
-        tol = 1e-1                                                     # the ResNet cases' bf16 bound (tests/test_model_gpu.py), 152-layer trunk
+        tol = 2 * 0.2765
         assert rel_err(logits.detach().float().cpu(), ref_logits) < tol
-        assert abs(float(got_loss) - loss) <= tol * loss
-        _bf16_grad_check(got, {k: v for k, v in want.items() if ".embed_images." not in k}, tol)
+        assert abs(float(got_loss) - loss) <= 0.1 * loss
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                assert bool(torch.isfinite(p.grad.float()).all()), k
 
 
 def test_cfg3_two_task_step_resnet101():

@@ -17,6 +17,13 @@ CASE = {"arch": "tiny", "active": {"text"}, "overrides": {"use_self_attn_bias": 
         "adaptor_overrides": {"text": {"entangle_position_embedding": True}}}
 
 
+# the reference's DEFAULT configuration (use_self_attn_bias: abs-pos + rel-pos bias in every attention): packed since round 3 -- the bias
+# is computed inside the attention kernels from packed pos_q / pos_k rows and position-indexed bucket ids (ops.PosBias)
+BIASED = {"arch": "tiny", "active": {"text"}, "overrides": {"dropout": 0.0}, "adaptor_overrides": {}}
+BIASED_IMG = {"arch": "tiny", "active": {"text", "image_resnet"}, "overrides": {"dropout": 0.0},
+              "adaptor_overrides": {"image_resnet": {"resnet_type": "resnet50"}}}
+
+
 def _tok(key, shape, lengths=None, bos=False):
     return recipe.tokens("pack." + key, shape, V, lengths, bos=0 if bos else None)
 
@@ -33,12 +40,20 @@ def _batch(two_slots):
     return vals, make_target(prev), enc_tokens.eq(1), prev.eq(1)
 
 
-@pytest.mark.parametrize("two_slots", [False, True])
-def test_packed_forward_backward_equals_padded(two_slots):
+@pytest.mark.parametrize("two_slots,case_name", [(False, "bias-free"), (True, "bias-free"), (False, "biased"), ("image", "biased")])
+def test_packed_forward_backward_equals_padded(two_slots, case_name):
     from ofasys_amd import ops
     from ofasys_amd.packing import build_pack_plan
-    vals, target, enc_mask, dec_mask = _batch(two_slots)
+    CASE = globals()["CASE"] if case_name == "bias-free" else (BIASED_IMG if two_slots == "image" else BIASED)
+    if two_slots == "image":          # [IMAGE (16 positions, all valid)][TEXT ragged] -> [TEXT]: the valid positions stay a prefix
+        vals, target, enc_mask, dec_mask = _batch(False)
+        img = recipe.floats("pack.image", (enc_mask.shape[0], 3, 64, 64))
+        vals = [("IMAGE", True, img, None)] + vals
+        enc_mask = torch.cat([torch.zeros(enc_mask.shape[0], 16, dtype=torch.bool), enc_mask], 1)
+    else:
+        vals, target, enc_mask, dec_mask = _batch(two_slots)
     plan = build_pack_plan(enc_mask, dec_mask, bucket=64)
+    assert plan.enc_prefix == (two_slots is not True) and plan.dec_prefix
     assert plan.enc_tokens == int((~enc_mask).sum()) and plan.dec_tokens == int((~dec_mask).sum())
     assert plan.enc_index.numel() % 64 == 0 and plan.enc_index.numel() < enc_mask.numel()       # really fewer rows
     assert all(int(o) % 8 == 0 for o in plan.enc_self.table[:, 0])
@@ -79,7 +94,8 @@ def test_packed_forward_backward_equals_padded(two_slots):
     assert set(gp) == set(gk)
     for k in gp:
         a, b = gp[k], gk[k]
-        assert float((a - b).norm()) <= 3e-2 * float(a.norm()) + 2e-3 * gmax, k
+        t = 1e-1 if ".embed_images." in k else 3e-2                       # (bf16 through the BatchNorm trunk: see tests/test_model_gpu.py)
+        assert float((a - b).norm()) <= t * float(a.norm()) + 2e-3 * gmax, k
 
 
 def test_packed_train_step_and_graph_replay():
@@ -119,10 +135,13 @@ def test_packing_refuses_what_it_cannot_run():
     from ofasys_amd.packing import build_pack_plan
     vals, target, enc_mask, dec_mask = _batch(False)
     plan = build_pack_plan(enc_mask, dec_mask, bucket=64).to(DEV)
-    biased = {"arch": "tiny", "active": {"text"}, "overrides": {"dropout": 0.0}, "adaptor_overrides": {}}
-    model, d = build_model(biased, DEV, torch.bfloat16)
-    with pytest.raises(NotImplementedError, match="row packing"):
-        model(make_slots(vals, DEV, torch.bfloat16), pack=plan)
+    # a rel-pos bias over packed rows needs "packed row r == padded position r": two ragged source slots break that
+    vals2, _, enc_mask2, dec_mask2 = _batch(True)
+    plan2 = build_pack_plan(enc_mask2, dec_mask2, bucket=64).to(DEV)
+    assert not plan2.enc_prefix
+    model, d = build_model(BIASED, DEV, torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="prefix"):
+        model(make_slots(vals2, DEV, torch.bfloat16), pack=plan2)
     model, d = build_model(CASE, DEV, torch.float32)                         # fp32: no fused ragged attention kernel
     with pytest.raises(NotImplementedError, match="fused"):
         model(make_slots(vals, DEV), pack=plan)

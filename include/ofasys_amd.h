@@ -186,45 +186,28 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, 
                  void* dv, void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo,
                  float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 
-/* ---- Attention with the POSITION BIAS computed inside the kernels.
- * Replaces, for the default OFASys configuration (use_self_attn_bias = True, model/ofa.py:110-113), the dense [B*A, T, S] bias the
- * reference builds per layer and adds to the scores (multihead_attention.py:308-311):
- *   abs-pos  (pos_q_linear(pos) * pos_scaling) pos_k_linear(pos)^T per head   adaptor/general.py:223-243; decoder cross attention:
- *            cross_pos_q_linear / cross_pos_k_linear, model/transformer.py:280-299
- *   rel-pos  + table_l[bucket[i][j]] on every slot's diagonal block           adaptor/general.py:265-280 with the slot values of
- *            adaptor/text.py:101-104, image_resnet.py:116-128, audio.py, video_image_sequence.py:187-204 (frame table + image table)
- * pos_q [B, T, heads*64] (ld = ldpq) and pos_k [B, S, heads*64] (ld = ldpk) are the two projections; pos_q must arrive multiplied by
- * pos_scaling / scale (= 1 for every OFA architecture: both are (2 * head_dim)^-0.5), so that the kernels contract over [q | pos_q] .
- * [k | pos_k] and multiply once by `scale`.  relmap (optional; NULL = abs-pos only, the cross-attention case): uint16
- * [relmap_planes][Tm][relmap_ld] COMPACT bucket ids by (query position, key position), 0 = no rel-pos bias; relmap_ld a multiple of 32
- * >= S rounded up to 32 (rows padded with 0), planes relmap_plane_stride elements apart, 1 plane or 2 (video: bias = table[id0] +
- * table[id1]).  used: int32 [ncompact], used[c] = (table slot << 20) | table row for c >= 1 (used[0] ignored); tab0..tab3: THIS
- * layer's tables [rows, heads] in `dtype` (slots not referenced by `used` may be NULL); ncompact <= 4096.  Positions are sample-local
- * (ragged mode: row index inside the segment), so the ids are batch-, head- and layer-independent.  Everything else as ofa_attn_fwd. */
-int ofa_attn_pos_fwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k, const uint16_t* relmap,
-                     int relmap_planes, int relmap_ld, int64_t relmap_plane_stride, const int32_t* used, int ncompact,
-                     const void* tab0, const void* tab1, const void* tab2, const void* tab3, const uint8_t* kpm, const void* c_attn,
-                     int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk,
-                     int64_t ldo, int64_t ldpq, int64_t ldpk, float scale, int causal, const int32_t* seg, int rows_q, int rows_k,
-                     int dtype, void* stream);
-/* Backward of ofa_attn_pos_fwd (out != NULL always: delta is computed on the way in and written).  Besides dq / dk / dv it writes
- * dpos_q [B,T,D] (ld = ldpq) and dpos_k [B,S,D] (ld = ldpk), and -- with relmap -- dtab_slab: fp32 [B*heads][ofa_attn_pos_qtiles(T)]
- * [ncompact] partial sums of dS by compact id, one row per query tile (the dQ kernel histograms dS in LDS, one private histogram per
- * wave, added in a fixed order: bitwise reproducible).  ofa_relpos_table_grad folds them into the tables' gradients. */
-int ofa_attn_pos_bwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k, const uint16_t* relmap,
-                     int relmap_planes, int relmap_ld, int64_t relmap_plane_stride, const int32_t* used, int ncompact,
-                     const void* tab0, const void* tab1, const void* tab2, const void* tab3, const void* dout, const uint8_t* kpm,
-                     const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out, void* dq, void* dk,
-                     void* dv, void* dpos_q, void* dpos_k, float* dtab_slab, int B, int heads, int T, int S, int Tpad, int64_t ldq,
-                     int64_t ldk, int64_t ldo, int64_t ldpq, int64_t ldpk, float scale, int causal, const int32_t* seg, int rows_q,
-                     int rows_k, int dtype, void* stream);
-/* Query tiles per (batch, head) of the positional kernels (the middle dimension of dtab_slab). */
-int ofa_attn_pos_qtiles(int T);
-/* dtab_s[row, h] (+)= sum over (b, query tile) of slab[(b*heads + h)][tile][c] for every compact id c >= 1 with used[c] = (s << 20) |
- * row -- the gradient of the rel-pos tables (an nn.Embedding backward in the reference: text.py:101-104 etc.), deterministic.
- * dtab0..3: [rows, heads] in `dtype` (the gradient arena when accumulate != 0). */
-int ofa_relpos_table_grad(const float* slab, const int32_t* used, int ncompact, int B, int heads, int qtiles, void* dtab0, void* dtab1,
-                          void* dtab2, void* dtab3, int accumulate, int dtype, void* stream);
+/* ---- Attention with a batch-SHARED position bias.
+ * The reference adds a dense bias [B*A, T, S] to the scores of every attention of its default configuration (use_self_attn_bias,
+ * model/ofa.py:110-113; multihead_attention.py:308-311): abs-pos (pos_q_linear(pos) * pos_scaling) pos_k_linear(pos)^T per head
+ * (adaptor/general.py:223-243; cross attention: model/transformer.py:280-299) + table_l[bucket[i][j]] on every slot's diagonal block
+ * (general.py:265-280; text.py:101-104, image_resnet.py:116-128, video_image_sequence.py:187-204).  Position embeddings do not depend
+ * on the batch row (text: arange; image / video: the patch grid), so that tensor is B copies of ONE [A, T, S] matrix per layer -- which
+ * is what these entry points take: bias [heads, Tb, Sb] in `dtype` (dense), indexed by (head, query position, key position) for
+ * every sample; in ragged mode by the position INSIDE the sample (so a batch whose valid positions are a prefix of each padded row
+ * packs without touching the bias).  Tb >= T, Sb >= S.  Everything else as ofa_attn_fwd (seg != NULL: kpm must be NULL). */
+int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias, int Tb, int Sb, const uint8_t* kpm,
+                       const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
+                       int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k,
+                       int dtype, void* stream);
+/* Backward (out != NULL always: delta is computed on the way in and written).  dbias_sum (optional): fp32 [heads, Tb, Sb] =
+ * sum over the batch of dS -- the gradient of the shared bias.  The reference obtains it by materialising dS as [B*A, T, S] and
+ * reducing the expand; here a third kernel walks the batch per [128 x 64 / 128] tile of one head, recomputes S and dP of that tile
+ * (lse / delta are known) and accumulates dS in registers: written once, no atomics, bitwise reproducible. */
+int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
+                       const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out,
+                       void* dq, void* dk, void* dv, float* dbias_sum, int B, int heads, int T, int S, int Tpad, int64_t ldq,
+                       int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype,
+                       void* stream);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */

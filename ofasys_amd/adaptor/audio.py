@@ -97,6 +97,8 @@ class Postnet(nn.Module):                                                      #
 
 @register_config("ofasys.adaptor", "audio_fbank", AudioFbankAdaptorConfig)
 class AudioFbankAdaptor(BaseAdaptor):
+    pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: AudioFbankAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
@@ -124,12 +126,6 @@ class AudioFbankAdaptor(BaseAdaptor):
         self.mask_emb = nn.Parameter(torch.FloatTensor(cfg.embed_dim).uniform_())
         self.mask_prob = cfg.mask_prob
         self.mask_channel_prob = cfg.mask_channel_prob
-
-    def rel_pos_planes(self, seq_length, **kwargs):
-        if seq_length > self.audio_rp_bucket.size(0):
-            return None
-        return (("audio", id(self), seq_length),
-                lambda: [(self.audio_rp_bucket[:seq_length, :seq_length], self.audio_rel_pos_table_list)])
 
     def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
         if seq_length > self.audio_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)

@@ -24,6 +24,7 @@ class AdaptorOutput:
     pos_embed: torch.Tensor
     self_attn_bias: List[torch.Tensor]
     modal_mask: torch.Tensor = None
+    pos_shared: bool = False      # pos_embed (and the rel-pos bias) is the same for every batch row: see BaseAdaptor.pos_batch_invariant
 
     def __post_init__(self):
         assert self.embed is not None
@@ -75,6 +76,12 @@ class BaseAdaptorConfig(BaseDataclass):
 
 
 class BaseAdaptor(torch.nn.Module):
+    # True when the adaptor's pos_embed rows do not depend on the batch row (text: embed_positions(arange), adaptor/text.py:124;
+    # image / video: the patch grid, image_resnet.py:153-157; audio: arange).  The position bias of such slots is ONE [A, T, T]
+    # matrix per layer and the general adaptor builds it once instead of B times (ops.SharedBias).  A custom adaptor whose
+    # positions vary per sample keeps the default False and gets the reference's dense [B, A, T, T] assembly.
+    pos_batch_invariant = False
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: BaseAdaptorConfig):
         super().__init__()
@@ -114,27 +121,15 @@ class BaseAdaptor(torch.nn.Module):
         if self.layernorm_position is not None and output.pos_embed is not None:
             output.pos_embed = self.layernorm_position(output.pos_embed)
         output.embed = self.dropout_module(embed)
+        output.pos_shared = bool(self.pos_batch_invariant)
         if not output.self_attn_bias and self.cfg.use_self_attn_bias:
             output.self_attn_bias = []
             batch_size, seq_length = output.embed.size()[:2]
             num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
             for idx in range(num_rel_pos_tables):
-                output.self_attn_bias.append(self.lazy_rel_pos_bias(batch_size, seq_length, idx))
+                values = self.get_rel_pos_bias(batch_size, seq_length, idx)
+                output.self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
         return output
-
-    # ---- the rel-pos bias, deferred.  The reference materialises `expand_rel_pos_bias(get_rel_pos_bias(...))` -- [B,A,T,T] per layer
-    # -- right here (adaptor/base.py:183-189).  This build hands over an ops.LazyBias instead: `.expand()` IS that tensor (computed on
-    # demand: fp32 tier, attention-weight outputs, custom consumers), and `.planes` is what it is made of -- integer bucket ids +
-    # the per-layer tables -- which the general adaptor turns into the in-kernel form (ops.PosBias, csrc/attention.hip MODE 2).
-    def rel_pos_planes(self, seq_length, **kwargs):
-        """(key, fn) or None.  fn() -> [(bucket ids LongTensor [n, n], per-layer tables nn.ModuleList), ...] such that
-        get_rel_pos_bias(.., idx) == sum_p tables_p[idx].weight[ids_p]; key: hashable, identifies the ids (they are cached per slot
-        layout, fn only runs on a miss).  None (the default, a custom adaptor): the bias is taken dense from get_rel_pos_bias."""
-        return None
-
-    def lazy_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
-        return ops.LazyBias(lambda: self.get_rel_pos_bias(batch_size, seq_length, idx, **kwargs), batch_size,
-                            self.rel_pos_planes(seq_length, **kwargs), idx)
 
     @abstractmethod
     def forward(self, inputs: Union[Slot, List[Slot]], **kwargs) -> AdaptorOutput:

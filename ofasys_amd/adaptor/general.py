@@ -119,53 +119,8 @@ class OFAGeneralAdaptor(torch.nn.Module):
         return torch.zeros(batch_size, self.num_attention_heads, seq_length, seq_length, dtype=pos_embed.dtype,
                            device=pos_embed.device)
 
-    def attn_scaling(self):
-        """The score scale of this side's attention layers, (head_dim * attn_scale_factor)^-0.5 (multihead_attention.py:54)."""
-        embed_dim = self.cfg.encoder_embed_dim if self.is_src else self.cfg.decoder_embed_dim
-        return float(embed_dim // self.num_attention_heads * self.cfg.attn_scale_factor) ** -0.5
-
-    def _rel_map(self, modality_outputs, starts, seq_length, device):
-        """ops.RelMap of this slot layout (cached: the ids depend on the adaptors and the slot lengths only), the per-slot table
-        lists by RelMap slot -- or None when some slot's bias is only known as a tensor."""
-        keys = []
-        for mo in modality_outputs:
-            b = mo.self_attn_bias[0] if mo.self_attn_bias else None
-            if b is None:
-                keys.append(None)
-            elif isinstance(b, ops.LazyBias) and b.planes_key is not None:
-                keys.append(b.planes_key)
-            else:
-                return None
-        key = (tuple(keys), tuple(mo.seq_length for mo in modality_outputs), str(device))
-        cache = self.__dict__.setdefault("_rel_cache", {})
-        hit = cache.get(key)
-        if hit is None:
-            blocks, table_lists = [], []
-            for mo, s0 in zip(modality_outputs, starts):
-                b = mo.self_attn_bias[0] if mo.self_attn_bias else None
-                if b is None:
-                    continue
-                planes = []
-                for ids, tables in b.planes_fn():
-                    slot = next((i for i, t in enumerate(table_lists) if t is tables), None)
-                    if slot is None:
-                        table_lists.append(tables)
-                        slot = len(table_lists) - 1
-                    planes.append((ids, slot))
-                blocks.append((s0, mo.seq_length, planes))
-            if not blocks or len(table_lists) > 4 or any(len(pl) > 2 for _, _, pl in blocks):
-                hit = False
-            else:
-                hit = (ops.RelMap(blocks, seq_length, device), table_lists)
-            if len(cache) > 256:
-                cache.clear()
-            cache[key] = hit
-        return hit or None
-
     def concat(self, modality_outputs: List[AdaptorOutput]) -> AdaptorOutput:
-        """general.py:245-282.  The per-layer bias list holds ops.PosBias objects -- the reference's [B,A,T,T] tensors
-        un-materialised (`.dense()` is the tensor) -- whenever every slot's rel-pos bias is known by its bucket ids and tables
-        (all built-in adaptors); a slot bias that is only a tensor (a custom adaptor) makes the list dense as in the reference."""
+        """general.py:245-282."""
         if len(modality_outputs) == 1:
             o = modality_outputs[0]
             output = AdaptorOutput(o.embed, o.masks, o.pos_embed, None)
@@ -176,9 +131,16 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 torch.cat(tuple(x.pos_embed for x in modality_outputs), dim=1),
                 None,
             )
+        self.last_pos_shared = all(getattr(mo, "pos_shared", False) for mo in modality_outputs)    # (read by the stacks)
         if not self.cfg.use_self_attn_bias:
             return output
         output.self_attn_bias = []
+        # The position bias is the same for every sample when every slot's positions are (all built-in adaptors): it is then built
+        # ONCE from row 0 -- [1, A, T, T] instead of general.py:223-282's [B, A, T, T], 154 MB per layer at cfg-2b -- and handed to
+        # the attention kernels as an ops.SharedBias, which also sum its gradient over the batch in-kernel
+        shared = self.last_pos_shared
+        output.pos_shared = shared
+        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed[:1] if shared else output.pos_embed)
         num_layers = self.cfg.encoder.layers if self.is_src else self.cfg.decoder.layers
         num_rel_pos_tables = 1 if self.cfg.share_attn_bias else num_layers
         starts, s = [], 0
@@ -186,26 +148,14 @@ class OFAGeneralAdaptor(torch.nn.Module):
             starts.append(s)
             s += mo.seq_length
         assert s == output.seq_length
-        rel = None if self.cfg.entangle_position_embedding else self._rel_map(modality_outputs, starts, s, output.embed.device)
-        if not self.cfg.entangle_position_embedding and (rel is not None or not any(mo.self_attn_bias for mo in modality_outputs)):
-            scaling = self.attn_scaling()
-            pos_q = self.pos_q_linear(output.pos_embed, alpha=self.pos_scaling / scaling)      # (= 1 for every OFA architecture)
-            pos_k = self.pos_k_linear(output.pos_embed)
-            shared = {}
-            for idx in range(num_rel_pos_tables):
-                blocks = [(s0, (mo.self_attn_bias[idx] if mo.self_attn_bias else None)) for mo, s0 in zip(modality_outputs, starts)]
-                tables = [tl[idx].weight for tl in rel[1]] if rel is not None else ()
-                output.self_attn_bias.append(ops.PosBias(pos_q, pos_k, self.num_attention_heads, scaling, rel[0] if rel is not None else None,
-                                                         tables, blocks if rel is not None else (), shared))
-            return output
-        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed)
         for idx in range(num_rel_pos_tables):
             values = []
             for mo in modality_outputs:
                 b = mo.self_attn_bias[idx] if mo.self_attn_bias else None
                 # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values; take the values back
                 values.append(_unexpand(b))
-            output.self_attn_bias.append(ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values))
+            b = ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values)
+            output.self_attn_bias.append(ops.SharedBias(b[0]) if shared else b)
         return output
 
     def upgrade_state_dict_named(self, state_dict, name):
@@ -224,8 +174,6 @@ def _unexpand(b):
     per-sample bias (no adaptor in scope produces one) is rejected."""
     if b is None:
         return None
-    if isinstance(b, ops.LazyBias):
-        return b.values()
     if b.dim() == 4 and (b.stride(0) == 0 or b.size(0) == 1):      # (a batch of one: nothing to expand, any stride)
         return b[0].permute(1, 2, 0)
     if b.dim() == 3:

@@ -24,6 +24,8 @@ class ImagePatchEmbedAdaptorConfig(BaseAdaptorConfig):
 
 @register_config("ofasys.adaptor", "image_patch_embed", ImagePatchEmbedAdaptorConfig)
 class ImagePatchEmbedAdaptor(BaseAdaptor):
+    pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: ImagePatchEmbedAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)

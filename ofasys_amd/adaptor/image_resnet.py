@@ -45,6 +45,8 @@ class ImageResnetAdaptorConfig(BaseAdaptorConfig):
 
 @register_config("ofasys.adaptor", "image_resnet", ImageResnetAdaptorConfig)
 class ImageResnetAdaptor(BaseAdaptor):
+    pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: ImageResnetAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
@@ -81,17 +83,11 @@ class ImageResnetAdaptor(BaseAdaptor):
         rp_bucket = self.image_rp_bucket[ids][:, ids].contiguous()             # integer double gather, bit-exact
         return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight)
 
-    def rel_pos_planes(self, seq_length, **kwargs):
-        ids = kwargs["image_position_ids"]                             # arange-derived from the feature map's (h, w): the key
-        return (("image", id(self), seq_length, self._last_hw),
-                lambda: [(self.image_rp_bucket[ids][:, ids], self.image_rel_pos_table_list)])
-
     def get_patch_images_info(self, patch_images):
         """image_resnet.py:130-164 -> (embed rows [B, h*w, 1024], n, mask, position ids [T], pos_embed [B, T, D])."""
         device = patch_images.device
         B = patch_images.size(0)
         rows, h, w = self.embed_images(patch_images)
-        self._last_hw = (int(h), int(w))
         n = h * w
         image_embed = rows.view(B, n, rows.shape[-1])
         image_padding_mask = torch.zeros((B, n), dtype=torch.bool, device=device)
@@ -109,5 +105,6 @@ class ImageResnetAdaptor(BaseAdaptor):
         if self.cfg.use_self_attn_bias:
             num_rel_pos_tables = 1 if self.cfg.share_attn_bias else self.num_layers
             for idx in range(num_rel_pos_tables):
-                self_attn_bias.append(self.lazy_rel_pos_bias(batch_size, seq_length, idx, image_position_ids=position_ids))
+                values = self.get_rel_pos_bias(batch_size, seq_length, idx, image_position_ids=position_ids)
+                self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
         return AdaptorOutput(image_embed, mask, pos_embed, self_attn_bias)

@@ -41,6 +41,8 @@ class TextAdaptorConfig(BaseAdaptorConfig):
 
 @register_config("ofasys.adaptor", "text", TextAdaptorConfig)
 class TextAdaptor(BaseAdaptor):
+    pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: TextAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
@@ -71,12 +73,6 @@ class TextAdaptor(BaseAdaptor):
             raise ValueError(f"sequence length {seq_length} exceeds the {self.token_rp_bucket.size(0)} positions of token_rp_bucket")
         rp_bucket = self.token_rp_bucket[:seq_length, :seq_length].contiguous()
         return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight)
-
-    def rel_pos_planes(self, seq_length, **kwargs):
-        if seq_length > self.token_rp_bucket.size(0):
-            return None                                                 # (get_rel_pos_bias raises the reference's error)
-        return (("text", id(self), seq_length),
-                lambda: [(self.token_rp_bucket[:seq_length, :seq_length], self.token_rel_pos_table_list)])
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         src_tokens = slot.value

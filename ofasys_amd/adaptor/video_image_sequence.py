@@ -31,6 +31,8 @@ def make_video_bucket_position(bucket_size, max_position=8192):
 
 @register_config("ofasys.adaptor", "video_image_sequence", VideoImageSequenceAdaptorConfig)
 class VideoImageSequenceAdaptor(BaseAdaptor):
+    pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
+
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: VideoImageSequenceAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
@@ -65,7 +67,6 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         clips = clip_videos.transpose(1, 2)                                               # [B, F, 3, H, W]
         B, Fr = clips.size(0), clips.size(1)
         rows, h, w = ira.embed_images(clips.reshape(-1, clips.size(2), clips.size(3), clips.size(4)))
-        ira._last_hw = (int(h), int(w))
         P = h * w
         T = P * Fr
         video_embed = rows.view(B, T, rows.shape[-1])                                     # rows are (b, f, h, w) ordered
@@ -89,20 +90,12 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         Fr = seq_length // P
         self_attn_bias = []
         if self.cfg.use_self_attn_bias:
-            def values(idx):
+            for idx in range(self.num_layers):
                 vi = ira.get_rel_pos_bias(batch_size, P, idx, image_position_ids=image_position_idx)   # [P,P,A]
                 vf = self.get_rel_pos_bias(batch_size, Fr, idx)                                        # [F,F,A]
                 A = vi.shape[-1]
-                return (vf.view(Fr, 1, Fr, 1, A) + vi.view(1, P, 1, P, A)).reshape(Fr * P, Fr * P, A)   # :187-204
-            # the same sum as two id planes over the [F*P, F*P] block: frame table[frame ids] + image table[patch ids]
-            def plane_ids():
-                fb = self.video_rp_bucket[:Fr, :Fr]
-                ib = ira.image_rp_bucket[image_position_idx][:, image_position_idx]
-                return [(fb.view(Fr, 1, Fr, 1).expand(Fr, P, Fr, P).reshape(Fr * P, Fr * P), self.video_rel_pos_table_list),
-                        (ib.view(1, P, 1, P).expand(Fr, P, Fr, P).reshape(Fr * P, Fr * P), ira.image_rel_pos_table_list)]
-            planes = (("video", id(self), Fr, ira._last_hw), plane_ids) if Fr <= self.video_rp_bucket.size(0) else None
-            for idx in range(self.num_layers):
-                self_attn_bias.append(ops.LazyBias(lambda idx=idx: values(idx), batch_size, planes, idx))
+                values = (vf.view(Fr, 1, Fr, 1, A) + vi.view(1, P, 1, P, A)).reshape(Fr * P, Fr * P, A)   # :187-204
+                self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
         else:
             self_attn_bias = [None] * self.num_layers
         return AdaptorOutput(video_embed, mask, pos_embed, self_attn_bias)

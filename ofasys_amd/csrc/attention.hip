@@ -29,7 +29,6 @@
 //   * operands contracting over head_dim are plain ds_read_b128 of the same tiles.
 // Fragment reads are inline asm (an in-flight LDS-DMA makes hipcc put vmcnt(0) in front of every visible ds_read).
 // MFMA-bound in principle; algorithmic flops 4*B*heads*T*S*64 forward, 2.5x that backward.
-#include <cstdlib>
 #include "common.h"
 
 namespace ofa {
@@ -53,11 +52,10 @@ struct AttnL {
   float scale; int causal;
   const int* seg;   // ragged ("packed rows") mode: int32 [B][4] = {q_off, q_len, k_off, k_len}, see seg_enter()
   int rows_q, rows_k;   // ragged mode: total packed rows (filler rows between / behind the segments are zero-filled here)
-  // positional mode (MODE 2, see "position bias inside the kernels" below): the [B,A,T,S] bias tensor of the reference is never built
-  const bf16_t* pq; const bf16_t* pk; bf16_t* dpq; bf16_t* dpk; int64_t ldpq, ldpk;   // abs-pos projections, rows like q / k
-  const uint16_t* rmap; int64_t rmap_plane; int rmap_ld, rmap_n;                       // compact bucket ids [rmap_n][Tm][rmap_ld], or NULL
-  const int* used; int ncompact; const void* tab[4];                                   // id -> (table slot << 20 | row); this layer's tables [rows, heads]
-  float* dtab;                                                                         // dQ kernel: [B*heads][q tiles][ncompact] partial table gradients
+  // additive bias addressing: bias[b * bias_bs + h * bias_hs + q * bias_ld + key].  The reference's tensor is [B*A, T, S] dense
+  // (bias_ld = S, bias_hs = T*S, bias_bs = A*T*S); a POSITION bias is the same for every sample (positions do not depend on the
+  // batch row), so it arrives once -- [A, Tb, Sb], bias_bs = 0 -- indexed by the position inside the sample (also in ragged mode)
+  int64_t bias_ld, bias_hs, bias_bs;
 };
 
 // Ragged mode: the rows between sample b's last row and sample b+1's first (alignment filler, and behind the last sample the
@@ -113,10 +111,6 @@ __device__ __forceinline__ bool seg_enter(AttnL& a, int& b, int& bh, int h, int 
   a.v += (int64_t)s.z * a.ldk;
   if (a.dk) a.dk += (int64_t)s.z * a.ldk;
   if (a.dv) a.dv += (int64_t)s.z * a.ldk;
-  if (a.pq) a.pq += (int64_t)s.x * a.ldpq;
-  if (a.dpq) a.dpq += (int64_t)s.x * a.ldpq;
-  if (a.pk) a.pk += (int64_t)s.z * a.ldpk;
-  if (a.dpk) a.dpk += (int64_t)s.z * a.ldpk;
   a.T = s.y;
   a.S = s.w;
   b = 0;
@@ -190,15 +184,15 @@ __device__ __forceinline__ uint32_t dead_ballot(int flag) { return (uint32_t)__b
 struct BiasRow {
   uint2 raw[4];
   bool vec;
-  __device__ __forceinline__ void issue(const bf16_t* brow, int key0, int S, int hi) {
-    vec = brow && (S & 3) == 0 && key0 + 32 <= S;
+  __device__ __forceinline__ void issue(const bf16_t* brow, int key0, int S, int hi, int64_t ld) {
+    vec = brow && (ld & 3) == 0 && key0 + 32 <= S;
     if (vec) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) raw[g4] = *reinterpret_cast<const uint2*>(brow + key0 + 8 * g4 + 4 * hi);
     }
   }
 };
-template <bool F16> __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]);
+template <bool F16> __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16], bool aligned = true);
 template <bool F16>
 __device__ __forceinline__ void bias_row_take(const BiasRow& p, const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
   if (!brow) return;
@@ -211,7 +205,7 @@ __device__ __forceinline__ void bias_row_take(const BiasRow& p, const bf16_t* br
       b[4 * g4 + 3] = hi16<F16>(p.raw[g4].y) * LOG2E;
     }
   } else {
-    bias16<F16>(brow, key0, S, hi, b);     // ragged tail block / unaligned rows: in place
+    bias16<F16>(brow, key0, S, hi, b, false);     // ragged tail block / unaligned rows: in place, element by element
   }
 }
 struct BiasCol {
@@ -233,8 +227,8 @@ struct BiasCol {
 
 // additive bias of the 16 scores a lane holds for a 32-key block (keys key0 + crowl(r, hi)), pre-multiplied by log2(e)
 template <bool F16>
-__device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16]) {
-  if ((S & 3) == 0 && key0 + 32 <= S) {
+__device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16], bool aligned) {
+  if (aligned && (S & 3) == 0 && key0 + 32 <= S) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const uint2 u = *reinterpret_cast<const uint2*>(brow + key0 + 8 * g4 + 4 * hi);
@@ -249,111 +243,6 @@ __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int 
       const int key = key0 + crowl(r, hi);
       b[r] = key < S ? dec1<F16>(brow[key]) * LOG2E : 0.f;
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ position bias inside the kernels
-// The reference adds a dense bias [B*A, T, S] to the scores: abs-pos (pos_q * pos_scaling) pos_k^T per head (adaptor/general.py:223-243,
-// model/transformer.py:280-299) + on every slot's diagonal block the rel-pos values table_l[bucket[i][j]] (adaptor/text.py:101-104,
-// image_resnet.py:116-128, video_image_sequence.py:187-204: frame table + image table), 154 MB per layer at cfg-2b and rebuilt per
-// layer.  MODE 2 computes the same numbers inside the attention kernels:
-//   * abs-pos: the contraction runs over [q | pq] . [k | pk] (128 instead of 64): four more MFMAs into the SAME score accumulator
-//     (pq arrives scaled by pos_scaling / attention scale -- 1 for every OFA architecture -- so one multiply by `scale` serves both
-//     halves); the PK rows ride through LDS as a third tile next to K and V; dpq / dpk come out like dq / dk;
-//   * rel-pos: `rmap` holds, per (query position, key position), a COMPACT id of the bucket (0 = no rel-pos bias: another slot), one
-//     plane per table that applies (two for video: frame + image); the kernel gathers this layer's table column of head h into LDS
-//     once (`used`: id -> table slot and row) and reads table[id] per score; the dQ kernel histograms dS by id (one private LDS
-//     histogram per wave, fixed order: deterministic) and leaves [workgroup][id] partial sums that ofa_relpos_table_grad folds into
-//     the tables' gradients.  The ids are position-only: batch, head and layer independent (L2 resident).
-constexpr int POS_TAB_MAX = 4096;                          // compact ids per attention call (LDS: 16 KiB table + 4 x 16 KiB histograms at most)
-
-// ids of one query row's 16 keys in a 32-key block (keys key0 + 8*g4 + 4*hi + 0..3): four 8-byte loads per plane, issued at the top of
-// the block's iteration IN FRONT of the next block's LDS-DMA (behind it they would drain the DMA queue, see BiasRow); they are consumed
-// after the score MFMAs, so their L2 latency hides under the fragment reads (rmap rows are padded to whole blocks, zero = no bias)
-struct MapRow {
-  uint2 raw[2][4];
-  __device__ __forceinline__ void issue(const uint16_t* mrow, int64_t plane, int nmap, int key0, int hi) {
-    if (!mrow) return;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) raw[0][g4] = *reinterpret_cast<const uint2*>(mrow + key0 + 8 * g4 + 4 * hi);
-    if (nmap > 1) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) raw[1][g4] = *reinterpret_cast<const uint2*>(mrow + plane + key0 + 8 * g4 + 4 * hi);
-    }
-  }
-  __device__ __forceinline__ uint32_t id(int m, int r) const {      // r = 4*g4 + e
-    const uint2 u = raw[m][r >> 2];
-    const uint32_t w = (r & 2) ? u.y : u.x;
-    return (r & 1) ? (w >> 16) : (w & 0xffffu);
-  }
-};
-// ids of one KEY's 16 query rows (rows q0 + crowl(r, hi)): 16 two-byte loads per plane (dK/dV kernel), one block ahead
-struct MapCol {
-  unsigned short raw[2][16];
-  __device__ __forceinline__ void issue(const uint16_t* mcol, int64_t plane, int nmap, int q0, int T, int ld, int hi) {
-    if (!mcol) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = q0 + crowl(r, hi);
-      raw[0][r] = q < T ? mcol[(int64_t)q * ld] : (unsigned short)0;
-    }
-    if (nmap > 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = q0 + crowl(r, hi);
-        raw[1][r] = q < T ? mcol[plane + (int64_t)q * ld] : (unsigned short)0;
-      }
-    }
-  }
-};
-// b[r] (+)= tab[id r] for 16 ids: LDS gathers as inline asm (a visible LDS read behind an in-flight LDS-DMA gets a vmcnt(0) from hipcc)
-__device__ __forceinline__ void tab_gather16(uint32_t tab_addr, const uint32_t (&id)[16], float (&b)[16]) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) asm volatile("ds_read_b32 %0, %1" : "=v"(b[r]) : "v"(tab_addr + id[r] * 4u));
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]),
-                 "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]));
-}
-// rel-pos bias of a lane's 16 scores from the staged ids (row form), pre-multiplied by log2(e) in the LDS table
-__device__ __forceinline__ void rel_bias_row(const MapRow& m, int nmap, uint32_t tab_addr, float (&b)[16]) {
-  uint32_t id[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) id[r] = m.id(0, r);
-  tab_gather16(tab_addr, id, b);
-  if (nmap > 1) {
-    float b2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) id[r] = m.id(1, r);
-    tab_gather16(tab_addr, id, b2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b[r] += b2[r];
-  }
-}
-__device__ __forceinline__ void rel_bias_col(const MapCol& m, int nmap, uint32_t tab_addr, float (&b)[16]) {
-  uint32_t id[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) id[r] = m.raw[0][r];
-  tab_gather16(tab_addr, id, b);
-  if (nmap > 1) {
-    float b2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) id[r] = m.raw[1][r];
-    tab_gather16(tab_addr, id, b2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b[r] += b2[r];
-  }
-}
-// this layer's table column of head h, by compact id, into LDS (fp32, times log2(e)); id 0 = "no bias"
-__device__ __forceinline__ void tab_stage(const AttnL& a, int h, float* tab_lds, int tid, bool f16) {
-  for (int c = tid; c < a.ncompact; c += 256) {
-    float v = 0.f;
-    if (c > 0) {
-      const int u = a.used[c];
-      const bf16_t* t = (const bf16_t*)a.tab[u >> 20];
-      const uint16_t raw = t[(int64_t)(u & 0xfffff) * a.heads + h];
-      v = (f16 ? (float)__builtin_bit_cast(f16_t, raw) : bf2f(raw)) * LOG2E;
-    }
-    tab_lds[c] = v;
   }
 }
 
@@ -464,30 +353,19 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// MODE: 0 no bias, 1 dense additive bias [B*A, T, S] (bz: this block's values), 2 positional (abs-pos contraction + rel-pos table)
-template <int BUF, int MODE, bool F16>   // BUF selects the double-buffer half at compile time (immediates)
+template <int BUF, bool BIAS, bool F16>   // BUF selects the double-buffer half at compile time (immediates)
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
-                                          const bf16x8 (&pqf)[4], f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0,
-                                          int qi, int hi, uint32_t dead_now, float (&bz)[16], const MapRow& mr, uint32_t tab_addr,
-                                          float sc ATT_FS_ARG) {
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int KOFF = BUF * NT * TILE_BYTES, VOFF = KOFF + TILE_BYTES, PKOFF = KOFF + 2 * TILE_BYTES;
-  constexpr bool has_bias = MODE != 0;
+                                          f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
+                                          uint32_t dead_now, const float (&bz)[16], float sc ATT_FS_ARG) {
+  constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
+  constexpr bool has_bias = BIAS;
   ATT_FS(0, m_run);
   u64x2 kf[4];
   rd128<KOFF>(kf[0], ta.km[0]);
   rd128<KOFF>(kf[1], ta.km[1]);
   rd128<KOFF>(kf[2], ta.km[2]);
   rd128<KOFF>(kf[3], ta.km[3]);
-  u64x2 pkf[4];
-  if constexpr (MODE == 2) {
-    rd128<PKOFF>(pkf[0], ta.km[0]);
-    rd128<PKOFF>(pkf[1], ta.km[1]);
-    rd128<PKOFF>(pkf[2], ta.km[2]);
-    rd128<PKOFF>(pkf[3], ta.km[3]);
-  }
   ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
-  if constexpr (MODE == 2) ATT_WAIT4(pkf[0], pkf[1], pkf[2], pkf[3]);
   ATT_FS(1, m_run);
   u64x2 vf[2][2];   // [j][dt]
   rdtr<VOFF, 0>(vf[0][0], ta.tr[0], trx[0]);
@@ -498,16 +376,6 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   zero16f(st);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) st = ATT_MFMA(kf[kk], qf[kk], st);
-  if constexpr (MODE == 2) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) st = ATT_MFMA(pkf[kk], pqf[kk], st);      // + pos_k . pos_q: the abs-pos bias, same scale
-    if (a.rmap) {
-      rel_bias_row(mr, a.rmap_n, tab_addr, bz);                             // LDS gathers under the MFMAs (this also lands vf)
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = 0.f;
-    }
-  }
   float s[16];
   float mx = -INFINITY;
   const bool diag = a.causal && (key0 + 31 > q0);
@@ -574,13 +442,10 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   ATT_FS(7, l_run);
 }
 
-template <int MODE, bool F16>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int BUF_EL = NT * TILE_BYTES / 2;            // bf16 elements per double-buffer half
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile (| PK tile)], 4 KiB each; MODE 2: then the table
-  float* tab_lds = reinterpret_cast<float*>(smem + 2 * NT * TILE_BYTES);
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile], 4 KiB each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
@@ -605,33 +470,17 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   const int qi = q0 + i;
   const int qrow = qi < a.T ? qi : a.T - 1;
   const bf16_t* qp = a.q + ((int64_t)b * a.T + qrow) * a.ldq + h * HD + hi * 8;
-  bf16x8 qf[4], pqf[4];
+  bf16x8 qf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) qf[kk] = ld16(qp + kk * 16);
-  if constexpr (MODE == 2) {
-    const bf16_t* pqp = a.pq + ((int64_t)b * a.T + qrow) * a.ldpq + h * HD + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) pqf[kk] = ld16(pqp + kk * 16);
-  }
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* pkbase = MODE == 2 ? a.pk + (int64_t)b * a.S * a.ldpk : nullptr;
-  const bf16_t* brow = MODE == 1 ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
-  const uint16_t* mrow = (MODE == 2 && a.rmap) ? a.rmap + (int64_t)qrow * a.rmap_ld : nullptr;
+  const bf16_t* brow = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
   ta.init((uint32_t)(uintptr_t)smem, lane);
   const uint32_t* trx = ta.trx;
-  const uint32_t tab_addr = (uint32_t)(uintptr_t)tab_lds;
-  if constexpr (MODE == 2) {
-    if (a.rmap) tab_stage(a, h, tab_lds, tid, F16);      // (visible after the first stage barrier below)
-  }
-  auto stage = [&](int kb, int buf) {                    // the K / V (/ PK) tiles of key block kb into double-buffer half `buf`
-    tile_dma(kbase, a.ldk, kb * 32, a.S, h * HD, lds + buf * BUF_EL, tid, wave_u);
-    tile_dma(vbase, a.ldk, kb * 32, a.S, h * HD, lds + buf * BUF_EL + TILE_BYTES / 2, tid, wave_u);
-    if constexpr (MODE == 2) tile_dma(pkbase, a.ldpk, kb * 32, a.S, h * HD, lds + buf * BUF_EL + TILE_BYTES, tid, wave_u);
-  };
 
   f32x16 ot[2];
   zero16f(ot[0]);
@@ -645,9 +494,9 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  MapRow mcur;                                           // MODE 2: the bucket ids of the block being computed
-  if constexpr (MODE == 1) bpre.issue(brow, 0, a.S, hi);
-  stage(0, 0);
+  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
+  tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
 #ifdef OFA_ATTN_TIMELINE
   fsv[9] = __builtin_amdgcn_s_memtime();
@@ -658,16 +507,16 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
-      if constexpr (MODE == 2) mcur.issue(mrow, a.rmap_plane, a.rmap_n, kb * 32, hi);   // THIS block's ids, in front of the next block's DMA
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        if constexpr (MODE == 1) bpre.issue(brow, (kb + 1) * 32, a.S, hi);
-        stage(kb + 1, 1);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
+        tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (MODE == 1) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
-        fwd_block<0, MODE, F16>(a, ta, trx, qf, pqf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, mcur, tab_addr, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        fwd_block<0, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
       }
       ATT_SYNC();
 #ifdef OFA_ATTN_TIMELINE
@@ -677,16 +526,16 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
-      if constexpr (MODE == 2) mcur.issue(mrow, a.rmap_plane, a.rmap_n, (kb + 1) * 32, hi);
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        if constexpr (MODE == 1) bpre.issue(brow, (kb + 2) * 32, a.S, hi);
-        stage(kb + 2, 0);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
+        tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (MODE == 1) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        fwd_block<1, MODE, F16>(a, ta, trx, qf, pqf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, mcur, tab_addr, sc ATT_FS_PASS(false));
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        fwd_block<1, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(false));
       }
       ATT_SYNC();
     }
@@ -711,32 +560,25 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
 #endif
 }
 
-// three waves per SIMD for the bias-free form (its registers fit 168); the biased ones keep two
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<0, false>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<1, false>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_pos_lds_kernel(AttnL a) { attn_fwd_body<2, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_f16_lds_kernel(AttnL a) { attn_fwd_body<0, true>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_bias_f16_lds_kernel(AttnL a) { attn_fwd_body<1, true>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_pos_f16_lds_kernel(AttnL a) { attn_fwd_body<2, true>(a); }
+// three waves per SIMD for the bias-free form (its registers fit 168); the biased one keeps two
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<false, false>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_f16_lds_kernel(AttnL a) { attn_fwd_body<false, true>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_f16_lds_kernel(AttnL a) { attn_fwd_body<true, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int BUF, int MODE, bool F16>
+template <int BUF, bool BIAS, bool F16>
 __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
-                                         const bf16x8 (&pqf)[4], const bf16x8 (&dof)[4], f32x16 (&dqt)[2], f32x16 (&dpqt)[2], int key0,
-                                         int q0, int qi, int hi, uint32_t dead_now, float (&bz)[16], const MapRow& mr, uint32_t tab_addr,
-                                         uint32_t hist_addr, bf16_t* dbrow, float sc, float lse_q, float delta_q, float c) {
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int KOFF = BUF * NT * TILE_BYTES, VOFF = KOFF + TILE_BYTES, PKOFF = KOFF + 2 * TILE_BYTES;
-  constexpr bool has_bias = MODE != 0;
-  u64x2 kf[4], vf[4], pkf[4];
+                                         const bf16x8 (&dof)[4], f32x16 (&dqt)[2], int key0, int q0, int qi, int hi,
+                                         uint32_t dead_now, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
+                                         float delta_q, float c) {
+  constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
+  constexpr bool has_bias = BIAS;
+  u64x2 kf[4], vf[4];
   rd128<KOFF>(kf[0], ta.km[0]); rd128<KOFF>(kf[1], ta.km[1]); rd128<KOFF>(kf[2], ta.km[2]); rd128<KOFF>(kf[3], ta.km[3]);
   rd128<VOFF>(vf[0], ta.km[0]); rd128<VOFF>(vf[1], ta.km[1]); rd128<VOFF>(vf[2], ta.km[2]); rd128<VOFF>(vf[3], ta.km[3]);
-  if constexpr (MODE == 2) {
-    rd128<PKOFF>(pkf[0], ta.km[0]); rd128<PKOFF>(pkf[1], ta.km[1]); rd128<PKOFF>(pkf[2], ta.km[2]); rd128<PKOFF>(pkf[3], ta.km[3]);
-  }
   ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
   ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
-  if constexpr (MODE == 2) ATT_WAIT4(pkf[0], pkf[1], pkf[2], pkf[3]);
   f32x16 st, dp;
   zero16f(st);
   zero16f(dp);
@@ -745,28 +587,12 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
     st = ATT_MFMA(kf[kk], qf[kk], st);
     dp = ATT_MFMA(vf[kk], dof[kk], dp);
   }
-  if constexpr (MODE == 2) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) st = ATT_MFMA(pkf[kk], pqf[kk], st);
-  }
   __builtin_amdgcn_sched_barrier(0);       // the transposed K reads go out behind the MFMAs, into the registers those have consumed
-  u64x2 ktf[2][2], pktf[2][2];
+  u64x2 ktf[2][2];
   rdtr<KOFF, 0>(ktf[0][0], ta.tr[0], trx[0]);
   rdtr<KOFF, 0>(ktf[0][1], ta.tr[1], trx[1]);
   rdtr<KOFF, 1>(ktf[1][0], ta.tr[0], trx[0]);
   rdtr<KOFF, 1>(ktf[1][1], ta.tr[1], trx[1]);
-  if constexpr (MODE == 2) {
-    rdtr<PKOFF, 0>(pktf[0][0], ta.tr[0], trx[0]);
-    rdtr<PKOFF, 0>(pktf[0][1], ta.tr[1], trx[1]);
-    rdtr<PKOFF, 1>(pktf[1][0], ta.tr[0], trx[0]);
-    rdtr<PKOFF, 1>(pktf[1][1], ta.tr[1], trx[1]);
-    if (a.rmap) {
-      rel_bias_row(mr, a.rmap_n, tab_addr, bz);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = 0.f;
-    }
-  }
   float ds[16];
   const bool diag = a.causal && (key0 + 31 > q0);
   if (has_bias || dead_now || diag) {
@@ -787,7 +613,7 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
       ds[r] = p * (dp[r] * c - delta_q);
     }
   }
-  if (MODE == 1 && dbrow && qi < a.T) {
+  if (BIAS && dbrow && qi < a.T) {
     if ((a.S & 3) == 0 && key0 + 32 <= a.S) {             // 4 consecutive keys per register quad: 8-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
@@ -800,38 +626,19 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
       }
     }
   }
-  if constexpr (MODE == 2) {
-    // table gradient: dS by compact id into this wave's private LDS histogram (rows of the clamped tail lanes are duplicates: skipped)
-    if (a.rmap && a.dtab && qi < a.T) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("ds_add_f32 %0, %1" ::"v"(hist_addr + mr.id(0, r) * 4u), "v"(ds[r]) : "memory");
-      if (a.rmap_n > 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("ds_add_f32 %0, %1" ::"v"(hist_addr + mr.id(1, r) * 4u), "v"(ds[r]) : "memory");
-      }
-    }
-  }
   ATT_WAIT4(ktf[0][0], ktf[0][1], ktf[1][0], ktf[1][1]);
-  if constexpr (MODE == 2) ATT_WAIT4(pktf[0][0], pktf[0][1], pktf[1][0], pktf[1][1]);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const bf16x8 dsf = pack8f<F16>(ds + 8 * j);
     dqt[0] = ATT_MFMA(ktf[j][0], dsf, dqt[0]);
     dqt[1] = ATT_MFMA(ktf[j][1], dsf, dqt[1]);
-    if constexpr (MODE == 2) {
-      dpqt[0] = ATT_MFMA(pktf[j][0], dsf, dpqt[0]);
-      dpqt[1] = ATT_MFMA(pktf[j][1], dsf, dpqt[1]);
-    }
   }
 }
 
-template <int MODE, bool F16>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int BUF_EL = NT * TILE_BYTES / 2;
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2][K | V (| PK)]; MODE 2: then the table [ncompact] and 4 histograms [ncompact]
-  float* tab_lds = reinterpret_cast<float*>(smem + 2 * NT * TILE_BYTES);
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
@@ -839,32 +646,20 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   const int h = bh % a.heads;
   const int qb0 = blockIdx.x * 128;
   if (a.seg && blockIdx.x == gridDim.x - 1) {
-    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, (MODE == 2) ? a.dpq : nullptr, a.ldpq, tid,
-                  a.out ? a.delta + (int64_t)h * a.Tpad : nullptr);
+    seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, nullptr, 0, tid, a.out ? a.delta + (int64_t)h * a.Tpad : nullptr);
     return;
   }
-  const bool hist_on = MODE == 2 && a.rmap && a.dtab;
-  float* slab = hist_on ? a.dtab + ((int64_t)blockIdx.y * (gridDim.x - (a.seg ? 1 : 0)) + blockIdx.x) * a.ncompact : nullptr;
-  if (!seg_enter(a, b, bh, h, qb0, true)) {
-    if (hist_on)                                          // an empty tile of a ragged batch still owns a slab row
-      for (int cc = tid; cc < a.ncompact; cc += 256) slab[cc] = 0.f;
-    return;
-  }
+  if (!seg_enter(a, b, bh, h, qb0, true)) return;
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
   const int qrow = qi < a.T ? qi : a.T - 1;
   const bf16_t* qp = a.q + ((int64_t)b * a.T + qrow) * a.ldq + h * HD + hi * 8;
   const bf16_t* dop = a.dout + ((int64_t)b * a.T + qrow) * a.ldo + h * HD + hi * 8;
-  bf16x8 qf[4], dof[4], pqf[4];
+  bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     qf[kk] = ld16(qp + kk * 16);
     dof[kk] = ld16(dop + kk * 16);
-  }
-  if constexpr (MODE == 2) {
-    const bf16_t* pqp = a.pq + ((int64_t)b * a.T + qrow) * a.ldpq + h * HD + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) pqf[kk] = ld16(pqp + kk * 16);
   }
   const float lse_q = a.lse[(int64_t)bh * a.Tpad + qrow];
   float delta_q;
@@ -890,37 +685,17 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   const float c = head_scale(a, h);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* pkbase = MODE == 2 ? a.pk + (int64_t)b * a.S * a.ldpk : nullptr;
-  const bf16_t* brow = MODE == 1 ? a.bias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
-  bf16_t* dbrow = (MODE == 1 && a.dbias) ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;
-  const uint16_t* mrow = (MODE == 2 && a.rmap) ? a.rmap + (int64_t)qrow * a.rmap_ld : nullptr;
+  const bf16_t* brow = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
+  bf16_t* dbrow = (BIAS && a.dbias) ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;      // (dense [B*A, T, S] only)
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
   ta.init((uint32_t)(uintptr_t)smem, lane);
   const uint32_t* trx = ta.trx;
-  const uint32_t tab_addr = (uint32_t)(uintptr_t)tab_lds;
-  const uint32_t hist_addr = tab_addr + (uint32_t)(a.ncompact * 4 * (1 + wave_u));
-  if constexpr (MODE == 2) {
-    if (a.rmap) {
-      tab_stage(a, h, tab_lds, tid, F16);
-      if (hist_on)
-        for (int cc = tid; cc < 4 * a.ncompact; cc += 256) tab_lds[a.ncompact + cc] = 0.f;
-    }
-  }
-  auto stage = [&](int kb, int buf) {
-    tile_dma(kbase, a.ldk, kb * 32, a.S, h * HD, lds + buf * BUF_EL, tid, wave_u);
-    tile_dma(vbase, a.ldk, kb * 32, a.S, h * HD, lds + buf * BUF_EL + TILE_BYTES / 2, tid, wave_u);
-    if constexpr (MODE == 2) tile_dma(pkbase, a.ldpk, kb * 32, a.S, h * HD, lds + buf * BUF_EL + TILE_BYTES, tid, wave_u);
-  };
 
-  f32x16 dqt[2], dpqt[2];
+  f32x16 dqt[2];
   zero16f(dqt[0]);
   zero16f(dqt[1]);
-  if constexpr (MODE == 2) {
-    zero16f(dpqt[0]);
-    zero16f(dpqt[1]);
-  }
   int nkb = (a.S + 31) / 32;
   const int nkb_all = nkb;
   if (a.causal) {
@@ -930,9 +705,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  MapRow mcur;                                           // MODE 2: the bucket ids of the block being computed
-  if constexpr (MODE == 1) bpre.issue(brow, 0, a.S, hi);
-  stage(0, 0);
+  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
+  tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
   const bool live_wave = q0 < a.T;
   float bz[16];
@@ -941,17 +716,16 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
-      if constexpr (MODE == 2) mcur.issue(mrow, a.rmap_plane, a.rmap_n, kb * 32, hi);   // THIS block's ids, in front of the next block's DMA
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        if constexpr (MODE == 1) bpre.issue(brow, (kb + 1) * 32, a.S, hi);
-        stage(kb + 1, 1);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
+        tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (MODE == 1) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
-        dq_block<0, MODE, F16>(a, ta, trx, qf, pqf, dof, dqt, dpqt, kb * 32, q0, qi, hi, dead_now, bz, mcur, tab_addr, hist_addr, dbrow, sc,
-                               lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        dq_block<0, BIAS, F16>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
       ATT_SYNC();
@@ -959,17 +733,16 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
-      if constexpr (MODE == 2) mcur.issue(mrow, a.rmap_plane, a.rmap_n, (kb + 1) * 32, hi);
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        if constexpr (MODE == 1) bpre.issue(brow, (kb + 2) * 32, a.S, hi);
-        stage(kb + 2, 0);
+        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
+        tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (MODE == 1) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
-        dq_block<1, MODE, F16>(a, ta, trx, qf, pqf, dof, dqt, dpqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, mcur, tab_addr, hist_addr, dbrow,
-                               sc, lse_q, delta_q, c);
+        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        dq_block<1, BIAS, F16>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
       ATT_SYNC();
@@ -989,35 +762,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
       for (int qq = 0; qq < 4; ++qq)
         st4<F16>(op + dt * 32 + 8 * qq + 4 * hi, dqt[dt][4 * qq] * a.scale, dqt[dt][4 * qq + 1] * a.scale,
             dqt[dt][4 * qq + 2] * a.scale, dqt[dt][4 * qq + 3] * a.scale);
-    if constexpr (MODE == 2) {
-      bf16_t* pp = a.dpq + ((int64_t)b * a.T + qi) * a.ldpq + h * HD;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          st4<F16>(pp + dt * 32 + 8 * qq + 4 * hi, dpqt[dt][4 * qq] * a.scale, dpqt[dt][4 * qq + 1] * a.scale,
-              dpqt[dt][4 * qq + 2] * a.scale, dpqt[dt][4 * qq + 3] * a.scale);
-    }
-  }
-  if constexpr (MODE == 2) {
-    if (hist_on) {                                        // the four waves' histograms, added in a fixed order -> this tile's slab row
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-      const float* hst = tab_lds + a.ncompact;
-      for (int cc = tid; cc < a.ncompact; cc += 256)
-        slab[cc] = (hst[cc] + hst[a.ncompact + cc]) + (hst[2 * a.ncompact + cc] + hst[3 * a.ncompact + cc]);
-    }
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<0, false>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<1, false>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_pos_lds_kernel(AttnL a) { attn_bwd_dq_body<2, false>(a); }
-// (the same at two waves per SIMD: 39 spilled registers; which of the two runs is decided by measurement, tools/attn_pos_bench.py)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_pos_w2_lds_kernel(AttnL a) { attn_bwd_dq_body<2, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<0, true>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<1, true>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_pos_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<2, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<false, false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<false, true>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<true, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Register budget.  Round 1's form of this kernel held 400 registers (one wave per SIMD: nothing ran while a wave waited for
@@ -1035,19 +786,15 @@ __device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const
   }
 }
 
-template <int BUF, int MODE, bool F16>
+template <int BUF, bool BIAS, bool F16>
 __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, uint32_t stat_addr,
-                                          const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], const bf16x8 (&pkf)[4], f32x16 (&dvt)[2],
-                                          f32x16 (&dkt)[2], f32x16 (&dpkt)[2], int q0, int key0, int ki, int hi, bool key_dead, float live,
-                                          float (&bz)[16], const MapCol& mc, uint32_t tab_addr, float sc, float c) {
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int QOFF = BUF * NT * TILE_BYTES, DOOFF = QOFF + TILE_BYTES, PQOFF = QOFF + 2 * TILE_BYTES, SOFF = BUF * STAT_BYTES;
-  u64x2 qf[4], dof[4], pqf[4];
+                                          const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0,
+                                          int key0, int ki, int hi, bool key_dead, float live, const float (&bz)[16], float sc,
+                                          float c) {
+  constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES, SOFF = BUF * STAT_BYTES;
+  u64x2 qf[4], dof[4];
   rd128<QOFF>(qf[0], ta.km[0]); rd128<QOFF>(qf[1], ta.km[1]); rd128<QOFF>(qf[2], ta.km[2]); rd128<QOFF>(qf[3], ta.km[3]);
   rd128<DOOFF>(dof[0], ta.km[0]); rd128<DOOFF>(dof[1], ta.km[1]); rd128<DOOFF>(dof[2], ta.km[2]); rd128<DOOFF>(dof[3], ta.km[3]);
-  if constexpr (MODE == 2) {
-    rd128<PQOFF>(pqf[0], ta.km[0]); rd128<PQOFF>(pqf[1], ta.km[1]); rd128<PQOFF>(pqf[2], ta.km[2]); rd128<PQOFF>(pqf[3], ta.km[3]);
-  }
   // lse / delta of this lane's 16 query rows (rows 8g + 4hi + 0..3): four 16-byte reads each, the 32 lanes of a half read the
   // same address (broadcast)
   u64x2 l2[4], d2[4];
@@ -1055,7 +802,6 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   rd128<SOFF + 128>(d2[0], stat_addr); rd128<SOFF + 160>(d2[1], stat_addr); rd128<SOFF + 192>(d2[2], stat_addr); rd128<SOFF + 224>(d2[3], stat_addr);
   ATT_WAIT4(qf[0], qf[1], qf[2], qf[3]);
   ATT_WAIT4(dof[0], dof[1], dof[2], dof[3]);
-  if constexpr (MODE == 2) ATT_WAIT4(pqf[0], pqf[1], pqf[2], pqf[3]);
   ATT_WAIT4(l2[0], l2[1], l2[2], l2[3]);
   ATT_WAIT4(d2[0], d2[1], d2[2], d2[3]);
   f32x16 st, dp;
@@ -1066,12 +812,8 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     st = ATT_MFMA(qf[kk], kf[kk], st);     // S[q][key]
     dp = ATT_MFMA(dof[kk], vf[kk], dp);    // dP[q][key]
   }
-  if constexpr (MODE == 2) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) st = ATT_MFMA(pqf[kk], pkf[kk], st);   // + pos_q . pos_k
-  }
   __builtin_amdgcn_sched_barrier(0);       // the transposed reads go out behind the MFMAs (hipcc would hoist them: +32 registers)
-  u64x2 qtf[2][2], dotf[2][2], pqtf[2][2];
+  u64x2 qtf[2][2], dotf[2][2];
   rdtr<QOFF, 0>(qtf[0][0], ta.tr[0], trx[0]);
   rdtr<QOFF, 0>(qtf[0][1], ta.tr[1], trx[1]);
   rdtr<QOFF, 1>(qtf[1][0], ta.tr[0], trx[0]);
@@ -1080,18 +822,6 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   rdtr<DOOFF, 0>(dotf[0][1], ta.tr[1], trx[1]);
   rdtr<DOOFF, 1>(dotf[1][0], ta.tr[0], trx[0]);
   rdtr<DOOFF, 1>(dotf[1][1], ta.tr[1], trx[1]);
-  if constexpr (MODE == 2) {
-    rdtr<PQOFF, 0>(pqtf[0][0], ta.tr[0], trx[0]);
-    rdtr<PQOFF, 0>(pqtf[0][1], ta.tr[1], trx[1]);
-    rdtr<PQOFF, 1>(pqtf[1][0], ta.tr[0], trx[0]);
-    rdtr<PQOFF, 1>(pqtf[1][1], ta.tr[1], trx[1]);
-    if (a.rmap) {
-      rel_bias_col(mc, a.rmap_n, tab_addr, bz);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bz[r] = 0.f;
-    }
-  }
   float lv[16], dv16[16];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
@@ -1100,13 +830,13 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     dv16[4 * g4] = d4.x; dv16[4 * g4 + 1] = d4.y; dv16[4 * g4 + 2] = d4.z; dv16[4 * g4 + 3] = d4.w;
   }
   float p[16], ds[16];
-  const bool general = MODE != 0 || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
+  const bool general = BIAS || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
   if (general) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = q0 + crowl(r, hi);
       float t = st[r] * sc;
-      if (MODE != 0) t += bz[r];
+      if (BIAS) t += bz[r];
       bool dead = key_dead || q >= a.T;
       if (a.causal) dead |= ki > q;
       const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[r]);
@@ -1123,7 +853,6 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   }
   ATT_WAIT4(qtf[0][0], qtf[0][1], qtf[1][0], qtf[1][1]);
   ATT_WAIT4(dotf[0][0], dotf[0][1], dotf[1][0], dotf[1][1]);
-  if constexpr (MODE == 2) ATT_WAIT4(pqtf[0][0], pqtf[0][1], pqtf[1][0], pqtf[1][1]);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const bf16x8 pf = pack8f<F16>(p + 8 * j);
@@ -1132,21 +861,14 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     dvt[1] = ATT_MFMA(dotf[j][1], pf, dvt[1]);
     dkt[0] = ATT_MFMA(qtf[j][0], dsf, dkt[0]);
     dkt[1] = ATT_MFMA(qtf[j][1], dsf, dkt[1]);
-    if constexpr (MODE == 2) {
-      dpkt[0] = ATT_MFMA(pqtf[j][0], dsf, dpkt[0]);
-      dpkt[1] = ATT_MFMA(pqtf[j][1], dsf, dpkt[1]);
-    }
   }
 }
 
-template <int MODE, bool F16>
+template <bool BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NT = MODE == 2 ? 3 : 2;
-  constexpr int BUF_EL = NT * TILE_BYTES / 2;
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][Q tile | dO tile (| PQ tile)], then [2][lse | delta], then (MODE 2) the table
-  unsigned char* lds_stat = smem + 2 * NT * TILE_BYTES;
-  float* tab_lds = reinterpret_cast<float*>(lds_stat + 2 * STAT_BYTES);
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][Q tile | dO tile], then [2][lse | delta]
+  unsigned char* lds_stat = smem + 4 * TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
@@ -1155,7 +877,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const int kb0 = blockIdx.x * 128;
   if (a.seg && blockIdx.x == gridDim.x - 1) {
     seg_zero_fill(a.seg, a.B, b, h, true, a.rows_k, a.dk, a.ldk, a.dv, a.ldk, tid);
-    if constexpr (MODE == 2) seg_zero_fill(a.seg, a.B, b, h, true, a.rows_k, a.dpk, a.ldpk, nullptr, 0, tid);
     return;
   }
   if (!seg_enter(a, b, bh, h, kb0, false)) return;
@@ -1164,84 +885,66 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const int krow = ki < a.S ? ki : a.S - 1;
   const bf16_t* kp_ = a.k + ((int64_t)b * a.S + krow) * a.ldk + h * HD + hi * 8;
   const bf16_t* vp_ = a.v + ((int64_t)b * a.S + krow) * a.ldk + h * HD + hi * 8;
-  bf16x8 kf[4], vf[4], pkf[4];
+  bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     kf[kk] = ld16(kp_ + kk * 16);
     vf[kk] = ld16(vp_ + kk * 16);
-  }
-  if constexpr (MODE == 2) {
-    const bf16_t* pkp = a.pk + ((int64_t)b * a.S + krow) * a.ldpk + h * HD + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) pkf[kk] = ld16(pkp + kk * 16);
   }
   const bool key_dead = ki >= a.S || (a.kpm && a.kpm[(int64_t)b * a.S + krow] != 0);
   const float live = key_dead ? 0.f : 1.f;
   const float c = head_scale(a, h);
   const bf16_t* qbase = a.q + (int64_t)b * a.T * a.ldq;
   const bf16_t* dobase = a.dout + (int64_t)b * a.T * a.ldo;
-  const bf16_t* pqbase = MODE == 2 ? a.pq + (int64_t)b * a.T * a.ldpq : nullptr;
   const float* lse_bh = a.lse + (int64_t)bh * a.Tpad;
   const float* delta_bh = a.delta + (int64_t)bh * a.Tpad;
-  const bf16_t* bcol = MODE == 1 ? a.bias + (int64_t)bh * a.T * a.S + krow : nullptr;
-  const uint16_t* mcol = (MODE == 2 && a.rmap) ? a.rmap + krow : nullptr;
+  const bf16_t* bcol = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + krow : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
   ta.init((uint32_t)(uintptr_t)smem, lane);
   const uint32_t* trx = ta.trx;
   const uint32_t stat_addr = (uint32_t)(uintptr_t)lds_stat + 16 * hi;
-  const uint32_t tab_addr = (uint32_t)(uintptr_t)tab_lds;
-  if constexpr (MODE == 2) {
-    if (a.rmap) tab_stage(a, h, tab_lds, tid, F16);
-  }
-  auto stage = [&](int qb, int buf) {                    // the Q / dO (/ PQ) tiles and lse | delta of query block qb
-    tile_dma(qbase, a.ldq, qb * 32, a.T, h * HD, lds + buf * BUF_EL, tid, wave_u);
-    tile_dma(dobase, a.ldo, qb * 32, a.T, h * HD, lds + buf * BUF_EL + TILE_BYTES / 2, tid, wave_u);
-    if constexpr (MODE == 2) tile_dma(pqbase, a.ldpq, qb * 32, a.T, h * HD, lds + buf * BUF_EL + TILE_BYTES, tid, wave_u);
-    stat_dma(lse_bh, delta_bh, qb * 32, lds_stat + buf * STAT_BYTES, lane, wave_u);
-  };
 
-  f32x16 dvt[2], dkt[2], dpkt[2];
+  f32x16 dvt[2], dkt[2];
   zero16f(dvt[0]); zero16f(dvt[1]); zero16f(dkt[0]); zero16f(dkt[1]);
-  if constexpr (MODE == 2) {
-    zero16f(dpkt[0]);
-    zero16f(dpkt[1]);
-  }
   const int nqb = (a.T + 31) / 32;
   const int qb_first = a.causal ? kb0 / 32 : 0;          // the workgroup starts where its FIRST wave needs
   const bool live_wave = key0 < a.S;
-  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (MODE 1 only)
-  MapCol mA;                                             // bucket ids of the query block being computed (MODE 2)
+  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (BIAS only)
   float bz[16];
   if (qb_first < nqb) {
-    if constexpr (MODE == 1) bA.issue(bcol, qb_first * 32, a.T, a.S, hi);
-    stage(qb_first, 0);
+    if constexpr (BIAS) bA.issue(bcol, qb_first * 32, a.T, a.bias_ld, hi);
+    tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
+    tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
+    stat_dma(lse_bh, delta_bh, qb_first * 32, lds_stat, lane, wave_u);
   }
   ATT_SYNC();
   for (int qb = qb_first; qb < nqb; qb += 2) {
     {
-      if constexpr (MODE == 2) mA.issue(mcol, a.rmap_plane, a.rmap_n, qb * 32, a.T, a.rmap_ld, hi);   // THIS block's ids, before the next DMA
       if (qb + 1 < nqb) {
-        if constexpr (MODE == 1) bB.issue(bcol, (qb + 1) * 32, a.T, a.S, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
-        stage(qb + 1, 1);
+        if constexpr (BIAS) bB.issue(bcol, (qb + 1) * 32, a.T, a.bias_ld, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
+        tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
+        tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 1) * 32, lds_stat + STAT_BYTES, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
-        if constexpr (MODE == 1) bA.template take<F16>(bcol, bz);
-        dkv_block<0, MODE, F16>(a, ta, trx, stat_addr, kf, vf, pkf, dvt, dkt, dpkt, qb * 32, key0, ki, hi, key_dead, live, bz, mA, tab_addr, sc, c);
+        if constexpr (BIAS) bA.template take<F16>(bcol, bz);
+        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
     if (qb + 1 < nqb) {
-      if constexpr (MODE == 2) mA.issue(mcol, a.rmap_plane, a.rmap_n, (qb + 1) * 32, a.T, a.rmap_ld, hi);
       if (qb + 2 < nqb) {
-        if constexpr (MODE == 1) bA.issue(bcol, (qb + 2) * 32, a.T, a.S, hi);
-        stage(qb + 2, 0);
+        if constexpr (BIAS) bA.issue(bcol, (qb + 2) * 32, a.T, a.bias_ld, hi);
+        tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
+        tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 2) * 32, lds_stat, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {
-        if constexpr (MODE == 1) bB.template take<F16>(bcol, bz);
-        dkv_block<1, MODE, F16>(a, ta, trx, stat_addr, kf, vf, pkf, dvt, dkt, dpkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, mA, tab_addr, sc, c);
+        if constexpr (BIAS) bB.template take<F16>(bcol, bz);
+        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c);
       }
       ATT_SYNC();
     }
@@ -1258,27 +961,180 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
             dkt[dt][4 * qq + 3] * a.scale);
         st4<F16>(dvp + d, dvt[dt][4 * qq] * c, dvt[dt][4 * qq + 1] * c, dvt[dt][4 * qq + 2] * c, dvt[dt][4 * qq + 3] * c);
       }
-    if constexpr (MODE == 2) {
-      bf16_t* dpp = a.dpk + ((int64_t)b * a.S + ki) * a.ldpk + h * HD;
+  }
+}
+
+// two waves per SIMD for both forms: the bias-free one fits 256 registers; the biased one spills 16 and is still 16 % faster that way
+// (tools/attn_bias_bench.py, 448 x 448: backward 409 -> 343 us)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, true>(a); }
+
+
+// ------------------------------------------------------------------------------------------------ backward: sum over the batch of dS
+// The gradient of a batch-SHARED additive bias [A, Tb, Sb] (the position bias: abs-pos + rel-pos, identical for every sample) is
+// G[h][i][j] = sum_b dS[b][h][i][j].  The reference gets it by materialising dS as [B*A, T, S] and letting autograd reduce the expand
+// (154 MB per layer at cfg-2b, 1.97 GB at cfg-4 / B = 32).  Here one workgroup owns a [128 query positions x 32*NKB key positions] tile
+// of ONE head, walks the batch, recomputes S = K Q^T and dP = V dO^T of that tile for every sample (two of the five products of the
+// backward pass; lse / delta come from the forward and the dQ kernel) and adds dS = P (dP c - delta) into registers: G is written
+// once, in fp32, with no atomics -- deterministic, and B times smaller than the tensor it replaces.  Ragged mode: the tile is
+// addressed by the position inside the sample, samples shorter than the tile's origin are skipped.
+template <int NKB, bool F16>
+__device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int i = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.z;
+  const int qb0 = blockIdx.y * 128, kc0 = blockIdx.x * NKB;      // first query position / first key block of the tile
+  const int q0 = qb0 + wave * 32, qi = q0 + i;
+  const float sc = a.scale * LOG2E;
+  const float c = head_scale(a, h);
+  TileAddr ta;
+  ta.init((uint32_t)(uintptr_t)smem, lane);
+  // the tile's bias values (times log2 e), loaded once: they do not depend on the sample
+  float bz[NKB][16];
+  {
+    const int qrow = qi < Tb ? qi : Tb - 1;
+    const bf16_t* brow = a.bias + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+    for (int j = 0; j < NKB; ++j)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          st4<F16>(dpp + dt * 32 + 8 * qq + 4 * hi, dpkt[dt][4 * qq] * a.scale, dpkt[dt][4 * qq + 1] * a.scale,
-              dpkt[dt][4 * qq + 2] * a.scale, dpkt[dt][4 * qq + 3] * a.scale);
+      for (int r = 0; r < 16; ++r) {
+        const int key = (kc0 + j) * 32 + crowl(r, hi);
+        bz[j][r] = key < Sb ? dec1<F16>(brow[key]) * LOG2E : 0.f;
+      }
+  }
+  float acc[NKB][16];
+#pragma unroll
+  for (int j = 0; j < NKB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // stage s = b * NKB + j; a stage is live when sample b reaches the tile (uniform over the workgroup)
+  auto geom = [&](int b, int& T_b, int& S_b, int64_t& qoff, int64_t& koff) {
+    if (a.seg) {
+      const int4 sg = reinterpret_cast<const int4*>(a.seg)[b];
+      T_b = sg.y; S_b = sg.w; qoff = sg.x; koff = sg.z;
+    } else {
+      T_b = a.T; S_b = a.S; qoff = (int64_t)b * a.T; koff = (int64_t)b * a.S;
+    }
+  };
+  auto live = [&](int s) {
+    int T_b, S_b; int64_t qo, ko;
+    geom(s / NKB, T_b, S_b, qo, ko);
+    return qb0 < T_b && (kc0 + s % NKB) * 32 < S_b;
+  };
+  auto next_live = [&](int s) {
+    ++s;
+    while (s < a.B * NKB && !live(s)) ++s;
+    return s;
+  };
+  auto stage = [&](int s, int buf) {
+    int T_b, S_b; int64_t qo, ko;
+    geom(s / NKB, T_b, S_b, qo, ko);
+    const int key0 = (kc0 + s % NKB) * 32;
+    tile_dma(a.k + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES, tid, wave_u);
+    tile_dma(a.v + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
+  };
+  const int lse_ld = a.Tpad;
+  int s = -1;
+  s = next_live(s);
+  if (s < a.B * NKB) stage(s, 0);
+  ATT_SYNC();
+  int buf = 0, cur_b = -1;
+  bf16x8 qf[4], dof[4];
+  float lse_q = 0.f, delta_q = 0.f;
+  int T_b = 0, S_b = 0;
+  int64_t qoff = 0, koff = 0;
+  const uint8_t* kp = nullptr;
+  while (s < a.B * NKB) {
+    const int sn = next_live(s);
+    const int b = s / NKB, j = s % NKB;
+    if (b != cur_b) {                                    // this sample's query-side operands (ordinary loads, in front of the DMA)
+      cur_b = b;
+      geom(b, T_b, S_b, qoff, koff);
+      const int qrow = qi < T_b ? qi : T_b - 1;
+      const bf16_t* qp = a.q + (qoff + qrow) * a.ldq + h * HD + hi * 8;
+      const bf16_t* dop = a.dout + (qoff + qrow) * a.ldo + h * HD + hi * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = ld16(qp + kk * 16);
+        dof[kk] = ld16(dop + kk * 16);
+      }
+      const int64_t srow = a.seg ? (int64_t)h * lse_ld + qoff + qrow : ((int64_t)b * a.heads + h) * lse_ld + qrow;
+      lse_q = a.lse[srow];
+      delta_q = a.delta[srow];
+      kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
+    }
+    const int key0 = (kc0 + j) * 32;
+    const uint32_t dead_now = dead_ballot(dead_flag(kp, key0, S_b, i));     // (the byte load goes out in front of the next DMA)
+    if (sn < a.B * NKB) stage(sn, buf ^ 1);
+    if (q0 < T_b) {
+      u64x2 kf[4], vf[4];
+      if (buf == 0) {
+        rd128<0>(kf[0], ta.km[0]); rd128<0>(kf[1], ta.km[1]); rd128<0>(kf[2], ta.km[2]); rd128<0>(kf[3], ta.km[3]);
+        rd128<TILE_BYTES>(vf[0], ta.km[0]); rd128<TILE_BYTES>(vf[1], ta.km[1]); rd128<TILE_BYTES>(vf[2], ta.km[2]); rd128<TILE_BYTES>(vf[3], ta.km[3]);
+      } else {
+        rd128<2 * TILE_BYTES>(kf[0], ta.km[0]); rd128<2 * TILE_BYTES>(kf[1], ta.km[1]); rd128<2 * TILE_BYTES>(kf[2], ta.km[2]); rd128<2 * TILE_BYTES>(kf[3], ta.km[3]);
+        rd128<3 * TILE_BYTES>(vf[0], ta.km[0]); rd128<3 * TILE_BYTES>(vf[1], ta.km[1]); rd128<3 * TILE_BYTES>(vf[2], ta.km[2]); rd128<3 * TILE_BYTES>(vf[3], ta.km[3]);
+      }
+      ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
+      ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
+      f32x16 st, dp;
+      zero16f(st);
+      zero16f(dp);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        st = ATT_MFMA(kf[kk], qf[kk], st);
+        dp = ATT_MFMA(vf[kk], dof[kk], dp);
+      }
+      const bool rowok = qi < T_b;
+#pragma unroll
+      for (int jj = 0; jj < NKB; ++jj) {
+        if (jj != j) continue;                           // (j is uniform: the compiler keeps acc / bz in registers by unrolling)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jk = crowl(r, hi), key = key0 + jk;
+          bool dead = !rowok || ((dead_now >> jk) & 1u);
+          if (a.causal) dead |= key > qi;
+          const float t = st[r] * sc + bz[jj][r];
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - lse_q);
+          acc[jj][r] += p * (dp[r] * c - delta_q);
+        }
+      }
+    }
+    ATT_SYNC();
+    buf ^= 1;
+    s = sn;
+  }
+  // G[h][qi][keys of the tile]
+  if (qi < Tb) {
+    float* gp = G + (int64_t)h * g_hs + (int64_t)qi * g_ld;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+      const int key0 = (kc0 + j) * 32;
+      if ((g_ld & 3) == 0 && key0 + 32 <= Sb) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(gp + key0 + 8 * g4 + 4 * hi) = make_float4(acc[j][4 * g4], acc[j][4 * g4 + 1], acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + crowl(r, hi);
+          if (key < Sb) gp[key] = acc[j][r];
+        }
+      }
     }
   }
 }
 
-// two waves per SIMD for the bias-free / dense-bias forms: the bias-free one fits 256 registers; the dense-bias one spills 16 and is
-// still 16 % faster that way (tools/attn_bias_bench.py, 448 x 448: backward 409 -> 343 us).  The positional form carries a third
-// accumulator pair (dpk) and the PQ fragments: one wave per SIMD without spills (forced to two it spills 352 registers)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<0, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, false>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dkv_pos_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<0, true>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, true>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dkv_pos_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum2_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<2, false>(a, G, g_ld, g_hs, Tb, Sb); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum4_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<4, false>(a, G, g_ld, g_hs, Tb, Sb); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum2_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<2, true>(a, G, g_ld, g_hs, Tb, Sb); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum4_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<4, true>(a, G, g_ld, g_hs, Tb, Sb); }
 
 static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int dtype) {
   OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 / fp16 only (dtype %d); use the unfused path", dtype);
@@ -1305,6 +1161,7 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
   a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
+  a.bias_ld = S; a.bias_hs = (int64_t)T * S; a.bias_bs = (int64_t)heads * T * S;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_fwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   const dim3 grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
   auto kern = dtype == OFA_F16 ? (bias ? attn_fwd_bias_f16_lds_kernel : attn_fwd_f16_lds_kernel) : (bias ? attn_fwd_bias_lds_kernel : attn_fwd_lds_kernel);
@@ -1329,6 +1186,7 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dbias = (bf16_t*)dbias; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   a.rows_q = rows_q; a.rows_k = rows_k;
+  a.bias_ld = S; a.bias_hs = (int64_t)T * S; a.bias_bs = (int64_t)heads * T * S;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_bwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
@@ -1343,129 +1201,78 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
 }
 
 
-// Positional mode: the shared argument block of ofa_attn_pos_fwd / _bwd
-static int pos_fill(AttnL& a, const void* pos_q, const void* pos_k, const uint16_t* relmap, int planes, int relmap_ld, int64_t plane_stride,
-                    const int32_t* used, int ncompact, const void* t0, const void* t1, const void* t2, const void* t3, int64_t ldpq,
-                    int64_t ldpk, int T, int S) {
-  OFA_REQUIRE(pos_q && pos_k, OFA_ERR_INVALID, "attn_pos: pos_q / pos_k are required (a bias-free call goes to ofa_attn_fwd)");
-  OFA_REQUIRE((ldpq % 8) == 0 && (ldpk % 8) == 0, OFA_ERR_INVALID, "attn_pos: pos_q / pos_k leading dims must be multiples of 8");
-  a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.ldpq = ldpq; a.ldpk = ldpk;
-  a.rmap = relmap; a.rmap_n = relmap ? planes : 0; a.rmap_ld = relmap_ld; a.rmap_plane = plane_stride; a.used = used;
-  a.ncompact = relmap ? ncompact : 0;
-  a.tab[0] = t0; a.tab[1] = t1; a.tab[2] = t2; a.tab[3] = t3;
-  if (relmap) {
-    OFA_REQUIRE(planes == 1 || planes == 2, OFA_ERR_INVALID, "attn_pos: 1 or 2 bucket-id planes, got %d", planes);
-    OFA_REQUIRE(used && ncompact >= 1 && ncompact <= POS_TAB_MAX, OFA_ERR_INVALID, "attn_pos: 1 <= ncompact <= %d (got %d) and `used`", POS_TAB_MAX, ncompact);
-    OFA_REQUIRE(relmap_ld % 32 == 0 && relmap_ld >= (S + 31) / 32 * 32, OFA_ERR_INVALID,
-                "attn_pos: the id rows must be padded to whole 32-key blocks (ld %d, S %d)", relmap_ld, S);
-    OFA_REQUIRE(!((uintptr_t)relmap & 7) && (plane_stride % 4) == 0, OFA_ERR_INVALID, "attn_pos: id planes must be 8-byte aligned");
-    OFA_REQUIRE(t0, OFA_ERR_INVALID, "attn_pos: table 0 is NULL");
-  }
+// ---- batch-SHARED position bias [heads, Tb, Sb]: the dense-bias kernels with a zero batch stride + the batch-summed dS kernel
+static int sbias_check(const void* bias, int Tb, int Sb, int T, int S, const int32_t* seg) {
+  OFA_REQUIRE(bias && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "attn_sbias: the bias [heads, Tb, Sb] is required (Tb=%d Sb=%d)", Tb, Sb);
+  OFA_REQUIRE(Tb >= T && Sb >= S, OFA_ERR_INVALID, "attn_sbias: the bias covers %d x %d positions, the call needs %d x %d", Tb, Sb, T, S);
+  (void)seg;
   return 0;
 }
 
-extern "C" int ofa_attn_pos_fwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k,
-                                const uint16_t* relmap, int relmap_planes, int relmap_ld, int64_t relmap_plane_stride,
-                                const int32_t* used, int ncompact, const void* tab0, const void* tab1, const void* tab2,
-                                const void* tab3, const uint8_t* kpm, const void* c_attn, int c_attn_dtype, void* out, float* lse,
-                                int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int64_t ldpq,
-                                int64_t ldpk, float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype,
-                                void* stream) {
+extern "C" int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias, int Tb, int Sb, const uint8_t* kpm,
+                                  const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S,
+                                  int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
+                                  int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
-  OFA_REQUIRE(q && k && v && out && lse, OFA_ERR_INVALID, "attn_pos_fwd: null pointer");
-  OFA_REQUIRE(scale > 0.f, OFA_ERR_INVALID, "attn_pos_fwd: the score scale must be positive, got %g", (double)scale);
+  if (int rc = sbias_check(bias, Tb, Sb, T, S, seg)) return rc;
+  OFA_REQUIRE(q && k && v && out && lse, OFA_ERR_INVALID, "attn_sbias_fwd: null pointer");
+  OFA_REQUIRE(scale > 0.f, OFA_ERR_INVALID, "attn_sbias_fwd: the score scale must be positive, got %g", (double)scale);
   OFA_REQUIRE(!seg || (!kpm && !((uintptr_t)seg & 15) && rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID,
-              "attn_pos_fwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
-  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_pos_fwd: bad c_attn dtype %d", c_attn_dtype);
+              "attn_sbias_fwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_sbias_fwd: bad c_attn dtype %d", c_attn_dtype);
   AttnL a{};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kpm = kpm;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
   a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
-  if (int rc = pos_fill(a, pos_q, pos_k, relmap, relmap_planes, relmap_ld, relmap_plane_stride, used, ncompact, tab0, tab1, tab2, tab3,
-                        ldpq, ldpk, T, S)) return rc;
+  a.bias_ld = Sb; a.bias_hs = (int64_t)Tb * Sb; a.bias_bs = 0;
   const dim3 grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  auto kern = dtype == OFA_F16 ? attn_fwd_pos_f16_lds_kernel : attn_fwd_pos_lds_kernel;
-  const size_t lds = 6 * TILE_BYTES + (size_t)a.ncompact * 4;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a);
-  return check_launch("attn_pos_fwd");
+  auto kern = dtype == OFA_F16 ? attn_fwd_bias_f16_lds_kernel : attn_fwd_bias_lds_kernel;
+  hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
+  return check_launch("attn_sbias_fwd");
 }
 
-extern "C" int ofa_attn_pos_qtiles(int T) { return cdiv(T, 128); }
-
-extern "C" int ofa_attn_pos_bwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k,
-                                const uint16_t* relmap, int relmap_planes, int relmap_ld, int64_t relmap_plane_stride,
-                                const int32_t* used, int ncompact, const void* tab0, const void* tab1, const void* tab2,
-                                const void* tab3, const void* dout, const uint8_t* kpm, const void* c_attn, int c_attn_dtype,
-                                const float* lse, float* delta, const void* out, void* dq, void* dk, void* dv, void* dpos_q,
-                                void* dpos_k, float* dtab_slab, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk,
-                                int64_t ldo, int64_t ldpq, int64_t ldpk, float scale, int causal, const int32_t* seg, int rows_q,
-                                int rows_k, int dtype, void* stream) {
+extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
+                                  const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                                  const void* out, void* dq, void* dk, void* dv, float* dbias_sum, int B, int heads, int T, int S,
+                                  int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
+                                  int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
+  if (int rc = sbias_check(bias, Tb, Sb, T, S, seg)) return rc;
   OFA_REQUIRE(!seg || (!kpm && !((uintptr_t)seg & 15) && rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID,
-              "attn_pos_bwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
-  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_pos_bwd: bad c_attn dtype %d", c_attn_dtype);
-  OFA_REQUIRE(q && k && v && dout && lse && delta && out && dq && dk && dv && dpos_q && dpos_k, OFA_ERR_INVALID, "attn_pos_bwd: null pointer");
+              "attn_sbias_bwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
+  OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_sbias_bwd: bad c_attn dtype %d", c_attn_dtype);
+  OFA_REQUIRE(q && k && v && dout && lse && delta && out && dq && dk && dv, OFA_ERR_INVALID, "attn_sbias_bwd: null pointer");
   AttnL a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
-  a.kpm = kpm; a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.bias = (const bf16_t*)bias; a.kpm = kpm; a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.out = (bf16_t*)const_cast<void*>(out);
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.B = B; a.heads = heads; a.T = T;
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   a.rows_q = rows_q; a.rows_k = rows_k;
-  if (int rc = pos_fill(a, pos_q, pos_k, relmap, relmap_planes, relmap_ld, relmap_plane_stride, used, ncompact, tab0, tab1, tab2, tab3,
-                        ldpq, ldpk, T, S)) return rc;
-  a.dpq = (bf16_t*)dpos_q; a.dpk = (bf16_t*)dpos_k; a.dtab = relmap ? dtab_slab : nullptr;
+  a.bias_ld = Sb; a.bias_hs = (int64_t)Tb * Sb; a.bias_bs = 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  static const bool dq_w2 = getenv("OFA_ATTN_POS_DQ_W2") != nullptr;               // A/B switch (tools/attn_pos_bench.py)
-  auto dq_kern = dtype == OFA_F16 ? attn_bwd_dq_pos_f16_lds_kernel : (dq_w2 ? attn_bwd_dq_pos_w2_lds_kernel : attn_bwd_dq_pos_lds_kernel);
-  const size_t lds_q = 6 * TILE_BYTES + (size_t)a.ncompact * 4 * (a.dtab ? 5 : 1);
-  if (lds_q > 64 * 1024) (void)hipFuncSetAttribute((const void*)dq_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-  hipLaunchKernelGGL(dq_kern, q_grid, dim3(256), lds_q, st, a);
-  int rc = check_launch("attn_pos_bwd_dq");
+  auto dq_kern = dtype == OFA_F16 ? attn_bwd_dq_bias_f16_lds_kernel : attn_bwd_dq_bias_lds_kernel;
+  hipLaunchKernelGGL(dq_kern, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
+  int rc = check_launch("attn_sbias_bwd_dq");
   if (rc) return rc;
   const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);
-  auto kv_kern = dtype == OFA_F16 ? attn_bwd_dkv_pos_f16_lds_kernel : attn_bwd_dkv_pos_lds_kernel;
-  hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 6 * TILE_BYTES + 2 * STAT_BYTES + (size_t)a.ncompact * 4, st, a);
-  return check_launch("attn_pos_bwd_dkv");
-}
-
-namespace ofa {
-// Table gradients from the dQ kernel's slab [B*heads][q tiles][ncompact]: dtable_s[row, h] (+)= sum over (b, tile), in a fixed order
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_table_grad_kernel(const float* __restrict__ slab, const int* __restrict__ used, int ncompact,
-                                                                int B, int heads, int qtiles, T* d0, T* d1, T* d2, T* d3, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
-  if (c < 1 || c >= ncompact) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* p = slab + ((int64_t)(b * heads + h) * qtiles) * ncompact + c;
-    for (int x = 0; x < qtiles; ++x) s += p[(int64_t)x * ncompact];
+  auto kv_kern = dtype == OFA_F16 ? attn_bwd_dkv_bias_f16_lds_kernel : attn_bwd_dkv_bias_lds_kernel;
+  hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
+  rc = check_launch("attn_sbias_bwd_dkv");
+  if (rc || !dbias_sum) return rc;
+  // G = sum_b dS (after the dQ kernel: it wrote delta).  Tiles of 64 key positions fill the chip at short sequences; 128 at long ones
+  const bool wide = (int64_t)cdiv(Sb, 64) * cdiv(Tb, 128) * heads >= 2048;
+  if (wide) {
+    const dim3 g(cdiv(Sb, 128), cdiv(Tb, 128), heads);
+    auto kn = dtype == OFA_F16 ? attn_bwd_dsum4_f16_kernel : attn_bwd_dsum4_kernel;
+    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dbias_sum, (int64_t)Sb, (int64_t)Tb * Sb, Tb, Sb);
+  } else {
+    const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads);
+    auto kn = dtype == OFA_F16 ? attn_bwd_dsum2_f16_kernel : attn_bwd_dsum2_kernel;
+    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dbias_sum, (int64_t)Sb, (int64_t)Tb * Sb, Tb, Sb);
   }
-  const int u = used[c];
-  T* d = (u >> 20) == 0 ? d0 : (u >> 20) == 1 ? d1 : (u >> 20) == 2 ? d2 : d3;
-  T* o = d + (int64_t)(u & 0xfffff) * heads + h;
-  if (accumulate) s += ld1<T>(o);
-  st1<T>(o, s);
-}
-}  // namespace ofa
-
-extern "C" int ofa_relpos_table_grad(const float* slab, const int32_t* used, int ncompact, int B, int heads, int qtiles, void* dtab0,
-                                     void* dtab1, void* dtab2, void* dtab3, int accumulate, int dtype, void* stream) {
-  OFA_REQUIRE(slab && used && dtab0 && ncompact >= 1 && B > 0 && heads > 0 && qtiles > 0, OFA_ERR_INVALID, "relpos_table_grad: bad arguments");
-  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "relpos_table_grad: bad dtype %d", dtype);
-  const dim3 grid(cdiv(ncompact, 256), heads);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == OFA_F32)
-    hipLaunchKernelGGL(relpos_table_grad_kernel<float>, grid, dim3(256), 0, st, slab, used, ncompact, B, heads, qtiles, (float*)dtab0,
-                       (float*)dtab1, (float*)dtab2, (float*)dtab3, accumulate);
-  else if (dtype == OFA_F16)
-    hipLaunchKernelGGL(relpos_table_grad_kernel<f16_t>, grid, dim3(256), 0, st, slab, used, ncompact, B, heads, qtiles, (f16_t*)dtab0,
-                       (f16_t*)dtab1, (f16_t*)dtab2, (f16_t*)dtab3, accumulate);
-  else
-    hipLaunchKernelGGL(relpos_table_grad_kernel<bf16_t>, grid, dim3(256), 0, st, slab, used, ncompact, B, heads, qtiles, (bf16_t*)dtab0,
-                       (bf16_t*)dtab1, (bf16_t*)dtab2, (bf16_t*)dtab3, accumulate);
-  return check_launch("relpos_table_grad");
+  return check_launch("attn_sbias_bwd_dsum");
 }
 
 #ifdef OFA_ATTN_TIMELINE

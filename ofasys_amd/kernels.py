@@ -412,15 +412,42 @@ def c_attn_grad(delta, c_attn, B, heads, T, out=None, accumulate=False):
     return out
 
 
-def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, seg=None):
+def _shared_bias(bias, heads, q):
+    """A batch-shared position bias: [heads, Tb, Sb] (the reference's [B*A, T, S] tensor is B copies of it), contiguous, q's dtype."""
+    assert bias.dim() == 3 and bias.shape[0] == heads, (tuple(bias.shape), heads)
+    if bias.dtype != q.dtype:
+        bias = bias.to(q.dtype)
+    return bias.contiguous()
+
+
+def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, seg=None, bias_shared=False):
     """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad].
     seg (packing.Segments): ragged mode -- q [1,rows_q,D], k, v [1,rows_k,D] hold the samples back to back, out rows outside
-    every segment are zero, lse is [heads, pad32(rows_q)] by packed row."""
+    every segment are zero, lse is [heads, pad32(rows_q)] by packed row.
+    bias_shared: bias is [heads, Tb, Sb], the same for every sample, indexed by the position inside the sample (ofa_attn_sbias_*)."""
     q, ldq = _rows3(q)
     k, v, ldk = _same_ld(k, v)
     B, T, D = q.shape
     S = k.shape[1]
     Tpad = pad32(T)
+    if bias_shared:
+        bias = _shared_bias(bias, heads, q)
+        Tb, Sb = bias.shape[1], bias.shape[2]
+        if seg is not None:
+            assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S and Tb >= seg.max_q - 31 and Sb >= seg.max_k - 31
+            out = torch.empty(1, T, D, dtype=q.dtype, device=q.device)
+            lse = torch.empty(heads, Tpad, dtype=torch.float32, device=q.device)
+            lib().call("ofa_attn_sbias_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), Tb, Sb, None, ptr(c_attn), _c_dtype(c_attn), ptr(out),
+                       ptr(lse), seg.batch, heads, min(seg.max_q, Tb), min(seg.max_k, Sb), Tpad, ldq, ldk, D, float(scale), int(causal),
+                       ptr(seg.table), T, S, dtype_code(q), stream())
+            return out, lse
+        out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
+        if kpm is not None:
+            kpm = _u8(kpm)
+        lib().call("ofa_attn_sbias_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), Tb, Sb, ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(out),
+                   ptr(lse), B, heads, T, S, Tpad, ldq, ldk, D, float(scale), int(causal), None, 0, 0, dtype_code(q), stream())
+        return out, lse
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and seg.rows_q == T and seg.rows_k == S, (B, T, S, seg.rows_q, seg.rows_k)
         out = torch.empty(1, T, D, dtype=q.dtype, device=q.device)          # filler rows are zeroed by the kernel
@@ -441,7 +468,7 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
 
 
 def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False,
-             outs=None, seg=None):
+             outs=None, seg=None, bias_shared=False):
     """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
     packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
     q, ldq = _rows3(q)
@@ -455,8 +482,8 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
     S = k.shape[1]
     Tpad = pad32(T)
     delta = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)   # rowsum(dO*O): written by the dQ kernel
-    dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if need_dbias else None
-    if bias is not None:
+    dbias = torch.empty(B * heads, T, S, dtype=q.dtype, device=q.device) if (need_dbias and not bias_shared) else None
+    if bias is not None and not bias_shared:
         bias = bias.contiguous()
     if kpm is not None:
         kpm = _u8(kpm)
@@ -474,6 +501,21 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)     # (ragged mode: the kernels zero the filler rows)
         dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
         dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+    if bias_shared:
+        # dbias (when asked for): fp32 [heads, Tb, Sb] = the sum over the batch of dS, from the batch-walking third kernel
+        bias = _shared_bias(bias, heads, q)
+        Tb, Sb = bias.shape[1], bias.shape[2]
+        dbias = torch.empty(heads, Tb, Sb, dtype=torch.float32, device=q.device) if need_dbias else None
+        if seg is not None:
+            assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S
+            dims = (seg.batch, heads, min(seg.max_q, Tb), min(seg.max_k, Sb), Tpad, ldq, ldk, ldo, float(scale), int(causal), ptr(seg.table), T, S)
+            kp = None
+        else:
+            dims = (B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal), None, 0, 0)
+            kp = ptr(kpm)
+        lib().call("ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), Tb, Sb, kp, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
+                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), *dims, dtype_code(q), stream())
+        return dq, dk, dv, dbias, delta
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
         lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
@@ -484,109 +526,6 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
                ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
                int(causal), None, 0, 0, dtype_code(q), stream())
     return dq, dk, dv, dbias, delta
-
-
-def _pos_args(pos):
-    """C-ABI argument run shared by ofa_attn_pos_fwd / _bwd for an ops.PosBias-like object `pos` (pos_q, pos_k [B,T|S,D] row views,
-    rel: ops.RelMap or None, tables: this layer's table weights by slot)."""
-    pq, pk = pos.pos_q.contiguous(), pos.pos_k.contiguous()          # dense rows: dpos_q / dpos_k share the leading dimension
-    ldpq, ldpk = pq.stride(1), pk.stride(1)
-    rel = pos.rel
-    tabs = [None] * 4
-    if rel is not None:
-        assert len(pos.tables) == rel.ntables <= 4
-        for i, t in enumerate(pos.tables):
-            assert t.is_contiguous() and t.dtype == pq.dtype and t.shape[1] == pos.heads, (t.shape, t.dtype)
-            tabs[i] = t
-        head = (ptr(rel.ids), rel.planes, rel.ld, rel.ids.shape[1] * rel.ld, ptr(rel.used), rel.ncompact)
-    else:
-        head = (None, 0, 0, 0, None, 0)
-    return pq, pk, ldpq, ldpk, head + tuple(ptr(t) for t in tabs)
-
-
-def attn_pos_fwd(q, k, v, heads, scale, pos, kpm=None, c_attn=None, causal=False, seg=None):
-    """ofa_attn_fwd with the position bias computed in the kernel (csrc/attention.hip, MODE 2).  pos: see _pos_args."""
-    q, ldq = _rows3(q)
-    k, v, ldk = _same_ld(k, v)
-    B, T, D = q.shape
-    S = k.shape[1]
-    Tpad = pad32(T)
-    pq, pk, ldpq, ldpk, pargs = _pos_args(pos)
-    assert pq.shape == q.shape and pk.shape[:2] == k.shape[:2], (pq.shape, q.shape, pk.shape, k.shape)
-    if pos.rel is not None:
-        assert pos.rel.ld >= pad32(S if seg is None else seg.max_k) and pos.rel.ids.shape[1] >= (T if seg is None else seg.max_q)
-    if seg is not None:
-        assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S
-        out = torch.empty(1, T, D, dtype=q.dtype, device=q.device)
-        lse = torch.empty(heads, Tpad, dtype=torch.float32, device=q.device)
-        lib().call("ofa_attn_pos_fwd", ptr(q), ptr(k), ptr(v), ptr(pq), ptr(pk), *pargs, None, ptr(c_attn), _c_dtype(c_attn), ptr(out),
-                   ptr(lse), seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, D, ldpq, ldpk, float(scale), int(causal),
-                   ptr(seg.table), T, S, dtype_code(q), stream())
-        return out, lse
-    out = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
-    lse = torch.empty(B * heads, Tpad, dtype=torch.float32, device=q.device)
-    if kpm is not None:
-        kpm = _u8(kpm)
-    lib().call("ofa_attn_pos_fwd", ptr(q), ptr(k), ptr(v), ptr(pq), ptr(pk), *pargs, ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(out),
-               ptr(lse), B, heads, T, S, Tpad, ldq, ldk, D, ldpq, ldpk, float(scale), int(causal), None, 0, 0, dtype_code(q), stream())
-    return out, lse
-
-
-def attn_pos_bwd(q, k, v, out, dout, lse, heads, scale, pos, kpm=None, c_attn=None, causal=False, outs=None, seg=None):
-    """-> dq, dk, dv, dpos_q, dpos_k, slab (fp32 [B*heads, qtiles, ncompact] or None), delta.  outs as in attn_bwd."""
-    q, ldq = _rows3(q)
-    k, v, ldk = _same_ld(k, v)
-    dout, ldo = _rows3(dout)
-    out, ldo2 = _rows3(out)
-    if ldo != ldo2:
-        dout, out = dout.contiguous(), out.contiguous()
-        ldo = dout.stride(1)
-    B, T, D = q.shape
-    S = k.shape[1]
-    Tpad = pad32(T)
-    pq, pk, ldpq, ldpk, pargs = _pos_args(pos)
-    nb = B if seg is None else seg.batch
-    delta = torch.empty((B if seg is None else 1) * heads, Tpad, dtype=torch.float32, device=q.device)
-    if outs is not None:
-        dq, dk, dv = outs
-        assert dq.stride(1) == ldq and dk.stride(1) == ldk and dv.stride(1) == ldk
-    else:
-        if ldq != D:
-            q = q.contiguous()
-            ldq = D
-        if ldk != D:
-            k, v = k.contiguous(), v.contiguous()
-            ldk = D
-        dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)
-        dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-        dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
-    dpq = torch.empty(pq.shape, dtype=q.dtype, device=q.device)      # (ragged mode: the kernels zero the filler rows)
-    dpk = torch.empty(pk.shape, dtype=q.dtype, device=q.device)
-    slab = None
-    if pos.rel is not None and pos.want_table_grad:
-        qt = lib().cdll.ofa_attn_pos_qtiles(T if seg is None else seg.max_q)
-        slab = torch.empty(nb * heads, qt, pos.rel.ncompact, dtype=torch.float32, device=q.device)
-    if kpm is not None:
-        kpm = _u8(kpm)
-    if seg is not None:
-        assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S
-        dims = (seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo, pq.stride(1), pk.stride(1), float(scale), int(causal),
-                ptr(seg.table), T, S)
-    else:
-        dims = (B, heads, T, S, Tpad, ldq, ldk, ldo, pq.stride(1), pk.stride(1), float(scale), int(causal), None, 0, 0)
-    lib().call("ofa_attn_pos_bwd", ptr(q), ptr(k), ptr(v), ptr(pq), ptr(pk), *pargs, ptr(dout), ptr(kpm), ptr(c_attn), _c_dtype(c_attn),
-               ptr(lse), ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dpq), ptr(dpk), ptr(slab), *dims, dtype_code(q), stream())
-    return dq, dk, dv, dpq, dpk, slab, delta
-
-
-def relpos_table_grad(slab, rel, heads, dtabs, accumulate):
-    """dtabs[s][row, h] (+)= the slab's sums (ofa_relpos_table_grad); dtabs: per table slot a [rows, heads] tensor (or None when the
-    slot's table takes no gradient -- its ids then land in a scratch row... not supported: every slot needs an output)."""
-    nbh, qt, nc = slab.shape
-    assert nc == rel.ncompact and all(d is not None and d.is_contiguous() for d in dtabs) and len(dtabs) == rel.ntables
-    p = [ptr(d) for d in dtabs] + [None] * (4 - len(dtabs))
-    lib().call("ofa_relpos_table_grad", ptr(slab), ptr(rel.used), nc, nbh // heads, heads, qt, *p, int(accumulate), dtype_code(dtabs[0]),
-               stream())
 
 
 def attn_decode(q, k_cache, v_cache, S, heads, scale, bias=None, kpm=None, c_attn=None, need_probs=False):

@@ -19,25 +19,23 @@ from ..preprocessor import Dictionary, Slot
 
 
 def _check_packable(cfg, wants_unsupported):
-    """Packed rows produce no per-layer extras (no [B,A,T,S] attention map exists in this mode)."""
+    """Packed rows produce no per-layer extras (no [B,A,Tt,Ts] attention map exists in this mode)."""
     if wants_unsupported:
         raise NotImplementedError("row packing: hidden-state / attention-weight outputs, incremental decoding and full-context "
                                   "alignment are only available on padded batches")
 
 
-def _packed_bias(bias_list, q_index, q_inverse, k_index, k_inverse, prefix_ok, what):
-    """The per-layer ops.PosBias list over packed rows (pos_q / pos_k gathered ONCE: the layers share them)."""
+def _packed_bias_ok(bias_list, prefix_ok, what):
+    """A position bias over packed rows: it has to be the batch-shared form (indexed by the position inside the sample), and packed
+    row r of a sample has to BE padded position r -- the sample's valid positions a prefix of its padded row (packing.PackPlan)."""
     if not bias_list:
-        return None
-    first = bias_list[0]
-    if not isinstance(first, ops.PosBias):
-        raise NotImplementedError(f"row packing: the {what} position bias is a dense [B,A,T,T] tensor (a custom adaptor produced it); "
-                                  "run such batches padded")
-    if first.rel is not None and not prefix_ok:
-        raise NotImplementedError(f"row packing with a rel-pos bias needs every sample's valid {what} positions to be a prefix of its "
+        return
+    if not isinstance(bias_list[0], ops.SharedBias):
+        raise NotImplementedError(f"row packing: the {what} position bias is a per-sample [B,A,T,T] tensor (an adaptor whose positions "
+                                  "depend on the batch row produced it); run such batches padded")
+    if not prefix_ok:
+        raise NotImplementedError(f"row packing with a position bias needs every sample's valid {what} positions to be a prefix of its "
                                   "padded row (one ragged slot, at the end); run this batch padded")
-    base = first.packed(q_index, q_inverse, k_index, k_inverse)
-    return [ops.PosBias(base.pos_q, base.pos_k, b.heads, b.attn_scaling, b.rel, b.tables, ()) for b in bias_list]
 
 
 class TransformerEncoder(nn.Module):
@@ -64,14 +62,12 @@ class TransformerEncoder(nn.Module):
         if len(slots) == 0:
             return None
         adaptor_output = AdaptorOutput(*self.adaptor(slots))
-        layer_bias = adaptor_output.self_attn_bias if self.cfg.use_self_attn_bias else None
         if pack is not None:
             _check_packable(self.cfg, return_all_hiddens or return_all_attention_weights)
+            if self.cfg.use_self_attn_bias:
+                _packed_bias_ok(adaptor_output.self_attn_bias, pack.enc_prefix, "encoder")
             x = ops.pack_rows(adaptor_output.embed, pack.enc_index, pack.enc_inverse).transpose(0, 1)   # [rows, 1, C] view
             layer_mask = pack.enc_self                               # padded rows are simply absent: nothing to zero or mask
-            if layer_bias is not None:
-                layer_bias = _packed_bias(layer_bias, pack.enc_index, pack.enc_inverse, pack.enc_index, pack.enc_inverse,
-                                          pack.enc_prefix, "encoder")
         else:
             # zero the padded positions (transformer.py:110-112); unconditional, no host sync
             adaptor_output.embed = ops.add_rowvec_mask(adaptor_output.embed, None, None, adaptor_output.masks)
@@ -82,9 +78,9 @@ class TransformerEncoder(nn.Module):
         encoder_attention_states = []
         chain = LayerChain()
         for idx, layer in enumerate(self.layers):
-            if layer_bias is not None:
-                b = layer_bias[0 if self.cfg.share_attn_bias else idx]
-                self_attn_bias = b if isinstance(b, ops.PosBias) else b.view(-1, T, T)     # (PosBias: the same tensor, un-materialised)
+            if self.cfg.use_self_attn_bias:
+                b = adaptor_output.self_attn_bias[0 if self.cfg.share_attn_bias else idx]
+                self_attn_bias = b if isinstance(b, ops.SharedBias) else b.view(-1, T, T)   # (SharedBias: [A,T,T], one for the batch)
             else:
                 self_attn_bias = None
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
@@ -106,6 +102,7 @@ class TransformerEncoder(nn.Module):
             "encoder_embedding": [adaptor_output.embed],            # B x T x C
             "encoder_states": encoder_states,
             "position_embeddings": [adaptor_output.pos_embed],      # B x T x C
+            "position_embeddings_shared": [bool(getattr(self.adaptor, "last_pos_shared", False))],   # (every row identical: see SharedBias)
             "encoder_attention_weights": encoder_attention_states,
         }
 
@@ -117,6 +114,7 @@ class TransformerEncoder(nn.Module):
             "encoder_embedding": sel("encoder_embedding", 0),
             "encoder_states": [s.index_select(1, new_order) for s in encoder_out["encoder_states"]],
             "position_embeddings": sel("position_embeddings", 0),
+            "position_embeddings_shared": list(encoder_out.get("position_embeddings_shared", [])),
         }
 
     def max_positions(self):
@@ -156,13 +154,21 @@ class TransformerDecoder(nn.Module):
     def build_decoder_layer(self, cfg, no_encoder_attn=False, drop_path_rate=0.0):
         return TransformerDecoderLayer(cfg, no_encoder_attn, drop_path_rate=drop_path_rate)
 
-    def get_cross_pos_info(self, embed, tgt_pos_embed, src_pos_embed):
-        """abs position bias for cross attention (model/transformer.py:280-299): the reference's [B,A,Tt,Ts] tensor as an
-        un-materialised ops.PosBias (`.dense()` is the tensor)."""
-        scaling = self.adaptor.attn_scaling()
-        pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling / scaling)     # (= 1 for every OFA architecture)
+    def get_cross_pos_info(self, embed, tgt_pos_embed, src_pos_embed, shared=False):
+        """abs position bias for cross attention -> [B,A,Tt,Ts] (model/transformer.py:280-299); shared (both position embeddings are
+        the same for every batch row): built once from row 0 -> ops.SharedBias [A,Tt,Ts]."""
+        if shared:
+            tgt_pos_embed, src_pos_embed = tgt_pos_embed[:1], src_pos_embed[:1]
+        pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling)
         pos_k = self.cross_pos_k_linear(src_pos_embed)
-        return ops.PosBias(pos_q, pos_k, self.num_attention_heads, scaling)
+        b = ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
+        return ops.SharedBias(b[0]) if shared else b
+
+    def _pos_shared(self, adaptor_output, encoder_out):
+        """Are the target AND the source position embeddings identical for every batch row (all built-in adaptors)?"""
+        tgt = bool(getattr(self.adaptor, "last_pos_shared", False))
+        src = bool(encoder_out is not None and encoder_out.get("position_embeddings_shared") and encoder_out["position_embeddings_shared"][0])
+        return tgt and src
 
     def forward(self, slots: List[Slot], encoder_out: Optional[Dict[str, List[Tensor]]] = None,
                 incremental_state=None, features_only: bool = False, full_context_alignment: bool = False,
@@ -198,10 +204,13 @@ class TransformerDecoder(nn.Module):
         tgt_embed, tgt_pos_embed = adaptor_output.embed, adaptor_output.pos_embed
         self_attn_padding_mask = adaptor_output.masks
         all_self_attn_bias = adaptor_output.self_attn_bias
+        pos_shared = self._pos_shared(adaptor_output, encoder_out)
         if not self.cfg.entangle_position_embedding:
-            cross_abs_pos_bias = self.get_cross_pos_info(tgt_embed, tgt_pos_embed, src_pos_embed=src_pos_embed)
-            if incremental_state is not None:                        # (a decoding step slices the bias: the tensor form)
-                cross_abs_pos_bias = cross_abs_pos_bias.dense()
+            cross_abs_pos_bias = self.get_cross_pos_info(tgt_embed, tgt_pos_embed, src_pos_embed=src_pos_embed, shared=pos_shared)
+            if isinstance(cross_abs_pos_bias, ops.SharedBias):
+                if incremental_state is not None:                    # (a decoding step slices the bias: the tensor form)
+                    cross_abs_pos_bias = ops.expand_shared_bias(cross_abs_pos_bias.t, bsz, tgt_pos_embed.shape[1], src_pos_embed.shape[1])
+            else:
                 cross_abs_pos_bias = cross_abs_pos_bias.reshape(-1, *cross_abs_pos_bias.size()[-2:])
         else:
             cross_abs_pos_bias = None
@@ -220,10 +229,11 @@ class TransformerDecoder(nn.Module):
                               else None)
             if self.cfg.use_self_attn_bias:
                 b = all_self_attn_bias[0 if self.cfg.share_attn_bias else idx]
-                if isinstance(b, ops.PosBias) and incremental_state is None:
-                    self_attn_bias = b                                # un-materialised: the fused kernels compute it
+                if isinstance(b, ops.SharedBias) and incremental_state is None:
+                    self_attn_bias = b
                 else:
-                    b = b.dense() if isinstance(b, ops.PosBias) else b
+                    if isinstance(b, ops.SharedBias):
+                        b = ops.expand_shared_bias(b.t, bsz, b.t.shape[1], b.t.shape[2])
                     self_attn_bias = b.view(-1, *b.size()[-2:])
                 if incremental_state is not None:
                     self_attn_bias = self_attn_bias[:, -1:, :]        # the new position's row against every cached key
@@ -271,12 +281,13 @@ class TransformerDecoder(nn.Module):
         tag = causal_tag(x.device)
         self_bias = cross_bias = None
         if self.cfg.use_self_attn_bias:
-            self_bias = _packed_bias(adaptor_output.self_attn_bias, pack.dec_index, pack.dec_inverse, pack.dec_index, pack.dec_inverse,
-                                     pack.dec_prefix, "decoder")
+            self_bias = adaptor_output.self_attn_bias
+            _packed_bias_ok(self_bias, pack.dec_prefix, "decoder")
         if not self.cfg.entangle_position_embedding:
-            src_pos = encoder_out["position_embeddings"][0]           # [B, Ts, C] padded, like the target's: packed here
-            cross_bias = self.get_cross_pos_info(None, adaptor_output.pos_embed, src_pos_embed=src_pos).packed(
-                pack.dec_index, pack.dec_inverse, pack.enc_index, pack.enc_inverse)
+            if not (self._pos_shared(adaptor_output, encoder_out) and pack.dec_prefix and pack.enc_prefix):
+                _packed_bias_ok([None], False, "cross-attention")
+            cross_bias = self.get_cross_pos_info(None, adaptor_output.pos_embed, src_pos_embed=encoder_out["position_embeddings"][0],
+                                                 shared=True)
         chain = LayerChain()
         for idx, layer in enumerate(self.layers):
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm

@@ -90,53 +90,50 @@ class MultiheadAttention(nn.Module):
         scale = (1.0 / math.sqrt(self.head_dim)) if fast else self.scaling
         c_attn = None if fast else self.c_attn
 
-        # attn_bias: the reference's dense [B*A, T, S] tensor, False (decoder: slow path, no bias, :311), or an ops.PosBias -- the
-        # SAME bias un-materialised (abs-pos projections + rel-pos ids / tables), computed inside the fused kernels when they run
-        pos = attn_bias if isinstance(attn_bias, ops.PosBias) else None
-        bias = attn_bias if torch.is_tensor(attn_bias) else None
-        if bias is not None:
+        # attn_bias: the reference's dense [B*A, T, S] tensor, False (decoder: slow path, no bias, :311), or an ops.SharedBias: a
+        # POSITION bias does not depend on the batch row, so the stacks hand it over once, as [A, Tb, Sb] (general.py's [B, A, T, T]
+        # is B copies of it); the fused kernels index it by (head, position, position) for every sample -- also over packed rows --
+        # and return the batch-summed gradient
+        shared = isinstance(attn_bias, ops.SharedBias)
+        bias = attn_bias.t if shared else (attn_bias if torch.is_tensor(attn_bias) else None)
+        if bias is not None and not shared:
             bias = bias.reshape(bsz * self.num_heads, tgt_len, src_len)
         causal = False
-        plain_mask = None
         if attn_mask is not None:
             if getattr(attn_mask, "_ofa_causal", False):
                 causal = True                                                # triu(-inf, 1) from buffered_future_mask
-            else:
-                plain_mask = attn_mask
+            else:                                                            # arbitrary additive mask: fold into the bias
+                if shared:
+                    bias, shared = ops.expand_shared_bias(bias, bsz, tgt_len, src_len), False
+                m = attn_mask.to(xq.dtype).unsqueeze(0).expand(bsz * self.num_heads, tgt_len, src_len).contiguous()
+                bias = m if bias is None else ops.add_rowvec_mask(bias.contiguous(), m)
         if torch.is_tensor(key_padding_mask) and key_padding_mask.dim() == 0:
             key_padding_mask = None
         p_drop = self.dropout_module.p if (self.training or self.dropout_module.apply_during_inference) else 0.0
         fused = (xq.dtype in (torch.bfloat16, torch.float16) and self.head_dim == 64 and p_drop == 0.0 and not need_weights
                  and self.q_proj.bias is not None)
-        if pos is not None and not (fused and plain_mask is None and abs(pos.attn_scaling - scale) <= 1e-9 * scale
-                                    and (pos.rel is None or (xk is xq and xv is xq))):
-            if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):
-                raise NotImplementedError("packed (ragged) batches need the fused attention kernels (16-bit, head_dim 64, no attention "
-                                          "dropout / weights output): there is no dense position bias over packed rows")
-            bias = pos.dense().reshape(bsz * self.num_heads, tgt_len, src_len)     # exact tier / weights output: the reference's tensor
-            pos = None
-        if plain_mask is not None:                                           # arbitrary additive mask: fold into the bias
-            m = plain_mask.to(xq.dtype).unsqueeze(0).expand(bsz * self.num_heads, tgt_len, src_len).contiguous()
-            bias = m if bias is None else ops.add_rowvec_mask(bias.contiguous(), m)
         if bias is not None and bias.dtype != xq.dtype:
             bias = bias.to(xq.dtype)
         probs = None
         if fused and xk is xq and xv is xq:
             # one packed k|v|q projection + fused attention (csrc/gemm_mfma.hip, csrc/attention.hip)
-            extra = (pos.rel, pos.pos_q, pos.pos_k, *pos.tables) if pos is not None else ()
             out = ops.PackedSelfAttentionFn.apply(
                 xq, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
-                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, causal, self._pack, *extra)
+                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, causal, self._pack, shared)
         elif fused and xv is xk:
-            extra = (pos.pos_q, pos.pos_k) if pos is not None else ()
             out = ops.PackedCrossAttentionFn.apply(
                 xq, xk, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
-                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, self._pack, *extra)
+                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, self._pack, shared)
         else:
+            if shared:                                                       # exact tier / weights output: the reference's tensor
+                if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):
+                    raise NotImplementedError("packed (ragged) batches need the fused attention kernels (16-bit, head_dim 64, no "
+                                              "attention dropout / weights output): a position bias over packed rows exists only there")
+                bias = ops.expand_shared_bias(bias, bsz, tgt_len, src_len)
             q = self.q_proj(xq)
             k = self.k_proj(xk)
             v = self.v_proj(xv)
-            out, probs = ops.attention(q, k, v, self.num_heads, scale, bias=(pos if pos is not None else bias), key_padding_mask=key_padding_mask,
+            out, probs = ops.attention(q, k, v, self.num_heads, scale, bias=bias, key_padding_mask=key_padding_mask,
                                        c_attn=c_attn, causal=causal, dropout_p=p_drop, need_weights=need_weights)
         out = self.out_proj(out, skip_bias_grad=out_proj_skip_bias_grad).transpose(0, 1)   # back to T x B x C (a view)
         attn_weights = None
@@ -257,8 +254,6 @@ class MultiheadAttention(nn.Module):
         tgt_len, bsz, embed_dim = query.size()
         if tgt_len != 1:
             raise NotImplementedError("incremental decoding feeds one target position per call (model/transformer.py:447-450)")
-        if isinstance(attn_bias, ops.PosBias):
-            raise NotImplementedError("incremental decoding takes the bias ROW of the new position as a tensor (PosBias.dense()[:, -1:])")
         if attn_mask is not None:
             raise NotImplementedError("attn_mask together with incremental_state (the reference passes None, :464-467)")
         H, D = self.num_heads, self.embed_dim
@@ -318,6 +313,8 @@ class MultiheadAttention(nn.Module):
                     c["kpm"][:, n] = False
             c["len"] = n + 1
         S = c["len"]
+        if isinstance(attn_bias, ops.SharedBias):
+            raise NotImplementedError("incremental decoding takes the new position's bias ROW as a [B*A, 1, S] tensor")
         bias = attn_bias if torch.is_tensor(attn_bias) else None
         if bias is not None:
             bias = bias.reshape(bsz * H, S)

@@ -51,7 +51,11 @@ class Bottleneck(nn.Module):
     def forward(self, fm):
         """fm = (rows [B*H*W, C], B, H, W)   -- module/resnet.py:112-137."""
         x, B, H, W = fm
-        out, _, _ = _conv(x, self.conv1, B, H, W)
+        # an identity block reads x twice (conv1 and the residual add): the residual's gradient is handed to conv1's input-gradient
+        # GEMM, which accumulates onto it, instead of a separate add of two [B*H*W, C] tensors per block (ops.batch_norm)
+        mailbox = [] if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
+        out, _, _ = ops.conv2d(x, self.conv1.weight, self.conv1.bias, B, H, W, self.conv1.stride[0], self.conv1.padding[0],
+                               grad_mailbox=mailbox)
         out = ops.batch_norm(out, self.bn1, relu=True)
         out, Ho, Wo = _conv(out, self.conv2, B, H, W)
         out = ops.batch_norm(out, self.bn2, relu=True)
@@ -60,7 +64,7 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             identity, _, _ = _conv(x, self.downsample[0], B, H, W)
             identity = ops.batch_norm(identity, self.downsample[1])
-        out = ops.batch_norm(out, self.bn3, relu=True, residual=identity)       # relu(identity + bn3(out))
+        out = ops.batch_norm(out, self.bn3, relu=True, residual=identity, grad_mailbox=mailbox)   # relu(identity + bn3(out))
         return out, B, Ho, Wo
 
 

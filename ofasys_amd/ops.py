@@ -583,125 +583,6 @@ def embedding(ids, weight, padding_idx=None):
     return EmbeddingFn.apply(ids, weight, padding_idx)
 
 
-# ---------------------------------------------------------------------------------------------- position bias, un-materialised
-class RelMap:
-    """The batch-, head- and layer-independent part of a slot layout's rel-pos bias (csrc/attention.hip, "position bias inside the
-    kernels"): ids int16 [planes, T, ld] COMPACT bucket ids by (query position, key position) -- 0 = none, ld = T rounded up to whole
-    32-key blocks -- and used int32 [ncompact]: id -> (table slot << 20 | table row).  Built on the host from the adaptors' integer
-    bucket tables (bit-exact by construction: the same buffers the reference indexes), once per slot layout."""
-
-    def __init__(self, blocks, T, device):
-        """blocks: [(start, n, [(bucket LongTensor [n, n], table slot), ...planes])] for the slots that carry a rel-pos bias."""
-        import numpy as np
-        planes = max(len(pl) for _, _, pl in blocks)
-        assert 1 <= planes <= 2
-        ld = (T + 31) // 32 * 32
-        pairs = set()
-        host = []
-        for start, n, pl in blocks:
-            hp = []
-            for bucket, ts in pl:
-                b = bucket.detach().cpu().numpy().astype(np.int64)
-                assert b.shape == (n, n) and b.min() >= 0 and b.max() < (1 << 20) and 0 <= ts < 4
-                pairs.update((ts << 20 | int(r)) for r in np.unique(b))
-                hp.append((b, ts))
-            host.append((start, n, hp))
-        used = sorted(pairs)
-        if len(used) + 1 > 4096:
-            raise OfaError(f"rel-pos bias: {len(used)} distinct buckets in one attention call (the kernels take 4095)")
-        lut = {u: c + 1 for c, u in enumerate(used)}
-        ids = np.zeros((planes, T, ld), dtype=np.int16)
-        for start, n, hp in host:
-            for pi, (b, ts) in enumerate(hp):
-                keys = (ts << 20) | b
-                uniq, inv = np.unique(keys, return_inverse=True)
-                comp = np.array([lut[int(u)] for u in uniq], dtype=np.int16)
-                ids[pi, start:start + n, start:start + n] = comp[inv].reshape(n, n)
-        self.planes, self.ld, self.T = planes, ld, T
-        self.ncompact = len(used) + 1
-        self.ntables = 1 + max(u >> 20 for u in used)
-        self.ids = torch.from_numpy(ids).to(device)
-        self.used = torch.tensor([0] + used, dtype=torch.int32, device=device)
-
-
-class LazyBias:
-    """A slot's rel-pos bias as the adaptors hand it to the general adaptor: the reference's [B,A,T,T] tensor on demand
-    (`expand()`, adaptor/base.py:242-256) -- and, for the kernels, what it is MADE of: `planes_fn()` = [(bucket ids [n,n], tables)]
-    with tables the per-layer nn.ModuleList and `idx` the layer; `planes_key` identifies the ids (they are built once per slot
-    layout and cached, so planes_fn only runs on a cache miss).  planes_key None: a bias only known as a tensor."""
-
-    def __init__(self, values_fn, batch_size, planes=None, idx=0):
-        self._fn, self.batch_size, self.idx = values_fn, batch_size, idx
-        self.planes_key, self.planes_fn = planes if planes is not None else (None, None)
-        self._values = None
-
-    def values(self):
-        if self._values is None:
-            self._values = self._fn()                                       # [n, n, A]
-        return self._values
-
-    def expand(self):
-        return self.values().unsqueeze(0).expand(self.batch_size, -1, -1, -1).permute([0, 3, 1, 2])
-
-
-class PosBias:
-    """The attention bias of one layer, not materialised: abs-pos projections + (optionally) the rel-pos ids and THIS layer's tables.
-    MultiheadAttention hands it to the fused kernels (16-bit, head_dim 64) or asks `dense()` for the reference's [B*A, T, S] tensor
-    (fp32 tier, attention-weight outputs, incremental decoding).
-      pos_q: [B,T,D] = pos_q_linear(pos) * (pos_scaling / attn_scaling)  -- attn_scaling: the layers' (head_dim*scale_factor)^-0.5;
-      pos_k: [B,S,D]; rel: RelMap or None; tables: the layer's table weights by RelMap slot; dense_blocks: [(start, LazyBias|None)]."""
-
-    def __init__(self, pos_q, pos_k, heads, attn_scaling, rel=None, tables=(), dense_blocks=(), shared=None):
-        self.pos_q, self.pos_k, self.heads, self.attn_scaling = pos_q, pos_k, heads, float(attn_scaling)
-        self.rel, self.tables, self.dense_blocks = rel, tuple(tables), tuple(dense_blocks)
-        self._dense = None
-        self._shared = shared if shared is not None else {}      # the layers of one stack share pos_q / pos_k: one abs-pos product
-
-    def dense(self):
-        """[B, A, T, S] as adaptor/general.py:265-280 / model/transformer.py:280-299 build it."""
-        if self._dense is None:
-            ab = self._shared.get("abs")
-            if ab is None:
-                ab = self._shared["abs"] = heads_matmul_nt(self.pos_q, self.pos_k, self.heads, alpha=self.attn_scaling)
-            if self.dense_blocks:
-                ab = BiasAssembleFn.apply(ab, [s_ for s_, _ in self.dense_blocks],
-                                          *[(b.values() if b is not None else None) for _, b in self.dense_blocks])
-            self._dense = ab
-        return self._dense
-
-    def packed(self, q_index, q_inverse, k_index, k_inverse):
-        """The same bias over packed rows: pos_q / pos_k gathered like the activations (packing.PackPlan indices)."""
-        B, T, D = self.pos_q.shape
-        pq = PackRowsFn.apply(self.pos_q.reshape(B * T, D), q_index, q_inverse).view(1, -1, D)
-        S = self.pos_k.shape[1]
-        pk = PackRowsFn.apply(self.pos_k.reshape(B * S, D), k_index, k_inverse).view(1, -1, D)
-        return PosBias(pq, pk, self.heads, self.attn_scaling, self.rel, self.tables, ())
-
-
-class _PosCall:
-    """What kernels.attn_pos_* read (tensors detached from autograd bookkeeping)."""
-    __slots__ = ("pos_q", "pos_k", "rel", "tables", "heads", "want_table_grad")
-
-    def __init__(self, pos_q, pos_k, rel, tables, heads, want_table_grad=True):
-        self.pos_q, self.pos_k, self.rel, self.tables, self.heads, self.want_table_grad = pos_q, pos_k, rel, tables, heads, want_table_grad
-
-
-def _pos_table_grads(slab, rel, heads, tables):
-    """Gradients of the layer's rel-pos tables from the dQ kernel's slab: into the arena where the table has a sink (-> None), else
-    fresh tensors."""
-    if slab is None:
-        return [None] * len(tables)
-    sinks = [_sink(t) for t in tables]
-    if all(s_ is not None for s_ in sinks):
-        K.relpos_table_grad(slab, rel, heads, sinks, True)
-        for t in tables:
-            _sink_done(t)
-        return [None] * len(tables)
-    outs = [torch.zeros_like(t) for t in tables]
-    K.relpos_table_grad(slab, rel, heads, outs, False)
-    return outs
-
-
 # ---------------------------------------------------------------------------------------------- attention
 def _c_attn_grad(delta, c_attn, B, heads, T):
     """d c_attn[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]  (O = c * PV): one kernel, straight into the gradient arena when
@@ -743,45 +624,37 @@ def pack_rows(x, index, inverse):
     return PackRowsFn.apply(x.reshape(B * T, D), index, inverse).view(1, -1, D)
 
 
+def _shared_dbias(dbias, bias, shared):
+    """The batch-summed dS of a shared bias comes back as fp32 [heads, Tb, Sb]: in the bias' own dtype and shape for autograd."""
+    if dbias is None or not shared:
+        return dbias
+    return dbias.to(bias.dtype).view(bias.shape)
+
+
 class FusedAttentionFn(torch.autograd.Function):
-    """bf16 fused attention on [B,T,D] rows (csrc/attention.hip).  rel / pos_q / pos_k / tables: the un-materialised position bias
-    (PosBias) -- mutually exclusive with the dense `bias`."""
+    """bf16 fused attention on [B,T,D] rows (csrc/attention.hip)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal, rel=None, pos_q=None, pos_k=None, *tables):
+    def forward(ctx, q, k, v, bias, kpm, c_attn, heads, scale, causal, bias_shared=False):
         kpm, seg = _split_seg(kpm)
-        pos = _PosCall(pos_q, pos_k, rel, tables, heads) if pos_q is not None else None
-        if pos is not None:
-            assert bias is None
-            out, lse = K.attn_pos_fwd(q, k, v, heads, scale, pos, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg)
-        else:
-            out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg)
-        ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn, pos_q, pos_k, *tables)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg, bias_shared=bias_shared)
+        ctx.save_for_backward(q, k, v, out, lse, bias, kpm, c_attn)
         ctx.c_ref = c_attn                                  # the Parameter object (carries the gradient sink)
-        ctx.table_refs = tables
-        ctx.heads, ctx.scale, ctx.causal, ctx.seg, ctx.rel = heads, scale, causal, seg, rel
+        ctx.heads, ctx.scale, ctx.causal, ctx.seg, ctx.bias_shared = heads, scale, causal, seg, bias_shared
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, out, lse, bias, kpm, c_attn, pos_q, pos_k, *tables = ctx.saved_tensors
-        nt = len(tables)
-        if pos_q is not None:
-            pos = _PosCall(pos_q, pos_k, ctx.rel, tables, ctx.heads, any(ctx.needs_input_grad[12:]))
-            dq, dk, dv, dpq, dpk, slab, delta = K.attn_pos_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, pos, kpm=kpm, c_attn=c_attn,
-                                                               causal=ctx.causal, seg=ctx.seg)
-            dtabs = _pos_table_grads(slab, ctx.rel, ctx.heads, ctx.table_refs)
-            dbias = None
-        else:
-            need_dbias = bias is not None and ctx.needs_input_grad[3]
-            dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
-                                                  c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias, seg=ctx.seg)
-            dpq = dpk = None
-            dtabs = [None] * nt
+        q, k, v, out, lse, bias, kpm, c_attn = ctx.saved_tensors
+        need_dbias = bias is not None and ctx.needs_input_grad[3]
+        dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
+                                              c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias, seg=ctx.seg,
+                                              bias_shared=ctx.bias_shared)
+        dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         dc = None
         if c_attn is not None and ctx.needs_input_grad[5]:
             dc = _c_attn_grad(delta, ctx.c_ref, q.shape[0], ctx.heads, q.shape[1])
-        return (dq, dk, dv, dbias, None, dc, None, None, None, None, dpq, dpk, *dtabs)
+        return dq, dk, dv, dbias, None, dc, None, None, None, None
 
 
 def _packed(ws, arena_view):
@@ -818,11 +691,10 @@ def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
 class PackedSelfAttentionFn(torch.autograd.Function):
     """Self-attention core with ONE packed k|v|q projection (N = 3D) in front of the fused attention kernels
     (multihead_attention.py:199-346 up to, not including, out_proj).  The attention backward writes dk|dv|dq as column
-    slices of one [B,T,3D] buffer, which then feeds one dgrad GEMM (K = 3D), one wgrad GEMM and one bias reduce.
-    rel / pos_q / pos_k / tables: the un-materialised position bias (PosBias), exclusive with the dense `bias`."""
+    slices of one [B,T,3D] buffer, which then feeds one dgrad GEMM (K = 3D), one wgrad GEMM and one bias reduce."""
 
     @staticmethod
-    def forward(ctx, x, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, causal, pack, rel=None, pos_q=None, pos_k=None, *tables):
+    def forward(ctx, x, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, causal, pack, bias_shared=False):
         B, T, D = x.shape
         W = _packed((wk, wv, wq), pack.get("w"))
         Bv = _packed((bk, bv, bq), pack.get("b"))
@@ -830,41 +702,28 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         kvq = K.gemm(x2d, W, False, True, bias=Bv).view(B, T, 3 * D)
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
         kpm, seg = _split_seg(kpm)
-        if pos_q is not None:
-            assert bias is None
-            out, lse = K.attn_pos_fwd(q, k, v, heads, scale, _PosCall(pos_q, pos_k, rel, tables, heads), kpm=kpm, c_attn=c_attn,
-                                      causal=causal, seg=seg)
-        else:
-            out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg)
-        ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W, pos_q, pos_k, *tables)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=causal, seg=seg, bias_shared=bias_shared)
+        ctx.save_for_backward(x2d, kvq, out, lse, bias, kpm, c_attn, W)
         ctx.c_ref = c_attn
-        ctx.table_refs = tables
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, causal, pack)
-        ctx.seg, ctx.rel = seg, rel
+        ctx.seg, ctx.bias_shared = seg, bias_shared
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2d, kvq, out, lse, bias, kpm, c_attn, W, pos_q, pos_k, *tables = ctx.saved_tensors
+        x2d, kvq, out, lse, bias, kpm, c_attn, W = ctx.saved_tensors
         heads, scale, causal, pack = ctx.cfg
         wk, wv, wq, bk, bv, bq = ctx.params
         B, T, D3 = kvq.shape
         D = D3 // 3
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
         dkvq = torch.empty_like(kvq)                                   # (ragged mode: the kernels zero the filler rows)
-        outs = (dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D])
-        dpq = dpk = dbias = None
-        dtabs = [None] * len(tables)
-        if pos_q is not None:
-            pos = _PosCall(pos_q, pos_k, ctx.rel, tables, heads, any(ctx.needs_input_grad[17:]))
-            _, _, _, dpq, dpk, slab, delta = K.attn_pos_bwd(q, k, v, out, dout, lse, heads, scale, pos, kpm=kpm, c_attn=c_attn,
-                                                            causal=causal, seg=ctx.seg, outs=outs)
-            dtabs = _pos_table_grads(slab, ctx.rel, heads, ctx.table_refs)
-        else:
-            need_dbias = bias is not None and ctx.needs_input_grad[7]
-            _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
-                                               causal=causal, need_dbias=need_dbias, seg=ctx.seg, outs=outs)
+        need_dbias = bias is not None and ctx.needs_input_grad[7]
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
+                                           causal=causal, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
+                                           outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
+        dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         gws = _packed_wgrads((wk, wv, wq), pack.get("gw"), d2, x2d)
@@ -873,15 +732,15 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         dc = None
         if c_attn is not None and ctx.needs_input_grad[9]:
             dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
-        return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None, None, dpq, dpk, *dtabs)
+        return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None, None)
 
 
 class PackedCrossAttentionFn(torch.autograd.Function):
     """Encoder-decoder attention core: q projection from the decoder stream, ONE packed k|v projection (N = 2D) from the
-    encoder output (multihead_attention.py:203-211).  pos_q / pos_k: the un-materialised cross abs-pos bias (no rel-pos part)."""
+    encoder output (multihead_attention.py:203-211)."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, pack, pos_q=None, pos_k=None):
+    def forward(ctx, xq, xkv, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, pack, bias_shared=False):
         B, T, D = xq.shape
         S = xkv.shape[1]
         W = _packed((wk, wv), pack.get("w"))
@@ -891,22 +750,17 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         kpm, seg = _split_seg(kpm)
-        if pos_q is not None:
-            assert bias is None
-            out, lse = K.attn_pos_fwd(q, k, v, heads, scale, _PosCall(pos_q, pos_k, None, (), heads), kpm=kpm, c_attn=c_attn, causal=False,
-                                      seg=seg)
-        else:
-            out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False, seg=seg)
-        ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W, pos_q, pos_k)
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False, seg=seg, bias_shared=bias_shared)
+        ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
         ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, pack)
-        ctx.seg = seg
+        ctx.seg, ctx.bias_shared = seg, bias_shared
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W, pos_q, pos_k = ctx.saved_tensors
+        xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W = ctx.saved_tensors
         heads, scale, pack = ctx.cfg
         wk, wv, wq, bk, bv, bq = ctx.params
         B, T, D = q.shape
@@ -914,15 +768,11 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         dq = torch.empty_like(q)                                       # (ragged mode: the kernels zero the filler rows)
         dkv = torch.empty_like(kv)
-        outs = (dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D])
-        dpq = dpk = dbias = None
-        if pos_q is not None:
-            _, _, _, dpq, dpk, _, delta = K.attn_pos_bwd(q, k, v, out, dout, lse, heads, scale, _PosCall(pos_q, pos_k, None, (), heads),
-                                                         kpm=kpm, c_attn=c_attn, causal=False, seg=ctx.seg, outs=outs)
-        else:
-            need_dbias = bias is not None and ctx.needs_input_grad[8]
-            _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
-                                               causal=False, need_dbias=need_dbias, seg=ctx.seg, outs=outs)
+        need_dbias = bias is not None and ctx.needs_input_grad[8]
+        _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
+                                           causal=False, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
+                                           outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
+        dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
@@ -935,7 +785,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         dc = None
         if c_attn is not None and ctx.needs_input_grad[10]:
             dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
-        return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None, dpq, dpk)
+        return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None, None)
 
 
 class UnfusedAttentionFn(torch.autograd.Function):
@@ -1005,19 +855,37 @@ def _scale_heads(x, c_attn, heads):
     return K.mul_rowvec(x.view(-1, D), vec).view(B, T, D)
 
 
+class SharedBias:
+    """A position bias that is the same for every sample: t = [A, Tb, Sb] (the reference's [B, A, T, T] / [B*A, T, S] tensor is B
+    copies of it).  MultiheadAttention hands t to the fused kernels (ofa_attn_sbias_*: indexed by the position inside the sample,
+    gradient summed over the batch in-kernel) or expands it for the exact tier."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        assert t.dim() == 3
+        self.t = t
+
+
+def expand_shared_bias(bias, B, T, S):
+    """[A, Tb, Sb] shared position bias -> the reference's dense [B*A, T, S] (exact tier / attention-weight outputs); autograd
+    reduces the expand."""
+    A = bias.shape[0]
+    return bias[:, :T, :S].unsqueeze(0).expand(B, A, T, S).reshape(B * A, T, S)
+
+
 def attention(q, k, v, heads, scale, bias=None, key_padding_mask=None, c_attn=None, causal=False, dropout_p=0.0,
               need_weights=False):
-    """Attention core on [B,T,D] rows.  Returns (out [B,T,D], probs [B*heads,T,S] or None).  bias: dense [B*heads,T,S] or a PosBias."""
+    """Attention core on [B,T,D] rows.  Returns (out [B,T,D], probs [B*heads,T,S] or None)."""
     fused_ok = (q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] // heads == 64 and dropout_p == 0.0 and not need_weights)
-    if isinstance(bias, PosBias):
-        if fused_ok and abs(bias.attn_scaling - scale) <= 1e-9 * scale:
-            return FusedAttentionFn.apply(q, k, v, None, key_padding_mask, c_attn, heads, scale, causal, bias.rel, bias.pos_q, bias.pos_k,
-                                          *bias.tables), None
-        bias = bias.dense().reshape(-1, q.shape[1], k.shape[1])
     if bias is not None and bias.dtype != q.dtype:
         bias = bias.to(q.dtype)
+    shared = bias is not None and bias.dim() == 3 and bias.shape[0] == heads          # [A, T, S]: one bias for every sample
     if fused_ok:
-        return FusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal), None
+        return FusedAttentionFn.apply(q, k, v, bias, key_padding_mask, c_attn, heads, scale, causal, shared), None
+    if shared:
+        if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):
+            raise NotImplementedError("packed (ragged) batches run on the fused attention kernels only")
+        bias = expand_shared_bias(bias, q.shape[0], q.shape[1], k.shape[1])
     if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):
         raise NotImplementedError("packed (ragged) batches run on the fused bf16 attention kernels only "
                                   "(bf16, head_dim 64, no attention dropout, no attention-weight output)")
@@ -1331,8 +1199,9 @@ class Conv2dFn(torch.autograd.Function):
     (module/resnet.py:22-38, module/subsample.py:29-35).  weight keeps torch's [Cout, Cin, kh, kw] layout (state dict)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom):
+    def forward(ctx, x, weight, bias, geom, mailbox=None):
         B, H, W, stride, pad, nchw = geom
+        ctx.mailbox = mailbox
         Cout, Cin, kh, kw = weight.shape
         direct = kh == 1 and kw == 1 and stride == 1 and pad == 0 and not nchw
         if direct:
@@ -1359,8 +1228,14 @@ class Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0] and not nchw:
-            dcol = K.gemm(dy, w2, False, False)
-            dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
+            skip = ctx.mailbox.pop() if ctx.mailbox else None          # the residual branch's gradient of the same input (ResidualMailbox)
+            if skip is not None and direct and skip.shape == col.shape and skip.dtype == dy.dtype and skip.is_contiguous():
+                dx = K.gemm(dy, w2, False, False, out=skip, accumulate=True)      # dX = dY W + dres: the add rides in the GEMM epilogue
+            else:
+                dcol = K.gemm(dy, w2, False, False)
+                dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
+                if skip is not None:
+                    dx = dx + skip
         gw = _sink(weight) if direct else None
         if gw is not None:                                                        # 1x1 convolution: dW += dY^T X straight into the arena,
             _wgrad(dy, col, gw.view(Cout, Cin), 1.0, weight)                      # in groups of up to 8 products (flush_wgrads)
@@ -1372,13 +1247,13 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw = dw2[:, :kh * kw * Cin].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
         db = K.colsum(dy, out_dtype=weight.dtype) if bias is not None else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, nchw=False):
-    """-> (rows [B*Ho*Wo, Cout], Ho, Wo)."""
+def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, nchw=False, grad_mailbox=None):
+    """-> (rows [B*Ho*Wo, Cout], Ho, Wo).  grad_mailbox: see batch_norm."""
     kh, kw = weight.shape[2], weight.shape[3]
-    y = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw))
+    y = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw), grad_mailbox)
     return y, K.conv_out_size(H, kh, stride, pad), K.conv_out_size(W, kw, stride, pad)
 
 
@@ -1406,9 +1281,10 @@ class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ optional residual add and ReLU fused, module/resnet.py:105-128) on NHWC rows."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, mailbox=None):
         y, mean, rstd = K.batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual)
         ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.mailbox = mailbox
         ctx.cfg = (training, relu, residual is not None)
         ctx.bias_ref = bias
         return y
@@ -1425,11 +1301,18 @@ class BatchNormFn(torch.autograd.Function):
             dg = db = None
         else:
             dx, dres, dg, db = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res)
-        return dx, dres, dg, db, None, None, None, None, None, None
+        if ctx.mailbox is not None and dres is not None:
+            ctx.mailbox.append(dres)             # handed to the consumer named at forward time, which adds it inside its own kernel
+            dres = None
+        return dx, dres, dg, db, None, None, None, None, None, None, None
 
 
-def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None):
-    """bn holds torch's parameters / buffers (state-dict parity); statistics follow bn.training like nn.BatchNorm2d."""
+def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mailbox=None):
+    """bn holds torch's parameters / buffers (state-dict parity); statistics follow bn.training like nn.BatchNorm2d.
+    grad_mailbox (a list shared with ONE conv2d call on the same tensor `residual`): in backward the residual's gradient is not
+    returned to autograd (which would add it to the other consumer's gradient with a separate elementwise kernel) but left in the
+    mailbox, and that convolution's input-gradient GEMM accumulates onto it in its epilogue (an identity bottleneck: x feeds conv1
+    AND the residual add, module/resnet.py:112-137)."""
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     if training and bn.num_batches_tracked is not None:
@@ -1441,7 +1324,7 @@ def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None):
     cast = rm is not None and rm.dtype != torch.float32       # model.bfloat16() casts the buffers too: keep the update in fp32
     if cast:
         rm, rv = rm.float(), rv.float()
-    y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu)
+    y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, grad_mailbox)
     if cast and training:
         bn.running_mean.copy_(rm)
         bn.running_var.copy_(rv)

@@ -1,0 +1,128 @@
+"""GPU: attention with a batch-SHARED position bias (ofa_attn_sbias_fwd / _bwd, csrc/attention.hip): the reference's dense [B*A, T, S]
+bias (abs-pos + rel-pos, adaptor/general.py:223-282, model/transformer.py:280-299) is B copies of one [A, T, S] matrix, which the
+kernels take once and index by (head, position, position) for every sample; its gradient -- the sum over the batch of dS -- comes from
+a third backward kernel that walks the batch per tile.  Checked against a plain PyTorch fp32 reference that EXPANDS the bias over the
+batch (autograd then reduces the expand: exactly the reference's arithmetic), incl. causal masks, key padding, ragged (segment) mode
+with position-local indexing, and bitwise reproducibility.  Tolerances as tests/test_kernels_gpu.py::test_fused_attention."""
+import pytest
+import torch
+
+from tests.test_kernels_gpu import _attn_ref, rel
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")]
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from ofasys_amd import kernels
+    return kernels
+
+
+def _mk(B, heads, T, S, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    D = heads * 64
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV).bfloat16()                  # noqa: E731
+    return mk(B, T, D), mk(B, S, D), mk(B, S, D), mk(heads, T, S), mk(B, T, D)
+
+
+@pytest.mark.parametrize("B,heads,T,S,causal,use_kpm", [
+    (2, 4, 64, 64, False, False),
+    (3, 2, 45, 45, True, True),              # decoder self-attention: causal, ragged tails, odd S (unaligned bias rows)
+    (2, 12, 130, 130, False, True),
+    (4, 4, 20, 77, False, True),             # cross attention
+    (5, 2, 300, 300, False, True),
+    (2, 3, 448, 448, False, False),          # the cfg-2b encoder shape (196 + 252)
+    (2, 2, 64, 1600, False, True),           # long keys: the 128-key tile form of the batch-sum kernel
+])
+def test_shared_bias_attention_matches_reference(K, B, heads, T, S, causal, use_kpm):
+    q, k, v, bias, dout = _mk(B, heads, T, S, 7 + T + S)
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        kpm[-1, S - 5:] = True
+        kpm[0, S - 2:] = True
+    c = (1 + 0.2 * torch.randn(heads, device=DEV)).float()
+    scale = (64 * 2) ** -0.5
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    br = bias.float().requires_grad_(True)
+    cr = c.clone().requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, heads, scale, br.unsqueeze(0).expand(B, heads, T, S).reshape(B * heads, T, S), kpm, cr, causal)
+    ref.backward(dout.float())
+    out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal, bias_shared=True)
+    assert rel(out, ref) < 2e-2
+    dq, dk, dv, G, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal,
+                                      need_dbias=True, bias_shared=True)
+    assert rel(dq, qr.grad) < 3e-2 and rel(dk, kr.grad) < 3e-2 and rel(dv, vr.grad) < 3e-2
+    assert G.dtype == torch.float32 and G.shape == (heads, T, S)
+    assert rel(G, br.grad) < 3e-2                                               # sum over the batch of dS
+    dc = delta.view(B, heads, -1)[:, :, :T].sum((0, 2)) / c
+    assert rel(dc, cr.grad) < 3e-2
+    # the same numbers as this build's dense-bias kernels fed B copies of the bias; and bitwise reproducible
+    dense = bias.unsqueeze(0).expand(B, heads, T, S).reshape(B * heads, T, S).contiguous()
+    out_d, _ = K.attn_fwd(q, k, v, heads, scale, bias=dense, kpm=kpm, c_attn=c, causal=causal)
+    assert torch.equal(out_d, out)
+    again = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=True)
+    assert torch.equal(again[3], G) and torch.equal(again[0], dq)
+
+
+def test_shared_bias_over_ragged_segments(K):
+    """Ragged mode: samples packed back to back, the bias indexed by the position INSIDE the sample -- equal to the padded call at
+    every valid row (forward, dq / dk / dv, the batch-summed bias gradient), filler rows of the outputs exactly zero."""
+    from ofasys_amd.packing import build_pack_plan
+    B, heads, T = 4, 2, 96
+    lens = [96, 41, 70, 9]
+    q, k, v, bias, dout = _mk(B, heads, T, T, 21)
+    scale = (64 * 2) ** -0.5
+    kpm = torch.zeros(B, T, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        kpm[b, n:] = True
+    plan = build_pack_plan(kpm, kpm, bucket=64).to(DEV)
+    assert plan.enc_prefix
+    idx = plan.enc_index
+    pack = lambda t: K.gather_rows(t.reshape(B * T, -1).contiguous(), idx).view(1, -1, t.shape[-1])      # noqa: E731
+    c = (1 + 0.1 * torch.randn(heads, device=DEV)).float()
+    # padded rows carry garbage in a padded run; zero dout there so that the two runs see the same gradient signal
+    dout = dout.masked_fill(kpm.to(DEV).unsqueeze(-1), 0.0)
+    for causal in (False, True):
+        out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm.to(DEV), c_attn=c, causal=causal, bias_shared=True)
+        g = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm.to(DEV), c_attn=c, causal=causal, need_dbias=True,
+                       bias_shared=True)
+        pout, plse = K.attn_fwd(pack(q), pack(k), pack(v), heads, scale, bias=bias, c_attn=c, causal=causal, seg=plan.enc_self,
+                                bias_shared=True)
+        pg = K.attn_bwd(pack(q), pack(k), pack(v), pout, pack(dout), plse, heads, scale, bias=bias, c_attn=c, causal=causal,
+                        need_dbias=True, seg=plan.enc_self, bias_shared=True)
+        rows = torch.nonzero(idx >= 0).squeeze(1)
+        filler = torch.nonzero(idx < 0).squeeze(1)
+        src = idx[rows]
+
+        def same(packed, padded, name, tol=2e-2):
+            pr = packed.reshape(-1, packed.shape[-1])
+            assert rel(pr[rows], padded.reshape(B * T, -1)[src].float()) < tol, name
+            assert float(pr[filler].float().abs().max()) == 0.0, name + " filler rows"
+        same(pout, out, "out", 1e-2)
+        same(pg[0], g[0], "dq")
+        same(pg[1], g[1], "dk")
+        same(pg[2], g[2], "dv")
+        # the batch-summed bias gradient: padded query rows carry dO = 0 (so dS = 0), padded keys are masked: the two runs agree everywhere
+        assert rel(pg[3], g[3]) < 3e-2
+
+
+def test_shared_bias_through_autograd_functions():
+    """ops.attention with a [A, T, S] bias: the fused path (shared kernels) and the exact tier (bias expanded over the batch, autograd
+    reducing it) give the same gradients, incl. the bias'."""
+    from ofasys_amd import ops
+    B, heads, T = 3, 2, 48
+    q, k, v, bias, dout = _mk(B, heads, T, T, 5)
+    scale = (64 * 2) ** -0.5
+    grads = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (q, k, v, bias)]
+        if fused:
+            out, _ = ops.attention(leaves[0], leaves[1], leaves[2], heads, scale, bias=leaves[3])
+        else:
+            out, _ = ops.attention(leaves[0].float(), leaves[1].float(), leaves[2].float(), heads, scale, bias=leaves[3].float())
+        (out.float() * dout.float()).sum().backward()
+        grads.append([t.grad.float() for t in leaves])
+    for a, b, name in zip(grads[0], grads[1], ("dq", "dk", "dv", "dbias")):
+        assert rel(a, b) < 4e-2, name

@@ -215,50 +215,3 @@ def test_bench_self_launches_ranks_when_no_launcher_started_it():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world"] == 2
 
-
-def test_relmap_ids_reproduce_every_adaptors_bucket_lookup():
-    """ops.RelMap (the in-kernel form of the rel-pos bias): for every built-in adaptor the compact ids + `used` list give back exactly
-    the (table, row) the reference's lookup `table[bucket[i][j]]` reads (adaptor/text.py:101-104, image_resnet.py:116-128,
-    video_image_sequence.py:187-204 = frame plane + image plane), off-diagonal slot blocks hold id 0, rows are padded to whole 32-key
-    blocks.  Integer work: bit-exact."""
-    from ofasys_amd import ops
-    from tests.model_util import build_model
-    case = {"arch": "tiny", "active": {"text", "image_resnet", "video_image_sequence", "audio_fbank"}, "overrides": {},
-            "adaptor_overrides": {"image_resnet": {"resnet_type": "resnet50"}}}
-    model, _ = build_model(case)
-    ga = model.encoder.adaptor
-    ira, txt, vid, aud = ga.name2adaptor["image_resnet"], ga.name2adaptor["text"], ga.name2adaptor["video_image_sequence"], \
-        ga.name2adaptor["audio_fbank"]
-    h = w = 4
-    pos_ids = (torch.arange(w).unsqueeze(0).expand(h, w) + torch.arange(h).unsqueeze(1) * ira.cfg.image_bucket_size + 1).view(-1)
-    ira._last_hw = (h, w)
-    Fr, P = 3, h * w
-    fb = vid.video_rp_bucket[:Fr, :Fr]
-    ib = ira.image_rp_bucket[pos_ids][:, pos_ids]
-    vplanes = [(fb.view(Fr, 1, Fr, 1).expand(Fr, P, Fr, P).reshape(Fr * P, Fr * P), 0), (ib.view(1, P, 1, P).expand(Fr, P, Fr, P).reshape(Fr * P, Fr * P), 1)]
-    tplane = txt.rel_pos_planes(11)[1]()[0][0]
-    aplane = aud.rel_pos_planes(7)[1]()[0][0]
-    iplane = ira.rel_pos_planes(P, image_position_ids=pos_ids)[1]()[0][0]
-    # layout: video (2 planes: tables 0, 1) | text (table 2) | image (table 1 again) | a slot without bias | audio (table 3)
-    blocks, s0 = [], 0
-    blocks.append((s0, Fr * P, vplanes)); s0 += Fr * P
-    blocks.append((s0, 11, [(tplane, 2)])); s0 += 11
-    blocks.append((s0, P, [(iplane, 1)])); s0 += P
-    s0 += 5
-    blocks.append((s0, 7, [(aplane, 3)])); s0 += 7
-    T = s0
-    rel = ops.RelMap(blocks, T, "cpu")
-    assert rel.planes == 2 and rel.ld % 32 == 0 and rel.ld >= T and rel.ids.shape == (2, T, rel.ld) and rel.ntables == 4
-    used = rel.used.tolist()
-    assert used[0] == 0 and used[1:] == sorted(set(used[1:])) and rel.ncompact == len(used)
-    ids = rel.ids.long()
-    want = torch.zeros(2, T, T, dtype=torch.long) - 1                     # (table << 20 | row), -1 = no bias
-    for start, n, pl in blocks:
-        for pi, (b, ts) in enumerate(pl):
-            want[pi, start:start + n, start:start + n] = (ts << 20) | b
-    got = torch.tensor(used)[ids[:, :, :T]]
-    got = torch.where(ids[:, :, :T] == 0, torch.full_like(got, -1), got)
-    assert torch.equal(got, want)
-    assert int(ids[:, :, T:].abs().sum()) == 0                            # the padding of the rows
-    # and the general adaptor's cache key separates layouts
-    assert txt.rel_pos_planes(11)[0] != txt.rel_pos_planes(12)[0]

@@ -201,13 +201,18 @@ int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* 
                        int dtype, void* stream);
 /* Backward (out != NULL always: delta is computed on the way in and written).  dbias_sum (optional): fp32 [heads, Tb, Sb] =
  * sum over the batch of dS -- the gradient of the shared bias.  The reference obtains it by materialising dS as [B*A, T, S] and
- * reducing the expand; here a third kernel walks the batch per [128 x 64 / 128] tile of one head, recomputes S and dP of that tile
- * (lse / delta are known) and accumulates dS in registers: written once, no atomics, bitwise reproducible. */
+ * reducing the expand; here a third kernel walks (a chunk of) the batch per [128 x 64] tile of one head, recomputes S and dP of that
+ * tile (lse / delta are known) and accumulates dS in registers: no [B*A,T,S] tensor, no atomics, bitwise reproducible.
+ * ws / ws_bytes: see ofa_attn_sbias_chunks. */
 int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
                        const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out,
-                       void* dq, void* dk, void* dv, float* dbias_sum, int B, int heads, int T, int S, int Tpad, int64_t ldq,
-                       int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype,
-                       void* stream);
+                       void* dq, void* dk, void* dv, float* dbias_sum, float* ws, int64_t ws_bytes, int B, int heads, int T, int S,
+                       int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
+                       int rows_k, int dtype, void* stream);
+/* Batch chunks the dS-sum kernel of ofa_attn_sbias_bwd cuts B samples into (short sequences: the [128 x 64] tiles of the heads alone
+ * would leave the chip idle).  1: it writes dbias_sum itself, ws may be NULL.  n > 1: ws must hold n * heads * Tb * Sb floats (the
+ * chunks' partial sums, folded in chunk order by ofa_fold_batched inside the call). */
+int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
  * ofa_attn_bwd_prep: dc[h] (+)= sum_b sum_{t<T} delta[(b*heads+h)*ld + t] / c_attn[h]; dc has c_attn's dtype. */
@@ -238,6 +243,12 @@ int ofa_gather_rows(const void* src, const int64_t* index, void* out, int64_t n,
                     void* stream);
 int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
                       void* stream);
+/* dweight[seg_row[s], :] (+)= sum over p in [seg_off[s], seg_off[s+1]) of dout[order[p], :]   (D <= 64 columns).
+ * The embedding gradient of a lookup whose ids are the same every step -- the rel-pos bias `table[bucket[i][j]]` (adaptor/text.py:
+ * 101-104, image_resnet.py:116-128): order = positions sorted by id (stable), one segment per distinct id, built once per lookup
+ * by the caller.  One wave per segment, fixed order: deterministic; accumulate != 0 adds to dweight (the gradient arena). */
+int ofa_segment_rowsum(const void* dout, const int32_t* order, const int32_t* seg_off, const int32_t* seg_row, void* dweight, int nseg,
+                       int D, int accumulate, int dtype, void* stream);
 int ofa_embedding_bwd_slices(int64_t V, int D);
 int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dweight, int64_t n, int D, int64_t V,
                       int64_t padding_idx, uint8_t* present_ws, float* slice_ws, int dtype, void* stream);

@@ -143,9 +143,12 @@ class BaseAdaptor(torch.nn.Module):
         raise NotImplementedError
 
     def expand_rel_pos_bias(self, values: Tensor, batch_size: int):
-        """[T,T,A] -> [B,A,T,T] expand view (adaptor/base.py:242-256)."""
-        values = values.unsqueeze(0).expand(batch_size, -1, -1, -1)
-        return values.permute([0, 3, 1, 2])
+        """[T,T,A] -> [B,A,T,T] expand view (adaptor/base.py:242-256).  The view remembers the values it expands (`_ofa_values`): the
+        general adaptor's bias assembly takes them back directly -- through autograd the round trip expand -> [0] would cost a
+        zero-filled [B,A,T,T] gradient and a reduction over the batch per slot and layer."""
+        out = values.unsqueeze(0).expand(batch_size, -1, -1, -1).permute([0, 3, 1, 2])
+        out._ofa_values = values
+        return out
 
     def upgrade_state_dict_named(self, state_dict, name):
         pass

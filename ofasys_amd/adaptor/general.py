@@ -174,6 +174,9 @@ def _unexpand(b):
     per-sample bias (no adaptor in scope produces one) is rejected."""
     if b is None:
         return None
+    v = getattr(b, "_ofa_values", None)                              # BaseAdaptor.expand_rel_pos_bias: the values themselves
+    if v is not None:
+        return v
     if b.dim() == 4 and (b.stride(0) == 0 or b.size(0) == 1):      # (a batch of one: nothing to expand, any stride)
         return b[0].permute(1, 2, 0)
     if b.dim() == 3:

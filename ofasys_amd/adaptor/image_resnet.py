@@ -81,13 +81,15 @@ class ImageResnetAdaptor(BaseAdaptor):
         computed once and handed to the bias assembly as the usual batch-expanded view."""
         ids = kwargs["image_position_ids"]
         rp_bucket = self.image_rp_bucket[ids][:, ids].contiguous()             # integer double gather, bit-exact
-        return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight)
+        # (the position ids are arange-derived from the feature map's (h, w): with the shape, that identifies the lookup)
+        return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight, plan_key=("image", id(self), getattr(self, "_hw", None)))
 
     def get_patch_images_info(self, patch_images):
         """image_resnet.py:130-164 -> (embed rows [B, h*w, 1024], n, mask, position ids [T], pos_embed [B, T, D])."""
         device = patch_images.device
         B = patch_images.size(0)
         rows, h, w = self.embed_images(patch_images)
+        self._hw = (int(h), int(w))
         n = h * w
         image_embed = rows.view(B, n, rows.shape[-1])
         image_padding_mask = torch.zeros((B, n), dtype=torch.bool, device=device)

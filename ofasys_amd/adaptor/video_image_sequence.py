@@ -58,7 +58,7 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         if seq_length > self.video_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.video_rp_bucket.size(0)} positions of video_rp_bucket")
         rp_bucket = self.video_rp_bucket[:seq_length, :seq_length].contiguous()
-        return ops.embedding(rp_bucket, self.video_rel_pos_table_list[idx].weight)        # [F,F,A]
+        return ops.embedding(rp_bucket, self.video_rel_pos_table_list[idx].weight, plan_key=("video", id(self)))        # [F,F,A]
 
     def get_clip_videos_info(self, clip_videos: torch.Tensor):
         """video_image_sequence.py:111-154.  clip_videos: [B, 3, F, H, W]."""
@@ -67,6 +67,7 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         clips = clip_videos.transpose(1, 2)                                               # [B, F, 3, H, W]
         B, Fr = clips.size(0), clips.size(1)
         rows, h, w = ira.embed_images(clips.reshape(-1, clips.size(2), clips.size(3), clips.size(4)))
+        ira._hw = (int(h), int(w))
         P = h * w
         T = P * Fr
         video_embed = rows.view(B, T, rows.shape[-1])                                     # rows are (b, f, h, w) ordered

@@ -975,19 +975,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // ------------------------------------------------------------------------------------------------ backward: sum over the batch of dS
 // The gradient of a batch-SHARED additive bias [A, Tb, Sb] (the position bias: abs-pos + rel-pos, identical for every sample) is
 // G[h][i][j] = sum_b dS[b][h][i][j].  The reference gets it by materialising dS as [B*A, T, S] and letting autograd reduce the expand
-// (154 MB per layer at cfg-2b, 1.97 GB at cfg-4 / B = 32).  Here one workgroup owns a [128 query positions x 32*NKB key positions] tile
-// of ONE head, walks the batch, recomputes S = K Q^T and dP = V dO^T of that tile for every sample (two of the five products of the
-// backward pass; lse / delta come from the forward and the dQ kernel) and adds dS = P (dP c - delta) into registers: G is written
-// once, in fp32, with no atomics -- deterministic, and B times smaller than the tensor it replaces.  Ragged mode: the tile is
-// addressed by the position inside the sample, samples shorter than the tile's origin are skipped.
-template <int NKB, bool F16>
-__device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) {
+// (154 MB per layer at cfg-2b, 1.97 GB at cfg-4 / B = 32).  Here one workgroup owns a [128 query positions x 64 key positions] tile of
+// ONE head and a CHUNK of the batch, walks its samples, recomputes S = K Q^T and dP = V dO^T of that tile for every sample (two of
+// the five products of the backward pass; lse / delta come from the forward and the dQ kernel) and adds dS = P (dP c - delta) into
+// registers: no atomics, no [B*A, T, S] tensor.  One chunk (long sequences: the tiles alone fill the chip) writes G itself; several
+// chunks (short sequences) write fp32 partials [chunk][A][Tb][Sb] that ofa_fold_batched adds in chunk order -- deterministic either
+// way.  The next sample's query-side operands (Q / dO rows, lse, delta) are fetched while the current one is being computed.
+// Ragged mode: the tile is addressed by the position inside the sample, samples shorter than the tile's origin are skipped.
+struct DsumQ {                    // the query-side operands of one sample for this lane's row
+  bf16x8 qf[4], dof[4];
+  float lse, delta;
+};
+template <bool F16>
+__device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb,
+                                                   int nchunk, int bper) {
+  constexpr int NKB = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.z;
+  const int h = blockIdx.z / nchunk, chunk = blockIdx.z % nchunk;
+  const int b_lo = chunk * bper, b_hi = (b_lo + bper < a.B) ? b_lo + bper : a.B;
   const int qb0 = blockIdx.y * 128, kc0 = blockIdx.x * NKB;      // first query position / first key block of the tile
   const int q0 = qb0 + wave * 32, qi = q0 + i;
   const float sc = a.scale * LOG2E;
@@ -1022,6 +1031,7 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
       T_b = a.T; S_b = a.S; qoff = (int64_t)b * a.T; koff = (int64_t)b * a.S;
     }
   };
+  const int s_end = b_hi * NKB;
   auto live = [&](int s) {
     int T_b, S_b; int64_t qo, ko;
     geom(s / NKB, T_b, S_b, qo, ko);
@@ -1029,7 +1039,7 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
   };
   auto next_live = [&](int s) {
     ++s;
-    while (s < a.B * NKB && !live(s)) ++s;
+    while (s < s_end && !live(s)) ++s;
     return s;
   };
   auto stage = [&](int s, int buf) {
@@ -1039,39 +1049,44 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
     tile_dma(a.k + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES, tid, wave_u);
     tile_dma(a.v + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
   };
-  const int lse_ld = a.Tpad;
-  int s = -1;
-  s = next_live(s);
-  if (s < a.B * NKB) stage(s, 0);
+  auto fetch_q = [&](int b, DsumQ& d) {                  // ordinary loads, always issued in front of a stage's DMA
+    int T_b, S_b; int64_t qoff, koff;
+    geom(b, T_b, S_b, qoff, koff);
+    const int qrow = qi < T_b ? qi : T_b - 1;
+    const bf16_t* qp = a.q + (qoff + qrow) * a.ldq + h * HD + hi * 8;
+    const bf16_t* dop = a.dout + (qoff + qrow) * a.ldo + h * HD + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      d.qf[kk] = ld16(qp + kk * 16);
+      d.dof[kk] = ld16(dop + kk * 16);
+    }
+    const int64_t srow = a.seg ? (int64_t)h * a.Tpad + qoff + qrow : ((int64_t)b * a.heads + h) * a.Tpad + qrow;
+    d.lse = a.lse[srow];
+    d.delta = a.delta[srow];
+  };
+  int s = next_live(b_lo * NKB - 1);
+  DsumQ cur, nxt;
+  if (s < s_end) {
+    fetch_q(s / NKB, cur);
+    stage(s, 0);
+  }
   ATT_SYNC();
-  int buf = 0, cur_b = -1;
-  bf16x8 qf[4], dof[4];
-  float lse_q = 0.f, delta_q = 0.f;
-  int T_b = 0, S_b = 0;
-  int64_t qoff = 0, koff = 0;
-  const uint8_t* kp = nullptr;
-  while (s < a.B * NKB) {
+  int buf = 0, nxt_b = -1;
+  while (s < s_end) {
     const int sn = next_live(s);
     const int b = s / NKB, j = s % NKB;
-    if (b != cur_b) {                                    // this sample's query-side operands (ordinary loads, in front of the DMA)
-      cur_b = b;
-      geom(b, T_b, S_b, qoff, koff);
-      const int qrow = qi < T_b ? qi : T_b - 1;
-      const bf16_t* qp = a.q + (qoff + qrow) * a.ldq + h * HD + hi * 8;
-      const bf16_t* dop = a.dout + (qoff + qrow) * a.ldo + h * HD + hi * 8;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        qf[kk] = ld16(qp + kk * 16);
-        dof[kk] = ld16(dop + kk * 16);
-      }
-      const int64_t srow = a.seg ? (int64_t)h * lse_ld + qoff + qrow : ((int64_t)b * a.heads + h) * lse_ld + qrow;
-      lse_q = a.lse[srow];
-      delta_q = a.delta[srow];
-      kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
-    }
+    int T_b, S_b; int64_t qoff, koff;
+    geom(b, T_b, S_b, qoff, koff);
+    const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
     const int key0 = (kc0 + j) * 32;
     const uint32_t dead_now = dead_ballot(dead_flag(kp, key0, S_b, i));     // (the byte load goes out in front of the next DMA)
-    if (sn < a.B * NKB) stage(sn, buf ^ 1);
+    if (sn < s_end) {
+      if (sn / NKB != b && sn / NKB != nxt_b) {          // the sample after this one: its query rows travel while this stage computes
+        nxt_b = sn / NKB;
+        fetch_q(nxt_b, nxt);
+      }
+      stage(sn, buf ^ 1);
+    }
     if (q0 < T_b) {
       u64x2 kf[4], vf[4];
       if (buf == 0) {
@@ -1088,31 +1103,32 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
       zero16f(dp);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        st = ATT_MFMA(kf[kk], qf[kk], st);
-        dp = ATT_MFMA(vf[kk], dof[kk], dp);
+        st = ATT_MFMA(kf[kk], cur.qf[kk], st);
+        dp = ATT_MFMA(vf[kk], cur.dof[kk], dp);
       }
       const bool rowok = qi < T_b;
 #pragma unroll
       for (int jj = 0; jj < NKB; ++jj) {
-        if (jj != j) continue;                           // (j is uniform: the compiler keeps acc / bz in registers by unrolling)
+        if (jj != j) continue;                           // (j is uniform: acc / bz stay in registers, the loop is unrolled)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int jk = crowl(r, hi), key = key0 + jk;
           bool dead = !rowok || ((dead_now >> jk) & 1u);
           if (a.causal) dead |= key > qi;
           const float t = st[r] * sc + bz[jj][r];
-          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - lse_q);
-          acc[jj][r] += p * (dp[r] * c - delta_q);
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - cur.lse);
+          acc[jj][r] += p * (dp[r] * c - cur.delta);
         }
       }
     }
     ATT_SYNC();
     buf ^= 1;
+    if (sn < s_end && sn / NKB != b) cur = nxt;          // (landed: ATT_SYNC waited for vmcnt(0))
     s = sn;
   }
-  // G[h][qi][keys of the tile]
+  // G[h][qi][keys of the tile] (or this chunk's partial)
   if (qi < Tb) {
-    float* gp = G + (int64_t)h * g_hs + (int64_t)qi * g_ld;
+    float* gp = G + (int64_t)chunk * g_cs + (int64_t)h * g_hs + (int64_t)qi * g_ld;
 #pragma unroll
     for (int j = 0; j < NKB; ++j) {
       const int key0 = (kc0 + j) * 32;
@@ -1131,10 +1147,8 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum2_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<2, false>(a, G, g_ld, g_hs, Tb, Sb); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum4_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<4, false>(a, G, g_ld, g_hs, Tb, Sb); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum2_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<2, true>(a, G, g_ld, g_hs, Tb, Sb); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum4_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int Tb, int Sb) { attn_bwd_dsum_body<4, true>(a, G, g_ld, g_hs, Tb, Sb); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper) { attn_bwd_dsum_body<false>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper) { attn_bwd_dsum_body<true>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper); }
 
 static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int dtype) {
   OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 / fp16 only (dtype %d); use the unfused path", dtype);
@@ -1231,11 +1245,20 @@ extern "C" int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, c
   return check_launch("attn_sbias_fwd");
 }
 
+// batch chunks of the dS-sum kernel: enough workgroups to fill 256 CUs a few times over, never more chunks than samples
+extern "C" int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb) {
+  const int64_t tiles = (int64_t)cdiv(Sb, 64) * cdiv(Tb, 128) * heads;
+  int64_t n = (1024 + tiles - 1) / tiles;
+  n = n < 1 ? 1 : (n > B ? B : n);
+  const int bper = cdiv(B, (int)n);
+  return cdiv(B, bper);
+}
+
 extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
                                   const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
-                                  const void* out, void* dq, void* dk, void* dv, float* dbias_sum, int B, int heads, int T, int S,
-                                  int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
-                                  int rows_q, int rows_k, int dtype, void* stream) {
+                                  const void* out, void* dq, void* dk, void* dv, float* dbias_sum, float* ws, int64_t ws_bytes, int B,
+                                  int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
+                                  const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   if (int rc = sbias_check(bias, Tb, Sb, T, S, seg)) return rc;
   OFA_REQUIRE(!seg || (!kpm && !((uintptr_t)seg & 15) && rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID,
@@ -1261,18 +1284,22 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
   hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
   rc = check_launch("attn_sbias_bwd_dkv");
   if (rc || !dbias_sum) return rc;
-  // G = sum_b dS (after the dQ kernel: it wrote delta).  Tiles of 64 key positions fill the chip at short sequences; 128 at long ones
-  const bool wide = (int64_t)cdiv(Sb, 64) * cdiv(Tb, 128) * heads >= 2048;
-  if (wide) {
-    const dim3 g(cdiv(Sb, 128), cdiv(Tb, 128), heads);
-    auto kn = dtype == OFA_F16 ? attn_bwd_dsum4_f16_kernel : attn_bwd_dsum4_kernel;
-    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dbias_sum, (int64_t)Sb, (int64_t)Tb * Sb, Tb, Sb);
-  } else {
-    const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads);
-    auto kn = dtype == OFA_F16 ? attn_bwd_dsum2_f16_kernel : attn_bwd_dsum2_kernel;
-    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dbias_sum, (int64_t)Sb, (int64_t)Tb * Sb, Tb, Sb);
+  // G = sum_b dS (after the dQ kernel: it wrote delta): [128 x 64] tiles of one head; the batch is cut into chunks when the tiles
+  // alone would leave the chip idle, the chunks' fp32 partials are folded in chunk order
+  const int nchunk = ofa_attn_sbias_chunks(B, heads, Tb, Sb);
+  OFA_REQUIRE(nchunk == 1 || (ws && ws_bytes >= (int64_t)nchunk * heads * Tb * Sb * 4), OFA_ERR_INVALID,
+              "attn_sbias_bwd: the batch-sum kernel needs %lld bytes of workspace for %d chunks", (long long)nchunk * heads * Tb * Sb * 4, nchunk);
+  const int bper = cdiv(B, nchunk);
+  {
+    const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads * nchunk);
+    auto kn = dtype == OFA_F16 ? attn_bwd_dsum_f16_kernel : attn_bwd_dsum_kernel;
+    float* dst = nchunk == 1 ? dbias_sum : ws;
+    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
+    rc = check_launch("attn_sbias_bwd_dsum");
+    if (rc || nchunk == 1) return rc;
+    ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, OFA_F32};
+    return ofa_fold_batched(&job, 1, stream);
   }
-  return check_launch("attn_sbias_bwd_dsum");
 }
 
 #ifdef OFA_ATTN_TIMELINE

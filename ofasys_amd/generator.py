@@ -46,7 +46,7 @@ class StepDecoder:
         shape = (out.shape[1], out.shape[0], out.dtype, fingerprint)
         if shape != self._shape:                          # another batch shape: new buffers, new graphs
             self._shape, self._graphs, self._pool, self._seq = shape, {}, None, 0
-            self.enc = {k: [t.clone() for t in v] if isinstance(v, list) else v for k, v in enc.items()}
+            self.enc = {k: [t.clone() if torch.is_tensor(t) else t for t in v] if isinstance(v, list) else v for k, v in enc.items()}
             self.tokens = torch.zeros(shape[0], self.max_len, dtype=torch.long, device=out.device)
             self.inc = {"__capacity__": self.max_len, "__static__": True}
         else:
@@ -54,7 +54,8 @@ class StepDecoder:
                 for k, v in enc.items():
                     if isinstance(v, list):
                         for dst, srct in zip(self.enc[k], v):
-                            dst.copy_(srct)
+                            if torch.is_tensor(dst):
+                                dst.copy_(srct)
             for mod in m.decoder.modules():
                 if hasattr(mod, "reset_incremental_state"):
                     mod.reset_incremental_state(self.inc)

@@ -506,6 +506,12 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         bias = _shared_bias(bias, heads, q)
         Tb, Sb = bias.shape[1], bias.shape[2]
         dbias = torch.empty(heads, Tb, Sb, dtype=torch.float32, device=q.device) if need_dbias else None
+        ws, ws_bytes = None, 0
+        if need_dbias:
+            nchunk = lib().cdll.ofa_attn_sbias_chunks(B if seg is None else seg.batch, heads, Tb, Sb)
+            if nchunk > 1:
+                ws = torch.empty(nchunk, heads, Tb, Sb, dtype=torch.float32, device=q.device)
+                ws_bytes = ws.numel() * 4
         if seg is not None:
             assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S
             dims = (seg.batch, heads, min(seg.max_q, Tb), min(seg.max_k, Sb), Tpad, ldq, ldk, ldo, float(scale), int(causal), ptr(seg.table), T, S)
@@ -514,7 +520,7 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
             dims = (B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal), None, 0, 0)
             kp = ptr(kpm)
         lib().call("ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), Tb, Sb, kp, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
-                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), *dims, dtype_code(q), stream())
+                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), ptr(ws), ws_bytes, *dims, dtype_code(q), stream())
         return dq, dk, dv, dbias, delta
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
@@ -624,6 +630,14 @@ def embedding_bwd(dout, ids, V, padding_idx=-1, dweight=None):
     slices = workspace(S * V * D * 4, dout.device, "embed_slices") if S > 1 else None
     lib().call("ofa_embedding_bwd", ptr(dout), ptr(ids), ptr(dweight), ids.numel(), D, V,
                -1 if padding_idx is None else padding_idx, ptr(present), ptr(slices), dtype_code(dout), stream())
+    return dweight
+
+
+def segment_rowsum(dout2d, plan, dweight, accumulate):
+    """dweight[plan.rows[s]] (+)= sum of the rows of dout2d in segment s (ofa_segment_rowsum); plan: ops.SegmentPlan."""
+    assert dout2d.dim() == 2 and dout2d.is_contiguous() and dweight.is_contiguous() and dout2d.dtype == dweight.dtype
+    lib().call("ofa_segment_rowsum", ptr(dout2d), ptr(plan.order), ptr(plan.seg_off), ptr(plan.seg_row), ptr(dweight), plan.nseg,
+               dout2d.shape[1], int(accumulate), dtype_code(dout2d), stream())
     return dweight
 
 

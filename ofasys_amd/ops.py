@@ -558,12 +558,46 @@ def drop_path(x, drop_prob, batch_axis=1, scale_by_keep=True):
 
 
 # ---------------------------------------------------------------------------------------------- embedding
+class SegmentPlan:
+    """The positions of an id tensor sorted by id (stable) and cut into one segment per distinct id: what ofa_segment_rowsum needs to
+    scatter-add a narrow table's gradient without scanning the id list per table row.  Built on the device (sort + unique) with ONE
+    host sync for the segment count -- once per lookup: the ids of a rel-pos bias (bucket[:T, :T]) are the same every step."""
+    _cache = {}
+
+    def __init__(self, ids):
+        flat = ids.reshape(-1)
+        assert flat.numel() < 2 ** 31
+        sorted_ids, order = torch.sort(flat, stable=True)
+        rows, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
+        self.nseg = int(rows.numel())                                    # (the sync)
+        self.order = order.to(torch.int32)
+        self.seg_row = rows.to(torch.int32)
+        off = torch.zeros(self.nseg + 1, dtype=torch.int32, device=ids.device)
+        off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.seg_off = off
+        self.min_row, self.max_row = (int(rows.min()), int(rows.max())) if self.nseg else (0, -1)
+
+    @classmethod
+    def get(cls, key, ids):
+        """The cached plan of lookup `key`; None while a hipGraph is being captured and the plan does not exist yet (building it
+        syncs), in which case the caller takes the scan kernel."""
+        plan = cls._cache.get(key)
+        if plan is None:
+            if ids.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            if len(cls._cache) > 512:
+                cls._cache.clear()
+            plan = cls._cache[key] = cls(ids)
+        return plan
+
+
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, weight, padding_idx):
+    def forward(ctx, ids, weight, padding_idx, plan_key=None):
         ctx.save_for_backward(ids)
         ctx.V, ctx.padding_idx = weight.shape[0], padding_idx
         ctx.weight_ref = weight
+        ctx.plan_key = plan_key
         return K.embedding_fwd(weight, ids)
 
     @staticmethod
@@ -571,16 +605,32 @@ class EmbeddingFn(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         pad = -1 if ctx.padding_idx is None else ctx.padding_idx
         gw = _sink(ctx.weight_ref)
+        D = dout.shape[-1]
+        plan = None
+        if ctx.plan_key is not None and D <= 64 and ctx.padding_idx is None:
+            plan = SegmentPlan.get((ctx.plan_key, tuple(ids.shape), str(ids.device)), ids)
+            if plan is not None and not (0 <= plan.min_row and plan.max_row < ctx.V):
+                plan = None
+        if plan is not None:                                            # narrow table, ids known in advance: one wave per distinct id
+            d2 = dout.reshape(-1, D)
+            d2 = d2 if d2.is_contiguous() else d2.contiguous()
+            if gw is not None:
+                K.segment_rowsum(d2, plan, gw, True)
+                _sink_done(ctx.weight_ref)
+                return None, None, None, None
+            return None, K.segment_rowsum(d2, plan, torch.zeros(ctx.V, D, dtype=dout.dtype, device=dout.device), False), None, None
         if gw is not None:
             K.embedding_bwd(dout, ids, ctx.V, pad, dweight=gw)       # the kernel accumulates into dweight
             _sink_done(ctx.weight_ref)
-            return None, None, None
+            return None, None, None, None
         dw = K.embedding_bwd(dout, ids, ctx.V, pad)
-        return None, dw, None
+        return None, dw, None, None
 
 
-def embedding(ids, weight, padding_idx=None):
-    return EmbeddingFn.apply(ids, weight, padding_idx)
+def embedding(ids, weight, padding_idx=None, plan_key=None):
+    """F.embedding.  plan_key (hashable, optional): promises that every call with this key and shape looks up the SAME ids (a rel-pos
+    bucket table slice) -- the gradient then uses a cached sort of the ids (SegmentPlan) instead of scanning them per table row."""
+    return EmbeddingFn.apply(ids, weight, padding_idx, plan_key)
 
 
 # ---------------------------------------------------------------------------------------------- attention

@@ -126,3 +126,34 @@ def test_shared_bias_through_autograd_functions():
         grads.append([t.grad.float() for t in leaves])
     for a, b, name in zip(grads[0], grads[1], ("dq", "dk", "dv", "dbias")):
         assert rel(a, b) < 4e-2, name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,V,D", [(252, 511, 12), (196, 6892, 12), (37, 511, 4), (64, 2047, 16), (20, 30, 40)])
+def test_planned_table_gradient_matches_scan_kernel_and_torch(K, dtype, n, V, D):
+    """ops.embedding(..., plan_key=): the rel-pos table lookup `table[bucket[i][j]]` whose gradient uses a cached sort of the ids
+    (ofa_segment_rowsum) instead of the scan kernel -- same sums as torch's index_add in fp32 and as the scan kernel, reproducible,
+    also when accumulating into an existing gradient."""
+    from ofasys_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n + V)
+    ids = torch.randint(0, V, (n, n), generator=g).to(DEV)
+    ids[0, 0], ids[-1, -1] = 0, V - 1
+    w = torch.randn(V, D, generator=g).to(DEV).to(dtype)
+    dout = torch.randn(n, n, D, generator=g).to(DEV).to(dtype)
+    want = torch.zeros(V, D, device=DEV).index_add_(0, ids.reshape(-1), dout.reshape(-1, D).float())
+    res = []
+    for key in (("test", n, V, D, str(dtype)), None):
+        wl = w.clone().requires_grad_(True)
+        out = ops.embedding(ids, wl, plan_key=key)
+        assert torch.equal(out, w[ids])
+        out.backward(dout)
+        res.append(wl.grad.float())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(res[0], want) < tol and rel(res[1], want) < tol
+    plan = ops.SegmentPlan.get((("test", n, V, D, str(dtype)), tuple(ids.shape), str(ids.device)), ids)
+    acc = torch.ones(V, D, device=DEV, dtype=dtype)
+    K.segment_rowsum(dout.reshape(-1, D).contiguous(), plan, acc, True)
+    assert rel(acc.float(), want + 1.0) < tol
+    again = torch.zeros(V, D, device=DEV, dtype=dtype)
+    K.segment_rowsum(dout.reshape(-1, D).contiguous(), plan, again, False)
+    assert torch.equal(again.float(), res[0])

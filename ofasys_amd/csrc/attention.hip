@@ -1022,70 +1022,91 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // stage s = b * NKB + j; a stage is live when sample b reaches the tile (uniform over the workgroup)
-  auto geom = [&](int b, int& T_b, int& S_b, int64_t& qoff, int64_t& koff) {
+  // The geometry {q_len, k_len, q_off, k_off} of this chunk's samples goes through LDS once (behind the tiles): in ragged mode every
+  // look-up of the segment table would otherwise be a scalar memory round trip, several per stage.
+  int4* geo = reinterpret_cast<int4*>(smem + 4 * TILE_BYTES);
+  const int nb = b_hi - b_lo;
+  for (int t = tid; t < nb; t += 256) {
+    const int b = b_lo + t;
+    int4 g4;
     if (a.seg) {
       const int4 sg = reinterpret_cast<const int4*>(a.seg)[b];
-      T_b = sg.y; S_b = sg.w; qoff = sg.x; koff = sg.z;
+      g4 = make_int4(sg.y, sg.w, sg.x, sg.z);
     } else {
-      T_b = a.T; S_b = a.S; qoff = (int64_t)b * a.T; koff = (int64_t)b * a.S;
+      g4 = make_int4(a.T, a.S, b * a.T, b * a.S);
     }
+    geo[t] = g4;
+  }
+  __syncthreads();
+  auto geom = [&](int b) {                               // (uniform: one LDS read, broadcast)
+    const int4 g4 = geo[b - b_lo];
+    return make_int4(__builtin_amdgcn_readfirstlane(g4.x), __builtin_amdgcn_readfirstlane(g4.y), __builtin_amdgcn_readfirstlane(g4.z),
+                     __builtin_amdgcn_readfirstlane(g4.w));
   };
+  // stage s = b * NKB + j; a stage is live when sample b reaches the tile (uniform over the workgroup)
   const int s_end = b_hi * NKB;
-  auto live = [&](int s) {
-    int T_b, S_b; int64_t qo, ko;
-    geom(s / NKB, T_b, S_b, qo, ko);
-    return qb0 < T_b && (kc0 + s % NKB) * 32 < S_b;
-  };
   auto next_live = [&](int s) {
     ++s;
-    while (s < s_end && !live(s)) ++s;
+    while (s < s_end) {
+      const int4 g4 = geom(s / NKB);
+      if (qb0 < g4.x && (kc0 + s % NKB) * 32 < g4.y) break;
+      ++s;
+    }
     return s;
   };
-  auto stage = [&](int s, int buf) {
-    int T_b, S_b; int64_t qo, ko;
-    geom(s / NKB, T_b, S_b, qo, ko);
+  auto stage = [&](int s, const int4& g4, int buf) {
     const int key0 = (kc0 + s % NKB) * 32;
-    tile_dma(a.k + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES, tid, wave_u);
-    tile_dma(a.v + ko * a.ldk, a.ldk, key0, S_b, h * HD, lds + buf * TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
+    tile_dma(a.k + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + buf * TILE_BYTES, tid, wave_u);
+    tile_dma(a.v + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + buf * TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
   };
-  auto fetch_q = [&](int b, DsumQ& d) {                  // ordinary loads, always issued in front of a stage's DMA
-    int T_b, S_b; int64_t qoff, koff;
-    geom(b, T_b, S_b, qoff, koff);
-    const int qrow = qi < T_b ? qi : T_b - 1;
-    const bf16_t* qp = a.q + (qoff + qrow) * a.ldq + h * HD + hi * 8;
-    const bf16_t* dop = a.dout + (qoff + qrow) * a.ldo + h * HD + hi * 8;
+  auto fetch_q = [&](int b, const int4& g4, DsumQ& d) {  // ordinary loads, always issued in front of a stage's DMA
+    const int qrow = qi < g4.x ? qi : g4.x - 1;
+    const bf16_t* qp = a.q + ((int64_t)g4.z + qrow) * a.ldq + h * HD + hi * 8;
+    const bf16_t* dop = a.dout + ((int64_t)g4.z + qrow) * a.ldo + h * HD + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       d.qf[kk] = ld16(qp + kk * 16);
       d.dof[kk] = ld16(dop + kk * 16);
     }
-    const int64_t srow = a.seg ? (int64_t)h * a.Tpad + qoff + qrow : ((int64_t)b * a.heads + h) * a.Tpad + qrow;
+    const int64_t srow = a.seg ? (int64_t)h * a.Tpad + g4.z + qrow : ((int64_t)b * a.heads + h) * a.Tpad + qrow;
     d.lse = a.lse[srow];
     d.delta = a.delta[srow];
   };
+  auto kflag_of = [&](int s, const int4& g4) {           // dead-key flag of this lane's key in stage s (byte load: one stage AHEAD)
+    const uint8_t* kp = a.kpm ? a.kpm + (int64_t)(s / NKB) * a.S : nullptr;
+    return dead_flag(kp, (kc0 + s % NKB) * 32, g4.y, i);
+  };
   int s = next_live(b_lo * NKB - 1);
   DsumQ cur, nxt;
+  int4 gc = make_int4(0, 0, 0, 0), gn = gc;
+  int kflag = 0;
   if (s < s_end) {
-    fetch_q(s / NKB, cur);
-    stage(s, 0);
+    gc = geom(s / NKB);
+    fetch_q(s / NKB, gc, cur);
+    kflag = kflag_of(s, gc);
+    stage(s, gc, 0);
   }
   ATT_SYNC();
   int buf = 0, nxt_b = -1;
   while (s < s_end) {
     const int sn = next_live(s);
     const int b = s / NKB, j = s % NKB;
-    int T_b, S_b; int64_t qoff, koff;
-    geom(b, T_b, S_b, qoff, koff);
-    const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
+    const int T_b = gc.x;
     const int key0 = (kc0 + j) * 32;
-    const uint32_t dead_now = dead_ballot(dead_flag(kp, key0, S_b, i));     // (the byte load goes out in front of the next DMA)
+    const uint32_t dead_now = dead_ballot(kflag);
     if (sn < s_end) {
-      if (sn / NKB != b && sn / NKB != nxt_b) {          // the sample after this one: its query rows travel while this stage computes
-        nxt_b = sn / NKB;
-        fetch_q(nxt_b, nxt);
+      if (sn / NKB != b) {
+        if (sn / NKB != nxt_b) {                         // the sample after this one: its query rows travel while this stage computes
+          nxt_b = sn / NKB;
+          gn = geom(nxt_b);
+          fetch_q(nxt_b, gn, nxt);
+        }
+        kflag = kflag_of(sn, gn);
+        stage(sn, gn, buf ^ 1);
+      } else {
+        kflag = kflag_of(sn, gc);
+        stage(sn, gc, buf ^ 1);
       }
-      stage(sn, buf ^ 1);
     }
     if (q0 < T_b) {
       u64x2 kf[4], vf[4];
@@ -1123,7 +1144,10 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
     }
     ATT_SYNC();
     buf ^= 1;
-    if (sn < s_end && sn / NKB != b) cur = nxt;          // (landed: ATT_SYNC waited for vmcnt(0))
+    if (sn < s_end && sn / NKB != b) {                   // (landed: ATT_SYNC waited for vmcnt(0))
+      cur = nxt;
+      gc = gn;
+    }
     s = sn;
   }
   // G[h][qi][keys of the tile] (or this chunk's partial)
@@ -1294,7 +1318,9 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
     const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads * nchunk);
     auto kn = dtype == OFA_F16 ? attn_bwd_dsum_f16_kernel : attn_bwd_dsum_kernel;
     float* dst = nchunk == 1 ? dbias_sum : ws;
-    hipLaunchKernelGGL(kn, g, dim3(256), 4 * TILE_BYTES, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
+    const size_t lds = 4 * TILE_BYTES + (size_t)bper * 16;
+    OFA_REQUIRE(lds <= 64 * 1024, OFA_ERR_UNSUPPORTED, "attn_sbias_bwd: %d samples per chunk exceed the batch-sum kernel's geometry table", bper);
+    hipLaunchKernelGGL(kn, g, dim3(256), lds, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
     rc = check_launch("attn_sbias_bwd_dsum");
     if (rc || nchunk == 1) return rc;
     ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, OFA_F32};

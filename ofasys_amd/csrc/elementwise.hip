@@ -497,7 +497,19 @@ __global__ __launch_bounds__(256) void segment_rowsum_kernel(const T* __restrict
   const int g = lane / CPL, c = lane % CPL;
   const int lo = seg_off[sg], hi = seg_off[sg + 1];
   float acc = 0.f;
-  for (int p = lo + g; p < hi; p += G) {
+  int p = lo + g;
+  for (; p + 3 * G < hi; p += 4 * G) {                    // four dependent index -> row gathers in flight per lane
+    const int64_t r0 = order[p], r1 = order[p + G], r2 = order[p + 2 * G], r3 = order[p + 3 * G];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (c < D) {
+      v0 = ld1<T>(dout + r0 * D + c);
+      v1 = ld1<T>(dout + r1 * D + c);
+      v2 = ld1<T>(dout + r2 * D + c);
+      v3 = ld1<T>(dout + r3 * D + c);
+    }
+    acc += (v0 + v1) + (v2 + v3);
+  }
+  for (; p < hi; p += G) {
     const int64_t row = order[p];
     if (c < D) acc += ld1<T>(dout + row * D + c);
   }

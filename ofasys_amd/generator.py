@@ -112,7 +112,8 @@ class StepDecoder:
         for k, v in enc.items():
             if isinstance(v, list):
                 for dst, srct in zip(self.enc[k], v):
-                    dst.copy_(srct)
+                    if torch.is_tensor(dst):
+                        dst.copy_(srct)
         self.tokens.copy_(self.tokens.index_select(0, new_order))
 
     # ------------------------------------------------------------------ minimal loop

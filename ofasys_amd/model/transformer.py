@@ -164,6 +164,18 @@ class TransformerDecoder(nn.Module):
         b = ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
         return ops.SharedBias(b[0]) if shared else b
 
+    def _cross_kv(self, enc, incremental_state):
+        """ops.CrossKVShared for this forward -- the k|v projections of the encoder output for ALL layers as one GEMM -- when the
+        layers' projection weights sit adjacent in a trainer's arena (trainer.FlatParams) and the fused 16-bit path runs; else None
+        (every layer projects for itself)."""
+        if enc is None or incremental_state is not None or enc.dtype not in (torch.bfloat16, torch.float16):
+            return None
+        packs = [getattr(getattr(layer, "encoder_attn", None), "_cross_all", None) for layer in self.layers]
+        if any(p is None for p in packs) or any(p[0] is not packs[0][0] for p in packs) or packs[0][0]["layers"] != len(self.layers):
+            return None
+        rows = ops.batch_major(enc)                                   # [B, S, D] storage (a view: the stacks keep batch-major rows)
+        return ops.CrossKVShared(rows.reshape(-1, rows.shape[-1]), packs[0][0])
+
     def _pos_shared(self, adaptor_output, encoder_out):
         """Are the target AND the source position embeddings identical for every batch row (all built-in adaptors)?"""
         tgt = bool(getattr(self.adaptor, "last_pos_shared", False))
@@ -223,6 +235,7 @@ class TransformerDecoder(nn.Module):
         inner_states: List[Optional[Tensor]] = [x] if return_all_hiddens else []
         decoder_attentions, cross_attentions = [], []
         chain = LayerChain()
+        cross_kv = self._cross_kv(enc, incremental_state)
         for idx, layer in enumerate(self.layers):
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
             self_attn_mask = (self.buffered_future_mask(x) if incremental_state is None and not full_context_alignment
@@ -244,7 +257,7 @@ class TransformerDecoder(nn.Module):
                 self_attn_padding_mask=self_attn_padding_mask,
                 need_attn=bool((idx == alignment_layer) or return_all_attention_weights),
                 need_head_weights=bool(idx == alignment_layer), self_attn_bias=self_attn_bias,
-                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask, chain=chain)
+                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask, chain=chain, cross_kv=cross_kv)
             if return_all_attention_weights:
                 decoder_attentions.append(layer_self_attn)
                 cross_attentions.append(layer_cross_attn)
@@ -289,12 +302,13 @@ class TransformerDecoder(nn.Module):
             cross_bias = self.get_cross_pos_info(None, adaptor_output.pos_embed, src_pos_embed=encoder_out["position_embeddings"][0],
                                                  shared=True)
         chain = LayerChain()
+        cross_kv = self._cross_kv(enc, incremental_state)
         for idx, layer in enumerate(self.layers):
             chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
             sb = self_bias[0 if self.cfg.share_attn_bias else idx] if self_bias is not None else False
             x, _, _ = layer(x, enc, pack.cross, None, self_attn_mask=tag, self_attn_padding_mask=pack.dec_self, need_attn=False,
                             need_head_weights=False, self_attn_bias=sb, cross_attn_bias=cross_bias,
-                            modal_mask=adaptor_output.modal_mask, chain=chain)
+                            modal_mask=adaptor_output.modal_mask, chain=chain, cross_kv=cross_kv)
         normed = chain.take()
         if normed is not None:
             x = normed

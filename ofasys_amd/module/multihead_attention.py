@@ -66,7 +66,8 @@ class MultiheadAttention(nn.Module):
     def forward(self, query, key: Optional[Tensor], value: Optional[Tensor], key_padding_mask: Optional[Tensor] = None,
                 incremental_state: Optional[Dict[str, Dict[str, Optional[Tensor]]]] = None, need_weights: bool = True,
                 static_kv: bool = False, attn_mask: Optional[Tensor] = None, need_head_weights: bool = False,
-                attn_bias: Optional[Tensor] = None, out_proj_skip_bias_grad: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+                attn_bias: Optional[Tensor] = None, out_proj_skip_bias_grad: bool = False,
+                kv_shared=None) -> Tuple[Tensor, Optional[Tensor]]:
         """Input shape: Time x Batch x Channel (see the reference docstring, :126-140).  out_proj_skip_bias_grad (not in
         the reference): the caller's residual join produces out_proj's bias gradient (see OfaLinear.forward)."""
         if need_head_weights:
@@ -121,9 +122,14 @@ class MultiheadAttention(nn.Module):
                 xq, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
                 self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, causal, self._pack, shared)
         elif fused and xv is xk:
+            # kv_shared (ops.CrossKVShared, from the decoder stack): k | v of this layer are a column slice of the ONE projection of
+            # the encoder output that serves all decoder layers
+            layer = self._cross_all[1] if (kv_shared is not None and getattr(self, "_cross_all", None) is not None
+                                           and self._cross_all[0] is kv_shared.pack) else None
             out = ops.PackedCrossAttentionFn.apply(
                 xq, xk, self.k_proj.weight, self.v_proj.weight, self.q_proj.weight, self.k_proj.bias, self.v_proj.bias,
-                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, self._pack, shared)
+                self.q_proj.bias, bias, key_padding_mask, c_attn, self.num_heads, scale, self._pack, shared,
+                kv_shared if layer is not None else None, layer or 0)
         else:
             if shared:                                                       # exact tier / weights output: the reference's tensor
                 if key_padding_mask is not None and not torch.is_tensor(key_padding_mask):

@@ -328,7 +328,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 prev_attn_state: Optional[List[torch.Tensor]] = None, self_attn_mask: Optional[torch.Tensor] = None,
                 self_attn_padding_mask: Optional[torch.Tensor] = None, need_attn: bool = False,
                 need_head_weights: bool = False, self_attn_bias: Optional[Tensor] = None,
-                cross_attn_bias: Optional[Tensor] = None, modal_mask=None, chain: Optional[LayerChain] = None):
+                cross_attn_bias: Optional[Tensor] = None, modal_mask=None, chain: Optional[LayerChain] = None, cross_kv=None):
         """x: (seq_len, batch, embed_dim); see transformer_layer.py:367-385.  chain: LayerChain of the enclosing stack."""
         if need_head_weights:
             need_attn = True
@@ -376,7 +376,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 query=x, key=encoder_out, value=encoder_out, key_padding_mask=encoder_padding_mask,
                 incremental_state=incremental_state, static_kv=True,
                 need_weights=need_attn or (not self.training and self.need_attn), need_head_weights=need_head_weights,
-                attn_bias=cross_attn_bias, out_proj_skip_bias_grad=own)
+                attn_bias=cross_attn_bias, out_proj_skip_bias_grad=own, kv_shared=cross_kv)
             if join:
                 x, h = self._join(x, residual, self.cross_attn_ln, self.final_layer_norm,
                                   x_bias=self.encoder_attn.out_proj.bias if own else None)

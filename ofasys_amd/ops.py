@@ -785,23 +785,88 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None, None)
 
 
+class CrossKVShared:
+    """The k|v projections of the encoder output for ALL decoder layers as one GEMM (multihead_attention.py:203-211 runs k_proj and
+    v_proj of every layer's encoder_attn on the same encoder_out): kv_all = enc W_all^T + b_all, [rows, layers * 2D], layer l's k | v
+    in columns [l*2D, (l+1)*2D).  Backward: every layer's attention backward writes its dk | dv slice of ONE buffer; the layer-0 node
+    -- the last cross-attention backward to run, by data dependence -- then issues the single input-gradient GEMM (K = layers * 2D)
+    for the encoder output, queues the single weight-gradient product and the bias column sums.  pack: trainer.FlatParams' arena
+    views of the packed weights (the parameters are adjacent there)."""
+
+    def __init__(self, enc_rows, pack):
+        self.pack, self.L, self.D = pack, pack["layers"], pack["D"]
+        self.enc2d = enc_rows
+        self.kv_all = K.gemm(enc_rows, pack["w"], False, True, bias=pack["b"])          # [rows, L * 2D]
+        self.dkv_all = None
+        self.done = 0
+        self.users = set()                                  # layers whose fused attention reads its slice (registered in forward)
+
+    def use(self, layer):
+        self.users.add(layer)
+
+    def kv(self, layer, B, S):
+        lo = layer * 2 * self.D
+        return self.kv_all[:, lo:lo + 2 * self.D].view(B, S, 2 * self.D)               # (row stride L * 2D: a column slice)
+
+    def dkv(self, layer, B, S):
+        if self.dkv_all is None:
+            self.dkv_all = torch.empty_like(self.kv_all)
+        lo = layer * 2 * self.D
+        return self.dkv_all[:, lo:lo + 2 * self.D].view(B, S, 2 * self.D)
+
+    def finish(self, need_dx):
+        """After the last participating layer's slice has been written: d enc, d W_all, d b_all.  A layer that did not take part
+        (it needed the attention weights: exact tier, own projection, own gradients) contributes zeros here."""
+        assert self.done == len(self.users), (self.done, sorted(self.users))
+        p = self.pack
+        for layer in range(self.L):
+            if layer not in self.users:
+                self.dkv_all[:, layer * 2 * self.D:(layer + 1) * 2 * self.D].zero_()
+        dx = K.gemm(self.dkv_all, p["w"], False, False) if need_dx else None
+        L, D = self.L, self.D
+        if len(self.users) == L:                            # every layer took part: ONE weight-gradient product, ONE column sum
+            _wgrad(self.dkv_all, self.enc2d, p["gw"], 1.0, *p["params"][:2 * L])
+            K.colsum(self.dkv_all, out=p["gb"], accumulate=True, out_dtype=self.dkv_all.dtype, fold=_fold())
+        else:
+            # a layer that kept its own projection already owns (and may already be all-reducing) its gradient rows: touch only
+            # the participating layers' slices
+            for layer in sorted(self.users):
+                sl = slice(layer * 2 * D, (layer + 1) * 2 * D)
+                _wgrad(self.dkv_all[:, sl], self.enc2d, p["gw"][sl], 1.0, *p["params"][2 * layer:2 * layer + 2])
+                K.colsum(self.dkv_all[:, sl], out=p["gb"][sl], accumulate=True, out_dtype=self.dkv_all.dtype, fold=_fold())
+        for layer in sorted(self.users):                    # (a non-participating layer's own backward reports its parameters)
+            for b in p["params"][2 * L + 2 * layer:2 * L + 2 * layer + 2]:
+                _sink_done(b)
+        return dx
+
+
 class PackedCrossAttentionFn(torch.autograd.Function):
     """Encoder-decoder attention core: q projection from the decoder stream, ONE packed k|v projection (N = 2D) from the
     encoder output (multihead_attention.py:203-211)."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, pack, bias_shared=False):
+    def forward(ctx, xq, xkv, wk, wv, wq, bk, bv, bq, bias, kpm, c_attn, heads, scale, pack, bias_shared=False, kv_all=None, layer=0):
+        """kv_all (CrossKVShared) / layer: the k|v rows come from the stack-wide projection; xkv is then only an input of layer 0 (so
+        that its node can hand the encoder output's gradient back), None elsewhere."""
         B, T, D = xq.shape
-        S = xkv.shape[1]
-        W = _packed((wk, wv), pack.get("w"))
-        Bv = _packed((bk, bv), pack.get("b"))
-        xq2, xkv2 = xq.view(B * T, D), xkv.view(B * S, D)
+        xq2 = xq.view(B * T, D)
         q = K.gemm(xq2, wq, False, True, bias=bq).view(B, T, D)
-        kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
+        ctx.kv_all, ctx.layer = kv_all, layer
+        if kv_all is not None:
+            S = kv_all.kv_all.shape[0] // B
+            W = xkv2 = None
+            kv = kv_all.kv(layer, B, S)
+            kv_all.use(layer)
+        else:
+            S = xkv.shape[1]
+            W = _packed((wk, wv), pack.get("w"))
+            Bv = _packed((bk, bv), pack.get("b"))
+            xkv2 = xkv.view(B * S, D)
+            kv = K.gemm(xkv2, W, False, True, bias=Bv).view(B, S, 2 * D)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         kpm, seg = _split_seg(kpm)
         out, lse = K.attn_fwd(q, k, v, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn, causal=False, seg=seg, bias_shared=bias_shared)
-        ctx.save_for_backward(xq2, xkv2, q, kv, out, lse, bias, kpm, c_attn, W)
+        ctx.save_for_backward(xq2, xkv2, q, (kv if kv_all is None else None), out, lse, bias, kpm, c_attn, W)
         ctx.c_ref = c_attn
         ctx.params = (wk, wv, wq, bk, bv, bq)
         ctx.cfg = (heads, scale, pack)
@@ -814,28 +879,44 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         heads, scale, pack = ctx.cfg
         wk, wv, wq, bk, bv, bq = ctx.params
         B, T, D = q.shape
-        S = kv.shape[1]
+        shared_kv = ctx.kv_all
+        if shared_kv is not None:
+            S = shared_kv.kv_all.shape[0] // B
+            kv = shared_kv.kv(ctx.layer, B, S)
+            dkv = shared_kv.dkv(ctx.layer, B, S)
+        else:
+            S = kv.shape[1]
+            dkv = torch.empty_like(kv)
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         dq = torch.empty_like(q)                                       # (ragged mode: the kernels zero the filler rows)
-        dkv = torch.empty_like(kv)
         need_dbias = bias is not None and ctx.needs_input_grad[8]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=False, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
                                            outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
-        dq2, dkv2 = dq.view(B * T, D), dkv.view(B * S, 2 * D)
+        dq2 = dq.view(B * T, D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
-        dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
         gq = _packed_wgrads((wq,), _sink(wq), dq2, xq2)
         gbq = _packed_grads((bq,), _sink(bq), lambda o, acc, f: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype, fold=f),
                             (dq2,))
-        gws = _packed_wgrads((wk, wv), pack.get("gw"), dkv2, xkv2)
-        gbs = _packed_grads((bk, bv), pack.get("gb"),
-                            lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
+        if shared_kv is not None:
+            # the slice is written; layer 0 -- the last cross-attention backward of the stack -- closes the shared projection
+            shared_kv.done += 1
+            dxkv = None
+            if ctx.layer == min(shared_kv.users):
+                dx2 = shared_kv.finish(ctx.needs_input_grad[1])
+                dxkv = dx2.view(B, S, D) if dx2 is not None else None
+            gws, gbs = [None, None], [None, None]
+        else:
+            dkv2 = dkv.view(B * S, 2 * D)
+            dxkv = K.gemm(dkv2, W, False, False).view(B, S, D) if ctx.needs_input_grad[1] else None
+            gws = _packed_wgrads((wk, wv), pack.get("gw"), dkv2, xkv2)
+            gbs = _packed_grads((bk, bv), pack.get("gb"),
+                                lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
         dc = None
         if c_attn is not None and ctx.needs_input_grad[10]:
             dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
-        return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None, None)
+        return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None, None, None, None)
 
 
 class UnfusedAttentionFn(torch.autograd.Function):

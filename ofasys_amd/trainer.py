@@ -36,15 +36,30 @@ class FlatParams:
                 mhas.append(m)
                 for p in (m.k_proj.weight, m.v_proj.weight, m.q_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.bias):
                     mha_of[id(p)] = m
+        # ... and the k|v projections of ALL the decoder layers' encoder-decoder attentions are made adjacent across layers: they
+        # all read the encoder output, so the stack runs them as ONE GEMM (N = layers * 2D; ops.CrossKVShared)
+        cross = [m for m in mhas if getattr(m, "encoder_decoder_attention", False) and not m.self_attention]
+        cross_ok = len(cross) > 1 and len({tuple(m.k_proj.weight.shape) for m in cross}) == 1 and \
+            all(m.kdim == m.vdim and m.k_proj.weight.shape == m.v_proj.weight.shape for m in cross) and \
+            all(q.requires_grad for m in cross for q in (m.k_proj.weight, m.v_proj.weight, m.k_proj.bias, m.v_proj.bias))
+        cross_group = []
+        if cross_ok:
+            cross_group = [w for m in cross for w in (m.k_proj.weight, m.v_proj.weight)] + \
+                [b for m in cross for b in (m.k_proj.bias, m.v_proj.bias)]
+        cross_ids = {id(q) for q in cross_group}
         seen, params = set(), []
         for p in model.parameters():
             if not p.requires_grad or id(p) in seen:
                 continue
             m = mha_of.get(id(p))
             group = [p]
-            if m is not None:
+            if id(p) in cross_ids:
+                group = cross_group
+            elif m is not None:
                 if m.self_attention:
                     group = [m.k_proj.weight, m.v_proj.weight, m.q_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.bias]
+                elif cross_ok and m in cross:
+                    group = [m.q_proj.weight, m.q_proj.bias]
                 else:
                     group = [m.k_proj.weight, m.v_proj.weight, m.k_proj.bias, m.v_proj.bias, m.q_proj.weight, m.q_proj.bias]
                 if not all(g.requires_grad for g in group):
@@ -85,6 +100,18 @@ class FlatParams:
             if ok:
                 m._pack = {"w": self.flat[ow:ow + n * D * Kin].view(n * D, Kin), "b": self.flat[ob:ob + n * D],
                            "gw": self.grad[ow:ow + n * D * Kin].view(n * D, Kin), "gb": self.grad[ob:ob + n * D]}
+        if cross_ok:
+            L = len(cross)
+            D, Kin = cross[0].k_proj.weight.shape
+            ow, ob = off_of[id(cross[0].k_proj.weight)], off_of[id(cross[0].k_proj.bias)]
+            ok = all(off_of.get(id(w)) == ow + i * D * Kin for i, w in enumerate(cross_group[:2 * L])) and \
+                all(off_of.get(id(b)) == ob + i * D for i, b in enumerate(cross_group[2 * L:])) and (D * Kin) % 8 == 0 and D % 8 == 0
+            if ok:
+                pack = {"w": self.flat[ow:ow + 2 * L * D * Kin].view(2 * L * D, Kin), "b": self.flat[ob:ob + 2 * L * D],
+                        "gw": self.grad[ow:ow + 2 * L * D * Kin].view(2 * L * D, Kin), "gb": self.grad[ob:ob + 2 * L * D],
+                        "params": tuple(cross_group), "layers": L, "D": D}
+                for i, m in enumerate(cross):
+                    m._cross_all = (pack, i)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -991,7 +991,7 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
                                                    int nchunk, int bper) {
   constexpr int NKB = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile]
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][2 key blocks][K tile | V tile], then the chunk's geometry table
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int i = lane & 31, hi = lane >> 5;
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
 
   // The geometry {q_len, k_len, q_off, k_off} of this chunk's samples goes through LDS once (behind the tiles): in ragged mode every
   // look-up of the segment table would otherwise be a scalar memory round trip, several per stage.
-  int4* geo = reinterpret_cast<int4*>(smem + 4 * TILE_BYTES);
+  int4* geo = reinterpret_cast<int4*>(smem + 8 * TILE_BYTES);
   const int nb = b_hi - b_lo;
   for (int t = tid; t < nb; t += 256) {
     const int b = b_lo + t;
@@ -1043,21 +1043,24 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
     return make_int4(__builtin_amdgcn_readfirstlane(g4.x), __builtin_amdgcn_readfirstlane(g4.y), __builtin_amdgcn_readfirstlane(g4.z),
                      __builtin_amdgcn_readfirstlane(g4.w));
   };
-  // stage s = b * NKB + j; a stage is live when sample b reaches the tile (uniform over the workgroup)
-  const int s_end = b_hi * NKB;
-  auto next_live = [&](int s) {
-    ++s;
-    while (s < s_end) {
-      const int4 g4 = geom(s / NKB);
-      if (qb0 < g4.x && (kc0 + s % NKB) * 32 < g4.y) break;
-      ++s;
+  // One stage per SAMPLE: the K / V tiles of both key blocks of the tile land together (4 tiles, 16 KiB, double buffered), so the
+  // stage barrier and the DMA latency are paid once per two blocks of work.  A sample is live when it reaches the tile (uniform).
+  auto next_live = [&](int b) {
+    ++b;
+    while (b < b_hi) {
+      const int4 g4 = geom(b);
+      if (qb0 < g4.x && kc0 * 32 < g4.y) break;
+      ++b;
     }
-    return s;
+    return b;
   };
-  auto stage = [&](int s, const int4& g4, int buf) {
-    const int key0 = (kc0 + s % NKB) * 32;
-    tile_dma(a.k + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + buf * TILE_BYTES, tid, wave_u);
-    tile_dma(a.v + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + buf * TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
+  auto stage = [&](const int4& g4, int buf) {
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+      const int key0 = (kc0 + j) * 32;                   // (a block beyond the sample's keys re-reads its last row: masked below)
+      tile_dma(a.k + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + (buf * 2 * NKB + 2 * j) * (TILE_BYTES / 2), tid, wave_u);
+      tile_dma(a.v + (int64_t)g4.w * a.ldk, a.ldk, key0, g4.y, h * HD, lds + (buf * 2 * NKB + 2 * j + 1) * (TILE_BYTES / 2), tid, wave_u);
+    }
   };
   auto fetch_q = [&](int b, const int4& g4, DsumQ& d) {  // ordinary loads, always issued in front of a stage's DMA
     const int qrow = qi < g4.x ? qi : g4.x - 1;
@@ -1072,83 +1075,79 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
     d.lse = a.lse[srow];
     d.delta = a.delta[srow];
   };
-  auto kflag_of = [&](int s, const int4& g4) {           // dead-key flag of this lane's key in stage s (byte load: one stage AHEAD)
-    const uint8_t* kp = a.kpm ? a.kpm + (int64_t)(s / NKB) * a.S : nullptr;
-    return dead_flag(kp, (kc0 + s % NKB) * 32, g4.y, i);
+  auto kflag_of = [&](int b, int j, const int4& g4) {    // dead-key flag of this lane's key in block j of sample b (byte load: a stage AHEAD)
+    const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
+    return dead_flag(kp, (kc0 + j) * 32, g4.y, i);
   };
-  int s = next_live(b_lo * NKB - 1);
+  int b = next_live(b_lo - 1);
   DsumQ cur, nxt;
   int4 gc = make_int4(0, 0, 0, 0), gn = gc;
-  int kflag = 0;
-  if (s < s_end) {
-    gc = geom(s / NKB);
-    fetch_q(s / NKB, gc, cur);
-    kflag = kflag_of(s, gc);
-    stage(s, gc, 0);
+  int kflag[NKB], kflag_n[NKB];
+#pragma unroll
+  for (int j = 0; j < NKB; ++j) kflag[j] = kflag_n[j] = 0;
+  if (b < b_hi) {
+    gc = geom(b);
+    fetch_q(b, gc, cur);
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) kflag[j] = kflag_of(b, j, gc);
+    stage(gc, 0);
   }
   ATT_SYNC();
-  int buf = 0, nxt_b = -1;
-  while (s < s_end) {
-    const int sn = next_live(s);
-    const int b = s / NKB, j = s % NKB;
+  int buf = 0;
+  while (b < b_hi) {
+    const int bn = next_live(b);
     const int T_b = gc.x;
-    const int key0 = (kc0 + j) * 32;
-    const uint32_t dead_now = dead_ballot(kflag);
-    if (sn < s_end) {
-      if (sn / NKB != b) {
-        if (sn / NKB != nxt_b) {                         // the sample after this one: its query rows travel while this stage computes
-          nxt_b = sn / NKB;
-          gn = geom(nxt_b);
-          fetch_q(nxt_b, gn, nxt);
-        }
-        kflag = kflag_of(sn, gn);
-        stage(sn, gn, buf ^ 1);
-      } else {
-        kflag = kflag_of(sn, gc);
-        stage(sn, gc, buf ^ 1);
-      }
+    uint32_t dead_now[NKB];
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) dead_now[j] = dead_ballot(kflag[j]);
+    if (bn < b_hi) {                                     // the next sample's rows, flags and tiles travel while this one computes
+      gn = geom(bn);
+      fetch_q(bn, gn, nxt);
+#pragma unroll
+      for (int j = 0; j < NKB; ++j) kflag_n[j] = kflag_of(bn, j, gn);
+      stage(gn, buf ^ 1);
     }
     if (q0 < T_b) {
-      u64x2 kf[4], vf[4];
-      if (buf == 0) {
-        rd128<0>(kf[0], ta.km[0]); rd128<0>(kf[1], ta.km[1]); rd128<0>(kf[2], ta.km[2]); rd128<0>(kf[3], ta.km[3]);
-        rd128<TILE_BYTES>(vf[0], ta.km[0]); rd128<TILE_BYTES>(vf[1], ta.km[1]); rd128<TILE_BYTES>(vf[2], ta.km[2]); rd128<TILE_BYTES>(vf[3], ta.km[3]);
-      } else {
-        rd128<2 * TILE_BYTES>(kf[0], ta.km[0]); rd128<2 * TILE_BYTES>(kf[1], ta.km[1]); rd128<2 * TILE_BYTES>(kf[2], ta.km[2]); rd128<2 * TILE_BYTES>(kf[3], ta.km[3]);
-        rd128<3 * TILE_BYTES>(vf[0], ta.km[0]); rd128<3 * TILE_BYTES>(vf[1], ta.km[1]); rd128<3 * TILE_BYTES>(vf[2], ta.km[2]); rd128<3 * TILE_BYTES>(vf[3], ta.km[3]);
-      }
-      ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
-      ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
-      f32x16 st, dp;
-      zero16f(st);
-      zero16f(dp);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        st = ATT_MFMA(kf[kk], cur.qf[kk], st);
-        dp = ATT_MFMA(vf[kk], cur.dof[kk], dp);
-      }
       const bool rowok = qi < T_b;
 #pragma unroll
-      for (int jj = 0; jj < NKB; ++jj) {
-        if (jj != j) continue;                           // (j is uniform: acc / bz stay in registers, the loop is unrolled)
+      for (int j = 0; j < NKB; ++j) {
+        const int key0 = (kc0 + j) * 32;
+        if (key0 >= gc.y) continue;                      // (uniform)
+        u64x2 kf[4], vf[4];
+        const uint32_t koff = (uint32_t)((buf * 2 * NKB + 2 * j) * TILE_BYTES);
+        rd128<0>(kf[0], ta.km[0] + koff); rd128<0>(kf[1], ta.km[1] + koff); rd128<0>(kf[2], ta.km[2] + koff); rd128<0>(kf[3], ta.km[3] + koff);
+        rd128<TILE_BYTES>(vf[0], ta.km[0] + koff); rd128<TILE_BYTES>(vf[1], ta.km[1] + koff); rd128<TILE_BYTES>(vf[2], ta.km[2] + koff);
+        rd128<TILE_BYTES>(vf[3], ta.km[3] + koff);
+        ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
+        ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
+        f32x16 st, dp;
+        zero16f(st);
+        zero16f(dp);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          st = ATT_MFMA(kf[kk], cur.qf[kk], st);
+          dp = ATT_MFMA(vf[kk], cur.dof[kk], dp);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int jk = crowl(r, hi), key = key0 + jk;
-          bool dead = !rowok || ((dead_now >> jk) & 1u);
+          bool dead = !rowok || ((dead_now[j] >> jk) & 1u);
           if (a.causal) dead |= key > qi;
-          const float t = st[r] * sc + bz[jj][r];
+          const float t = st[r] * sc + bz[j][r];
           const float p = dead ? 0.f : __builtin_amdgcn_exp2f(t - cur.lse);
-          acc[jj][r] += p * (dp[r] * c - cur.delta);
+          acc[j][r] += p * (dp[r] * c - cur.delta);
         }
       }
     }
     ATT_SYNC();
     buf ^= 1;
-    if (sn < s_end && sn / NKB != b) {                   // (landed: ATT_SYNC waited for vmcnt(0))
+    if (bn < b_hi) {                                     // (landed: ATT_SYNC waited for vmcnt(0))
       cur = nxt;
       gc = gn;
+#pragma unroll
+      for (int j = 0; j < NKB; ++j) kflag[j] = kflag_n[j];
     }
-    s = sn;
+    b = bn;
   }
   // G[h][qi][keys of the tile] (or this chunk's partial)
   if (qi < Tb) {
@@ -1318,7 +1317,7 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
     const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads * nchunk);
     auto kn = dtype == OFA_F16 ? attn_bwd_dsum_f16_kernel : attn_bwd_dsum_kernel;
     float* dst = nchunk == 1 ? dbias_sum : ws;
-    const size_t lds = 4 * TILE_BYTES + (size_t)bper * 16;
+    const size_t lds = 8 * TILE_BYTES + (size_t)bper * 16;
     OFA_REQUIRE(lds <= 64 * 1024, OFA_ERR_UNSUPPORTED, "attn_sbias_bwd: %d samples per chunk exceed the batch-sum kernel's geometry table", bper);
     hipLaunchKernelGGL(kn, g, dim3(256), lds, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
     rc = check_launch("attn_sbias_bwd_dsum");

@@ -169,36 +169,44 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
 #pragma unroll
   for (int j = 0; j < N; ++j) { red[0][threadIdx.x][j] = s0[j]; red[1][threadIdx.x][j] = s1[j]; }
   __syncthreads();
-  if ((int)threadIdx.x < 2 * cw) {
-    const int q = threadIdx.x >> cw_log2, col = threadIdx.x & (cw - 1);
+  // every thread folds whole (quantity, column) outputs over the row lanes in a fixed order (2 * cw * N outputs: 128 .. 512)
+  constexpr int LN = N == 8 ? 3 : 2;
+  static_assert((1 << LN) == N, "vector width");
+  const int per_q = cw << LN;
+  for (int o = threadIdx.x; o < 2 * per_q; o += 256) {
+    const int q = o >> (cw_log2 + LN), rem = o & (per_q - 1);
+    const int col = rem >> LN, j = rem & (N - 1);
     const int cc = (blockIdx.x * cw + col) * N;
     if (cc < C) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        double t = 0.0;
-        for (int l = 0; l < rl; ++l) t += red[q][l * cw + col][j];          // fixed order
-        partial[((int64_t)blockIdx.y * 2 + q) * C + cc + j] = t;
-      }
+      double t = 0.0;
+      for (int l = 0; l < rl; ++l) t += red[q][l * cw + col][j];
+      partial[((int64_t)blockIdx.y * 2 + q) * C + cc + j] = t;
     }
   }
 }
 
-// fold the per-group fp64 partials of one quantity pair: 32 columns x 8 group-lanes per 256-thread block
+// fold the per-group fp64 partials of one quantity pair: 16 columns x 16 group-lanes per 256-thread block; a lane's (up to 16)
+// groups are all loaded before the first add -- one memory round trip instead of a serial chain of 32 (the kernel was 6.5 us)
 __device__ __forceinline__ void bn_fold_groups(const double* __restrict__ partial, int groups, int C, int c, int gl, double& s,
                                                double& q) {
-  __shared__ double red[2][8][32];
-  double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int g = gl; g < groups; g += 8) {
-      a += partial[((int64_t)g * 2) * C + c];
-      b += partial[((int64_t)g * 2 + 1) * C + c];
-    }
-  red[0][gl][threadIdx.x & 31] = a;
-  red[1][gl][threadIdx.x & 31] = b;
+  __shared__ double red[2][16][16];
+  double a[16], b[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int g = gl + 16 * i;
+    const bool ok = c < C && g < groups;                    // groups <= 256 (bn_groups)
+    a[i] = ok ? partial[((int64_t)g * 2) * C + c] : 0.0;
+    b[i] = ok ? partial[((int64_t)g * 2 + 1) * C + c] : 0.0;
+  }
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sa += a[i]; sb += b[i]; }
+  red[0][gl][threadIdx.x & 15] = sa;
+  red[1][gl][threadIdx.x & 15] = sb;
   __syncthreads();
   s = q = 0.0;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
+  for (int r = 0; r < 16; ++r) { s += red[0][r][threadIdx.x & 15]; q += red[1][r][threadIdx.x & 15]; }
 }
 
 // forward finalize: mean / rstd of the batch + running statistics (torch: running = (1-m)*running + m*stat, unbiased var)
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), gl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), gl = threadIdx.x >> 4;
   double s, q;
   bn_fold_groups(partial, groups, C, c, gl, s, q);
   if (gl != 0 || c >= C) return;
@@ -237,7 +245,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int groups, int C,
                                                               float* __restrict__ sums, T* __restrict__ dgamma,
                                                               T* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), gl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), gl = threadIdx.x >> 4;
   double s, q;
   bn_fold_groups(partial, groups, C, c, gl, s, q);
   if (gl != 0 || c >= C) return;
@@ -475,7 +483,7 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
       hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
     else
       hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
   if (rc) return rc;
@@ -504,14 +512,14 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
   if (dtype == OFA_F32) {
     hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else if (dtype == OFA_BF16) {
     hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
   }
   else {
     hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");
   if (rc) return rc;

@@ -80,7 +80,9 @@ class ImageResnetAdaptor(BaseAdaptor):
         row and returns [B,A,T,T]; every row of `image_position_ids` is the same arange-derived vector, so the values are
         computed once and handed to the bias assembly as the usual batch-expanded view."""
         ids = kwargs["image_position_ids"]
-        rp_bucket = self.image_rp_bucket[ids][:, ids].contiguous()             # integer double gather, bit-exact
+        hw = getattr(self, "_hw", None)                                        # integer double gather, bit-exact; the same for every layer
+        gather = lambda: self.image_rp_bucket[ids][:, ids].contiguous()        # noqa: E731   (and every step: ids come from (h, w))
+        rp_bucket = ops.cached_index(self, ("image", hw, int(ids.numel())), gather) if hw is not None else gather()
         # (the position ids are arange-derived from the feature map's (h, w): with the shape, that identifies the lookup)
         return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight, plan_key=("image", id(self), getattr(self, "_hw", None)))
 

@@ -71,7 +71,7 @@ class TextAdaptor(BaseAdaptor):
         """table_l[bucket[:T,:T]] -> [T,T,A]  (adaptor/text.py:101-104)."""
         if seq_length > self.token_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.token_rp_bucket.size(0)} positions of token_rp_bucket")
-        rp_bucket = self.token_rp_bucket[:seq_length, :seq_length].contiguous()
+        rp_bucket = ops.cached_index(self, ("text", seq_length), lambda: self.token_rp_bucket[:seq_length, :seq_length].contiguous())
         return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight, plan_key=("text", id(self)))
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:

@@ -1277,9 +1277,12 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   int maxs = has_ws ? g.K / 256 : 1;                 // every split keeps >= 4 K-tiles
   maxs = maxs < 1 ? 1 : (maxs > 32 ? 32 : maxs);
   // short contractions are not split: at K = 768 a split saves a few K-steps but costs a second (reduce) launch --
-  // 2048 x 2304 x 768: 28.9 us split in two + reduce vs 16.2 us unsplit; from K = 2304 up the split wins (21.5 vs 24.7 us)
-  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 1024;   // (tools/gemm_timeline.py)
-  if (g.K < split_min_k) maxs = 1;
+  // 2048 x 2304 x 768: 28.9 us split in two + reduce vs 16.2 us unsplit; from K = 2304 up the split wins (21.5 vs 24.7 us).
+  // Round 3 (tools/gemm_split_check.py, the ResNet trunk's 1 x 1 / 3 x 3 products): at K = 1024 the split loses too (18432 x 256 x 1024:
+  // 31.7 us in two slices + reduce vs 20.2 us as 64 x 128 tiles; 6272 x 256 x 1024: 22.4 vs 14.0 us as 64 x 64 tiles), and so does any
+  // split of a product whose 128 x 128 tiles already fill a round of the 256 CUs (18432 x 256 x 2304: 46.6 vs 37.6 us)
+  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 2048;   // (tools/gemm_timeline.py)
+  if (g.K < split_min_k || t22 >= 256) maxs = 1;
   const int64_t want = 384;
   int wm, wn;
   int64_t tiles;

@@ -267,42 +267,65 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
     if (wd != 0.f) p -= wd * lr * p;
     p -= step_size * mi / (sqrtf(vi) + eps);
   };
-  // four elements per thread and iteration: 16-byte accesses on the three fp32 state arrays, 8 / 16 bytes on the gradient
-  // and the model copy (HBM-bound: 28 B per parameter in bf16; the element-at-a-time loop reached 4.9 TB/s)
+  // Two quads (4 parameters each) per thread and trip, every load of the trip issued before the first update.  The fp32 state and
+  // the gradient are streamed with NONTEMPORAL loads / stores (each byte is touched once per step and the arrays are many times
+  // the size of L2 / MALL): tools/experiments/adam_stream_bench.hip, 141.6 M parameters = 3.96 GB per pass: plain accesses on a
+  // 4096-block grid 778 us (5.1 TB/s), nontemporal + 65536 blocks 620 us (6.4 TB/s).  The model-dtype copy is read by the next
+  // forward: plain store.
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
   const int64_t nq = n >> 2;
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
-    const int64_t i = q << 2;
-    float4 p4 = *reinterpret_cast<const float4*>(master + i);
-    float4 m4 = *reinterpret_cast<const float4*>(m + i);
-    float4 v4 = *reinterpret_cast<const float4*>(v + i);
-    float g[4];
-    if constexpr (sizeof(T) == 4) {
-      const float4 g4 = *reinterpret_cast<const float4*>(grad + i);
-      g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-    } else {
-      const uint2 gr = *reinterpret_cast<const uint2*>(grad + i);
-      if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {        // fp16
-        const f16x2_t a = __builtin_bit_cast(f16x2_t, gr.x), b = __builtin_bit_cast(f16x2_t, gr.y);
-        g[0] = (float)a[0]; g[1] = (float)a[1]; g[2] = (float)b[0]; g[3] = (float)b[1];
-      } else {
-        g[0] = __uint_as_float(gr.x << 16); g[1] = __uint_as_float(gr.x & 0xffff0000u);
-        g[2] = __uint_as_float(gr.y << 16); g[3] = __uint_as_float(gr.y & 0xffff0000u);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += 2 * stride) {
+    f4v p4[2], m4[2], v4[2], g4[2];
+    u2v g2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t q = q0 + k * stride;
+      if (q < nq) {
+        const int64_t i = q << 2;
+        p4[k] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(master + i));
+        m4[k] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + i));
+        v4[k] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + i));
+        if constexpr (sizeof(T) == 4) g4[k] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(grad + i));
+        else g2[k] = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(grad + i));
       }
     }
-    upd(g[0], p4.x, m4.x, v4.x);
-    upd(g[1], p4.y, m4.y, v4.y);
-    upd(g[2], p4.z, m4.z, v4.z);
-    upd(g[3], p4.w, m4.w, v4.w);
-    *reinterpret_cast<float4*>(m + i) = m4;
-    *reinterpret_cast<float4*>(v + i) = v4;
-    *reinterpret_cast<float4*>(master + i) = p4;
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<float4*>(model + i) = p4;
-    } else {
-      uint2 o;
-      o.x = pack2<T>(p4.x, p4.y);
-      o.y = pack2<T>(p4.z, p4.w);
-      *reinterpret_cast<uint2*>(model + i) = o;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t q = q0 + k * stride;
+      if (q < nq) {
+        const int64_t i = q << 2;
+        float g[4];
+        if constexpr (sizeof(T) == 4) {
+          g[0] = g4[k].x; g[1] = g4[k].y; g[2] = g4[k].z; g[3] = g4[k].w;
+        } else if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {        // fp16
+          const f16x2_t a = __builtin_bit_cast(f16x2_t, g2[k].x), b = __builtin_bit_cast(f16x2_t, g2[k].y);
+          g[0] = (float)a[0]; g[1] = (float)a[1]; g[2] = (float)b[0]; g[3] = (float)b[1];
+        } else {
+          g[0] = __uint_as_float(g2[k].x << 16); g[1] = __uint_as_float(g2[k].x & 0xffff0000u);
+          g[2] = __uint_as_float(g2[k].y << 16); g[3] = __uint_as_float(g2[k].y & 0xffff0000u);
+        }
+        float px = p4[k].x, py = p4[k].y, pz = p4[k].z, pw = p4[k].w;
+        float mx = m4[k].x, my = m4[k].y, mz = m4[k].z, mw = m4[k].w;
+        float vx = v4[k].x, vy = v4[k].y, vz = v4[k].z, vw = v4[k].w;
+        upd(g[0], px, mx, vx);
+        upd(g[1], py, my, vy);
+        upd(g[2], pz, mz, vz);
+        upd(g[3], pw, mw, vw);
+        const f4v mo = {mx, my, mz, mw}, vo = {vx, vy, vz, vw}, po = {px, py, pz, pw};
+        __builtin_nontemporal_store(mo, reinterpret_cast<f4v*>(m + i));
+        __builtin_nontemporal_store(vo, reinterpret_cast<f4v*>(v + i));
+        __builtin_nontemporal_store(po, reinterpret_cast<f4v*>(master + i));
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f4v*>(model + i) = po;
+        } else {
+          u2v o;
+          o.x = pack2<T>(px, py);
+          o.y = pack2<T>(pz, pw);
+          *reinterpret_cast<u2v*>(model + i) = o;
+        }
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // tail
@@ -556,7 +579,7 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   OFA_REQUIRE(!(((uintptr_t)master | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) && !(((uintptr_t)grad | (uintptr_t)model_param) & 7),
               OFA_ERR_INVALID, "adam_step: arenas must be 16-byte (fp32 state) / 8-byte (grad, model copy) aligned");
   int64_t nbl = (n + 255) / 256;
-  const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+  const int nb = (int)(nbl > 65536 ? 65536 : nbl);      // (small blocks of work: the tail of a 4096-block grid cost 15 %)
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((adam_kernel<float>), dim3(nb), dim3(256), 0, st, master, exp_avg, exp_avg_sq, (const float*)grad, (float*)model_param, coef, n, lr, beta1, beta2, eps, weight_decay, step_size, dev_sched);
   else if (dtype == OFA_BF16)

@@ -558,6 +558,22 @@ def drop_path(x, drop_prob, batch_axis=1, scale_by_keep=True):
 
 
 # ---------------------------------------------------------------------------------------------- embedding
+def cached_index(owner, key, make):
+    """Constant integer index tensors derived from a module's buffers and a shape (rel-pos bucket windows): built once per (owner,
+    key, device) instead of by one slicing / gather launch per layer and step.  Nothing is inserted while a graph is being captured
+    (the tensor would belong to that graph's pool and only hold data after its replay)."""
+    cache = owner.__dict__.setdefault("_ofa_index_cache", {})
+    hit = cache.get(key)
+    if hit is not None and hit.device == next(owner.buffers()).device:
+        return hit
+    t = make()
+    if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(cache) >= 64:
+            cache.clear()
+        cache[key] = t
+    return t
+
+
 class SegmentPlan:
     """The positions of an id tensor sorted by id (stable) and cut into one segment per distinct id: what ofa_segment_rowsum needs to
     scatter-add a narrow table's gradient without scanning the id list per table row.  Built on the device (sort + unique) with ONE
@@ -1340,7 +1356,9 @@ class Conv2dFn(torch.autograd.Function):
             w2 = weight.view(Cout, Cin)
         else:
             col, Ho, Wo = K.im2col(x, B, H, W, Cin, kh, kw, stride, pad, nchw)
-            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin)        # taps (kh, kw, c), like the columns
+            # taps (kh, kw, c), like the columns: a view when the weight already lives in that order (trainer.FlatParams keeps
+            # spatial convolution weights channels_last in its arena), a permuted copy otherwise
+            w2 = weight.permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin)
             if col.shape[1] != w2.shape[1]:
                 w2 = torch.nn.functional.pad(w2, (0, col.shape[1] - w2.shape[1]))
             w2 = w2.contiguous()
@@ -1367,9 +1385,12 @@ class Conv2dFn(torch.autograd.Function):
                 dx = dcol if direct else K.col2im(dcol, B, H, W, Cin, kh, kw, stride, pad)
                 if skip is not None:
                     dx = dx + skip
-        gw = _sink(weight) if direct else None
-        if gw is not None:                                                        # 1x1 convolution: dW += dY^T X straight into the arena,
-            _wgrad(dy, col, gw.view(Cout, Cin), 1.0, weight)                      # in groups of up to 8 products (flush_wgrads)
+        gw = _sink(weight)
+        if gw is not None and not direct:                                         # spatial taps: only when the arena holds them in
+            g2 = gw.permute(0, 2, 3, 1)                                           # the GEMM's (kh, kw, c) order, unpadded
+            gw = g2 if (g2.is_contiguous() and col.shape[1] == kh * kw * Cin) else None
+        if gw is not None:                                                        # dW += dY^T X straight into the arena,
+            _wgrad(dy, col, gw.view(Cout, kh * kw * Cin), 1.0, weight)            # in groups of up to 8 products (flush_wgrads)
             dw = None
         else:
             dw2 = K.gemm(dy, col, True, False)                                    # [Cout, Kpad]

@@ -81,9 +81,9 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=dtype, device=device)
         with torch.no_grad():
             for p, o in zip(params, self.offsets):
-                self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
-                p.data = self.flat[o:o + p.numel()].view(p.shape)
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                self._view(self.flat, o, p).copy_(p.data)
+                p.data = self._view(self.flat, o, p)
+                p.grad = self._view(self.grad, o, p)
                 p._ofa_grad = p.grad          # backward kernels accumulate straight into the arena (ops._sink)
         off_of = {id(p): o for p, o in zip(params, self.offsets)}
         for m in mhas:
@@ -113,11 +113,23 @@ class FlatParams:
                 for i, m in enumerate(cross):
                     m._cross_all = (pack, i)
 
+    @staticmethod
+    def _view(buf, o, p):
+        """Parameter p's window of an arena.  Spatial convolution weights ([Cout, Cin, kh, kw], kh * kw > 1) live in the arena in
+        the order the im2col GEMM reads them -- [Cout][kh][kw][Cin], i.e. torch's channels_last strides for the same logical
+        shape -- so the forward needs no permuted copy of the weight and the weight-gradient GEMM writes the arena directly
+        (state dicts hold values, not strides: checkpoints interchange unchanged)."""
+        n = p.numel()
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and (p.shape[1] * p.shape[2] * p.shape[3]) % 8 == 0:
+            Cout, Cin, kh, kw = p.shape
+            return buf[o:o + n].view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+        return buf[o:o + n].view(p.shape)
+
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-point it at the arena
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p.grad = self._view(self.grad, o, p)
                 p._ofa_grad = p.grad
 
 

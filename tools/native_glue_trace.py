@@ -3,8 +3,8 @@
 
     python tools/native_glue_trace.py [cfg2|cfg2b|cfg4]
 
-Runs two eager steps of the bench workload to settle caches, then one under torch.profiler with Python stacks, and prints, per
-(aten op, innermost ofasys_amd frame), the number of device kernels and their summed device time.  Kernels of the package's own
+Runs two eager steps of the bench workload to settle caches, then one under a TorchDispatchMode and prints, per (aten op, innermost
+ofasys_amd frame), how many times it ran (each is one ~3-7 us launch inside the step graph) with its most frequent operand shapes.  Kernels of the package's own
 library (ctypes launches) do not pass through aten and are not listed: this is the glue only."""
 import argparse
 import collections
@@ -34,29 +34,43 @@ def main():
     for _ in range(2):
         trainer.train_step([batch])
     torch.cuda.synchronize()
-    from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    # attribute every aten call that launches a device kernel to the innermost ofasys_amd frame: a TorchDispatchMode sees the
+    # forward and (through the autograd engine's thread-local state) the custom Functions' backward bodies
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    skip = ("aten.view", "aten._unsafe_view", "aten.as_strided", "aten.detach", "aten.alias", "aten.t.", "aten.transpose", "aten.permute",
+            "aten.expand", "aten.select", "aten.slice", "aten.unsqueeze", "aten.squeeze", "aten.empty", "aten.reshape", "aten.unbind",
+            "aten.split", "aten.stride", "aten.sym_", "aten.size", "aten.is_", "aten._local_scalar", "aten.lift", "aten.unflatten",
+            "aten.new_empty", "aten.empty_like", "aten.narrow", "aten.chunk", "aten.view_as", "aten.record_stream", "aten.resize_")
+    agg = collections.Counter()
+
+    class Tap(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not name.startswith(skip):
+                frame = "?"
+                for f in reversed(traceback.extract_stack(limit=40)):
+                    if "ofasys_amd/" in f.filename and "native_glue" not in f.filename:
+                        frame = f"{f.filename[f.filename.find('ofasys_amd/'):]}:{f.lineno} {f.name}"
+                        break
+                shape = ""
+                for x in list(args) + list((kwargs or {}).values()):
+                    if torch.is_tensor(x):
+                        shape = f"{tuple(x.shape)} {str(x.dtype).replace('torch.', '')}"
+                        break
+                agg[(name, frame, shape)] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Tap():
         trainer.train_step([batch])
-        torch.cuda.synchronize()
-    agg = collections.defaultdict(lambda: [0, 0.0, ""])
-    for e in prof.events():
-        ks = getattr(e, "kernels", None)
-        if not ks or not e.name.startswith("aten::"):
-            continue
-        frame = "?"
-        for f in (e.stack or []):
-            if "ofasys_amd/" in f or "bench.py" in f:
-                frame = f[f.find("ofasys_amd/"):] if "ofasys_amd/" in f else f
-                break
-        a = agg[(e.name, frame)]
-        a[0] += len(ks)
-        a[1] += sum(k.duration for k in ks)
-        a[2] = ks[0].name[:70]
-    tot_n = sum(a[0] for a in agg.values())
-    tot_t = sum(a[1] for a in agg.values())
-    print(f"# {workload}: {tot_n} torch-native kernels, {tot_t / 1e3:.3f} ms of device time in one eager step")
-    for (name, frame), (n, t, kn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{t:9.1f} us {n:5d}  {name:28s} {frame:70s} {kn}")
+    torch.cuda.synchronize()
+    per_site = collections.Counter()
+    for (name, frame, shape), n in agg.items():
+        per_site[(name, frame)] += n
+    print(f"# {workload}: {sum(agg.values())} aten calls with a device kernel in one eager train step (views / allocations excluded)")
+    for (name, frame), n in per_site.most_common(70):
+        shapes = sorted(((s, c) for (nm, fr, s), c in agg.items() if nm == name and fr == frame), key=lambda t: -t[1])[:3]
+        print(f"{n:5d}  {name:32s} {frame:64s} " + " | ".join(f"{c}x{s}" for s, c in shapes))
 
 
 if __name__ == "__main__":

@@ -192,26 +192,34 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, 
  * (adaptor/general.py:223-243; cross attention: model/transformer.py:280-299) + table_l[bucket[i][j]] on every slot's diagonal block
  * (general.py:265-280; text.py:101-104, image_resnet.py:116-128, video_image_sequence.py:187-204).  Position embeddings do not depend
  * on the batch row (text: arange; image / video: the patch grid), so that tensor is B copies of ONE [A, T, S] matrix per layer -- which
- * is what these entry points take: bias [heads, Tb, Sb] in `dtype` (dense), indexed by (head, query position, key position) for
- * every sample; in ragged mode by the position INSIDE the sample (so a batch whose valid positions are a prefix of each padded row
- * packs without touching the bias).  Tb >= T, Sb >= S.  Everything else as ofa_attn_fwd (seg != NULL: kpm must be NULL). */
-int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias, int Tb, int Sb, const uint8_t* kpm,
+ * is what these entry points take, indexed by (head, query position, key position) for every sample; in ragged mode by the position
+ * INSIDE the sample (so a batch whose valid positions are a prefix of each padded row packs without touching the bias).  Tb >= T,
+ * Sb >= S.  Everything else as ofa_attn_fwd (seg != NULL: kpm must be NULL).
+ *
+ * The kernels do not read the row-major [heads, Tb, Sb] tensor but its two TILE-SWIZZLED images written by ofa_bias_build (which
+ * also does the per-layer assembly of general.py:265-280): per head and 32 x 32 block, the 16 values MFMA lane l = (hi << 5 | i)
+ * holds -- element r: row image  bias[32 qt + i][32 kt + (r & 3) + 8 (r >> 2) + 4 hi]  at ((h * nqt + qt) * nkt + kt) * 1024 + 16 l + r,
+ * column image  bias[32 qt + (r & 3) + 8 (r >> 2) + 4 hi][32 kt + i]  at ((h * nkt + kt) * nqt + qt) * 1024 + 16 l + r,
+ * nqt = ceil(Tb / 32), nkt = ceil(Sb / 32), positions outside [Tb, Sb] zero.  A wave then fetches a block's bias as 2 KiB of
+ * consecutive bytes and feeds it to the score MFMAs as their initial accumulator. */
+int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias_swz_row, int Tb, int Sb, const uint8_t* kpm,
                        const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
                        int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q, int rows_k,
                        int dtype, void* stream);
-/* Backward (out != NULL always: delta is computed on the way in and written).  dbias_sum (optional): fp32 [heads, Tb, Sb] =
- * sum over the batch of dS -- the gradient of the shared bias.  The reference obtains it by materialising dS as [B*A, T, S] and
+/* Backward (out != NULL always: delta is computed on the way in and written).  dbias_sum (optional): [heads, Tb, Sb] in dbias_dtype
+ * (OFA_F32, or a 16-bit code: rounded once, from the fp32 sum) = sum over the batch of dS -- the gradient of the shared bias.  The reference obtains it by materialising dS as [B*A, T, S] and
  * reducing the expand; here a third kernel walks (a chunk of) the batch per [128 x 64] tile of one head, recomputes S and dP of that
  * tile (lse / delta are known) and accumulates dS in registers: no [B*A,T,S] tensor, no atomics, bitwise reproducible.
+ * bias: the row-major [heads, Tb, Sb] tensor in `dtype` (read once per tile by that third kernel; may be NULL when dbias_sum is).
  * ws / ws_bytes: see ofa_attn_sbias_chunks. */
-int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
-                       const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out,
-                       void* dq, void* dk, void* dv, float* dbias_sum, float* ws, int64_t ws_bytes, int B, int heads, int T, int S,
-                       int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
-                       int rows_k, int dtype, void* stream);
+int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, const void* bias_swz_row,
+                       const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype,
+                       const float* lse, float* delta, const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype,
+                       float* ws, int64_t ws_bytes, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                       int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 /* Batch chunks the dS-sum kernel of ofa_attn_sbias_bwd cuts B samples into (short sequences: the [128 x 64] tiles of the heads alone
- * would leave the chip idle).  1: it writes dbias_sum itself, ws may be NULL.  n > 1: ws must hold n * heads * Tb * Sb floats (the
- * chunks' partial sums, folded in chunk order by ofa_fold_batched inside the call). */
+ * would leave the chip idle).  1 and dbias_dtype == OFA_F32: it writes dbias_sum itself, ws may be NULL.  Otherwise ws must hold
+ * n * heads * Tb * Sb floats (the chunks' partial sums, folded in chunk order -- and cast -- by ofa_fold_batched inside the call). */
 int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so
  * d c[h] = sum_{b,t} rowsum(dO*O)[b,h,t] / c[h]) from the delta rows of
@@ -286,6 +294,20 @@ int ofa_head_sum_f32(const float* x, float* out, int B, int heads, int T, int ld
 
 /* ---- attention-bias assembly (adaptor/general.py:265-280): bias [B,A,T,T] (in place) gets values [n,n,A] added on
  * the diagonal block [start, start+n)^2 of every (b,a); the gradient reduces that block over the batch. */
+/* Per-layer assembly of the batch-shared position bias, general.py:265-280 on ONE [heads, Tb, Sb] matrix:
+ *   out = abs_bias (NULL: zeros);  out[:, s:s+n, s:s+n] += values_k[i][j][h]  for each slot k (values_k: [n, n, heads], `dtype`)
+ * written as the row-major tensor (out, optional) and as the two swizzled images the ofa_attn_sbias_* kernels read (swz_row,
+ * swz_col: ofa_bias_swz_elems(heads, Tb, Sb) elements each, 16-byte aligned; layout: see ofa_attn_sbias_fwd).  16-bit dtypes only;
+ * slot blocks need Tb == Sb; heads <= 24. */
+typedef struct ofa_bias_slots {
+  const void* values[8];
+  int32_t start[8];
+  int32_t n[8];
+  int32_t count;
+} ofa_bias_slots;
+int64_t ofa_bias_swz_elems(int heads, int Tb, int Sb);
+int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots, void* out, void* swz_row, void* swz_col, int heads, int Tb,
+                   int Sb, int dtype, void* stream);
 int ofa_bias_block_add(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype, void* stream);
 int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
 

@@ -154,8 +154,8 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 b = mo.self_attn_bias[idx] if mo.self_attn_bias else None
                 # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values; take the values back
                 values.append(_unexpand(b))
-            b = ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values)
-            output.self_attn_bias.append(ops.SharedBias(b[0]) if shared else b)
+            b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values)
+            output.self_attn_bias.append(ops.SharedBias(b[0], (swz_row, swz_col) if swz_row is not None else None) if shared else b)
         return output
 
     def upgrade_state_dict_named(self, state_dict, name):

@@ -56,6 +56,11 @@ struct AttnL {
   // (bias_ld = S, bias_hs = T*S, bias_bs = A*T*S); a POSITION bias is the same for every sample (positions do not depend on the
   // batch row), so it arrives once -- [A, Tb, Sb], bias_bs = 0 -- indexed by the position inside the sample (also in ragged mode)
   int64_t bias_ld, bias_hs, bias_bs;
+  // the batch-shared position bias once more, in the two tile-swizzled images the forward / dQ kernels (bias_sr: a lane's 16 keys
+  // of its query row) and the dK/dV kernel (bias_sc: a lane's 16 query rows of its key) read with two 16-byte loads per lane and
+  // 32 x 32 block: see BiasSwz / csrc/bias.hip bias_build_kernel.  bias_nqt / bias_nkt: 32-row / 32-column tiles per head.
+  const bf16_t* bias_sr; const bf16_t* bias_sc;
+  int bias_nqt, bias_nkt;
 };
 
 // Ragged mode: the rows between sample b's last row and sample b+1's first (alignment filler, and behind the last sample the
@@ -225,6 +230,32 @@ struct BiasCol {
   }
 };
 
+// BIAS mode 2 -- the batch-shared position bias in a tile-swizzled image: the 16 values lane l = (hi << 5 | i) needs for the 32 x 32
+// block (qt, kt) are 32 contiguous bytes at ((qt * nkt + kt) * 64 + l) * 16 (row image; the column image swaps the roles), written
+// once per layer by bias_build_kernel.  A wave fetches a block's bias as 2 KiB of consecutive bytes (the row-major tensor cost it
+// 32 cache lines per load instruction), and the values go in as the INITIAL ACCUMULATOR of the score MFMAs -- times 1 / scale, the
+// scale rides in the exponent's multiply-add as in the bias-free kernels -- so a biased block runs the bias-free arithmetic.
+struct BiasSwz {
+  uint4 raw[2];
+  __device__ __forceinline__ void issue(const bf16_t* lane_base, int blk) {
+    const uint4* p = reinterpret_cast<const uint4*>(lane_base + (int64_t)blk * 1024);
+    raw[0] = p[0];
+    raw[1] = p[1];
+  }
+  template <bool F16> __device__ __forceinline__ void take(float inv_scale, float (&b)[16]) const {
+    const uint32_t w[8] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      b[2 * j] = lo16<F16>(w[j]) * inv_scale;
+      b[2 * j + 1] = hi16<F16>(w[j]) * inv_scale;
+    }
+  }
+};
+__device__ __forceinline__ void init16f(f32x16& a, const float (&b)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = b[r];
+}
+
 // additive bias of the 16 scores a lane holds for a 32-key block (keys key0 + crowl(r, hi)), pre-multiplied by log2(e)
 template <bool F16>
 __device__ __forceinline__ void bias16(const bf16_t* brow, int key0, int S, int hi, float (&b)[16], bool aligned) {
@@ -353,12 +384,12 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int BUF, bool BIAS, bool F16>   // BUF selects the double-buffer half at compile time (immediates)
+template <int BUF, int BIAS, bool F16>   // BUF selects the double-buffer half at compile time (immediates); BIAS: 0 none, 1 dense, 2 swizzled
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                           f32x16 (&ot)[2], float& m_run, float& l_run, int key0, int q0, int qi, int hi,
                                           uint32_t dead_now, const float (&bz)[16], float sc ATT_FS_ARG) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
-  constexpr bool has_bias = BIAS;
+  constexpr bool has_bias = BIAS == 1;
   ATT_FS(0, m_run);
   u64x2 kf[4];
   rd128<KOFF>(kf[0], ta.km[0]);
@@ -373,7 +404,8 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   rdtr<VOFF, 1>(vf[1][0], ta.tr[0], trx[0]);
   rdtr<VOFF, 1>(vf[1][1], ta.tr[1], trx[1]);
   f32x16 st;
-  zero16f(st);
+  if constexpr (BIAS == 2) init16f(st, bz);
+  else zero16f(st);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) st = ATT_MFMA(kf[kk], qf[kk], st);
   float s[16];
@@ -442,7 +474,7 @@ __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, co
   ATT_FS(7, l_run);
 }
 
-template <bool BIAS, bool F16>
+template <int BIAS, bool F16>
 __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][K tile | V tile], 4 KiB each
@@ -475,7 +507,13 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   for (int kk = 0; kk < 4; ++kk) qf[kk] = ld16(qp + kk * 16);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* brow = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
+  const bf16_t* brow = BIAS == 1 ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
+  const bf16_t* bswz = nullptr;                          // BIAS 2: this lane's 16 values of block (q0 / 32, 0) of head h
+  if constexpr (BIAS == 2) {
+    const int qt = (q0 >> 5) < a.bias_nqt ? (q0 >> 5) : a.bias_nqt - 1;
+    bswz = a.bias_sr + (((int64_t)h * a.bias_nqt + qt) * a.bias_nkt * 64 + lane) * 16;
+  }
+  const float inv_scale = 1.0f / a.scale;
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
@@ -494,7 +532,9 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  BiasSwz spre;
+  if constexpr (BIAS == 1) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  if constexpr (BIAS == 2) spre.issue(bswz, 0);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
@@ -507,15 +547,18 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
+      const BiasSwz scur = spre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 1) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 2) spre.issue(bswz, kb + 1);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        if constexpr (BIAS == 1) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        if constexpr (BIAS == 2) scur.template take<F16>(inv_scale, bz);
         fwd_block<0, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, kb * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(kb == 4 && wave_u == 0));
       }
       ATT_SYNC();
@@ -526,15 +569,18 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
+      const BiasSwz scur = spre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 1) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 2) spre.issue(bswz, kb + 2);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        if constexpr (BIAS == 1) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        if constexpr (BIAS == 2) scur.template take<F16>(inv_scale, bz);
         fwd_block<1, BIAS, F16>(a, ta, trx, qf, ot, m_run, l_run, (kb + 1) * 32, q0, qi, hi, dead_now, bz, sc ATT_FS_PASS(false));
       }
       ATT_SYNC();
@@ -561,26 +607,30 @@ __device__ __forceinline__ void attn_fwd_body(AttnL a) {
 }
 
 // three waves per SIMD for the bias-free form (its registers fit 168); the biased one keeps two
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<false, false>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<true, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_f16_lds_kernel(AttnL a) { attn_fwd_body<false, true>(a); }
-__global__ __launch_bounds__(256) void attn_fwd_bias_f16_lds_kernel(AttnL a) { attn_fwd_body<true, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_lds_kernel(AttnL a) { attn_fwd_body<0, false>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_lds_kernel(AttnL a) { attn_fwd_body<1, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_f16_lds_kernel(AttnL a) { attn_fwd_body<0, true>(a); }
+__global__ __launch_bounds__(256) void attn_fwd_bias_f16_lds_kernel(AttnL a) { attn_fwd_body<1, true>(a); }
+// the batch-shared position bias (swizzled image as the score accumulators' initial value): the bias-free arithmetic + two loads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_sbias_lds_kernel(AttnL a) { attn_fwd_body<2, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_sbias_f16_lds_kernel(AttnL a) { attn_fwd_body<2, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int BUF, bool BIAS, bool F16>
+template <int BUF, int BIAS, bool F16>
 __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
                                          const bf16x8 (&dof)[4], f32x16 (&dqt)[2], int key0, int q0, int qi, int hi,
                                          uint32_t dead_now, const float (&bz)[16], bf16_t* dbrow, float sc, float lse_q,
                                          float delta_q, float c) {
   constexpr int KOFF = BUF * 2 * TILE_BYTES, VOFF = KOFF + TILE_BYTES;
-  constexpr bool has_bias = BIAS;
+  constexpr bool has_bias = BIAS == 1;
   u64x2 kf[4], vf[4];
   rd128<KOFF>(kf[0], ta.km[0]); rd128<KOFF>(kf[1], ta.km[1]); rd128<KOFF>(kf[2], ta.km[2]); rd128<KOFF>(kf[3], ta.km[3]);
   rd128<VOFF>(vf[0], ta.km[0]); rd128<VOFF>(vf[1], ta.km[1]); rd128<VOFF>(vf[2], ta.km[2]); rd128<VOFF>(vf[3], ta.km[3]);
   ATT_WAIT4(kf[0], kf[1], kf[2], kf[3]);
   ATT_WAIT4(vf[0], vf[1], vf[2], vf[3]);
   f32x16 st, dp;
-  zero16f(st);
+  if constexpr (BIAS == 2) init16f(st, bz);
+  else zero16f(st);
   zero16f(dp);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -613,7 +663,7 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
       ds[r] = p * (dp[r] * c - delta_q);
     }
   }
-  if (BIAS && dbrow && qi < a.T) {
+  if (BIAS == 1 && dbrow && qi < a.T) {
     if ((a.S & 3) == 0 && key0 + 32 <= a.S) {             // 4 consecutive keys per register quad: 8-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
@@ -635,7 +685,7 @@ __device__ __forceinline__ void dq_block(const AttnL& a, const TileAddr& ta, con
   }
 }
 
-template <bool BIAS, bool F16>
+template <int BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
@@ -685,8 +735,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   const float c = head_scale(a, h);
   const bf16_t* kbase = a.k + (int64_t)b * a.S * a.ldk;
   const bf16_t* vbase = a.v + (int64_t)b * a.S * a.ldk;
-  const bf16_t* brow = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
-  bf16_t* dbrow = (BIAS && a.dbias) ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;      // (dense [B*A, T, S] only)
+  const bf16_t* brow = BIAS == 1 ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + (int64_t)qrow * a.bias_ld : nullptr;
+  bf16_t* dbrow = (BIAS == 1 && a.dbias) ? a.dbias + ((int64_t)bh * a.T + qrow) * a.S : nullptr;      // (dense [B*A, T, S] only)
+  const bf16_t* bswz = nullptr;                          // BIAS 2: this lane's 16 values of block (q0 / 32, 0) of head h
+  if constexpr (BIAS == 2) {
+    const int qt = (q0 >> 5) < a.bias_nqt ? (q0 >> 5) : a.bias_nqt - 1;
+    bswz = a.bias_sr + (((int64_t)h * a.bias_nqt + qt) * a.bias_nkt * 64 + lane) * 16;
+  }
+  const float inv_scale = 1.0f / a.scale;
   const uint8_t* kp = a.kpm ? a.kpm + (int64_t)b * a.S : nullptr;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
@@ -705,7 +761,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   }
   int kflag = dead_flag(kp, 0, a.S, i);
   BiasRow bpre;
-  if constexpr (BIAS) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  BiasSwz spre;
+  if constexpr (BIAS == 1) bpre.issue(brow, 0, a.S, hi, a.bias_ld);
+  if constexpr (BIAS == 2) spre.issue(bswz, 0);
   tile_dma(kbase, a.ldk, 0, a.S, h * HD, lds, tid, wave_u);
   tile_dma(vbase, a.ldk, 0, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
   ATT_SYNC();
@@ -716,15 +774,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
+      const BiasSwz scur = spre;
       if (kb + 1 < nkb) {
         kflag = dead_flag(kp, (kb + 1) * 32, a.S, i);
-        if constexpr (BIAS) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 1) bpre.issue(brow, (kb + 1) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 2) spre.issue(bswz, kb + 1);
         tile_dma(kbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 1) * 32, a.S, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && kb * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        if constexpr (BIAS == 1) bias_row_take<F16>(bcur, brow, kb * 32, a.S, hi, bz);
+        if constexpr (BIAS == 2) scur.template take<F16>(inv_scale, bz);
         dq_block<0, BIAS, F16>(a, ta, trx, qf, dof, dqt, kb * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb;
       }
@@ -733,15 +794,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     if (kb + 1 < nkb) {
       const uint32_t dead_now = dead_ballot(kflag);
       const BiasRow bcur = bpre;
+      const BiasSwz scur = spre;
       if (kb + 2 < nkb) {
         kflag = dead_flag(kp, (kb + 2) * 32, a.S, i);
-        if constexpr (BIAS) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 1) bpre.issue(brow, (kb + 2) * 32, a.S, hi, a.bias_ld);
+        if constexpr (BIAS == 2) spre.issue(bswz, kb + 2);
         tile_dma(kbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds, tid, wave_u);
         tile_dma(vbase, a.ldk, (kb + 2) * 32, a.S, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
       }
       const bool need = live_wave && !(a.causal && (kb + 1) * 32 > q0 + 31);
       if (need) {
-        if constexpr (BIAS) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        if constexpr (BIAS == 1) bias_row_take<F16>(bcur, brow, (kb + 1) * 32, a.S, hi, bz);
+        if constexpr (BIAS == 2) scur.template take<F16>(inv_scale, bz);
         dq_block<1, BIAS, F16>(a, ta, trx, qf, dof, dqt, (kb + 1) * 32, q0, qi, hi, dead_now, bz, dbrow, sc, lse_q, delta_q, c);
         my_last = kb + 1;
       }
@@ -765,10 +829,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<false, false>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<true, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<false, true>(a); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<true, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_lds_kernel(AttnL a) { attn_bwd_dq_body<0, false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_lds_kernel(AttnL a) { attn_bwd_dq_body<1, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bwd_dq_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<0, true>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<1, true>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_sbias_lds_kernel(AttnL a) { attn_bwd_dq_body<2, false>(a); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_sbias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<2, true>(a); }
+// (three waves per SIMD cost this form 16 spilled registers and measured the same: 302 vs 300 us backward at 32 x 12 x 448^2)
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Register budget.  Round 1's form of this kernel held 400 registers (one wave per SIMD: nothing ran while a wave waited for
@@ -786,11 +853,11 @@ __device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const
   }
 }
 
-template <int BUF, bool BIAS, bool F16>
+template <int BUF, int BIAS, bool F16>
 __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, uint32_t stat_addr,
                                           const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0,
                                           int key0, int ki, int hi, bool key_dead, float live, const float (&bz)[16], float sc,
-                                          float c) {
+                                          float c, const BiasSwz& sraw, float inv_scale) {
   constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES, SOFF = BUF * STAT_BYTES;
   u64x2 qf[4], dof[4];
   rd128<QOFF>(qf[0], ta.km[0]); rd128<QOFF>(qf[1], ta.km[1]); rd128<QOFF>(qf[2], ta.km[2]); rd128<QOFF>(qf[3], ta.km[3]);
@@ -829,14 +896,20 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     lv[4 * g4] = l4.x; lv[4 * g4 + 1] = l4.y; lv[4 * g4 + 2] = l4.z; lv[4 * g4 + 3] = l4.w;
     dv16[4 * g4] = d4.x; dv16[4 * g4 + 1] = d4.y; dv16[4 * g4 + 2] = d4.z; dv16[4 * g4 + 3] = d4.w;
   }
+  if constexpr (BIAS == 2) {                // swizzled shared bias: decoded only now (this kernel is at its register limit while the
+    float bs[16];                           // row-major fragments are live) and added onto the raw scores, times 1 / scale
+    sraw.template take<F16>(inv_scale, bs);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] += bs[r];
+  }
   float p[16], ds[16];
-  const bool general = BIAS || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
+  const bool general = BIAS == 1 || (q0 + 32 > a.T) || (a.causal && (key0 + 31 > q0));
   if (general) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = q0 + crowl(r, hi);
       float t = st[r] * sc;
-      if (BIAS) t += bz[r];
+      if (BIAS == 1) t += bz[r];
       bool dead = key_dead || q >= a.T;
       if (a.causal) dead |= ki > q;
       const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(t - lv[r]);
@@ -864,7 +937,7 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
   }
 }
 
-template <bool BIAS, bool F16>
+template <int BIAS, bool F16>
 __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][Q tile | dO tile], then [2][lse | delta]
@@ -898,7 +971,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const bf16_t* dobase = a.dout + (int64_t)b * a.T * a.ldo;
   const float* lse_bh = a.lse + (int64_t)bh * a.Tpad;
   const float* delta_bh = a.delta + (int64_t)bh * a.Tpad;
-  const bf16_t* bcol = BIAS ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + krow : nullptr;
+  const bf16_t* bcol = BIAS == 1 ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + krow : nullptr;
+  const bf16_t* bswz = nullptr;                          // BIAS 2: this lane's 16 values of block (0, key0 / 32) of head h (column image)
+  if constexpr (BIAS == 2) {
+    const int kt = (key0 >> 5) < a.bias_nkt ? (key0 >> 5) : a.bias_nkt - 1;
+    bswz = a.bias_sc + (((int64_t)h * a.bias_nkt + kt) * a.bias_nqt * 64 + lane) * 16;
+  }
+  const float inv_scale = 1.0f / a.scale;
   const float sc = a.scale * LOG2E;
   TileAddr ta;
   ta.init((uint32_t)(uintptr_t)smem, lane);
@@ -910,10 +989,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const int nqb = (a.T + 31) / 32;
   const int qb_first = a.causal ? kb0 / 32 : 0;          // the workgroup starts where its FIRST wave needs
   const bool live_wave = key0 < a.S;
-  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (BIAS only)
+  BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (BIAS 1 only)
+  BiasSwz sA, sB;                                        // (BIAS 2)
   float bz[16];
   if (qb_first < nqb) {
-    if constexpr (BIAS) bA.issue(bcol, qb_first * 32, a.T, a.bias_ld, hi);
+    if constexpr (BIAS == 1) bA.issue(bcol, qb_first * 32, a.T, a.bias_ld, hi);
+    if constexpr (BIAS == 2) sA.issue(bswz, qb_first);
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
     stat_dma(lse_bh, delta_bh, qb_first * 32, lds_stat, lane, wave_u);
@@ -922,29 +1003,31 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   for (int qb = qb_first; qb < nqb; qb += 2) {
     {
       if (qb + 1 < nqb) {
-        if constexpr (BIAS) bB.issue(bcol, (qb + 1) * 32, a.T, a.bias_ld, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
+        if constexpr (BIAS == 1) bB.issue(bcol, (qb + 1) * 32, a.T, a.bias_ld, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
+        if constexpr (BIAS == 2) sB.issue(bswz, qb + 1);
         tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
         stat_dma(lse_bh, delta_bh, (qb + 1) * 32, lds_stat + STAT_BYTES, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
-        if constexpr (BIAS) bA.template take<F16>(bcol, bz);
-        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c);
+        if constexpr (BIAS == 1) bA.template take<F16>(bcol, bz);
+        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c, sA, inv_scale);
       }
       ATT_SYNC();
     }
     if (qb + 1 < nqb) {
       if (qb + 2 < nqb) {
-        if constexpr (BIAS) bA.issue(bcol, (qb + 2) * 32, a.T, a.bias_ld, hi);
+        if constexpr (BIAS == 1) bA.issue(bcol, (qb + 2) * 32, a.T, a.bias_ld, hi);
+        if constexpr (BIAS == 2) sA.issue(bswz, qb + 2);
         tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
         stat_dma(lse_bh, delta_bh, (qb + 2) * 32, lds_stat, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {
-        if constexpr (BIAS) bB.template take<F16>(bcol, bz);
-        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c);
+        if constexpr (BIAS == 1) bB.template take<F16>(bcol, bz);
+        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c, sB, inv_scale);
       }
       ATT_SYNC();
     }
@@ -966,10 +1049,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
 
 // two waves per SIMD for both forms: the bias-free one fits 256 registers; the biased one spills 16 and is still 16 % faster that way
 // (tools/attn_bias_bench.py, 448 x 448: backward 409 -> 343 us)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<false, true>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<true, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_lds_kernel(AttnL a) { attn_bwd_dkv_body<0, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<0, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, true>(a); }
 
 
 // ------------------------------------------------------------------------------------------------ backward: sum over the batch of dS
@@ -1238,37 +1323,38 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
 }
 
 
-// ---- batch-SHARED position bias [heads, Tb, Sb]: the dense-bias kernels with a zero batch stride + the batch-summed dS kernel
-static int sbias_check(const void* bias, int Tb, int Sb, int T, int S, const int32_t* seg) {
-  OFA_REQUIRE(bias && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "attn_sbias: the bias [heads, Tb, Sb] is required (Tb=%d Sb=%d)", Tb, Sb);
+// ---- batch-SHARED position bias [heads, Tb, Sb]: the swizzled-image kernels (BIAS 2) + the batch-summed dS kernel
+static int sbias_check(const void* bias_sr, int Tb, int Sb, int T, int S, const int32_t* seg) {
+  OFA_REQUIRE(bias_sr && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "attn_sbias: the swizzled bias image of [heads, Tb, Sb] is required (Tb=%d Sb=%d)", Tb, Sb);
+  OFA_REQUIRE(!((uintptr_t)bias_sr & 15), OFA_ERR_INVALID, "attn_sbias: the swizzled bias image must be 16-byte aligned");
   OFA_REQUIRE(Tb >= T && Sb >= S, OFA_ERR_INVALID, "attn_sbias: the bias covers %d x %d positions, the call needs %d x %d", Tb, Sb, T, S);
   (void)seg;
   return 0;
 }
 
-extern "C" int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias, int Tb, int Sb, const uint8_t* kpm,
-                                  const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S,
-                                  int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg,
-                                  int rows_q, int rows_k, int dtype, void* stream) {
+// bias_swz_row: the row image of the [heads, Tb, Sb] bias written by ofa_bias_build (ofa_bias_swz_elems elements)
+extern "C" int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, const void* bias_swz_row, int Tb, int Sb, const uint8_t* kpm,
+                                  const void* c_attn, int c_attn_dtype, void* out, float* lse, int B, int heads, int T, int S, int Tpad,
+                                  int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
+                                  int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
-  if (int rc = sbias_check(bias, Tb, Sb, T, S, seg)) return rc;
+  if (int rc = sbias_check(bias_swz_row, Tb, Sb, T, S, seg)) return rc;
   OFA_REQUIRE(q && k && v && out && lse, OFA_ERR_INVALID, "attn_sbias_fwd: null pointer");
   OFA_REQUIRE(scale > 0.f, OFA_ERR_INVALID, "attn_sbias_fwd: the score scale must be positive, got %g", (double)scale);
   OFA_REQUIRE(!seg || (!kpm && !((uintptr_t)seg & 15) && rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID,
               "attn_sbias_fwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
   OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_sbias_fwd: bad c_attn dtype %d", c_attn_dtype);
   AttnL a{};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.bias = (const bf16_t*)bias; a.kpm = kpm;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kpm = kpm;
   a.c_attn = c_attn; a.c_dt = c_attn_dtype; a.out = (bf16_t*)out; a.lse = lse; a.B = B; a.heads = heads; a.T = T; a.S = S; a.Tpad = Tpad;
   a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg; a.rows_q = rows_q; a.rows_k = rows_k;
-  a.bias_ld = Sb; a.bias_hs = (int64_t)Tb * Sb; a.bias_bs = 0;
+  a.bias_sr = (const bf16_t*)bias_swz_row; a.bias_nqt = cdiv(Tb, 32); a.bias_nkt = cdiv(Sb, 32);
   const dim3 grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  auto kern = dtype == OFA_F16 ? attn_fwd_bias_f16_lds_kernel : attn_fwd_bias_lds_kernel;
+  auto kern = dtype == OFA_F16 ? attn_fwd_sbias_f16_lds_kernel : attn_fwd_sbias_lds_kernel;
   hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, a);
   return check_launch("attn_sbias_fwd");
 }
 
-// batch chunks of the dS-sum kernel: enough workgroups to fill 256 CUs a few times over, never more chunks than samples
 extern "C" int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb) {
   const int64_t tiles = (int64_t)cdiv(Sb, 64) * cdiv(Tb, 128) * heads;
   int64_t n = (1024 + tiles - 1) / tiles;
@@ -1277,13 +1363,17 @@ extern "C" int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb) {
   return cdiv(B, bper);
 }
 
-extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias, int Tb, int Sb,
-                                  const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
-                                  const void* out, void* dq, void* dk, void* dv, float* dbias_sum, float* ws, int64_t ws_bytes, int B,
+// bias: the row-major [heads, Tb, Sb] tensor (read by the batch-sum kernel only: may be NULL when dbias_sum is);
+// bias_swz_row / bias_swz_col: its two swizzled images (ofa_bias_build)
+extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+                                  const void* bias_swz_row, const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                                  const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype, float* ws, int64_t ws_bytes, int B,
                                   int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
                                   const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
-  if (int rc = sbias_check(bias, Tb, Sb, T, S, seg)) return rc;
+  if (int rc = sbias_check(bias_swz_row, Tb, Sb, T, S, seg)) return rc;
+  OFA_REQUIRE(bias_swz_col && !((uintptr_t)bias_swz_col & 15) && (bias || !dbias_sum), OFA_ERR_INVALID,
+              "attn_sbias_bwd: the column image of the bias (16-byte aligned) and, for dbias_sum, the row-major tensor are required");
   OFA_REQUIRE(!seg || (!kpm && !((uintptr_t)seg & 15) && rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID,
               "attn_sbias_bwd: the ragged (seg) mode takes no key-padding mask, a 16-byte aligned table, rows_q / rows_k and Tpad >= rows_q");
   OFA_REQUIRE(OFA_DT_OK(c_attn_dtype), OFA_ERR_INVALID, "attn_sbias_bwd: bad c_attn dtype %d", c_attn_dtype);
@@ -1296,33 +1386,36 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
   a.S = S; a.Tpad = Tpad; a.ldq = ldq; a.ldk = ldk; a.ldo = ldo; a.scale = scale; a.causal = causal; a.seg = seg;
   a.rows_q = rows_q; a.rows_k = rows_k;
   a.bias_ld = Sb; a.bias_hs = (int64_t)Tb * Sb; a.bias_bs = 0;
+  a.bias_sr = (const bf16_t*)bias_swz_row; a.bias_sc = (const bf16_t*)bias_swz_col; a.bias_nqt = cdiv(Tb, 32); a.bias_nkt = cdiv(Sb, 32);
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
-  auto dq_kern = dtype == OFA_F16 ? attn_bwd_dq_bias_f16_lds_kernel : attn_bwd_dq_bias_lds_kernel;
+  auto dq_kern = dtype == OFA_F16 ? attn_bwd_dq_sbias_f16_lds_kernel : attn_bwd_dq_sbias_lds_kernel;
   hipLaunchKernelGGL(dq_kern, q_grid, dim3(256), 4 * TILE_BYTES, st, a);
   int rc = check_launch("attn_sbias_bwd_dq");
   if (rc) return rc;
   const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);
-  auto kv_kern = dtype == OFA_F16 ? attn_bwd_dkv_bias_f16_lds_kernel : attn_bwd_dkv_bias_lds_kernel;
+  auto kv_kern = dtype == OFA_F16 ? attn_bwd_dkv_sbias_f16_lds_kernel : attn_bwd_dkv_sbias_lds_kernel;
   hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
   rc = check_launch("attn_sbias_bwd_dkv");
   if (rc || !dbias_sum) return rc;
   // G = sum_b dS (after the dQ kernel: it wrote delta): [128 x 64] tiles of one head; the batch is cut into chunks when the tiles
   // alone would leave the chip idle, the chunks' fp32 partials are folded in chunk order
   const int nchunk = ofa_attn_sbias_chunks(B, heads, Tb, Sb);
-  OFA_REQUIRE(nchunk == 1 || (ws && ws_bytes >= (int64_t)nchunk * heads * Tb * Sb * 4), OFA_ERR_INVALID,
+  OFA_REQUIRE(OFA_DT_OK(dbias_dtype), OFA_ERR_INVALID, "attn_sbias_bwd: bad dbias dtype %d", dbias_dtype);
+  const bool direct = nchunk == 1 && dbias_dtype == OFA_F32;      // the kernel writes dbias_sum itself; otherwise the fold (+ cast) does
+  OFA_REQUIRE(direct || (ws && ws_bytes >= (int64_t)nchunk * heads * Tb * Sb * 4), OFA_ERR_INVALID,
               "attn_sbias_bwd: the batch-sum kernel needs %lld bytes of workspace for %d chunks", (long long)nchunk * heads * Tb * Sb * 4, nchunk);
   const int bper = cdiv(B, nchunk);
   {
     const dim3 g(cdiv(Sb, 64), cdiv(Tb, 128), heads * nchunk);
     auto kn = dtype == OFA_F16 ? attn_bwd_dsum_f16_kernel : attn_bwd_dsum_kernel;
-    float* dst = nchunk == 1 ? dbias_sum : ws;
+    float* dst = direct ? (float*)dbias_sum : ws;
     const size_t lds = 8 * TILE_BYTES + (size_t)bper * 16;
     OFA_REQUIRE(lds <= 64 * 1024, OFA_ERR_UNSUPPORTED, "attn_sbias_bwd: %d samples per chunk exceed the batch-sum kernel's geometry table", bper);
     hipLaunchKernelGGL(kn, g, dim3(256), lds, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
     rc = check_launch("attn_sbias_bwd_dsum");
-    if (rc || nchunk == 1) return rc;
-    ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, OFA_F32};
+    if (rc || direct) return rc;
+    ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, dbias_dtype};
     return ofa_fold_batched(&job, 1, stream);
   }
 }

@@ -36,8 +36,140 @@ __global__ __launch_bounds__(256) void bias_block_grad_kernel(const T* __restric
   }
 }
 
+// ---- the batch-shared position bias of one layer: assembly + the two swizzled images (include/ofasys_amd.h, ofa_bias_build)
+// One workgroup per 32 x 32 block (qt, kt), all heads: phase 1 gathers abs[h][q][k] (+ the slot's values[q - s][k - s][h] on a
+// diagonal block) into an LDS tile per head -- one rounding to the 16-bit type, as torch's in-place add on the bias tensor -- and
+// writes the row-major tensor; phase 2 writes each head's tile in the row image (lane (i, hi): row i, columns crowl(r, hi)) and the
+// column image (lane (i, hi): column i, rows crowl(r, hi)), 8 bytes per thread and store.
+struct BiasSlotsDev {
+  const void* values[8];
+  int start[8];
+  int n[8];
+  int count;
+};
+constexpr int BIAS_TP = 40;                                  // tile row pitch in elements: 80 bytes (16-byte aligned chunks)
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ abs_bias, BiasSlotsDev slots, T* __restrict__ out,
+                                                         T* __restrict__ swz_row, T* __restrict__ swz_col, int A, int Tb, int Sb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bias_smem[];
+  T* tile = reinterpret_cast<T*>(bias_smem);                // [A][32][BIAS_TP]
+  const int kt = blockIdx.x, qt = blockIdx.y;
+  const int nqt = gridDim.y, nkt = gridDim.x;
+  const int q0 = qt * 32, k0 = kt * 32;
+  const bool vec = (Sb & 7) == 0 && k0 + 32 <= Sb;           // whole 16-byte chunks of the row-major rows
+  // phase 1a: the abs-pos block of every head -> LDS, 8 columns per thread and trip (zeros outside [Tb, Sb] or without abs_bias)
+  for (int c = threadIdx.x; c < A * 128; c += 256) {
+    const int kc = (c & 3) * 8, qr = (c >> 2) & 31, h = c >> 7;
+    const int q = q0 + qr;
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (abs_bias && q < Tb) {
+      const T* src = abs_bias + ((int64_t)h * Tb + q) * Sb + k0 + kc;
+      if (vec) {
+        w = *reinterpret_cast<const uint4*>(src);
+      } else {
+        T e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          T z;
+          st1<T>(&z, 0.f);
+          e[j] = k0 + kc + j < Sb ? src[j] : z;
+        }
+        __builtin_memcpy(&w, e, 16);
+      }
+    }
+    *reinterpret_cast<uint4*>(tile + (h * 32 + qr) * BIAS_TP + kc) = w;
+  }
+  // phase 1b: a slot's values [n][n][A] on its diagonal block: a thread reads the A heads of one position (contiguous) and
+  // adds them onto the tiles -- one rounding to the 16-bit type, as torch's in-place add on the bias tensor
+  if (slots.count > 0) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int kc = e & 31, qr = e >> 5;
+      const int q = q0 + qr, k = k0 + kc;
+      if (q >= Tb || k >= Sb) continue;
+      for (int s = 0; s < slots.count; ++s) {
+        const int i = q - slots.start[s], j = k - slots.start[s], n = slots.n[s];
+        if (i < 0 || j < 0 || i >= n || j >= n) continue;
+        const T* vp = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)i * n + j) * A;
+        for (int h = 0; h < A; ++h) {
+          T* t = tile + (h * 32 + qr) * BIAS_TP + kc;
+          st1<T>(t, ld1<T>(t) + ld1<T>(vp + h));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // phase 1c: the row-major tensor
+  if (out) {
+    for (int c = threadIdx.x; c < A * 128; c += 256) {
+      const int kc = (c & 3) * 8, qr = (c >> 2) & 31, h = c >> 7;
+      const int q = q0 + qr;
+      if (q >= Tb) continue;
+      const T* src = tile + (h * 32 + qr) * BIAS_TP + kc;
+      T* dst = out + ((int64_t)h * Tb + q) * Sb + k0 + kc;
+      if (vec) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      } else {
+        for (int j = 0; j < 8; ++j)
+          if (k0 + kc + j < Sb) dst[j] = src[j];
+      }
+    }
+  }
+  // phase 2: the two images, 8 bytes per thread and store
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;    // lane of the MFMA layout; g: register quad r = 4g .. 4g + 3
+  const int i = l & 31, hi = l >> 5;
+  const int c0 = 8 * g + 4 * hi;                            // crowl(4g + e, hi) = e + 8g + 4hi
+  for (int h = 0; h < A; ++h) {
+    const T* th = tile + h * 32 * BIAS_TP;
+    T cv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cv[e] = th[(c0 + e) * BIAS_TP + i];
+    T* pr = swz_row + ((((int64_t)h * nqt + qt) * nkt + kt) * 64 + l) * 16 + 4 * g;
+    T* pc = swz_col + ((((int64_t)h * nkt + kt) * nqt + qt) * 64 + l) * 16 + 4 * g;
+    uint2 uc;
+    __builtin_memcpy(&uc, cv, 8);
+    *reinterpret_cast<uint2*>(pr) = *reinterpret_cast<const uint2*>(th + i * BIAS_TP + c0);
+    *reinterpret_cast<uint2*>(pc) = uc;
+  }
+}
+
 }  // namespace ofa
 using namespace ofa;
+
+extern "C" int64_t ofa_bias_swz_elems(int heads, int Tb, int Sb) {
+  if (heads <= 0 || Tb <= 0 || Sb <= 0) return 0;
+  return (int64_t)heads * ((Tb + 31) / 32) * ((Sb + 31) / 32) * 1024;
+}
+
+extern "C" int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots, void* out, void* swz_row, void* swz_col, int heads,
+                              int Tb, int Sb, int dtype, void* stream) {
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "bias_build: 16-bit dtypes only (got %d)", dtype);
+  OFA_REQUIRE(swz_row && swz_col && heads > 0 && heads <= 24 && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "bias_build: bad argument");
+  OFA_REQUIRE(!(((uintptr_t)swz_row | (uintptr_t)swz_col) & 15), OFA_ERR_INVALID, "bias_build: the swizzled images must be 16-byte aligned");
+  BiasSlotsDev d{};
+  if (slots) {
+    OFA_REQUIRE(slots->count >= 0 && slots->count <= 8, OFA_ERR_INVALID, "bias_build: %d slots (at most 8)", slots->count);
+    OFA_REQUIRE(slots->count == 0 || Tb == Sb, OFA_ERR_INVALID, "bias_build: slot blocks sit on the diagonal of a square bias (Tb=%d Sb=%d)", Tb, Sb);
+    d.count = slots->count;
+    for (int s = 0; s < d.count; ++s) {
+      OFA_REQUIRE(slots->values[s] && slots->start[s] >= 0 && slots->n[s] > 0 && slots->start[s] + slots->n[s] <= Tb, OFA_ERR_INVALID,
+                  "bias_build: slot %d (start %d, n %d) outside the %d positions", s, slots->start[s], slots->n[s], Tb);
+      d.values[s] = slots->values[s];
+      d.start[s] = slots->start[s];
+      d.n[s] = slots->n[s];
+    }
+  }
+  const dim3 grid((Sb + 31) / 32, (Tb + 31) / 32), block(256);
+  const size_t lds = (size_t)heads * 32 * BIAS_TP * 2;
+  if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((bias_build_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)abs_bias, d, (bf16_t*)out,
+                       (bf16_t*)swz_row, (bf16_t*)swz_col, heads, Tb, Sb);
+  else
+    hipLaunchKernelGGL((bias_build_kernel<f16_t>), grid, block, lds, (hipStream_t)stream, (const f16_t*)abs_bias, d, (f16_t*)out,
+                       (f16_t*)swz_row, (f16_t*)swz_col, heads, Tb, Sb);
+  return check_launch("bias_build");
+}
 
 static inline int bias_grid(int64_t work) {
   int64_t g = (work + 255) / 256;

@@ -420,6 +420,45 @@ def _shared_bias(bias, heads, q):
     return bias.contiguous()
 
 
+class _BiasSlots(ctypes.Structure):
+    _fields_ = [("values", ctypes.c_void_p * 8), ("start", ctypes.c_int32 * 8), ("n", ctypes.c_int32 * 8), ("count", ctypes.c_int32)]
+
+
+def bias_build(abs_bias, starts=(), values=(), heads=None, want_out=True):
+    """The batch-shared position bias of one layer (ofa_bias_build): out = abs_bias [A, Tb, Sb] (None: zeros) with values_k
+    [n_k, n_k, A] added on the diagonal block at starts[k] -> (out [A, Tb, Sb] or None, (row image, column image)): the two
+    tile-swizzled images the shared-bias attention kernels read."""
+    ref = abs_bias if abs_bias is not None else values[0]
+    slots = _BiasSlots()
+    live = [(s, v) for s, v in zip(starts, values) if v is not None]
+    assert len(live) <= 8, "at most 8 slots per bias"
+    keep = []
+    for i, (s, v) in enumerate(live):
+        v = v.to(ref.dtype).contiguous()
+        keep.append(v)
+        slots.values[i], slots.start[i], slots.n[i] = v.data_ptr(), int(s), v.shape[0]
+    slots.count = len(live)
+    if abs_bias is not None:
+        abs_bias = abs_bias.contiguous()
+        A, Tb, Sb = abs_bias.shape
+    else:
+        A = heads
+        Tb = Sb = max(s + v.shape[0] for s, v in live)
+    n = lib().cdll.ofa_bias_swz_elems(A, Tb, Sb)
+    swz = torch.empty(2, n, dtype=ref.dtype, device=ref.device)
+    out = torch.empty(A, Tb, Sb, dtype=ref.dtype, device=ref.device) if want_out else None
+    lib().call("ofa_bias_build", ptr(abs_bias), ctypes.addressof(slots), ptr(out), ptr(swz[0]), ptr(swz[1]), A, Tb, Sb,
+               dtype_code(ref), stream())
+    return out, (swz[0], swz[1])
+
+
+def _shared_swz(bias, bias_shared):
+    """bias_shared: True (the images are built here, one extra launch) or the (row image, column image) pair of bias_build."""
+    if isinstance(bias_shared, tuple):
+        return bias_shared
+    return bias_build(bias, want_out=False)[1]
+
+
 def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, seg=None, bias_shared=False):
     """q [B,T,D], k, v [B,S,D] (row views of a packed buffer are fine) -> out [B,T,D], lse [B*heads, Tpad].
     seg (packing.Segments): ragged mode -- q [1,rows_q,D], k, v [1,rows_k,D] hold the samples back to back, out rows outside
@@ -433,6 +472,7 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
     if bias_shared:
         bias = _shared_bias(bias, heads, q)
         Tb, Sb = bias.shape[1], bias.shape[2]
+        bias = _shared_swz(bias, bias_shared)[0]            # the kernel reads the row image
         if seg is not None:
             assert B == 1 and kpm is None and seg.rows_q == T and seg.rows_k == S and Tb >= seg.max_q - 31 and Sb >= seg.max_k - 31
             out = torch.empty(1, T, D, dtype=q.dtype, device=q.device)
@@ -468,7 +508,7 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
 
 
 def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False,
-             outs=None, seg=None, bias_shared=False):
+             outs=None, seg=None, bias_shared=False, dbias_dtype=torch.float32):
     """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
     packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
     q, ldq = _rows3(q)
@@ -505,11 +545,12 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         # dbias (when asked for): fp32 [heads, Tb, Sb] = the sum over the batch of dS, from the batch-walking third kernel
         bias = _shared_bias(bias, heads, q)
         Tb, Sb = bias.shape[1], bias.shape[2]
-        dbias = torch.empty(heads, Tb, Sb, dtype=torch.float32, device=q.device) if need_dbias else None
+        swz_row, swz_col = _shared_swz(bias, bias_shared)
+        dbias = torch.empty(heads, Tb, Sb, dtype=dbias_dtype, device=q.device) if need_dbias else None   # (16-bit: cast by the chunk fold)
         ws, ws_bytes = None, 0
         if need_dbias:
             nchunk = lib().cdll.ofa_attn_sbias_chunks(B if seg is None else seg.batch, heads, Tb, Sb)
-            if nchunk > 1:
+            if nchunk > 1 or dbias_dtype != torch.float32:
                 ws = torch.empty(nchunk, heads, Tb, Sb, dtype=torch.float32, device=q.device)
                 ws_bytes = ws.numel() * 4
         if seg is not None:
@@ -519,8 +560,10 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         else:
             dims = (B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal), None, 0, 0)
             kp = ptr(kpm)
-        lib().call("ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), Tb, Sb, kp, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
-                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), ptr(ws), ws_bytes, *dims, dtype_code(q), stream())
+        lib().call("ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(swz_row), ptr(swz_col), Tb, Sb, kp, ptr(c_attn),
+                   _c_dtype(c_attn), ptr(lse),
+                   ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), dtype_code(dbias) if dbias is not None else F32, ptr(ws),
+                   ws_bytes, *dims, dtype_code(q), stream())
         return dq, dk, dv, dbias, delta
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S

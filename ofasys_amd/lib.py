@@ -29,9 +29,9 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\s*\*)\s+(ofa_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|int64_t|const char\s*\*)\s+(ofa_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
         argtypes = []
         if args and args != "void":
             for a in args.split(","):

@@ -95,7 +95,7 @@ class MultiheadAttention(nn.Module):
         # POSITION bias does not depend on the batch row, so the stacks hand it over once, as [A, Tb, Sb] (general.py's [B, A, T, T]
         # is B copies of it); the fused kernels index it by (head, position, position) for every sample -- also over packed rows --
         # and return the batch-summed gradient
-        shared = isinstance(attn_bias, ops.SharedBias)
+        shared = attn_bias.shared_arg() if isinstance(attn_bias, ops.SharedBias) else False   # (True, or the swizzled images)
         bias = attn_bias.t if shared else (attn_bias if torch.is_tensor(attn_bias) else None)
         if bias is not None and not shared:
             bias = bias.reshape(bsz * self.num_heads, tgt_len, src_len)

@@ -690,6 +690,11 @@ def pack_rows(x, index, inverse):
     return PackRowsFn.apply(x.reshape(B * T, D), index, inverse).view(1, -1, D)
 
 
+def _dbias_dtype(bias, shared):
+    """A shared bias' batch-summed gradient leaves the kernels in the bias' own dtype (the chunk fold casts): no separate cast launch."""
+    return bias.dtype if (shared and bias is not None) else torch.float32
+
+
 def _shared_dbias(dbias, bias, shared):
     """The batch-summed dS of a shared bias comes back as fp32 [heads, Tb, Sb]: in the bias' own dtype and shape for autograd."""
     if dbias is None or not shared:
@@ -715,7 +720,7 @@ class FusedAttentionFn(torch.autograd.Function):
         need_dbias = bias is not None and ctx.needs_input_grad[3]
         dq, dk, dv, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.scale, bias=bias, kpm=kpm,
                                               c_attn=c_attn, causal=ctx.causal, need_dbias=need_dbias, seg=ctx.seg,
-                                              bias_shared=ctx.bias_shared)
+                                              bias_shared=ctx.bias_shared, dbias_dtype=_dbias_dtype(bias, ctx.bias_shared))
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         dc = None
         if c_attn is not None and ctx.needs_input_grad[5]:
@@ -788,7 +793,7 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         need_dbias = bias is not None and ctx.needs_input_grad[7]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=causal, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
-                                           outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
+                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
@@ -908,7 +913,7 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         need_dbias = bias is not None and ctx.needs_input_grad[8]
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=False, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
-                                           outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
+                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         dq2 = dq.view(B * T, D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
@@ -1006,11 +1011,24 @@ class SharedBias:
     """A position bias that is the same for every sample: t = [A, Tb, Sb] (the reference's [B, A, T, T] / [B*A, T, S] tensor is B
     copies of it).  MultiheadAttention hands t to the fused kernels (ofa_attn_sbias_*: indexed by the position inside the sample,
     gradient summed over the batch in-kernel) or expands it for the exact tier."""
-    __slots__ = ("t",)
+    __slots__ = ("t", "swz")
 
-    def __init__(self, t):
+    def __init__(self, t, swz=None):
         assert t.dim() == 3
         self.t = t
+        self.swz = swz               # (row image, column image) of t for the fused kernels (K.bias_build), or None: built per call
+
+    def shared_arg(self):
+        """What the attention Functions take as `bias_shared`: the swizzled images when they exist, else True."""
+        return self.swz if self.swz is not None else True
+
+    @staticmethod
+    def of(t):
+        """A shared bias that needs no assembly (the decoder's cross-attention abs-pos bias): t [A, Tt, Ts] + its swizzled images."""
+        swz = None
+        if t.is_cuda and t.dtype in (torch.bfloat16, torch.float16):
+            swz = K.bias_build(t.detach(), want_out=False)[1]
+        return SharedBias(t, swz)
 
 
 def expand_shared_bias(bias, B, T, S):
@@ -1085,18 +1103,21 @@ class BiasAssembleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, abs_bias, starts, *values):
+        ctx.blocks = [None if v is None else (s, v.shape[0], v.dtype) for s, v in zip(starts, values)]
+        if abs_bias.shape[0] == 1 and abs_bias.is_cuda and abs_bias.dtype in (torch.bfloat16, torch.float16):
+            # the batch-shared form: ONE launch assembles the layer's matrix and writes the two swizzled images the fused attention
+            # kernels read (ofa_bias_build) -- was a clone + one block add per slot
+            out, swz = K.bias_build(abs_bias[0], starts, values)
+            ctx.mark_non_differentiable(*swz)
+            return out.unsqueeze(0), swz[0], swz[1]
         out = abs_bias.clone(memory_format=torch.contiguous_format)
-        ctx.blocks = []
         for s, v in zip(starts, values):
             if v is not None:
                 K.bias_block_add_(out, v.to(out.dtype), s)
-                ctx.blocks.append((s, v.shape[0], v.dtype))
-            else:
-                ctx.blocks.append(None)
-        return out
+        return out, None, None
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dr=None, _dc=None):
         grads = []
         for blk in ctx.blocks:
             if blk is None:

@@ -58,10 +58,11 @@ def test_shared_bias_attention_matches_reference(K, B, heads, T, S, causal, use_
     assert rel(G, br.grad) < 3e-2                                               # sum over the batch of dS
     dc = delta.view(B, heads, -1)[:, :, :T].sum((0, 2)) / c
     assert rel(dc, cr.grad) < 3e-2
-    # the same numbers as this build's dense-bias kernels fed B copies of the bias; and bitwise reproducible
+    # the same numbers as this build's dense-bias kernels fed B copies of the bias (up to the last bf16 digit: the shared form feeds
+    # the bias to the score MFMAs as their initial accumulator, the dense one adds it afterwards); and bitwise reproducible
     dense = bias.unsqueeze(0).expand(B, heads, T, S).reshape(B * heads, T, S).contiguous()
     out_d, _ = K.attn_fwd(q, k, v, heads, scale, bias=dense, kpm=kpm, c_attn=c, causal=causal)
-    assert torch.equal(out_d, out)
+    assert rel(out_d, out) < 4e-3
     again = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=True)
     assert torch.equal(again[3], G) and torch.equal(again[0], dq)
 
@@ -157,3 +158,38 @@ def test_planned_table_gradient_matches_scan_kernel_and_torch(K, dtype, n, V, D)
     again = torch.zeros(V, D, device=DEV, dtype=dtype)
     K.segment_rowsum(dout.reshape(-1, D).contiguous(), plan, again, False)
     assert torch.equal(again.float(), res[0])
+
+
+@pytest.mark.parametrize("A,T,S,slots", [(12, 70, 70, ((0, 30), (30, 40))), (4, 64, 64, ((0, 64),)), (3, 45, 131, ()), (16, 33, 33, ((5, 20),))])
+@pytest.mark.parametrize("with_abs", [True, False])
+def test_bias_build_assembles_and_swizzles(K, A, T, S, slots, with_abs):
+    """ofa_bias_build: the row-major result is general.py:265-280's clone + diagonal block adds (bit-exact: one bf16 rounding per
+    element), and the two swizzled images hold exactly that matrix in the MFMA lane order documented in include/ofasys_amd.h."""
+    if not with_abs and (not slots or T != S or slots[-1][0] + slots[-1][1] != T):
+        pytest.skip("without an abs-pos matrix the slots define the size")
+    g = torch.Generator(device="cpu").manual_seed(A + T + S)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV).bfloat16()                  # noqa: E731
+    abs_b = mk(A, T, S) if with_abs else None
+    starts = [s for s, _ in slots]
+    values = [mk(n, n, A) for _, n in slots]
+    if with_abs:
+        out, (sr, sc) = K.bias_build(abs_b, starts, values)
+    else:
+        out, (sr, sc) = K.bias_build(None, starts, values, heads=A)
+    ref = abs_b.clone() if with_abs else torch.zeros(A, T, S, device=DEV, dtype=torch.bfloat16)
+    for s, v in zip(starts, values):
+        n = v.shape[0]
+        ref[:, s:s + n, s:s + n] += v.permute(2, 0, 1)
+    assert torch.equal(out, ref)
+    nqt, nkt = (T + 31) // 32, (S + 31) // 32
+    pad = torch.zeros(A, nqt * 32, nkt * 32, device=DEV, dtype=torch.bfloat16)
+    pad[:, :T, :S] = ref
+    lane = torch.arange(64, device=DEV)
+    i, hi = lane & 31, lane >> 5
+    r = torch.arange(16, device=DEV)
+    col = (r & 3)[None, :] + 8 * (r >> 2)[None, :] + 4 * hi[:, None]                # crowl(r, hi): [64, 16]
+    tiles = pad.view(A, nqt, 32, nkt, 32).permute(0, 1, 3, 2, 4)                  # [A, qt, kt, row, col]
+    row_img = tiles[:, :, :, i[:, None].expand(64, 16), col]                       # [A, qt, kt, 64, 16]
+    col_img = tiles[:, :, :, col, i[:, None].expand(64, 16)].permute(0, 2, 1, 3, 4)   # [A, kt, qt, 64, 16]
+    assert torch.equal(sr.view(A, nqt, nkt, 64, 16), row_img)
+    assert torch.equal(sc.view(A, nkt, nqt, 64, 16), col_img)

@@ -48,8 +48,10 @@ if B * A * T * S * 2 < 8e9:
     print(f"dense [B*A,T,S]     fwd {t:8.1f} us ({flops / t / 1e6:6.0f} TF/s)   bwd {tb:8.1f} us ({2.5 * flops / tb / 1e6:6.0f} TF/s)   + building the bias / reducing dbias over the batch elsewhere")
     del bias
 sb = torch.randn(A, T, S, device=dev).bfloat16()
-out, lse = K.attn_fwd(q, k, v, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, bias_shared=True)
-t = bench(lambda: K.attn_fwd(q, k, v, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, bias_shared=True))
-tb0 = bench(lambda: K.attn_bwd(q, k, v, out, dout, lse, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, need_dbias=False, bias_shared=True))
-tb = bench(lambda: K.attn_bwd(q, k, v, out, dout, lse, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=True))
-print(f"shared [A,T,S]      fwd {t:8.1f} us ({flops / t / 1e6:6.0f} TF/s)   bwd {tb:8.1f} us ({2.5 * flops / tb / 1e6:6.0f} TF/s)   of which the batch-summed dS kernel {tb - tb0:6.1f} us")
+sw = K.bias_build(sb, want_out=False)[1]            # the swizzled images: built once per layer by the bias assembly
+t_build = bench(lambda: K.bias_build(sb, want_out=False))
+out, lse = K.attn_fwd(q, k, v, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, bias_shared=sw)
+t = bench(lambda: K.attn_fwd(q, k, v, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, bias_shared=sw))
+tb0 = bench(lambda: K.attn_bwd(q, k, v, out, dout, lse, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, need_dbias=False, bias_shared=sw))
+tb = bench(lambda: K.attn_bwd(q, k, v, out, dout, lse, A, scale, bias=sb, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=sw))
+print(f"shared [A,T,S]      fwd {t:8.1f} us ({flops / t / 1e6:6.0f} TF/s)   bwd {tb:8.1f} us ({2.5 * flops / tb / 1e6:6.0f} TF/s)   of which the batch-summed dS kernel {tb - tb0:6.1f} us; building the swizzled images {t_build:5.1f} us per layer")

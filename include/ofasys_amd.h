@@ -418,6 +418,15 @@ typedef struct ofa_fold_job {
   int32_t out_dtype;   /* OFA_F32 / OFA_BF16 */
 } ofa_fold_job;
 int ofa_fold_batched(const ofa_fold_job* jobs, int njobs, void* stream);
+/* Batched device-to-device copy: dst_i[0 .. bytes_i) = src_i[0 .. bytes_i) for any number of (dense) buffers in as few launches as
+ * possible (96 jobs per launch) -- the static inputs of a replayed step graph (engine/trainer.py's _prepare_sample moves a batch to
+ * the device tensor by tensor; a replay has to copy each into the graph's input, ~3.5 us per launch).  `jobs` is a HOST array. */
+typedef struct ofa_copy_job {
+  const void* src;
+  void* dst;
+  int64_t bytes;
+} ofa_copy_job;
+int ofa_copy_batched(const ofa_copy_job* jobs, int njobs, void* stream);
 #define OFA_DEFER_FOLD 2
 /* partial-row count (`nslots`) the corresponding call writes; ws layouts: LayerNorm [q][nslots][cols] with q = dgamma,
  * dbeta(, dbias); colsum [nslots][cols]; split-K GEMM [splits][M][(N+3)&~3] (ofa_gemm_splits == 1: no partials). */

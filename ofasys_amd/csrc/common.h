@@ -219,4 +219,13 @@ template <bool EXACT> __device__ __forceinline__ void gauss_cdf(float x, float& 
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Workgroups are dispatched in linear order (x fastest, then y, then z) round-robin over the 8 XCDs, and each XCD has its own L2.
+// xcd_remap is the bijective "each XCD gets a contiguous chunk of the n logical ids" map: workgroups whose logical ids are
+// neighbours (the tiles of one GEMM operand panel, the query tiles of one (sample, head)) then run on the SAME XCD and share its L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, xcd = id & 7, local = id >> 3;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + local;
+}
+
 }  // namespace ofa

@@ -170,8 +170,67 @@ __global__ __launch_bounds__(256) void fold_batched_kernel(FoldJobs J) {
   }
 }
 
+// ---- batched device-to-device copy: the static inputs of a replayed step graph (a batch is ~30-80 small tensors: one ~3.5 us copy
+// launch each otherwise).  Job descriptors travel by value; a block copies one 32 KiB chunk of one job.
+constexpr int COPY_MAX_JOBS = 96;
+constexpr int COPY_CHUNK = 32768;
+struct CopyJobs {
+  const unsigned char* src[COPY_MAX_JOBS];
+  unsigned char* dst[COPY_MAX_JOBS];
+  int64_t bytes[COPY_MAX_JOBS];
+  unsigned block0[COPY_MAX_JOBS + 1];
+  int njobs;
+};
+
+__global__ __launch_bounds__(256) void copy_batched_kernel(CopyJobs J) {
+  int lo = 0, hi = J.njobs - 1;                             // the job of this block: the last one whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (J.block0[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t off = (int64_t)(blockIdx.x - J.block0[lo]) * COPY_CHUNK;
+  const int64_t left = J.bytes[lo] - off;
+  const int n = (int)(left < COPY_CHUNK ? left : COPY_CHUNK);
+  const unsigned char* s = J.src[lo] + off;
+  unsigned char* d = J.dst[lo] + off;
+  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    const int nv = n >> 4;
+    for (int i = threadIdx.x; i < nv; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (int i = (nv << 4) + threadIdx.x; i < n; i += 256) d[i] = s[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+  }
+}
+
 }  // namespace ofa
 using namespace ofa;
+
+extern "C" int ofa_copy_batched(const ofa_copy_job* jobs, int njobs, void* stream) {
+  OFA_REQUIRE(njobs >= 0 && (njobs == 0 || jobs), OFA_ERR_INVALID, "copy_batched: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < njobs; base += COPY_MAX_JOBS) {
+    CopyJobs J;
+    const int n = njobs - base < COPY_MAX_JOBS ? njobs - base : COPY_MAX_JOBS;
+    int m = 0;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      const ofa_copy_job& b = jobs[base + i];
+      OFA_REQUIRE(b.bytes >= 0 && (b.bytes == 0 || (b.src && b.dst)), OFA_ERR_INVALID, "copy_batched: bad job %d", base + i);
+      if (b.bytes == 0) continue;
+      J.src[m] = (const unsigned char*)b.src; J.dst[m] = (unsigned char*)b.dst; J.bytes[m] = b.bytes;
+      J.block0[m] = blocks;
+      blocks += (unsigned)((b.bytes + COPY_CHUNK - 1) / COPY_CHUNK);
+      ++m;
+    }
+    if (m == 0) continue;
+    J.block0[m] = blocks;
+    J.njobs = m;
+    hipLaunchKernelGGL(copy_batched_kernel, dim3(blocks), dim3(256), 0, st, J);
+    int rc = check_launch("copy_batched");
+    if (rc) return rc;
+  }
+  return 0;
+}
 
 extern "C" int ofa_fold_batched(const ofa_fold_job* jobs, int njobs, void* stream) {
   OFA_REQUIRE(njobs >= 0 && (njobs == 0 || jobs), OFA_ERR_INVALID, "fold_batched: bad argument");

@@ -244,13 +244,6 @@ __device__ __forceinline__ void glds_issue(const bf16_t* (&ptr)[NV], int64_t ste
   }
 }
 
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-  // bijective "each XCD gets a contiguous chunk" remap (blocks are dispatched round-robin over the 8 XCDs)
-  const int q = n >> 3, r = n & 7, xcd = id & 7, local = id >> 3;
-  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + local;
-}
-
 // (tile, K-slice) of this workgroup.  Workgroups are dispatched in linear order (x fastest, then y) round-robin over the 8 XCDs, and
 // each XCD has its own L2.  Without split-K the tile ids of an XCD are made contiguous (xcd_remap).  With split-K (gridDim.y
 // slices) the remap runs over the FLATTENED (slice, tile) index, slice-major: an XCD then works through whole K-slices -- every

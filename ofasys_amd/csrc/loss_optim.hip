@@ -299,12 +299,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ master, f
         float g[4];
         if constexpr (sizeof(T) == 4) {
           g[0] = g4[k].x; g[1] = g4[k].y; g[2] = g4[k].z; g[3] = g4[k].w;
-        } else if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) {        // fp16
-          const f16x2_t a = __builtin_bit_cast(f16x2_t, g2[k].x), b = __builtin_bit_cast(f16x2_t, g2[k].y);
-          g[0] = (float)a[0]; g[1] = (float)a[1]; g[2] = (float)b[0]; g[3] = (float)b[1];
         } else {
-          g[0] = __uint_as_float(g2[k].x << 16); g[1] = __uint_as_float(g2[k].x & 0xffff0000u);
-          g[2] = __uint_as_float(g2[k].y << 16); g[3] = __uint_as_float(g2[k].y & 0xffff0000u);
+          // (the two words as scalars first: hipcc 7.2 folds __builtin_bit_cast(f16x2_t, v.y) of an ext-vector ELEMENT to element 0 --
+          // the fp16 kernel updated elements 2, 3 of every quad with the gradients of elements 0, 1; tests/test_fp16_gpu.py)
+          const uint32_t gx = g2[k][0], gy = g2[k][1];
+          if constexpr (!__is_same(T, bf16_t)) {                                  // fp16
+            const f16x2_t a = __builtin_bit_cast(f16x2_t, gx), b = __builtin_bit_cast(f16x2_t, gy);
+            g[0] = (float)a[0]; g[1] = (float)a[1]; g[2] = (float)b[0]; g[3] = (float)b[1];
+          } else {
+            g[0] = __uint_as_float(gx << 16); g[1] = __uint_as_float(gx & 0xffff0000u);
+            g[2] = __uint_as_float(gy << 16); g[3] = __uint_as_float(gy & 0xffff0000u);
+          }
         }
         float px = p4[k].x, py = p4[k].y, pz = p4[k].z, pw = p4[k].w;
         float mx = m4[k].x, my = m4[k].y, mz = m4[k].z, mw = m4[k].w;

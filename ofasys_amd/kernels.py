@@ -31,6 +31,27 @@ class _FoldJob(ctypes.Structure):
                 ("out_dtype", ctypes.c_int32)]
 
 
+class _CopyJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_int64)]
+
+
+def copy_batched(pairs):
+    """dst.copy_(src) for every (dst, src) pair of same-shape, same-dtype, contiguous device tensors -- in ONE launch per 96 pairs
+    (ofa_copy_batched).  Pairs that do not qualify are copied by torch."""
+    jobs = []
+    for dst, src in pairs:
+        if (src.dtype == dst.dtype and src.shape == dst.shape and src.device == dst.device and dst.is_cuda
+                and src.is_contiguous() and dst.is_contiguous()):
+            jobs.append((src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()))
+        else:
+            dst.copy_(src, non_blocking=True)
+    if jobs:
+        arr = (_CopyJob * len(jobs))()
+        for it, (s_, d_, n) in zip(arr, jobs):
+            it.src, it.dst, it.bytes = s_, d_, n
+        lib().call("ofa_copy_batched", ctypes.addressof(arr), len(jobs), stream())
+
+
 DEFER_FOLD = 2            # OFA_DEFER_FOLD
 GEMM_DEFER_REDUCE = 128   # OFA_GEMM_DEFER_REDUCE
 

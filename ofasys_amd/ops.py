@@ -1104,6 +1104,7 @@ class BiasAssembleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, abs_bias, starts, *values):
         ctx.blocks = [None if v is None else (s, v.shape[0], v.dtype) for s, v in zip(starts, values)]
+        ctx.set_materialize_grads(False)         # (the two image outputs never carry a gradient: no zero tensors for them)
         if abs_bias.shape[0] == 1 and abs_bias.is_cuda and abs_bias.dtype in (torch.bfloat16, torch.float16):
             # the batch-shared form: ONE launch assembles the layer's matrix and writes the two swizzled images the fused attention
             # kernels read (ofa_bias_build) -- was a clone + one block add per slot
@@ -1118,6 +1119,8 @@ class BiasAssembleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dr=None, _dc=None):
+        if dout is None:
+            return (None, None) + (None,) * len(ctx.blocks)
         grads = []
         for blk in ctx.blocks:
             if blk is None:

@@ -397,21 +397,8 @@ class TrainStep:
 
     def _replay(self, entry, samples):
         if samples is not entry["static"]:
-            # one multi-tensor copy per (dtype, source device) instead of one ~3.5 us copy launch per tensor (34 per cfg-2 step)
-            groups = {}
-            for (_, dst), (_, src) in zip(entry["static_tensors"], sample_tensors(samples)):
-                if dst is not src:
-                    if src.dtype == dst.dtype and src.device == dst.device and src.shape == dst.shape:
-                        d, s = groups.setdefault(dst.dtype, ([], []))
-                        d.append(dst)
-                        s.append(src)
-                    else:
-                        dst.copy_(src, non_blocking=True)
-            for d, s in groups.values():
-                if len(d) == 1:
-                    d[0].copy_(s[0], non_blocking=True)
-                else:
-                    torch._foreach_copy_(d, s, non_blocking=True)
+            # ONE batched copy launch (K.copy_batched) instead of one ~3.5 us copy launch per tensor (34 per cfg-2 step, 77 per cfg-2b step)
+            K.copy_batched([(dst, src) for (_, dst), (_, src) in zip(entry["static_tensors"], sample_tensors(samples)) if dst is not src])
         entry["graphs"][0].replay()
         if len(entry["graphs"]) == 2:
             self.reducer.overlap = False

@@ -255,6 +255,25 @@ __device__ __forceinline__ void init16f(f32x16& a, const float (&b)[16]) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = b[r];
 }
+// BIAS mode 3 -- the same image, but a block's 2 KiB travel to LDS by DMA next to the block's K / V (Q / dO) tiles instead of waiting
+// in 8 registers per stage: the backward kernels sit at their register limits (dK/dV spilled 16 registers with mode 2, dQ could
+// not run three waves per SIMD).  Per stage and wave: [2][1 KiB] (the lanes' first / second 16 bytes), read back with two
+// ds_read_b128 right where the values are needed.
+constexpr int BIAS_STAGE_BYTES = 4 * 2048;                  // four waves x 2 KiB
+__device__ __forceinline__ void bias_dma(const bf16_t* lane_base, int blk, unsigned char* lds_wave_stage) {
+  const bf16_t* p = lane_base + (int64_t)blk * 1024;
+  __builtin_amdgcn_global_load_lds((gvoid_t*)p, (lvoid_t*)lds_wave_stage, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gvoid_t*)(p + 8), (lvoid_t*)(lds_wave_stage + 1024), 16, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ void bias_words(const u64x2& b0, const u64x2& b1, float inv_scale, float (&b)[16]) {
+  const uint4 u0 = __builtin_bit_cast(uint4, b0), u1 = __builtin_bit_cast(uint4, b1);
+  const uint32_t w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    b[2 * j] = lo16<F16>(w[j]) * inv_scale;
+    b[2 * j + 1] = hi16<F16>(w[j]) * inv_scale;
+  }
+}
 
 // additive bias of the 16 scores a lane holds for a 32-key block (keys key0 + crowl(r, hi)), pre-multiplied by log2(e)
 template <bool F16>
@@ -835,6 +854,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 __global__ __launch_bounds__(256) void attn_bwd_dq_bias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<1, true>(a); }
 __global__ __launch_bounds__(256) void attn_bwd_dq_sbias_lds_kernel(AttnL a) { attn_bwd_dq_body<2, false>(a); }
 __global__ __launch_bounds__(256) void attn_bwd_dq_sbias_f16_lds_kernel(AttnL a) { attn_bwd_dq_body<2, true>(a); }
+// (the bias through LDS as in dK/dV + three waves per SIMD: 9 spilled registers, backward 280 -> 274 us at 32 x 12 x 448^2, nothing in the step)
 // (three waves per SIMD cost this form 16 spilled registers and measured the same: 302 vs 300 us backward at 32 x 12 x 448^2)
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -857,7 +877,7 @@ template <int BUF, int BIAS, bool F16>
 __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, uint32_t stat_addr,
                                           const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dvt)[2], f32x16 (&dkt)[2], int q0,
                                           int key0, int ki, int hi, bool key_dead, float live, const float (&bz)[16], float sc,
-                                          float c, const BiasSwz& sraw, float inv_scale) {
+                                          float c, float inv_scale, uint32_t bias_addr) {
   constexpr int QOFF = BUF * 2 * TILE_BYTES, DOOFF = QOFF + TILE_BYTES, SOFF = BUF * STAT_BYTES;
   u64x2 qf[4], dof[4];
   rd128<QOFF>(qf[0], ta.km[0]); rd128<QOFF>(qf[1], ta.km[1]); rd128<QOFF>(qf[2], ta.km[2]); rd128<QOFF>(qf[3], ta.km[3]);
@@ -896,9 +916,16 @@ __device__ __forceinline__ void dkv_block(const AttnL& a, const TileAddr& ta, co
     lv[4 * g4] = l4.x; lv[4 * g4 + 1] = l4.y; lv[4 * g4 + 2] = l4.z; lv[4 * g4 + 3] = l4.w;
     dv16[4 * g4] = d4.x; dv16[4 * g4 + 1] = d4.y; dv16[4 * g4 + 2] = d4.z; dv16[4 * g4 + 3] = d4.w;
   }
-  if constexpr (BIAS == 2) {                // swizzled shared bias: decoded only now (this kernel is at its register limit while the
-    float bs[16];                           // row-major fragments are live) and added onto the raw scores, times 1 / scale
-    sraw.template take<F16>(inv_scale, bs);
+  if constexpr (BIAS == 3) {                // the swizzled shared bias of this block from the stage's LDS image (bias_dma), decoded only
+                                            // now -- the kernel is at its register limit while the row-major fragments are live -- and added
+                                            // onto the raw scores, times 1 / scale
+    constexpr int BOFF = 4 * TILE_BYTES + 2 * STAT_BYTES + BUF * BIAS_STAGE_BYTES;
+    u64x2 b0, b1;
+    rd128<BOFF>(b0, bias_addr);
+    rd128<BOFF + 1024>(b1, bias_addr);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1));
+    float bs[16];
+    bias_words<F16>(b0, b1, inv_scale, bs);
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] += bs[r];
   }
@@ -972,8 +999,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const float* lse_bh = a.lse + (int64_t)bh * a.Tpad;
   const float* delta_bh = a.delta + (int64_t)bh * a.Tpad;
   const bf16_t* bcol = BIAS == 1 ? a.bias + (int64_t)(blockIdx.y / a.heads) * a.bias_bs + (int64_t)h * a.bias_hs + krow : nullptr;
-  const bf16_t* bswz = nullptr;                          // BIAS 2: this lane's 16 values of block (0, key0 / 32) of head h (column image)
-  if constexpr (BIAS == 2) {
+  const bf16_t* bswz = nullptr;                          // BIAS 3: this lane's 16 values of block (0, key0 / 32) of head h (column image)
+  if constexpr (BIAS == 3) {
     const int kt = (key0 >> 5) < a.bias_nkt ? (key0 >> 5) : a.bias_nkt - 1;
     bswz = a.bias_sc + (((int64_t)h * a.bias_nkt + kt) * a.bias_nqt * 64 + lane) * 16;
   }
@@ -990,11 +1017,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
   const int qb_first = a.causal ? kb0 / 32 : 0;          // the workgroup starts where its FIRST wave needs
   const bool live_wave = key0 < a.S;
   BiasCol bA, bB;                                        // bias columns of the even / odd query block in flight (BIAS 1 only)
-  BiasSwz sA, sB;                                        // (BIAS 2)
+  unsigned char* lds_bias = smem + 4 * TILE_BYTES + 2 * STAT_BYTES + wave_u * 2048;      // (BIAS 3) this wave's 2 KiB of stage 0
+  const uint32_t bias_addr = (uint32_t)(uintptr_t)smem + wave * 2048 + lane * 16;
   float bz[16];
   if (qb_first < nqb) {
     if constexpr (BIAS == 1) bA.issue(bcol, qb_first * 32, a.T, a.bias_ld, hi);
-    if constexpr (BIAS == 2) sA.issue(bswz, qb_first);
+    if constexpr (BIAS == 3) bias_dma(bswz, qb_first, lds_bias);
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
     stat_dma(lse_bh, delta_bh, qb_first * 32, lds_stat, lane, wave_u);
@@ -1004,7 +1032,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
     {
       if (qb + 1 < nqb) {
         if constexpr (BIAS == 1) bB.issue(bcol, (qb + 1) * 32, a.T, a.bias_ld, hi);   // ordinary loads BEFORE the DMA: their wait leaves the DMA in flight
-        if constexpr (BIAS == 2) sB.issue(bswz, qb + 1);
+        if constexpr (BIAS == 3) bias_dma(bswz, qb + 1, lds_bias + BIAS_STAGE_BYTES);
         tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
         stat_dma(lse_bh, delta_bh, (qb + 1) * 32, lds_stat + STAT_BYTES, lane, wave_u);
@@ -1012,14 +1040,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
         if constexpr (BIAS == 1) bA.template take<F16>(bcol, bz);
-        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c, sA, inv_scale);
+        dkv_block<0, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, qb * 32, key0, ki, hi, key_dead, live, bz, sc, c, inv_scale, bias_addr);
       }
       ATT_SYNC();
     }
     if (qb + 1 < nqb) {
       if (qb + 2 < nqb) {
         if constexpr (BIAS == 1) bA.issue(bcol, (qb + 2) * 32, a.T, a.bias_ld, hi);
-        if constexpr (BIAS == 2) sA.issue(bswz, qb + 2);
+        if constexpr (BIAS == 3) bias_dma(bswz, qb + 2, lds_bias);
         tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
         stat_dma(lse_bh, delta_bh, (qb + 2) * 32, lds_stat, lane, wave_u);
@@ -1027,7 +1055,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {
         if constexpr (BIAS == 1) bB.template take<F16>(bcol, bz);
-        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c, sB, inv_scale);
+        dkv_block<1, BIAS, F16>(a, ta, trx, stat_addr, kf, vf, dvt, dkt, (qb + 1) * 32, key0, ki, hi, key_dead, live, bz, sc, c, inv_scale, bias_addr);
       }
       ATT_SYNC();
     }
@@ -1053,8 +1081,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, false>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<0, true>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_bias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<1, true>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, false>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<2, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_lds_kernel(AttnL a) { attn_bwd_dkv_body<3, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_sbias_f16_lds_kernel(AttnL a) { attn_bwd_dkv_body<3, true>(a); }
 
 
 // ------------------------------------------------------------------------------------------------ backward: sum over the batch of dS
@@ -1395,7 +1423,7 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
   if (rc) return rc;
   const dim3 kv_grid(cdiv(S, 128) + (seg ? 1 : 0), B * heads);
   auto kv_kern = dtype == OFA_F16 ? attn_bwd_dkv_sbias_f16_lds_kernel : attn_bwd_dkv_sbias_lds_kernel;
-  hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
+  hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES + 2 * BIAS_STAGE_BYTES, st, a);
   rc = check_launch("attn_sbias_bwd_dkv");
   if (rc || !dbias_sum) return rc;
   // G = sum_b dS (after the dQ kernel: it wrote delta): [128 x 64] tiles of one head; the batch is cut into chunks when the tiles

@@ -301,13 +301,22 @@ int ofa_head_sum_f32(const float* x, float* out, int B, int heads, int T, int ld
  * slot blocks need Tb == Sb; heads <= 24. */
 typedef struct ofa_bias_slots {
   const void* values[8];
+  const void* values2[8];  /* NULL: a dense slot.  Else an OUTER slot (video_image_sequence.py:187-204: frame-level + patch-level
+                            * rel-pos tables): value(i, j) = values[i / inner][j / inner] + values2[i % inner][j % inner], values
+                            * [n / inner, n / inner, heads], values2 [inner, inner, heads] -- summed in `dtype` first, like the
+                            * reference's broadcast add, without ever forming the [n, n, heads] tensor */
   int32_t start[8];
   int32_t n[8];
+  int32_t inner[8];
   int32_t count;
 } ofa_bias_slots;
 int64_t ofa_bias_swz_elems(int heads, int Tb, int Sb);
 int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots, void* out, void* swz_row, void* swz_col, int heads, int Tb,
                    int Sb, int dtype, void* stream);
+/* Gradient of an OUTER slot from the (batch-summed) bias gradient dbias [heads, T, T]: d_frames [F, F, heads] = sums over the patch
+ * pairs, d_patches [P, P, heads] = sums over the frame pairs of the slot's diagonal block (fp32 accumulation, fixed order). */
+int ofa_bias_outer_grad(const void* dbias, void* d_frames, void* d_patches, int heads, int T, int start, int F, int P, int dtype,
+                        void* stream);
 int ofa_bias_block_add(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype, void* stream);
 int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
 

@@ -154,7 +154,17 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 b = mo.self_attn_bias[idx] if mo.self_attn_bias else None
                 # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values; take the values back
                 values.append(_unexpand(b))
-            b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_pos_bias, starts, *values)
+            kinds, tensors = [], []
+            for v in values:
+                if v is None:
+                    kinds.append(None)
+                elif isinstance(v, ops.OuterRelPos):
+                    kinds.append("outer")
+                    tensors += [v.frames, v.patches]
+                else:
+                    kinds.append("dense")
+                    tensors.append(v)
+            b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_pos_bias, starts, kinds, *tensors)
             output.self_attn_bias.append(ops.SharedBias(b[0], (swz_row, swz_col) if swz_row is not None else None) if shared else b)
         return output
 
@@ -174,6 +184,8 @@ def _unexpand(b):
     per-sample bias (no adaptor in scope produces one) is rejected."""
     if b is None:
         return None
+    if isinstance(b, ops.LazyRelPosBias):                             # (video: frame-level + patch-level tables, never materialised)
+        return b.values
     v = getattr(b, "_ofa_values", None)                              # BaseAdaptor.expand_rel_pos_bias: the values themselves
     if v is not None:
         return v

@@ -94,9 +94,10 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
             for idx in range(self.num_layers):
                 vi = ira.get_rel_pos_bias(batch_size, P, idx, image_position_ids=image_position_idx)   # [P,P,A]
                 vf = self.get_rel_pos_bias(batch_size, Fr, idx)                                        # [F,F,A]
-                A = vi.shape[-1]
-                values = (vf.view(Fr, 1, Fr, 1, A) + vi.view(1, P, 1, P, A)).reshape(Fr * P, Fr * P, A)   # :187-204
-                self_attn_bias.append(self.expand_rel_pos_bias(values, batch_size))
+                # :187-204 adds the two broadcast views into [F P, F P, A] values (59 MB per layer at 8 x 196 positions) and expands them
+                # over the batch; here the two tables travel on as they are (ops.OuterRelPos): the bias assembly reads them, the
+                # gradient is summed straight into them
+                self_attn_bias.append(ops.LazyRelPosBias(ops.OuterRelPos(vf, vi), batch_size))
         else:
             self_attn_bias = [None] * self.num_layers
         return AdaptorOutput(video_embed, mask, pos_embed, self_attn_bias)

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void bias_block_grad_kernel(const T* __restric
 // column image (lane (i, hi): column i, rows crowl(r, hi)), 8 bytes per thread and store.
 struct BiasSlotsDev {
   const void* values[8];
+  const void* values2[8];   // != NULL: an OUTER slot (video): value(i, j) = values[i / inner][j / inner] + values2[i % inner][j % inner]
   int start[8];
   int n[8];
+  int inner[8];
   int count;
 };
 constexpr int BIAS_TP = 40;                                  // tile row pitch in elements: 80 bytes (16-byte aligned chunks)
@@ -103,6 +105,18 @@ __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ a
       for (int s = 0; s < slots.count; ++s) {
         const int i = q - slots.start[s], j = k - slots.start[s], n = slots.n[s];
         if (i < 0 || j < 0 || i >= n || j >= n) continue;
+        if (slots.values2[s]) {              // frame-level table + patch-level table (video_image_sequence.py:187-204), summed in
+          const int P = slots.inner[s], F = n / P;                      // the 16-bit type first, as the reference's broadcast add
+          const T* vf = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)(i / P) * F + j / P) * A;
+          const T* vi = reinterpret_cast<const T*>(slots.values2[s]) + ((int64_t)(i % P) * P + j % P) * A;
+          for (int h = 0; h < A; ++h) {
+            T v;
+            st1<T>(&v, ld1<T>(vf + h) + ld1<T>(vi + h));
+            T* t = tile + (h * 32 + qr) * BIAS_TP + kc;
+            st1<T>(t, ld1<T>(t) + ld1<T>(&v));
+          }
+          continue;
+        }
         const T* vp = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)i * n + j) * A;
         for (int h = 0; h < A; ++h) {
           T* t = tile + (h * 32 + qr) * BIAS_TP + kc;
@@ -146,8 +160,63 @@ __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ a
   }
 }
 
+// Gradient of an OUTER slot from the bias gradient G [A, T, T] (one matrix: the batch sum):
+//   d_vf[f][f'][a] = sum_{p, p'} G[a][s + f P + p][s + f' P + p'],   d_vi[p][p'][a] = sum_{f, f'} G[a][s + f P + p][s + f' P + p']
+// (the reference materialises the [F P, F P, A] values and lets autograd reduce the broadcast twice).  Fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_outer_grad_frames_kernel(const T* __restrict__ G, T* __restrict__ dvf, int A, int Tt, int s,
+                                                                     int F, int P) {
+  __shared__ float red[4];
+  const int f = blockIdx.x / F, f2 = blockIdx.x - f * F, a = blockIdx.y;
+  const T* base = G + ((int64_t)a * Tt + s + f * P) * Tt + s + f2 * P;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < P * P; e += 256) {
+    const int p = e / P, p2 = e - p * P;
+    acc += ld1<T>(base + (int64_t)p * Tt + p2);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) st1<T>(dvf + ((int64_t)f * F + f2) * A + a, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_outer_grad_patches_kernel(const T* __restrict__ G, T* __restrict__ dvi, int A, int Tt, int s,
+                                                                      int F, int P) {
+  const int p = blockIdx.x, a = blockIdx.y;
+  for (int p2 = threadIdx.x; p2 < P; p2 += 256) {
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const T* row = G + ((int64_t)a * Tt + s + f * P + p) * Tt + s + p2;
+      for (int f2 = 0; f2 < F; ++f2) acc += ld1<T>(row + f2 * P);
+    }
+    st1<T>(dvi + ((int64_t)p * P + p2) * A + a, acc);
+  }
+}
+
 }  // namespace ofa
 using namespace ofa;
+
+extern "C" int ofa_bias_outer_grad(const void* dbias, void* d_frames, void* d_patches, int A, int T, int start, int F, int P, int dtype,
+                                   void* stream) {
+  OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16 || dtype == OFA_F32, OFA_ERR_INVALID, "bias_outer_grad: bad dtype %d", dtype);
+  OFA_REQUIRE(dbias && d_frames && d_patches && A > 0 && F > 0 && P > 0 && start >= 0 && start + F * P <= T, OFA_ERR_INVALID,
+              "bias_outer_grad: bad argument (T=%d start=%d F=%d P=%d)", T, start, F, P);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 gf(F * F, A), gp(P, A), blk(256);
+  if (dtype == OFA_F32) {
+    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<float>), gf, blk, 0, st, (const float*)dbias, (float*)d_frames, A, T, start, F, P);
+    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<float>), gp, blk, 0, st, (const float*)dbias, (float*)d_patches, A, T, start, F, P);
+  } else if (dtype == OFA_BF16) {
+    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<bf16_t>), gf, blk, 0, st, (const bf16_t*)dbias, (bf16_t*)d_frames, A, T, start, F, P);
+    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<bf16_t>), gp, blk, 0, st, (const bf16_t*)dbias, (bf16_t*)d_patches, A, T, start, F, P);
+  } else {
+    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<f16_t>), gf, blk, 0, st, (const f16_t*)dbias, (f16_t*)d_frames, A, T, start, F, P);
+    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<f16_t>), gp, blk, 0, st, (const f16_t*)dbias, (f16_t*)d_patches, A, T, start, F, P);
+  }
+  return check_launch("bias_outer_grad");
+}
 
 extern "C" int64_t ofa_bias_swz_elems(int heads, int Tb, int Sb) {
   if (heads <= 0 || Tb <= 0 || Sb <= 0) return 0;
@@ -167,9 +236,13 @@ extern "C" int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots,
     for (int s = 0; s < d.count; ++s) {
       OFA_REQUIRE(slots->values[s] && slots->start[s] >= 0 && slots->n[s] > 0 && slots->start[s] + slots->n[s] <= Tb, OFA_ERR_INVALID,
                   "bias_build: slot %d (start %d, n %d) outside the %d positions", s, slots->start[s], slots->n[s], Tb);
+      OFA_REQUIRE(!slots->values2[s] || (slots->inner[s] > 0 && slots->n[s] % slots->inner[s] == 0), OFA_ERR_INVALID,
+                  "bias_build: outer slot %d: n=%d is not a multiple of the inner size %d", s, slots->n[s], slots->inner[s]);
       d.values[s] = slots->values[s];
+      d.values2[s] = slots->values2[s];
       d.start[s] = slots->start[s];
       d.n[s] = slots->n[s];
+      d.inner[s] = slots->inner[s];
     }
   }
   const dim3 grid((Sb + 31) / 32, (Tb + 31) / 32), block(256);

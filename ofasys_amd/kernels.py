@@ -442,29 +442,39 @@ def _shared_bias(bias, heads, q):
 
 
 class _BiasSlots(ctypes.Structure):
-    _fields_ = [("values", ctypes.c_void_p * 8), ("start", ctypes.c_int32 * 8), ("n", ctypes.c_int32 * 8), ("count", ctypes.c_int32)]
+    _fields_ = [("values", ctypes.c_void_p * 8), ("values2", ctypes.c_void_p * 8), ("start", ctypes.c_int32 * 8), ("n", ctypes.c_int32 * 8),
+                ("inner", ctypes.c_int32 * 8), ("count", ctypes.c_int32)]
 
 
 def bias_build(abs_bias, starts=(), values=(), heads=None, want_out=True):
     """The batch-shared position bias of one layer (ofa_bias_build): out = abs_bias [A, Tb, Sb] (None: zeros) with values_k
     [n_k, n_k, A] added on the diagonal block at starts[k] -> (out [A, Tb, Sb] or None, (row image, column image)): the two
     tile-swizzled images the shared-bias attention kernels read."""
-    ref = abs_bias if abs_bias is not None else values[0]
-    slots = _BiasSlots()
     live = [(s, v) for s, v in zip(starts, values) if v is not None]
+    ref = abs_bias if abs_bias is not None else (live[0][1][0] if isinstance(live[0][1], tuple) else live[0][1])
+    slots = _BiasSlots()
     assert len(live) <= 8, "at most 8 slots per bias"
-    keep = []
+    keep, ends = [], []
     for i, (s, v) in enumerate(live):
-        v = v.to(ref.dtype).contiguous()
-        keep.append(v)
-        slots.values[i], slots.start[i], slots.n[i] = v.data_ptr(), int(s), v.shape[0]
+        if isinstance(v, tuple):             # an OUTER slot (frames [F,F,A], patches [P,P,A]): value(i, j) = frames[i/P][j/P] + patches[i%P][j%P]
+            vf, vi = (t.to(ref.dtype).contiguous() for t in v)
+            keep += [vf, vi]
+            n = vf.shape[0] * vi.shape[0]
+            slots.values[i], slots.values2[i], slots.inner[i] = vf.data_ptr(), vi.data_ptr(), vi.shape[0]
+        else:
+            v = v.to(ref.dtype).contiguous()
+            keep.append(v)
+            n = v.shape[0]
+            slots.values[i], slots.values2[i], slots.inner[i] = v.data_ptr(), None, 0
+        slots.start[i], slots.n[i] = int(s), n
+        ends.append(int(s) + n)
     slots.count = len(live)
     if abs_bias is not None:
         abs_bias = abs_bias.contiguous()
         A, Tb, Sb = abs_bias.shape
     else:
         A = heads
-        Tb = Sb = max(s + v.shape[0] for s, v in live)
+        Tb = Sb = max(ends)
     n = lib().cdll.ofa_bias_swz_elems(A, Tb, Sb)
     swz = torch.empty(2, n, dtype=ref.dtype, device=ref.device)
     out = torch.empty(A, Tb, Sb, dtype=ref.dtype, device=ref.device) if want_out else None
@@ -864,6 +874,17 @@ def bias_block_add_(bias, values, start):
     assert bias.is_contiguous() and values.dtype == bias.dtype
     lib().call("ofa_bias_block_add", ptr(bias), ptr(values), B, A, T, start, n, dtype_code(bias), stream())
     return bias
+
+
+def bias_outer_grad(dbias, start, F, P):
+    """dbias [1|.., A, T, T] (one matrix) -> (d_frames [F,F,A], d_patches [P,P,A]) of an OUTER slot at `start` (ofa_bias_outer_grad)."""
+    dbias = dbias.contiguous()
+    A, T = dbias.shape[-3], dbias.shape[-1]
+    assert dbias.numel() == A * T * T
+    dvf = torch.empty(F, F, A, dtype=dbias.dtype, device=dbias.device)
+    dvi = torch.empty(P, P, A, dtype=dbias.dtype, device=dbias.device)
+    lib().call("ofa_bias_outer_grad", ptr(dbias), ptr(dvf), ptr(dvi), A, T, start, F, P, dtype_code(dbias), stream())
+    return dvf, dvi
 
 
 def bias_block_grad(dbias, start, n):

@@ -1097,13 +1097,49 @@ def heads_matmul_nt(x, y, heads, alpha=1.0):
     return HeadsMatmulNTFn.apply(x, y, heads, alpha)
 
 
+class OuterRelPos:
+    """The rel-pos values of a video slot, un-materialised: value(i, j) = frames[i // P][j // P] + patches[i % P][j % P]
+    (frames [F, F, A]: frame-level table lookups, patches [P, P, A]: the image adaptor's; video_image_sequence.py:187-204 adds the
+    two broadcast views into an [F P, F P, A] tensor per layer -- 59 MB at cfg-4 -- and autograd reduces its gradient twice).  The bias
+    assembly (BiasAssembleFn / ofa_bias_build) reads the two tables, the gradient kernels (ofa_bias_outer_grad) sum straight into them."""
+    __slots__ = ("frames", "patches")
+
+    def __init__(self, frames, patches):
+        assert frames.dim() == 3 and patches.dim() == 3 and frames.shape[-1] == patches.shape[-1]
+        self.frames, self.patches = frames, patches
+
+    @property
+    def n(self):
+        return self.frames.shape[0] * self.patches.shape[0]
+
+    def dense(self):
+        Fr, P, A = self.frames.shape[0], self.patches.shape[0], self.frames.shape[-1]
+        return (self.frames.view(Fr, 1, Fr, 1, A) + self.patches.view(1, P, 1, P, A)).reshape(Fr * P, Fr * P, A)
+
+
+class LazyRelPosBias:
+    """What an adaptor returns in `self_attn_bias` instead of the reference's [B, A, T, T] expand view when the values are an
+    OuterRelPos: the general adaptor's assembly takes `.values`; `.materialize()` is the reference's tensor."""
+    __slots__ = ("values", "batch_size")
+
+    def __init__(self, values, batch_size):
+        self.values, self.batch_size = values, batch_size
+
+    def materialize(self):
+        return self.values.dense().unsqueeze(0).expand(self.batch_size, -1, -1, -1).permute([0, 3, 1, 2])
+
+
 class BiasAssembleFn(torch.autograd.Function):
     """bias_l = abs.clone(); bias_l[:, :, s:e, s:e] += values_k for each slot k (adaptor/general.py:270-280).
-    values_k: [n_k, n_k, A] (the un-expanded rel-pos values) or None."""
+    kinds[k]: None (no values), "dense" (one tensor [n_k, n_k, A]: the un-expanded rel-pos values) or "outer" (two tensors, frames
+    [F,F,A] and patches [P,P,A]: an OuterRelPos); `tensors` holds them in slot order."""
 
     @staticmethod
-    def forward(ctx, abs_bias, starts, *values):
-        ctx.blocks = [None if v is None else (s, v.shape[0], v.dtype) for s, v in zip(starts, values)]
+    def forward(ctx, abs_bias, starts, kinds, *tensors):
+        it = iter(tensors)
+        values = [None if k is None else (next(it) if k == "dense" else (next(it), next(it))) for k in kinds]
+        ctx.blocks = [None if v is None else ((s, v[0].shape[0], v[1].shape[0], v[0].dtype) if isinstance(v, tuple) else (s, v.shape[0], v.dtype))
+                      for s, v in zip(starts, values)]
         ctx.set_materialize_grads(False)         # (the two image outputs never carry a gradient: no zero tensors for them)
         if abs_bias.shape[0] == 1 and abs_bias.is_cuda and abs_bias.dtype in (torch.bfloat16, torch.float16):
             # the batch-shared form: ONE launch assembles the layer's matrix and writes the two swizzled images the fused attention
@@ -1114,21 +1150,31 @@ class BiasAssembleFn(torch.autograd.Function):
         out = abs_bias.clone(memory_format=torch.contiguous_format)
         for s, v in zip(starts, values):
             if v is not None:
+                if isinstance(v, tuple):
+                    v = OuterRelPos(*v).dense()
                 K.bias_block_add_(out, v.to(out.dtype), s)
         return out, None, None
 
     @staticmethod
     def backward(ctx, dout, _dr=None, _dc=None):
         if dout is None:
-            return (None, None) + (None,) * len(ctx.blocks)
+            return (None, None, None) + (None,) * sum(0 if b is None else (2 if len(b) == 4 else 1) for b in ctx.blocks)
         grads = []
         for blk in ctx.blocks:
             if blk is None:
-                grads.append(None)
+                continue
+            if len(blk) == 4:                                   # outer slot: sum the block straight into the two tables
+                s, Fr, P, dt = blk
+                if dout.shape[0] == 1 and dout.is_cuda:
+                    dvf, dvi = K.bias_outer_grad(dout, s, Fr, P)
+                else:
+                    d = K.bias_block_grad(dout, s, Fr * P).view(Fr, P, Fr, P, -1).float()
+                    dvf, dvi = d.sum((1, 3)), d.sum((0, 2))
+                grads += [dvf.to(dt), dvi.to(dt)]
             else:
                 s, n, dt = blk
                 grads.append(K.bias_block_grad(dout, s, n).to(dt))
-        return (dout, None, *grads)
+        return (dout, None, None, *grads)
 
 
 class MulRowvecFn(torch.autograd.Function):

@@ -193,3 +193,35 @@ def test_bias_build_assembles_and_swizzles(K, A, T, S, slots, with_abs):
     col_img = tiles[:, :, :, col, i[:, None].expand(64, 16)].permute(0, 2, 1, 3, 4)   # [A, kt, qt, 64, 16]
     assert torch.equal(sr.view(A, nqt, nkt, 64, 16), row_img)
     assert torch.equal(sc.view(A, nkt, nqt, 64, 16), col_img)
+
+
+def test_bias_build_outer_slot_and_its_gradient(K):
+    """A video slot's rel-pos values are frames[i // P][j // P] + patches[i % P][j % P] (video_image_sequence.py:187-204): the assembly
+    reads the two tables (bit-exact against the reference's broadcast add + block add in bf16), the gradient kernels sum the bias
+    gradient's block straight into them (fp32 accumulation, against torch's two reductions)."""
+    from ofasys_amd import ops
+    A, Fr, P, s0, Tt = 6, 3, 13, 5, 50                       # block of 39 positions at 5 inside 50, a dense text slot behind it
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV).bfloat16()                  # noqa: E731
+    abs_b, vf, vi, vt = mk(A, Tt, Tt), mk(Fr, Fr, A), mk(P, P, A), mk(6, 6, A)
+    out, (sr, sc) = K.bias_build(abs_b, [s0, 44], [(vf, vi), vt])
+    dense = ops.OuterRelPos(vf, vi).dense()                                          # bf16 broadcast add, as the reference
+    ref = abs_b.clone()
+    ref[:, s0:s0 + Fr * P, s0:s0 + Fr * P] += dense.permute(2, 0, 1)
+    ref[:, 44:50, 44:50] += vt.permute(2, 0, 1)
+    assert torch.equal(out, ref)
+    G = mk(1, A, Tt, Tt)
+    dvf, dvi = K.bias_outer_grad(G, s0, Fr, P)
+    blk = G[0, :, s0:s0 + Fr * P, s0:s0 + Fr * P].float().view(A, Fr, P, Fr, P)
+    assert rel(dvf, blk.sum((2, 4)).permute(1, 2, 0)) < 4e-3 and rel(dvi, blk.sum((1, 3)).permute(1, 2, 0)) < 4e-3
+    # through autograd: BiasAssembleFn with an outer slot == the dense formulation
+    a1 = abs_b.unsqueeze(0).clone().requires_grad_(True)
+    f1, p1 = vf.clone().requires_grad_(True), vi.clone().requires_grad_(True)
+    b1, _, _ = ops.BiasAssembleFn.apply(a1, [s0], ["outer"], f1, p1)
+    a2 = abs_b.unsqueeze(0).clone().requires_grad_(True)
+    f2, p2 = vf.clone().requires_grad_(True), vi.clone().requires_grad_(True)
+    b2, _, _ = ops.BiasAssembleFn.apply(a2, [s0], ["dense"], ops.OuterRelPos(f2, p2).dense())
+    assert torch.equal(b1, b2)
+    b1.backward(G)
+    b2.backward(G)
+    assert rel(f1.grad, f2.grad) < 1e-2 and rel(p1.grad, p2.grad) < 1e-2 and torch.equal(a1.grad, a2.grad)

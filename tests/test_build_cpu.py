@@ -38,6 +38,12 @@ def _kernel_meta(src, tmp_path):
     # dQ runs THREE waves per SIMD (168 registers): the 3 registers it spills there were measured worth it (backward 156 -> 145 us
     # at 448 x 448 against two waves without spills, profiles/round2_attention_timeline.txt)
     ("attention.hip", r"attn_bwd_dq(_f16)?_lds_kernel", 4),
+    # the shared position bias: forward at three waves per SIMD (the bias image is the score MFMAs' initial accumulator: 8 staging
+    # registers), dQ at two waves without spills, dK/dV with the image staged through LDS (was 16 spilled registers with it in registers)
+    ("attention.hip", r"attn_fwd_sbias(_f16)?_lds_kernel", 2),
+    ("attention.hip", r"attn_bwd_dq_sbias(_f16)?_lds_kernel", 0),
+    ("attention.hip", r"attn_bwd_dkv_sbias_lds_kernel", 6),
+    ("attention.hip", r"attn_bwd_dkv_sbias_f16_lds_kernel", 16),          # (the fp16 decode holds more temporaries)
     ("gemm_mfma.hip", r"gemm_mfma_kernelILi2ELi2ELb[01]ELb[01]ELb0ELb1E", 0),   # 128x128 LDS-DMA kernels, bf16 out
     ("gemm_mfma.hip", r"gemm_ring_kernelILi[12]ELi[12]ELb[01]ELb[01]ELb0E", 0),  # 4-stage ring kernels, bf16 out
     ("gemm_mfma.hip", r"gemm_group_tn_kernel", 0),                               # grouped weight gradients (256 accumulator registers live)

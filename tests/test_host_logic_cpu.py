@@ -70,6 +70,39 @@ def test_flat_param_arena():
     assert float(fp.grad.abs().sum()) == 0
 
 
+def test_flat_param_arena_keeps_spatial_conv_weights_in_gemm_order():
+    """Spatial convolution weights sit in the arena as [Cout][kh][kw][Cin] (channels_last strides of the torch shape): the im2col GEMM
+    reads the parameter and the weight-gradient GEMM writes its arena gradient without a permuted copy.  Values, shapes and the
+    state dict are unchanged; autograd's own accumulation (CPU here) lands in the right elements."""
+    from ofasys_amd.trainer import FlatParams
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1, bias=False), torch.nn.Conv2d(16, 8, 1, bias=False),
+                              torch.nn.Conv2d(3, 8, 7, bias=False))        # 3x3: eligible; 1x1 and 3*7*7 = 147 (not a multiple of 8): plain
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = FlatParams(net)
+    w3, w1, w7 = net[0].weight, net[1].weight, net[2].weight
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]) and v.shape == before[k].shape
+    assert w3.permute(0, 2, 3, 1).is_contiguous() and not w3.is_contiguous()
+    assert w3.grad.permute(0, 2, 3, 1).is_contiguous() and w3.grad.shape == w3.shape
+    assert w1.is_contiguous() and w7.is_contiguous()
+    o3 = fp.offsets[0]
+    assert torch.equal(fp.flat[o3:o3 + w3.numel()].view(16, 3, 3, 8), before["0.weight"].permute(0, 2, 3, 1))
+    x = torch.randn(2, 8, 5, 5)
+    ref = torch.nn.functional.conv2d(x, before["0.weight"].clone().requires_grad_(True), padding=1)
+    wr = before["0.weight"].clone().requires_grad_(True)
+    torch.nn.functional.conv2d(x, wr, padding=1).sum().backward()
+    net[0](x).sum().backward()
+    assert torch.allclose(net[0](x), ref) and torch.allclose(w3.grad, wr.grad, atol=1e-5)
+    assert torch.allclose(fp.grad[o3:o3 + w3.numel()].view(16, 3, 3, 8), wr.grad.permute(0, 2, 3, 1), atol=1e-5)
+    fp.grad.zero_()
+    w3.grad = None                                  # autograd replaced it: zero_grad re-points it at the arena, same layout
+    fp.zero_grad()
+    assert w3.grad.data_ptr() == fp.grad.data_ptr() + o3 * 4 and w3.grad.permute(0, 2, 3, 1).is_contiguous()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.randn_like(v) for k, v in sd.items()})      # loading keeps the arena views
+    assert w3.data_ptr() == fp.flat.data_ptr() + o3 * 4 and w3.permute(0, 2, 3, 1).is_contiguous()
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

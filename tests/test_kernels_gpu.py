@@ -875,3 +875,23 @@ def test_step_schedule_kernel(K, clip):
     model = master.clone()
     K.adam_step(master, m, v, g, model, sched, 0.0, 0.9, 0.999, 1e-8, 0.01, 0)          # skip flag set: nothing moves
     assert torch.equal(master, w0) and float(m.abs().sum()) == 0.0 and float(v.abs().sum()) == 0.0
+
+
+def test_copy_batched(K):
+    """ofa_copy_batched: any number of (dst, src) pairs in one launch per 96 -- sizes from one byte to several chunks, unaligned
+    storage offsets, a dtype-converting pair left to torch."""
+    torch.manual_seed(5)
+    pairs = []
+    for i, n in enumerate([1, 3, 17, 4096, 32768 // 2 + 5, 100003, 7, 250000] * 14):          # 112 pairs: two launches
+        base = torch.randn(n + 3, device=DEV).to(torch.bfloat16 if i % 2 else torch.float32)
+        src = base[i % 3:i % 3 + n]                                                        # (2- / 4-byte steps off the 16-byte grid)
+        dst = torch.zeros(n + 3, device=DEV, dtype=src.dtype)[(i + 1) % 3:(i + 1) % 3 + n]
+        pairs.append((dst, src))
+    i64 = torch.arange(1000, device=DEV)
+    pairs.append((torch.zeros(1000, device=DEV, dtype=torch.int64), i64))
+    conv = (torch.zeros(64, device=DEV, dtype=torch.bfloat16), torch.randn(64, device=DEV))   # dtypes differ: torch's copy_
+    K.copy_batched(pairs + [conv])
+    torch.cuda.synchronize()
+    for dst, src in pairs:
+        assert torch.equal(dst, src)
+    assert torch.equal(conv[0], conv[1].to(torch.bfloat16))

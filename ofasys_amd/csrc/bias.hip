@@ -163,17 +163,39 @@ __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ a
 // Gradient of an OUTER slot from the bias gradient G [A, T, T] (one matrix: the batch sum):
 //   d_vf[f][f'][a] = sum_{p, p'} G[a][s + f P + p][s + f' P + p'],   d_vi[p][p'][a] = sum_{f, f'} G[a][s + f P + p][s + f' P + p']
 // (the reference materialises the [F P, F P, A] values and lets autograd reduce the broadcast twice).  Fixed summation order.
-template <typename T>
+// V = 4: rows of the block are read as 8-byte (16-bit types) / 16-byte (fp32) pieces (start, T and P multiples of 4), V = 1: element-wise.
+template <typename T, int V>
+__device__ __forceinline__ void ld_piece(const T* p, float (&o)[V]) {
+  if constexpr (V == 1) {
+    o[0] = ld1<T>(p);
+  } else if constexpr (sizeof(T) == 4) {
+    const float4 u = *reinterpret_cast<const float4*>(p);
+    o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w;
+  } else {
+    T e[4];
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    __builtin_memcpy(e, &u, 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ld1<T>(e + j);
+  }
+}
+
+// frames: one block per (f, f', head): 4 row lanes x 64 column lanes sweep the P x P block
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bias_outer_grad_frames_kernel(const T* __restrict__ G, T* __restrict__ dvf, int A, int Tt, int s,
                                                                      int F, int P) {
   __shared__ float red[4];
   const int f = blockIdx.x / F, f2 = blockIdx.x - f * F, a = blockIdx.y;
   const T* base = G + ((int64_t)a * Tt + s + f * P) * Tt + s + f2 * P;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int e = threadIdx.x; e < P * P; e += 256) {
-    const int p = e / P, p2 = e - p * P;
-    acc += ld1<T>(base + (int64_t)p * Tt + p2);
-  }
+  for (int c = cl * V; c < P; c += 64 * V)
+    for (int p = rl; p < P; p += 4) {
+      float o[V];
+      ld_piece<T, V>(base + (int64_t)p * Tt + c, o);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc += o[j];
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -181,17 +203,29 @@ __global__ __launch_bounds__(256) void bias_outer_grad_frames_kernel(const T* __
   if (threadIdx.x == 0) st1<T>(dvf + ((int64_t)f * F + f2) * A + a, red[0] + red[1] + red[2] + red[3]);
 }
 
-template <typename T>
+// patches: one block per (4 rows p, head): thread (row lane, column piece) sums its piece over the F x F frame pairs
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bias_outer_grad_patches_kernel(const T* __restrict__ G, T* __restrict__ dvi, int A, int Tt, int s,
                                                                       int F, int P) {
-  const int p = blockIdx.x, a = blockIdx.y;
-  for (int p2 = threadIdx.x; p2 < P; p2 += 256) {
-    float acc = 0.f;
+  const int a = blockIdx.y;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + rl;
+  if (p >= P) return;
+  for (int c = cl * V; c < P; c += 64 * V) {
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     for (int f = 0; f < F; ++f) {
-      const T* row = G + ((int64_t)a * Tt + s + f * P + p) * Tt + s + p2;
-      for (int f2 = 0; f2 < F; ++f2) acc += ld1<T>(row + f2 * P);
+      const T* row = G + ((int64_t)a * Tt + s + f * P + p) * Tt + s + c;
+      for (int f2 = 0; f2 < F; ++f2) {
+        float o[V];
+        ld_piece<T, V>(row + f2 * P, o);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += o[j];
+      }
     }
-    st1<T>(dvi + ((int64_t)p * P + p2) * A + a, acc);
+#pragma unroll
+    for (int j = 0; j < V; ++j) st1<T>(dvi + ((int64_t)p * P + c + j) * A + a, acc[j]);
   }
 }
 
@@ -204,17 +238,22 @@ extern "C" int ofa_bias_outer_grad(const void* dbias, void* d_frames, void* d_pa
   OFA_REQUIRE(dbias && d_frames && d_patches && A > 0 && F > 0 && P > 0 && start >= 0 && start + F * P <= T, OFA_ERR_INVALID,
               "bias_outer_grad: bad argument (T=%d start=%d F=%d P=%d)", T, start, F, P);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 gf(F * F, A), gp(P, A), blk(256);
-  if (dtype == OFA_F32) {
-    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<float>), gf, blk, 0, st, (const float*)dbias, (float*)d_frames, A, T, start, F, P);
-    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<float>), gp, blk, 0, st, (const float*)dbias, (float*)d_patches, A, T, start, F, P);
-  } else if (dtype == OFA_BF16) {
-    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<bf16_t>), gf, blk, 0, st, (const bf16_t*)dbias, (bf16_t*)d_frames, A, T, start, F, P);
-    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<bf16_t>), gp, blk, 0, st, (const bf16_t*)dbias, (bf16_t*)d_patches, A, T, start, F, P);
-  } else {
-    hipLaunchKernelGGL((bias_outer_grad_frames_kernel<f16_t>), gf, blk, 0, st, (const f16_t*)dbias, (f16_t*)d_frames, A, T, start, F, P);
-    hipLaunchKernelGGL((bias_outer_grad_patches_kernel<f16_t>), gp, blk, 0, st, (const f16_t*)dbias, (f16_t*)d_patches, A, T, start, F, P);
-  }
+  const dim3 gf(F * F, A), gp((P + 3) / 4, A), blk(256);
+  const bool v4 = (start & 3) == 0 && (T & 3) == 0 && (P & 3) == 0 && !((uintptr_t)dbias & 15);
+#define OFA_OUTER(TT)                                                                                                              \
+  do {                                                                                                                             \
+    if (v4) {                                                                                                                      \
+      hipLaunchKernelGGL((bias_outer_grad_frames_kernel<TT, 4>), gf, blk, 0, st, (const TT*)dbias, (TT*)d_frames, A, T, start, F, P);   \
+      hipLaunchKernelGGL((bias_outer_grad_patches_kernel<TT, 4>), gp, blk, 0, st, (const TT*)dbias, (TT*)d_patches, A, T, start, F, P); \
+    } else {                                                                                                                       \
+      hipLaunchKernelGGL((bias_outer_grad_frames_kernel<TT, 1>), gf, blk, 0, st, (const TT*)dbias, (TT*)d_frames, A, T, start, F, P);   \
+      hipLaunchKernelGGL((bias_outer_grad_patches_kernel<TT, 1>), gp, blk, 0, st, (const TT*)dbias, (TT*)d_patches, A, T, start, F, P); \
+    }                                                                                                                              \
+  } while (0)
+  if (dtype == OFA_F32) OFA_OUTER(float);
+  else if (dtype == OFA_BF16) OFA_OUTER(bf16_t);
+  else OFA_OUTER(f16_t);
+#undef OFA_OUTER
   return check_launch("bias_outer_grad");
 }
 

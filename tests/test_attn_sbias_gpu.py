@@ -195,20 +195,22 @@ def test_bias_build_assembles_and_swizzles(K, A, T, S, slots, with_abs):
     assert torch.equal(sc.view(A, nkt, nqt, 64, 16), col_img)
 
 
-def test_bias_build_outer_slot_and_its_gradient(K):
+@pytest.mark.parametrize("Fr,P,s0,Tt,nt", [(3, 13, 5, 50, 6), (2, 12, 4, 32, 4), (8, 196, 0, 1600, 32)])   # (element-wise / 8-byte pieces / cfg-4)
+def test_bias_build_outer_slot_and_its_gradient(K, Fr, P, s0, Tt, nt):
     """A video slot's rel-pos values are frames[i // P][j // P] + patches[i % P][j % P] (video_image_sequence.py:187-204): the assembly
     reads the two tables (bit-exact against the reference's broadcast add + block add in bf16), the gradient kernels sum the bias
     gradient's block straight into them (fp32 accumulation, against torch's two reductions)."""
     from ofasys_amd import ops
-    A, Fr, P, s0, Tt = 6, 3, 13, 5, 50                       # block of 39 positions at 5 inside 50, a dense text slot behind it
+    A = 6                                                    # the outer block at s0, a dense text slot in the last nt positions
     g = torch.Generator(device="cpu").manual_seed(3)
     mk = lambda *s: torch.randn(*s, generator=g).to(DEV).bfloat16()                  # noqa: E731
-    abs_b, vf, vi, vt = mk(A, Tt, Tt), mk(Fr, Fr, A), mk(P, P, A), mk(6, 6, A)
-    out, (sr, sc) = K.bias_build(abs_b, [s0, 44], [(vf, vi), vt])
+    abs_b, vf, vi, vt = mk(A, Tt, Tt), mk(Fr, Fr, A), mk(P, P, A), mk(nt, nt, A)
+    assert s0 + Fr * P <= Tt - nt
+    out, (sr, sc) = K.bias_build(abs_b, [s0, Tt - nt], [(vf, vi), vt])
     dense = ops.OuterRelPos(vf, vi).dense()                                          # bf16 broadcast add, as the reference
     ref = abs_b.clone()
     ref[:, s0:s0 + Fr * P, s0:s0 + Fr * P] += dense.permute(2, 0, 1)
-    ref[:, 44:50, 44:50] += vt.permute(2, 0, 1)
+    ref[:, Tt - nt:, Tt - nt:] += vt.permute(2, 0, 1)
     assert torch.equal(out, ref)
     G = mk(1, A, Tt, Tt)
     dvf, dvi = K.bias_outer_grad(G, s0, Fr, P)

@@ -18,12 +18,14 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/r3write -o p -- python $R/benc
 python $R/tools/pmc_traffic.py /tmp/r3fetch/p_results.db /tmp/r3write/p_results.db $O/round3_pmc_traffic.json 4 > $O/round3_pmc_traffic.txt 2>&1
 # MFMA busy / LDS activity / bank conflicts per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/r3mfma -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/mfma_run.log 2>&1
-(echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
+(set +x; echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
  echo "#   -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph   (MI355X, round 3, packed cfg-2 step; tools/pmc_dump.py)"
  echo "# Averages per launch, grouped by (kernel, grid x).  MFMA utilisation = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs);"
  echo "# LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.  Appended per line as [mfma xx% | lds-conflict yy%]."
  python $R/tools/pmc_dump.py /tmp/r3mfma/p_results.db) > $O/round3_pmc_mfma_lds.txt 2>&1
 cd $R
+# the bench lines below quote the kernel-trace / PMC summaries of THIS run (bench.py reads them from profiles/)
+cp $O/round3_rocprof_kernel_stats.json $O/round3_rocprof_cfg2b_kernel_stats.json $O/round3_rocprof_cfg4_kernel_stats.json $O/round3_pmc_traffic.json $R/profiles/
 python bench.py > $O/round3_bench.json 2> $O/bench_run.log
 tail -c 1200 $O/round3_bench.json
 python bench.py --workload cfg2b --steps 30 --warmup 5 > $O/round3_bench_cfg2b.json 2> $O/bench_cfg2b_run.log

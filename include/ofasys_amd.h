@@ -395,14 +395,15 @@ int ofa_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, i
 /* torch.nn.BatchNorm2d over the rows of [rows, C] (module/resnet.py:105-128): y = [relu]((x-mean)*rstd*gamma + beta
  * [+ residual]).  use_running == 0: batch statistics (biased variance), running buffers (fp32, optional) updated with
  * `momentum` and the unbiased variance; use_running != 0: eval mode.  mean/rstd: fp32 [C] outputs kept for backward.
- * ws: ofa_batchnorm_ws_floats(C) floats.  Backward: g = dy*[y>0] when relu; dres (optional) receives g. */
+ * ws: ofa_batchnorm_ws_floats(C) floats.  Backward: g = dy*[y>0] when relu; dres (optional) receives g.  beta (backward, optional;
+ * relu layers without a residual input only): the gate is recomputed as [(x-mean)*rstd*gamma + beta > 0] and y is not read. */
 int ofa_batchnorm_ws_floats(int C);
 int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
                       float* rstd, float* running_mean, float* running_var, float* ws, int64_t rows, int C, float eps,
                       float momentum, int use_running, int relu, int dtype, void* stream);
 int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
                       void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int batch_stats,
-                      int relu, int accumulate, int dtype, void* stream);
+                      int relu, int accumulate, const void* beta, int dtype, void* stream);
 /* MaxPool2d(K, stride, pad) on NHWC; arg: one byte per output element (arg-max tap), consumed by the backward. */
 int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, int dtype,
                     void* stream);

@@ -151,7 +151,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, double* __restrict__ partial,
-                                                         int64_t rows, int C, int relu, int cw_log2) {
+                                                         int64_t rows, int C, int relu, int cw_log2,
+                                                         const T* __restrict__ gamma = nullptr, const T* __restrict__ beta = nullptr) {
   constexpr int N = Vec<T>::N;
   // a block is cw column vectors (32, or C/N when the layer is narrower: 64 channels are 8 bf16 vectors -- with a fixed
   // 32 x 8 shape three quarters of the threads of those layers had no column) x 256/cw row lanes
@@ -162,13 +163,20 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
   // double accumulators: BatchNorm over few values per channel (B*h*w = 32 on a 64x64 image) makes the backward chain
   // ill-conditioned; fp64 VALU is full rate on this part and the kernel is HBM-bound anyway
   double s0[N], s1[N];
-  float mu[N], rs[N];
+  float mu[N], rs[N], gm[N], bt[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) { s0[j] = s1[j] = 0.0; mu[j] = 0.f; rs[j] = 1.f; }
+  for (int j = 0; j < N; ++j) { s0[j] = s1[j] = 0.0; mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f; }
+  // relu == 2: the ReLU gate is recomputed from x -- [(x - mean) * rstd * gamma + beta > 0], bn_apply's own expression -- instead of
+  // read from the layer's output y (no residual joins the sum there): one tensor less to stream in both backward passes
+  const bool regate = MODE == 1 && relu == 2;
   if (c < C) {
     if (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < N; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
+      if (regate) {
+        load_vec<T>(gamma + c, gm);
+        load_vec<T>(beta + c, bt);
+      }
     }
     const int64_t step = (int64_t)gridDim.y * rl;
     auto add = [&](const float (&a)[N], const float (&b)[N], const float (&yy)[N]) {
@@ -178,7 +186,8 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
       } else {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          const float g = (relu && !(yy[j] > 0.f)) ? 0.f : a[j];
+          const bool on = regate ? ((b[j] - mu[j]) * rs[j] * gm[j] + bt[j] > 0.f) : (!relu || yy[j] > 0.f);
+          const float g = on ? a[j] : 0.f;
           s0[j] += (double)g;
           s1[j] += (double)g * (double)((b[j] - mu[j]) * rs[j]);
         }
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
       if (MODE == 1) {
         load_vec<T>(dy + r * C + c, a0);
         load_vec<T>(dy + (r + step) * C + c, a1);
-        if (relu) {
+        if (relu == 1) {
           load_vec<T>(y + r * C + c, y0);
           load_vec<T>(y + (r + step) * C + c, y1);
         }
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
       load_vec<T>(x + r * C + c, b0);
       if (MODE == 1) {
         load_vec<T>(dy + r * C + c, a0);
-        if (relu) load_vec<T>(y + r * C + c, y0);
+        if (relu == 1) load_vec<T>(y + r * C + c, y0);
       }
       add(a0, b0, y0);
     }
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ sums, T* __restrict__ dx,
                                                         T* __restrict__ dres, int64_t rows, int C, int relu,
-                                                        int batch_stats) {
+                                                        int batch_stats, const T* __restrict__ beta = nullptr) {
   constexpr int N = Vec<T>::N;
   const int vpr = C / N;
   const int64_t total = rows * vpr;
@@ -360,7 +369,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
     ldf<N>(rstd + c, rs);
     ldf<N>(sums + c, sg);
     ldf<N>(sums + C + c, sx);
-    if (relu) {
+    if (relu == 2) {                                      // gate recomputed from x (see bn_colstat_kernel)
+      float bt[N];
+      load_vec<T>(beta + c, bt);
+#pragma unroll
+      for (int j = 0; j < N; ++j) g[j] = ((xx[j] - mu[j]) * rs[j] * gm[j] + bt[j] > 0.f) ? g[j] : 0.f;
+    } else if (relu) {
       float yy[N];
       load_vec<T>(y + v * N, yy);
 #pragma unroll
@@ -574,9 +588,11 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
 // dgamma/dbeta: [C] in `dtype` (accumulate != 0: added); dres (optional): gradient of the residual input (= gated dy).
 extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
                                  const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows,
-                                 int C, int batch_stats, int relu, int accumulate, int dtype, void* stream) {
+                                 int C, int batch_stats, int relu, int accumulate, const void* beta, int dtype, void* stream) {
   OFA_DT("batchnorm_bwd");
-  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && (!relu || y), OFA_ERR_INVALID, "batchnorm_bwd: bad argument");
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && (!relu || y || beta), OFA_ERR_INVALID, "batchnorm_bwd: bad argument");
+  OFA_REQUIRE(!beta || (relu && !dres), OFA_ERR_INVALID, "batchnorm_bwd: the gate can be recomputed from x (beta != NULL) only for a ReLU layer without a residual input");
+  if (beta) relu = 2;
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
   hipStream_t st = (hipStream_t)stream;
@@ -585,25 +601,25 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   float* sums = ws + (int64_t)4 * 256 * C;
   dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
   if (dtype == OFA_F32) {
-    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
+    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const float*)gamma, (const float*)beta);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else if (dtype == OFA_BF16) {
-    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
+    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const bf16_t*)gamma, (const bf16_t*)beta);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
   }
   else {
-    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
+    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const f16_t*)gamma, (const f16_t*)beta);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");
   if (rc) return rc;
   dim3 g2(grid_1d(rows * (C / n)));
   if (dtype == OFA_F32)
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats, (const float*)beta);
   else if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats, (const bf16_t*)beta);
   else
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<f16_t>), g2, block, 0, st, (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, (const f16_t*)gamma, mean, rstd, (const float*)sums, (f16_t*)dx, (f16_t*)dres, rows, C, relu, batch_stats);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<f16_t>), g2, block, 0, st, (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, (const f16_t*)gamma, mean, rstd, (const float*)sums, (f16_t*)dx, (f16_t*)dres, rows, C, relu, batch_stats, (const f16_t*)beta);
   return check_launch("batchnorm_bwd_dx");
 }
 

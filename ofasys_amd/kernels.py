@@ -950,7 +950,8 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, momentum,
     return y, mean, rstd
 
 
-def batchnorm_bwd(dy, y, x, gamma, mean, rstd, batch_stats, relu, want_dres=False, dgamma=None, dbeta=None):
+def batchnorm_bwd(dy, y, x, gamma, mean, rstd, batch_stats, relu, want_dres=False, dgamma=None, dbeta=None, beta=None):
+    """beta (relu layers without a residual only): the ReLU gate is recomputed from x instead of read from y."""
     dy = dy.contiguous()
     rows, C = x.shape
     dx = torch.empty_like(x)
@@ -961,7 +962,8 @@ def batchnorm_bwd(dy, y, x, gamma, mean, rstd, batch_stats, relu, want_dres=Fals
         dbeta = torch.empty(C, dtype=gamma.dtype, device=x.device)
     ws = workspace(lib().cdll.ofa_batchnorm_ws_floats(C) * 4, x.device, "bn")
     lib().call("ofa_batchnorm_bwd", ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dres), ptr(dgamma),
-               ptr(dbeta), ptr(ws), rows, C, int(batch_stats), int(relu), int(acc), dtype_code(x), stream())
+               ptr(dbeta), ptr(ws), rows, C, int(batch_stats), int(relu), int(acc), ptr(beta) if (relu and not want_dres) else None,
+               dtype_code(x), stream())
     return dx, dres, dgamma, dbeta
 
 

@@ -1517,12 +1517,13 @@ class BatchNormFn(torch.autograd.Function):
         training, relu, has_res = ctx.cfg
         gw, gb = _sink(weight), _sink(ctx.bias_ref)
         if gw is not None and gb is not None and weight.requires_grad:
-            dx, dres, _, _ = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res, dgamma=gw, dbeta=gb)
+            dx, dres, _, _ = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res, dgamma=gw, dbeta=gb,
+                                             beta=ctx.bias_ref)
             _sink_done(weight)
             _sink_done(ctx.bias_ref)
             dg = db = None
         else:
-            dx, dres, dg, db = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res)
+            dx, dres, dg, db = K.batchnorm_bwd(dy, y, x, weight, mean, rstd, training, relu, has_res, beta=ctx.bias_ref)
         if ctx.mailbox is not None and dres is not None:
             ctx.mailbox.append(dres)             # handed to the consumer named at forward time, which adds it inside its own kernel
             dres = None

@@ -20,7 +20,7 @@ for rows, C in SHAPES:
         return K.batchnorm_fwd(x, g, b, rm, rv, True, 0.1, 1e-5, relu=True)
     y, mean, rstd = fwd()
     def bwd():
-        return K.batchnorm_bwd(dy, y, x, g, mean, rstd, True, True)
+        return K.batchnorm_bwd(dy, y, x, g, mean, rstd, True, True, beta=b)
     bwd()
     torch.cuda.synchronize()
     out = []

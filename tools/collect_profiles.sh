@@ -33,3 +33,6 @@ python bench.py --workload cfg4 --steps 30 --warmup 5 > $O/round3_bench_cfg4.jso
 python bench.py --workload cfg2b --no-pack --steps 30 --warmup 5 --no-cpu-baseline > $O/round3_bench_cfg2b_padded.json 2> $O/bench_cfg2b_padded_run.log
 python tools/attn_bench.py > $O/round3_attn_bench.txt 2>&1
 for w in cfg2b cfg4 dec cross; do python tools/attn_sbias_bench.py $w 2>&1 | grep -v amdgpu.ids >> $O/round3_attn_sbias_bench.txt; done
+for w in cfg2 cfg2b cfg4; do python tools/native_glue_trace.py $w 2>&1 | grep -v amdgpu.ids > $O/round3_native_glue_$w.txt; done
+timeout 300 tools/experiments/_build/adam_stream_bench > $O/round3_adam_stream_bench.txt 2>&1 || true
+(python tools/gemm_split_check.py; OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round3_gemm_split_check.txt

@@ -41,9 +41,15 @@ q_ = lambda x: f"mean {x.mean():7.1f}  p10 {np.percentile(x, 10):7.1f}  p50 {np.
 print(f"  entry -> first K/V tiles landed [us] : {q_((tl[:, 9] - tl[:, 8]) * c2us)}")
 print(f"  key-block loop [us]                  : {q_((tl[:, 11] - tl[:, 9]) * c2us)}   (= {((tl[:, 11] - tl[:, 9]) * c2us).mean() / nkb:.2f} us per block)")
 print(f"  workgroup life [us]                  : {q_((tl[:, 11] - tl[:, 8]) * c2us)}")
+rt0 = (tl[:, 14] - tl[:, 14].min()) * 0.01                 # s_memrealtime: 100 MHz
+rt1 = (tl[:, 15] - tl[:, 14].min()) * 0.01
+print(f"  workgroup ENTRY after the first one [us]: {q_(rt0)}  max {rt0.max():.1f}")
+print(f"  workgroup EXIT  after the first entry   : {q_(rt1)}  max {rt1.max():.1f}   (device-side span of the launch)")
 ok = tl[tl[:, 7] != 0]
 names = ["K fragments: issue -> in registers", "4 S MFMAs + scale + row max (lane-local)", "cross-half max exchange (__shfl_xor)",
          "exp2 x16 + sum", "cross-half sum exchange", "rescale (if any) + wait for the V^T fragments", "pack + 4 PV MFMAs issued"]
+if len(ok) == 0:
+    sys.exit(0)
 d = np.diff(ok[:, 0:8], axis=1)
 print(f"  block 4 of wave 0, shader clocks ({len(ok)} workgroups):")
 for i, nm in enumerate(names):

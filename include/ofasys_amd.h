@@ -298,7 +298,7 @@ int ofa_head_sum_f32(const float* x, float* out, int B, int heads, int T, int ld
  *   out = abs_bias (NULL: zeros);  out[:, s:s+n, s:s+n] += values_k[i][j][h]  for each slot k (values_k: [n, n, heads], `dtype`)
  * written as the row-major tensor (out, optional) and as the two swizzled images the ofa_attn_sbias_* kernels read (swz_row,
  * swz_col: ofa_bias_swz_elems(heads, Tb, Sb) elements each, 16-byte aligned; layout: see ofa_attn_sbias_fwd).  16-bit dtypes only;
- * slot blocks need Tb == Sb; heads <= 24. */
+ * slot blocks need Tb == Sb. */
 typedef struct ofa_bias_slots {
   const void* values[8];
   const void* values2[8];  /* NULL: a dense slot.  Else an OUTER slot (video_image_sequence.py:187-204: frame-level + patch-level

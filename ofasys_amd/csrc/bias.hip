@@ -65,7 +65,8 @@ constexpr int BIAS_TP = 40;                                  // tile row pitch i
 
 template <typename T>
 __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ abs_bias, BiasSlotsDev slots, T* __restrict__ out,
-                                                         T* __restrict__ swz_row, T* __restrict__ swz_col, int A, int Tb, int Sb) {
+                                                         T* __restrict__ swz_row, T* __restrict__ swz_col, int A, int Tb, int Sb,
+                                                         int At, int h0) {   // heads h0 .. h0 + A - 1 of At (the slot values are [.., At])
   extern __shared__ __attribute__((aligned(16))) unsigned char bias_smem[];
   T* tile = reinterpret_cast<T*>(bias_smem);                // [A][32][BIAS_TP]
   const int kt = blockIdx.x, qt = blockIdx.y;
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ a
         if (i < 0 || j < 0 || i >= n || j >= n) continue;
         if (slots.values2[s]) {              // frame-level table + patch-level table (video_image_sequence.py:187-204), summed in
           const int P = slots.inner[s], F = n / P;                      // the 16-bit type first, as the reference's broadcast add
-          const T* vf = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)(i / P) * F + j / P) * A;
-          const T* vi = reinterpret_cast<const T*>(slots.values2[s]) + ((int64_t)(i % P) * P + j % P) * A;
+          const T* vf = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)(i / P) * F + j / P) * At + h0;
+          const T* vi = reinterpret_cast<const T*>(slots.values2[s]) + ((int64_t)(i % P) * P + j % P) * At + h0;
           for (int h = 0; h < A; ++h) {
             T v;
             st1<T>(&v, ld1<T>(vf + h) + ld1<T>(vi + h));
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void bias_build_kernel(const T* __restrict__ a
           }
           continue;
         }
-        const T* vp = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)i * n + j) * A;
+        const T* vp = reinterpret_cast<const T*>(slots.values[s]) + ((int64_t)i * n + j) * At + h0;
         for (int h = 0; h < A; ++h) {
           T* t = tile + (h * 32 + qr) * BIAS_TP + kc;
           st1<T>(t, ld1<T>(t) + ld1<T>(vp + h));
@@ -265,7 +266,7 @@ extern "C" int64_t ofa_bias_swz_elems(int heads, int Tb, int Sb) {
 extern "C" int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots, void* out, void* swz_row, void* swz_col, int heads,
                               int Tb, int Sb, int dtype, void* stream) {
   OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "bias_build: 16-bit dtypes only (got %d)", dtype);
-  OFA_REQUIRE(swz_row && swz_col && heads > 0 && heads <= 24 && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "bias_build: bad argument");
+  OFA_REQUIRE(swz_row && swz_col && heads > 0 && Tb > 0 && Sb > 0, OFA_ERR_INVALID, "bias_build: bad argument");
   OFA_REQUIRE(!(((uintptr_t)swz_row | (uintptr_t)swz_col) & 15), OFA_ERR_INVALID, "bias_build: the swizzled images must be 16-byte aligned");
   BiasSlotsDev d{};
   if (slots) {
@@ -285,13 +286,19 @@ extern "C" int ofa_bias_build(const void* abs_bias, const ofa_bias_slots* slots,
     }
   }
   const dim3 grid((Sb + 31) / 32, (Tb + 31) / 32), block(256);
-  const size_t lds = (size_t)heads * 32 * BIAS_TP * 2;
-  if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bias_build_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)abs_bias, d, (bf16_t*)out,
-                       (bf16_t*)swz_row, (bf16_t*)swz_col, heads, Tb, Sb);
-  else
-    hipLaunchKernelGGL((bias_build_kernel<f16_t>), grid, block, lds, (hipStream_t)stream, (const f16_t*)abs_bias, d, (f16_t*)out,
-                       (f16_t*)swz_row, (f16_t*)swz_col, heads, Tb, Sb);
+  const int64_t per_head = (int64_t)Tb * Sb, swz_head = (int64_t)grid.x * grid.y * 1024;
+  for (int h0 = 0; h0 < heads; h0 += 24) {                       // (a workgroup holds the block of up to 24 heads in LDS)
+    const int A = heads - h0 < 24 ? heads - h0 : 24;
+    const size_t lds = (size_t)A * 32 * BIAS_TP * 2;
+    if (dtype == OFA_BF16)
+      hipLaunchKernelGGL((bias_build_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream,
+                         abs_bias ? (const bf16_t*)abs_bias + h0 * per_head : nullptr, d, out ? (bf16_t*)out + h0 * per_head : nullptr,
+                         (bf16_t*)swz_row + h0 * swz_head, (bf16_t*)swz_col + h0 * swz_head, A, Tb, Sb, heads, h0);
+    else
+      hipLaunchKernelGGL((bias_build_kernel<f16_t>), grid, block, lds, (hipStream_t)stream,
+                         abs_bias ? (const f16_t*)abs_bias + h0 * per_head : nullptr, d, out ? (f16_t*)out + h0 * per_head : nullptr,
+                         (f16_t*)swz_row + h0 * swz_head, (f16_t*)swz_col + h0 * swz_head, A, Tb, Sb, heads, h0);
+  }
   return check_launch("bias_build");
 }
 

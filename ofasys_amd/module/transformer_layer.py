@@ -45,6 +45,18 @@ def _act_name(cfg):
     return getattr(cfg, "activation_fn", "gelu")
 
 
+def _activation(name, h):
+    """The FFN activation by its fairseq name (module/utils.py get_activation_fn): gelu (OFASys' default: erf form, fused with the
+    LayerNorm behind it where the layer allows), relu (the kernel of the ResNet stack), linear; the others are not implemented."""
+    if name == "gelu":
+        return ops.gelu(h)
+    if name == "relu":
+        return ops.relu(h)
+    if name == "linear":
+        return h
+    raise NotImplementedError(f"activation_fn={name!r}: gelu, relu and linear are implemented")
+
+
 class _FFNMixin:
     def _joinable(self):
         """The fused residual joins cover the pre-LN layer without scale_resids / DropPath (OFASys' defaults)."""
@@ -163,9 +175,7 @@ class _FFNMixin:
             residual = x
         act_p = self.activation_dropout_module.p if self.training else 0.0
         if self.modal_ffn:
-            if not self._gelu:
-                raise NotImplementedError("only activation_fn='gelu' (OFASys default) is implemented")
-            x = ops.gelu(self._modal_linear(modal_mask, x, self.experts_fc1))
+            x = _activation(self._act, self._modal_linear(modal_mask, x, self.experts_fc1))
             x = self.activation_dropout_module(x)
             if self.ffn_layernorm is not None:
                 x = self.ffn_layernorm(x)
@@ -173,10 +183,8 @@ class _FFNMixin:
             x = ops.linear_gelu_layer_norm(x, self.fc1.weight, self.fc1.bias, self.ffn_layernorm.weight,
                                            self.ffn_layernorm.bias, self.ffn_layernorm.eps)
         else:
-            if not self._gelu:
-                raise NotImplementedError("only activation_fn='gelu' (OFASys default) is implemented")
             h = self.fc1(x)
-            x = ops.gelu(h)
+            x = _activation(self._act, h)
             x = self.activation_dropout_module(x)
             if self.ffn_layernorm is not None:
                 x = self.ffn_layernorm(x)
@@ -206,7 +214,8 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         self.self_attn = self.build_self_attention(self.embed_dim, cfg)
         self.self_attn_layer_norm = LayerNorm(self.embed_dim)
         self.dropout_module = Dropout(cfg.dropout, module_name=self.__class__.__name__)
-        self._gelu = _act_name(cfg) == "gelu"
+        self._act = _act_name(cfg)
+        self._gelu = self._act == "gelu"
         activation_dropout_p = cfg.activation_dropout
         if activation_dropout_p == 0:
             activation_dropout_p = cfg.relu_dropout or 0
@@ -288,7 +297,8 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         self.cross_attn_ln = LayerNorm(self.embed_dim) if cfg.scale_attn else None
         self.nh = self.self_attn.num_heads
         self.head_dim = self.self_attn.head_dim
-        self._gelu = _act_name(cfg) == "gelu"
+        self._act = _act_name(cfg)
+        self._gelu = self._act == "gelu"
         activation_dropout_p = cfg.activation_dropout
         if activation_dropout_p == 0:
             activation_dropout_p = cfg.relu_dropout or 0

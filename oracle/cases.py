@@ -31,6 +31,14 @@ CASES = {
         full_grads=["encoder.adaptor.embed_tokens.weight", "encoder.adaptor.text.type_embedding.weight",
                     "encoder.adaptor.text.layernorm_embedding.weight", "encoder.layers.0.self_attn.q_proj.weight"],
     ),
+    # a non-default FFN activation (activation_fn, module/utils.py get_activation_fn): relu
+    "tiny_text_relu": dict(
+        arch="tiny", active={"text"}, overrides={"activation_fn": "relu"}, adaptor_overrides={},
+        slots=[("TEXT", True, ("tok", "src", (2, 16), [16, 11]), None),
+               ("TEXT", False, ("tok", "prev", (2, 12), [9, 12]), None)],
+        full_grads=["encoder.layers.0.fc1.weight", "decoder.layers.3.ffn_layernorm.weight", "encoder.layers.2.fc2.bias",
+                    "encoder.adaptor.embed_tokens.weight"],
+    ),
     # three source slots incl. BOX-as-tokens: slot order != ModalityType order, block-diagonal rel-pos bias
     "tiny_multislot": dict(
         arch="tiny", active={"text"}, overrides={}, adaptor_overrides={},

@@ -77,6 +77,7 @@ class OConfig:
     image_bucket_size: int = 42             # adaptor/image_resnet.py:62-65
     training: bool = False                  # BatchNorm batch statistics (dropout must be 0 for a deterministic oracle)
     modal_ffn: bool = False                 # ofa.py:119-121: one FFN expert per ModalityType
+    activation_fn: str = "gelu"             # module/utils.py get_activation_fn (ofa.py: activation_fn)
 
 
 # --------------------------------------------------------------------------------------------
@@ -460,7 +461,8 @@ def _ffn(state, p, cfg, x, modal_mask=None):
     """transformer_layer.py:186-208 / :471-494 (pre-LN, scale_fc LayerNorm over F inside the FFN)."""
     r = x
     x = layer_norm(state, p + ".final_layer_norm", x, cfg.eps)
-    x = gelu(modal_for_ffn(state, p + ".experts_fc1", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc1", x))
+    act = {"gelu": gelu, "relu": F.relu, "linear": lambda t: t}[cfg.activation_fn]
+    x = act(modal_for_ffn(state, p + ".experts_fc1", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc1", x))
     if (p + ".ffn_layernorm.weight") in state:
         x = layer_norm(state, p + ".ffn_layernorm", x, cfg.eps)
     x = modal_for_ffn(state, p + ".experts_fc2", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc2", x)

@@ -61,7 +61,8 @@ def oracle_cfg(case):
     return OConfig(**ARCH[case["arch"]], use_self_attn_bias=ov.get("use_self_attn_bias", True),
                    entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent,
                    adaptor_embed_scale=esc, adaptor_grad_scale=gsc,
-                   resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)))
+                   resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)),
+                   activation_fn=ov.get("activation_fn", "gelu"))
 
 
 def case_inputs(case):

@@ -160,7 +160,7 @@ def test_planned_table_gradient_matches_scan_kernel_and_torch(K, dtype, n, V, D)
     assert torch.equal(again.float(), res[0])
 
 
-@pytest.mark.parametrize("A,T,S,slots", [(12, 70, 70, ((0, 30), (30, 40))), (4, 64, 64, ((0, 64),)), (3, 45, 131, ()), (16, 33, 33, ((5, 20),))])
+@pytest.mark.parametrize("A,T,S,slots", [(12, 70, 70, ((0, 30), (30, 40))), (4, 64, 64, ((0, 64),)), (3, 45, 131, ()), (16, 33, 33, ((5, 20),)), (40, 40, 40, ((8, 32),))])   # (40 heads: two launches of <= 24)
 @pytest.mark.parametrize("with_abs", [True, False])
 def test_bias_build_assembles_and_swizzles(K, A, T, S, slots, with_abs):
     """ofa_bias_build: the row-major result is general.py:265-280's clone + diagonal block adds (bit-exact: one bf16 rounding per

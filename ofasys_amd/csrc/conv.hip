@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
 // partial[g][0][c] = sum_r a[r][c],  partial[g][1][c] = sum_r a[r][c]*b[r][c]   over the rows of group g, where
 //   MODE 0 (forward):  a = x,              b = x                      -> sum x, sum x^2
 //   MODE 1 (backward): a = g = dy*[y>0],   b = xhat = (x-mean)*rstd   -> sum g, sum g*xhat
+//   MODE 2: MODE 1 with the ReLU gate recomputed from x (no residual joins the sum there) instead of read from y
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
@@ -168,9 +169,9 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
   for (int j = 0; j < N; ++j) { s0[j] = s1[j] = 0.0; mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f; }
   // relu == 2: the ReLU gate is recomputed from x -- [(x - mean) * rstd * gamma + beta > 0], bn_apply's own expression -- instead of
   // read from the layer's output y (no residual joins the sum there): one tensor less to stream in both backward passes
-  const bool regate = MODE == 1 && relu == 2;
+  constexpr bool regate = MODE == 2;
   if (c < C) {
-    if (MODE == 1) {
+    if (MODE >= 1) {
 #pragma unroll
       for (int j = 0; j < N; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
       if (regate) {
@@ -198,10 +199,10 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
       float a0[N], b0[N], y0[N], a1[N], b1[N], y1[N];
       load_vec<T>(x + r * C + c, b0);
       load_vec<T>(x + (r + step) * C + c, b1);
-      if (MODE == 1) {
+      if (MODE >= 1) {
         load_vec<T>(dy + r * C + c, a0);
         load_vec<T>(dy + (r + step) * C + c, a1);
-        if (relu == 1) {
+        if (MODE == 1 && relu) {
           load_vec<T>(y + r * C + c, y0);
           load_vec<T>(y + (r + step) * C + c, y1);
         }
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
     if (r < rows) {
       float a0[N], b0[N], y0[N];
       load_vec<T>(x + r * C + c, b0);
-      if (MODE == 1) {
+      if (MODE >= 1) {
         load_vec<T>(dy + r * C + c, a0);
-        if (relu == 1) load_vec<T>(y + r * C + c, y0);
+        if (MODE == 1 && relu) load_vec<T>(y + r * C + c, y0);
       }
       add(a0, b0, y0);
     }
@@ -601,14 +602,17 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   float* sums = ws + (int64_t)4 * 256 * C;
   dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
   if (dtype == OFA_F32) {
-    hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const float*)gamma, (const float*)beta);
+    if (beta) hipLaunchKernelGGL((bn_colstat_kernel<float, 2>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const float*)gamma, (const float*)beta);
+    else hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else if (dtype == OFA_BF16) {
-    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const bf16_t*)gamma, (const bf16_t*)beta);
+    if (beta) hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const bf16_t*)gamma, (const bf16_t*)beta);
+    else hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
   }
   else {
-    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const f16_t*)gamma, (const f16_t*)beta);
+    if (beta) hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 2>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const f16_t*)gamma, (const f16_t*)beta);
+    else hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
   int rc = check_launch("batchnorm_bwd_stats");

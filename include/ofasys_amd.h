@@ -218,7 +218,7 @@ int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* 
                        float* ws, int64_t ws_bytes, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
                        int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 /* Batch chunks the dS-sum kernel of ofa_attn_sbias_bwd cuts B samples into (short sequences: the [128 x 64] tiles of the heads alone
- * would leave the chip idle).  1 and dbias_dtype == OFA_F32: it writes dbias_sum itself, ws may be NULL.  Otherwise ws must hold
+ * would leave the chip idle).  1 and dbias_dtype == OFA_F32 or == dtype: it writes dbias_sum itself, ws may be NULL.  Otherwise ws must hold
  * n * heads * Tb * Sb floats (the chunks' partial sums, folded in chunk order -- and cast -- by ofa_fold_batched inside the call). */
 int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb);
 /* Gradient of the per-head scale c_attn (multihead_attention.py:58, 342-345: attn[t,b,h,:] *= c_attn[h]; O = c * PV, so

@@ -1101,7 +1101,7 @@ struct DsumQ {                    // the query-side operands of one sample for t
 };
 template <bool F16>
 __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb,
-                                                   int nchunk, int bper) {
+                                                   int nchunk, int bper, int out16) {   // out16: G is the 16-bit gradient itself (one chunk)
   constexpr int NKB = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);         // [2 buffers][2 key blocks][K tile | V tile], then the chunk's geometry table
@@ -1263,7 +1263,24 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
     b = bn;
   }
   // G[h][qi][keys of the tile] (or this chunk's partial)
-  if (qi < Tb) {
+  if (qi < Tb && out16) {                                  // one chunk and a 16-bit gradient: rounded here, no fold launch
+    bf16_t* gp = reinterpret_cast<bf16_t*>(G) + (int64_t)h * g_hs + (int64_t)qi * g_ld;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+      const int key0 = (kc0 + j) * 32;
+      if ((g_ld & 3) == 0 && key0 + 32 <= Sb) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          st4<F16>(gp + key0 + 8 * g4 + 4 * hi, acc[j][4 * g4], acc[j][4 * g4 + 1], acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + crowl(r, hi);
+          if (key < Sb) gp[key] = enc1<F16>(acc[j][r]);
+        }
+      }
+    }
+  } else if (qi < Tb) {
     float* gp = G + (int64_t)chunk * g_cs + (int64_t)h * g_hs + (int64_t)qi * g_ld;
 #pragma unroll
     for (int j = 0; j < NKB; ++j) {
@@ -1283,8 +1300,8 @@ __device__ __forceinline__ void attn_bwd_dsum_body(AttnL a, float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper) { attn_bwd_dsum_body<false>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper) { attn_bwd_dsum_body<true>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper, int out16) { attn_bwd_dsum_body<false>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper, out16); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dsum_f16_kernel(AttnL a, float* G, int64_t g_ld, int64_t g_hs, int64_t g_cs, int Tb, int Sb, int nchunk, int bper, int out16) { attn_bwd_dsum_body<true>(a, G, g_ld, g_hs, g_cs, Tb, Sb, nchunk, bper, out16); }
 
 static int attnl_check(int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, int dtype) {
   OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_UNSUPPORTED, "fused attention is bf16 / fp16 only (dtype %d); use the unfused path", dtype);
@@ -1385,7 +1402,10 @@ extern "C" int ofa_attn_sbias_fwd(const void* q, const void* k, const void* v, c
 
 extern "C" int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb) {
   const int64_t tiles = (int64_t)cdiv(Sb, 64) * cdiv(Tb, 128) * heads;
-  int64_t n = (1024 + tiles - 1) / tiles;
+  // enough workgroups for one round of the 256 CUs; more chunks only add partial slabs to fold (sweep of the target at
+  // 32 x 12 heads: 448^2 119-120 us at 256 / 1024, 142 us at 2048; 64 x 448 35.5 us at 256, 41.3 at 1024, 48.3 at 2048)
+  const int64_t target = 256;
+  int64_t n = (target + tiles - 1) / tiles;
   n = n < 1 ? 1 : (n > B ? B : n);
   const int bper = cdiv(B, (int)n);
   return cdiv(B, bper);
@@ -1430,7 +1450,8 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
   // alone would leave the chip idle, the chunks' fp32 partials are folded in chunk order
   const int nchunk = ofa_attn_sbias_chunks(B, heads, Tb, Sb);
   OFA_REQUIRE(OFA_DT_OK(dbias_dtype), OFA_ERR_INVALID, "attn_sbias_bwd: bad dbias dtype %d", dbias_dtype);
-  const bool direct = nchunk == 1 && dbias_dtype == OFA_F32;      // the kernel writes dbias_sum itself; otherwise the fold (+ cast) does
+  const bool out16 = nchunk == 1 && dbias_dtype == dtype;          // one chunk, gradient in the operands' 16-bit type: rounded in the kernel
+  const bool direct = (nchunk == 1 && dbias_dtype == OFA_F32) || out16;   // the kernel writes dbias_sum itself; otherwise the fold (+ cast) does
   OFA_REQUIRE(direct || (ws && ws_bytes >= (int64_t)nchunk * heads * Tb * Sb * 4), OFA_ERR_INVALID,
               "attn_sbias_bwd: the batch-sum kernel needs %lld bytes of workspace for %d chunks", (long long)nchunk * heads * Tb * Sb * 4, nchunk);
   const int bper = cdiv(B, nchunk);
@@ -1440,7 +1461,7 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
     float* dst = direct ? (float*)dbias_sum : ws;
     const size_t lds = 8 * TILE_BYTES + (size_t)bper * 16;
     OFA_REQUIRE(lds <= 64 * 1024, OFA_ERR_UNSUPPORTED, "attn_sbias_bwd: %d samples per chunk exceed the batch-sum kernel's geometry table", bper);
-    hipLaunchKernelGGL(kn, g, dim3(256), lds, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper);
+    hipLaunchKernelGGL(kn, g, dim3(256), lds, st, a, dst, (int64_t)Sb, (int64_t)Tb * Sb, (int64_t)heads * Tb * Sb, Tb, Sb, nchunk, bper, (int)out16);
     rc = check_launch("attn_sbias_bwd_dsum");
     if (rc || direct) return rc;
     ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, dbias_dtype};

@@ -581,7 +581,7 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         ws, ws_bytes = None, 0
         if need_dbias:
             nchunk = lib().cdll.ofa_attn_sbias_chunks(B if seg is None else seg.batch, heads, Tb, Sb)
-            if nchunk > 1 or dbias_dtype != torch.float32:
+            if nchunk > 1 or dbias_dtype not in (torch.float32, q.dtype):
                 ws = torch.empty(nchunk, heads, Tb, Sb, dtype=torch.float32, device=q.device)
                 ws_bytes = ws.numel() * 4
         if seg is not None:

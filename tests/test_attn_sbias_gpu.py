@@ -65,6 +65,10 @@ def test_shared_bias_attention_matches_reference(K, B, heads, T, S, causal, use_
     assert rel(out_d, out) < 4e-3
     again = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=True)
     assert torch.equal(again[3], G) and torch.equal(again[0], dq)
+    # the gradient in the bias' own dtype (what autograd gets): the fp32 sum rounded once -- by the kernel (one chunk) or the chunk fold
+    g16 = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c, causal=causal, need_dbias=True, bias_shared=True,
+                     dbias_dtype=torch.bfloat16)[3]
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, G.to(torch.bfloat16))
 
 
 def test_shared_bias_over_ragged_segments(K):

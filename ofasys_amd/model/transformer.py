@@ -38,6 +38,20 @@ def _packed_bias_ok(bias_list, prefix_ok, what):
                                   "padded row (one ragged slot, at the end); run this batch padded")
 
 
+def kept_layers(layers, p, training):
+    """LayerDropModuleList.__iter__ (module/layer_drop.py:37-41): in training every layer survives an iteration with probability
+    1 - p -- one uniform draw per layer from torch's default CPU generator, as the reference does; evaluation keeps them all.  The
+    callers enumerate the SURVIVORS (so a survivor's `idx` -- which selects its per-layer position bias -- counts survivors, as in
+    the reference's `for idx, layer in enumerate(self.layers)`).  The kept set is a host decision per step: it cannot be part of a
+    captured step graph."""
+    if not training or p <= 0.0:
+        return list(layers)
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise NotImplementedError("LayerDrop draws the kept layers on the host every step: run the step eagerly (TrainStep(use_graph=False))")
+    probs = torch.empty(len(layers)).uniform_()
+    return [m for m, u in zip(layers, probs.tolist()) if u > p]
+
+
 class TransformerEncoder(nn.Module):
     def __init__(self, cfg, dictionary: Dictionary):
         super().__init__()
@@ -46,8 +60,9 @@ class TransformerEncoder(nn.Module):
         self.register_buffer("version", torch.Tensor([3]))
         OFAGeneralAdaptor._embed_tokens = None          # a fresh shared embedding per model (transformer.py:48)
         self.adaptor = OFAGeneralAdaptor(cfg, dictionary, True)
-        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations or cfg.encoder_layerdrop > 0:
-            raise NotImplementedError("activation checkpointing / LayerDrop are not implemented in ofasys_amd")
+        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations:
+            raise NotImplementedError("activation checkpointing is not implemented in ofasys_amd")
+        self.layerdrop = float(cfg.encoder_layerdrop)                 # (model/transformer.py:53-54)
         self.layers = nn.ModuleList([])
         dpr = torch.linspace(0, cfg.encode_drop_path_rate, cfg.encoder_layers)
         self.layers.extend([self.build_encoder_layer(cfg, drop_path_rate=float(dpr[i])) for i in range(cfg.encoder_layers)])
@@ -77,13 +92,14 @@ class TransformerEncoder(nn.Module):
         encoder_states = [x] if return_all_hiddens else []
         encoder_attention_states = []
         chain = LayerChain()
-        for idx, layer in enumerate(self.layers):
+        layers = kept_layers(self.layers, self.layerdrop, self.training)
+        for idx, layer in enumerate(layers):
             if self.cfg.use_self_attn_bias:
                 b = adaptor_output.self_attn_bias[0 if self.cfg.share_attn_bias else idx]
                 self_attn_bias = b if isinstance(b, ops.SharedBias) else b.view(-1, T, T)   # (SharedBias: [A,T,T], one for the batch)
             else:
                 self_attn_bias = None
-            chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
+            chain.next_ln = layers[idx + 1].self_attn_layer_norm if idx + 1 < len(layers) else self.layer_norm
             x, self_attn_weights = layer(x, encoder_padding_mask=layer_mask, self_attn_bias=self_attn_bias,
                                          need_attn=return_all_attention_weights, modal_mask=adaptor_output.modal_mask,
                                          chain=chain)
@@ -129,8 +145,9 @@ class TransformerDecoder(nn.Module):
         self.register_buffer("version", torch.Tensor([3]))
         self._future_mask = torch.empty(0)
         self.adaptor = OFAGeneralAdaptor(cfg, dictionary, False)
-        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations or cfg.decoder_layerdrop > 0:
-            raise NotImplementedError("activation checkpointing / LayerDrop are not implemented in ofasys_amd")
+        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations:
+            raise NotImplementedError("activation checkpointing is not implemented in ofasys_amd")
+        self.layerdrop = float(cfg.decoder_layerdrop)                 # (model/transformer.py:244-245)
         self.share_input_output_embed = cfg.share_decoder_input_output_embed
         self.num_attention_heads = cfg.decoder_attention_heads
         embed_dim = cfg.decoder_embed_dim
@@ -235,9 +252,10 @@ class TransformerDecoder(nn.Module):
         inner_states: List[Optional[Tensor]] = [x] if return_all_hiddens else []
         decoder_attentions, cross_attentions = [], []
         chain = LayerChain()
-        cross_kv = self._cross_kv(enc, incremental_state)
-        for idx, layer in enumerate(self.layers):
-            chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
+        layers = kept_layers(self.layers, self.layerdrop, self.training)
+        cross_kv = self._cross_kv(enc, incremental_state) if len(layers) == len(self.layers) else None   # (dropped layers: own projections)
+        for idx, layer in enumerate(layers):
+            chain.next_ln = layers[idx + 1].self_attn_layer_norm if idx + 1 < len(layers) else self.layer_norm
             self_attn_mask = (self.buffered_future_mask(x) if incremental_state is None and not full_context_alignment
                               else None)
             if self.cfg.use_self_attn_bias:
@@ -302,9 +320,10 @@ class TransformerDecoder(nn.Module):
             cross_bias = self.get_cross_pos_info(None, adaptor_output.pos_embed, src_pos_embed=encoder_out["position_embeddings"][0],
                                                  shared=True)
         chain = LayerChain()
-        cross_kv = self._cross_kv(enc, incremental_state)
-        for idx, layer in enumerate(self.layers):
-            chain.next_ln = self.layers[idx + 1].self_attn_layer_norm if idx + 1 < len(self.layers) else self.layer_norm
+        layers = kept_layers(self.layers, self.layerdrop, self.training)
+        cross_kv = self._cross_kv(enc, incremental_state) if len(layers) == len(self.layers) else None
+        for idx, layer in enumerate(layers):
+            chain.next_ln = layers[idx + 1].self_attn_layer_norm if idx + 1 < len(layers) else self.layer_norm
             sb = self_bias[0 if self.cfg.share_attn_bias else idx] if self_bias is not None else False
             x, _, _ = layer(x, enc, pack.cross, None, self_attn_mask=tag, self_attn_padding_mask=pack.dec_self, need_attn=False,
                             need_head_weights=False, self_attn_bias=sb, cross_attn_bias=cross_bias,

@@ -247,6 +247,9 @@ class TrainStep:
         self._sched = torch.zeros(5, dtype=torch.float32, device=dev)
         self._lr = float(lr)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
+        if self.use_graph and any(float(getattr(m, "layerdrop", 0.0) or 0.0) > 0.0 for m in model.modules()):
+            warnings.warn("ofasys_amd.TrainStep: LayerDrop draws the kept layers on the host every step; the step is not captured")
+            self.use_graph = False
         self.graph_warmup = graph_warmup
         default_dp = "full"
         if self.world > 1:

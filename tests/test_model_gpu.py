@@ -618,6 +618,49 @@ def test_drop_path_model_trains_and_is_identity_in_eval():
             assert torch.isfinite(p.grad).all(), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layerdrop_keeps_the_reference_s_survivor_semantics(dtype):
+    """encoder_layerdrop / decoder_layerdrop (module/layer_drop.py:13-41, model/transformer.py:53-54, 244-245): in training each layer
+    survives with probability 1 - p, one uniform CPU draw per layer, and the stacks enumerate the SURVIVORS (a survivor's index picks
+    its per-layer position bias).  With the draws replayed from the same seed, the model must equal a copy whose layer lists were cut
+    down to the survivors by hand; evaluation keeps every layer; gradients reach the survivors only."""
+    import copy
+    from ofasys_amd import ops
+    case = copy.deepcopy(CASES["tiny_text"])
+    case["overrides"] = dict(case["overrides"], encoder_layerdrop=0.5, decoder_layerdrop=0.4, dropout=0.0)
+    model, d = build_model(case, DEV, dtype)
+    assert model.encoder.layerdrop == 0.5 and model.decoder.layerdrop == 0.4
+    vals, target = case_inputs(case)
+    g = load_golden("tiny_text")
+    model.eval()
+    if dtype == torch.float32:
+        assert rel_err(model(make_slots(vals, DEV, dtype))[0].detach().cpu(), g["logits"]) < FP32_TOL      # eval: all layers
+    seed = 11
+    torch.manual_seed(seed)
+    ne, nd = len(model.encoder.layers), len(model.decoder.layers)
+    keep_e = [u > 0.5 for u in torch.empty(ne).uniform_().tolist()]
+    keep_d = [u > 0.4 for u in torch.empty(nd).uniform_().tolist()]
+    assert 0 < sum(keep_e) + sum(keep_d) < ne + nd                                                         # (something is dropped)
+    ref = copy.deepcopy(model)
+    ref.encoder.layers = torch.nn.ModuleList([l for l, k in zip(ref.encoder.layers, keep_e) if k])
+    ref.decoder.layers = torch.nn.ModuleList([l for l, k in zip(ref.decoder.layers, keep_d) if k])
+    ref.encoder.layerdrop = ref.decoder.layerdrop = 0.0
+    model.train()
+    ref.train()
+    torch.manual_seed(seed)
+    logits, _ = model(make_slots(vals, DEV, dtype))
+    loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+    loss.backward()
+    rl, _ = ref(make_slots(vals, DEV, dtype))
+    assert torch.equal(logits, rl)
+    dropped = [f"encoder.layers.{i}." for i, k in enumerate(keep_e) if not k] + [f"decoder.layers.{i}." for i, k in enumerate(keep_d) if not k]
+    for k, p in model.named_parameters():
+        if any(k.startswith(pre) for pre in dropped):
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+        elif p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+
+
 def test_overfit_one_batch_loss_goes_down():
     """End-to-end sanity of the whole update loop (fused backward kernels + gradient arena + clip + Adam, captured step):
     40 steps on one tiny batch with dropout on must drive the per-token loss well below its starting value, with

@@ -165,7 +165,8 @@ class OFAGeneralAdaptor(torch.nn.Module):
                     kinds.append("dense")
                     tensors.append(v)
             b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_pos_bias, starts, kinds, *tensors)
-            output.self_attn_bias.append(ops.SharedBias(b[0], (swz_row, swz_col) if swz_row is not None else None) if shared else b)
+            # (squeeze, not b[0]: a select's backward zero-fills a whole [1, A, T, T] tensor and copies the gradient into it, per layer)
+            output.self_attn_bias.append(ops.SharedBias(b.squeeze(0), (swz_row, swz_col) if swz_row is not None else None) if shared else b)
         return output
 
     def upgrade_state_dict_named(self, state_dict, name):

@@ -179,7 +179,7 @@ class TransformerDecoder(nn.Module):
         pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling)
         pos_k = self.cross_pos_k_linear(src_pos_embed)
         b = ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)
-        return ops.SharedBias.of(b[0]) if shared else b
+        return ops.SharedBias.of(b.squeeze(0)) if shared else b           # (squeeze: a view both ways; b[0]'s backward zero-fills + copies)
 
     def _cross_kv(self, enc, incremental_state):
         """ops.CrossKVShared for this forward -- the k|v projections of the encoder output for ALL layers as one GEMM -- when the

@@ -3,8 +3,9 @@ fbank [B,T,80] -> Conv2d(1,D,3,2)+ReLU -> Conv2d(D,D,3,2)+ReLU -> Linear(D*19, D
 the subsampled lengths; 1-D log-bucket relative-position bias (bucket table [4096,4096], 2*max_position-1 rows).
 
 The whole parameter set of the reference adaptor is mirrored (decoder prenet / postnet / feat_proj / eos_proj / mask_emb)
-so checkpoints interchange; the target-side branch (fbank generation, TTS) and the optional in-adaptor transformer
-layers are outside the train-step hot path and raise NotImplementedError."""
+so checkpoints interchange; the target-side branch (fbank generation, TTS) is outside the train-step hot path and raises
+NotImplementedError, as does is_transformer_layers (a branch the reference itself cannot construct).  The time / channel mask
+DRAWS (get_mask_indices, :401-450) belong to the speech-pretraining criterion, which hands them over in the slot value."""
 from dataclasses import dataclass, field
 
 import torch
@@ -40,6 +41,7 @@ class AudioFbankAdaptorConfig(BaseAdaptorConfig):
     use_mask: bool = field(default=False, metadata={"help": "use mask"})
     mask_prob: float = field(default=0.65, metadata={"help": "probability of replacing a token with mask"})
     mask_channel_prob: float = field(default=0.0, metadata={"help": "probability of replacing a feature with 0"})
+    mask_channel_before: bool = False        # zero the drawn channels before (True) or after (False) the mask_emb rows are written
 
 
 class Conv2dSubsampling4(nn.Module):
@@ -103,7 +105,10 @@ class AudioFbankAdaptor(BaseAdaptor):
                  cfg: AudioFbankAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
         if cfg.is_transformer_layers:
-            raise NotImplementedError("audio_fbank.is_transformer_layers is not implemented (reference default False)")
+            # adaptor/audio.py:208-217, 338-345 read cfg.encoder_config (no config class defines it) and import
+            # ofasys.model.transformer_layer (no such module): the reference cannot construct this branch either
+            raise NotImplementedError("audio_fbank.is_transformer_layers: the reference's own branch does not construct "
+                                      "(cfg.encoder_config / ofasys.model.transformer_layer do not exist); default False")
         self.audio_bucket_size = cfg.max_position
         self.out_dim = cfg.output_frame_dim * cfg.n_frames_per_step
         self.subsample = Conv2dSubsampling4(self.out_dim, cfg.embed_dim)
@@ -126,6 +131,7 @@ class AudioFbankAdaptor(BaseAdaptor):
         self.mask_emb = nn.Parameter(torch.FloatTensor(cfg.embed_dim).uniform_())
         self.mask_prob = cfg.mask_prob
         self.mask_channel_prob = cfg.mask_channel_prob
+        self.mask_channel_before = cfg.mask_channel_before
 
     def get_rel_pos_bias(self, batch_size, seq_length, idx, **kwargs):
         if seq_length > self.audio_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
@@ -148,11 +154,16 @@ class AudioFbankAdaptor(BaseAdaptor):
         pos = torch.arange(T2, device=feature.device)[None, :].expand(feature.shape[0], T2)
         pos_embed = self.embed_audio_positions(pos)
         if (slot.has_attr("use_mask") or self.use_mask) and mask_indices is not None:      # apply_mask, :452-466
-            if self.mask_channel_prob > 0:
-                raise NotImplementedError("channel masking (mask_channel_prob > 0) is not implemented (default 0)")
+            mch = None
+            if self.mask_channel_prob > 0:          # [B, C] channel draws of get_mask_indices: those channels are zeroed over all T
+                mch = slot.value["mask_channel_indices"].to(feature.device).unsqueeze(1)
+            if mch is not None and self.mask_channel_before:
+                feature = feature.masked_fill(mch, 0.0)
             if self.mask_prob > 0:
                 m = mask_indices.to(feature.device).unsqueeze(-1)
                 feature = torch.where(m, self.mask_emb.to(feature.dtype).view(1, 1, -1), feature)
+            if mch is not None and not self.mask_channel_before:
+                feature = feature.masked_fill(mch, 0.0)
         return AdaptorOutput(feature, padding_mask, pos_embed, [])
 
     def forward_output(self, x, extra, slot, **kwargs):

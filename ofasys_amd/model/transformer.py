@@ -4,6 +4,7 @@ layers.  Activations live batch-major ([B,T,C] storage); the [T,B,C] tensors han
 
 Deliberate differences (same results): no `masks.any()` host sync (transformer.py:110) -- padded rows are zeroed and
 the padding mask is passed unconditionally, which is arithmetically the identity when nothing is padded."""
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -38,6 +39,22 @@ def _packed_bias_ok(bias_list, prefix_ok, what):
                                   "padded row (one ragged slot, at the end); run this batch padded")
 
 
+_CKPT_NOTED = False
+
+
+def _note_activation_checkpointing(cfg):
+    """checkpoint_activations / offload_activations / checkpoint_adaptor_activations (model/transformer.py:50-51, 68-72, 230-231,
+    270-274; model/ofa.py:349-350): the reference wraps the adaptor / every layer so that its forward is re-run during backward
+    with the RNG state restored -- the SAME numbers for fewer live activations.  The flags are accepted and the activations are
+    simply kept: a cfg-2 step holds a few GB of them out of 288 GB of HBM per device, and re-running the forward would cost a
+    third more MFMA time per step for memory this part does not lack.  Results are those of the reference either way."""
+    global _CKPT_NOTED
+    if (cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations or cfg.offload_activations) and not _CKPT_NOTED:
+        _CKPT_NOTED = True
+        warnings.warn("ofasys_amd: checkpoint_activations / offload_activations are accepted but activations are kept resident "
+                      "(same results; 288 GB of HBM per device make the recompute a pure loss)")
+
+
 def kept_layers(layers, p, training):
     """LayerDropModuleList.__iter__ (module/layer_drop.py:37-41): in training every layer survives an iteration with probability
     1 - p -- one uniform draw per layer from torch's default CPU generator, as the reference does; evaluation keeps them all.  The
@@ -60,8 +77,7 @@ class TransformerEncoder(nn.Module):
         self.register_buffer("version", torch.Tensor([3]))
         OFAGeneralAdaptor._embed_tokens = None          # a fresh shared embedding per model (transformer.py:48)
         self.adaptor = OFAGeneralAdaptor(cfg, dictionary, True)
-        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations:
-            raise NotImplementedError("activation checkpointing is not implemented in ofasys_amd")
+        _note_activation_checkpointing(cfg)
         self.layerdrop = float(cfg.encoder_layerdrop)                 # (model/transformer.py:53-54)
         self.layers = nn.ModuleList([])
         dpr = torch.linspace(0, cfg.encode_drop_path_rate, cfg.encoder_layers)
@@ -145,8 +161,7 @@ class TransformerDecoder(nn.Module):
         self.register_buffer("version", torch.Tensor([3]))
         self._future_mask = torch.empty(0)
         self.adaptor = OFAGeneralAdaptor(cfg, dictionary, False)
-        if cfg.checkpoint_adaptor_activations or cfg.checkpoint_activations:
-            raise NotImplementedError("activation checkpointing is not implemented in ofasys_amd")
+        _note_activation_checkpointing(cfg)
         self.layerdrop = float(cfg.decoder_layerdrop)                 # (model/transformer.py:244-245)
         self.share_input_output_embed = cfg.share_decoder_input_output_embed
         self.num_attention_heads = cfg.decoder_attention_heads

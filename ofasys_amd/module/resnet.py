@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .layers import DropPath
 
 __all__ = ["resnet50_backbone", "resnet101_backbone", "resnet152_backbone"]
 
@@ -35,8 +36,6 @@ class Bottleneck(nn.Module):
         super().__init__()
         if norm_layer is None:
             norm_layer = nn.BatchNorm2d
-        if drop_path_rate != 0.0:
-            raise NotImplementedError("resnet_drop_path_rate > 0 is not implemented (reference default 0.0)")
         width = int(planes * (base_width / 64.0)) * groups
         self.conv1 = conv1x1(inplanes, width)
         self.bn1 = norm_layer(width)
@@ -47,13 +46,15 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
+        self.drop_path = DropPath(drop_path_rate, 0)          # per-sample stochastic depth of the residual branch (no parameters)
 
     def forward(self, fm):
         """fm = (rows [B*H*W, C], B, H, W)   -- module/resnet.py:112-137."""
         x, B, H, W = fm
         # an identity block reads x twice (conv1 and the residual add): the residual's gradient is handed to conv1's input-gradient
         # GEMM, which accumulates onto it, instead of a separate add of two [B*H*W, C] tensors per block (ops.batch_norm)
-        mailbox = [] if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
+        dropping = self.training and self.drop_path.drop_prob > 0.0
+        mailbox = [] if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad and not dropping) else None
         out, _, _ = ops.conv2d(x, self.conv1.weight, self.conv1.bias, B, H, W, self.conv1.stride[0], self.conv1.padding[0],
                                grad_mailbox=mailbox)
         out = ops.batch_norm(out, self.bn1, relu=True)
@@ -64,6 +65,10 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             identity, _, _ = _conv(x, self.downsample[0], B, H, W)
             identity = ops.batch_norm(identity, self.downsample[1])
+        if dropping:                                          # relu(identity + drop_path(bn3(out))), module/resnet.py:127-135
+            out = ops.batch_norm(out, self.bn3)
+            out = self.drop_path(out.view(B, Ho * Wo, out.shape[1])).reshape(B * Ho * Wo, out.shape[1])
+            return ops.relu(ops.dropout_add(out, identity, 0.0, False)), B, Ho, Wo
         out = ops.batch_norm(out, self.bn3, relu=True, residual=identity, grad_mailbox=mailbox)   # relu(identity + bn3(out))
         return out, B, Ho, Wo
 

@@ -544,11 +544,16 @@ class DropPathFn(torch.autograd.Function):
         return K.scale_row_groups(dy.contiguous(), scale, ctx.group), None, None
 
 
+def _drop_path_uniform(B, device):
+    """The U[0,1) draw per sample of module/droppath.py:52 (a seam: the parity tests replay the reference's recorded draws here)."""
+    return torch.rand(B, dtype=torch.float32, device=device)
+
+
 def drop_path(x, drop_prob, batch_axis=1, scale_by_keep=True):
     """Per-sample stochastic depth of a [T,B,C] (batch_axis=1) or [B,T,C] (batch_axis=0) activation."""
     keep = 1.0 - drop_prob
     B = x.shape[batch_axis]
-    mask = (keep + torch.rand(B, dtype=torch.float32, device=x.device)).floor_()
+    mask = (keep + _drop_path_uniform(B, x.device)).floor_()
     if keep > 0.0 and scale_by_keep:
         mask = mask / keep
     xb = batch_major(x) if batch_axis == 1 else x.contiguous()          # [B,T,C]: one sample = T consecutive rows

@@ -9,6 +9,7 @@ import torch
 from oracle import recipe
 
 VOCAB_EXTRA = 200
+AUDIO_EMBED_DIM = 256          # the tiny arch's embed_dim (the channel-mask case)
 
 CASES = {
     # cfg-1 family: text -> text, tiny, default flags (biased attention everywhere)
@@ -96,6 +97,21 @@ CASES = {
                  "encoder.adaptor.image_resnet.embed_images.layer2.0.downsample.1.running_mean",
                  "encoder.adaptor.image_resnet.embed_images.layer1.2.bn2.num_batches_tracked"],
     ),
+    # resnet_drop_path_rate > 0 (adaptor/image_resnet.py:49-52): per-sample stochastic depth of the residual branches, training mode.
+    # The keep draws are random inputs: gen_golden.py seeds torch ("drop_seed") and records them per DropPath call
+    # ("droppath_keep", [calls, B]); the oracle and the HIP model replay them.  B = 4 so that most draws keep some rows and drop others
+    "tiny_resnet_droppath": dict(
+        arch="tiny", active={"text", "image_resnet"}, overrides={"dropout": 0.0},
+        adaptor_overrides={"image_resnet": {"resnet_type": "resnet50", "resnet_drop_path_rate": 0.3}}, train=True, drop_seed=3,
+        slots=[("IMAGE", True, ("img", "image", (4, 3, 64, 64)), None),
+               ("TEXT", True, ("tok", "src", (4, 6), [6, 4, 5, 2]), None),
+               ("TEXT", False, ("tok", "prev", (4, 5), [5, 3, 4, 5]), None)],
+        full_grads=["encoder.adaptor.image_resnet.embed_images.layer2.1.conv2.weight",
+                    "encoder.adaptor.image_resnet.embed_images.layer3.5.bn3.weight",
+                    "encoder.adaptor.image_resnet.embed_images.layer1.2.bn3.bias",
+                    "encoder.adaptor.image_resnet.image_proj.bias"],
+        buffers=["encoder.adaptor.image_resnet.embed_images.layer3.5.bn3.running_var"],
+    ),
     # cfg-4 family: video clip (3 frames of 64x64, the middle frame of row 1 all-zero = padding) + text -> text
     "tiny_video": dict(
         arch="tiny", active={"text", "video_image_sequence"}, overrides={"dropout": 0.0},
@@ -120,6 +136,17 @@ CASES = {
                     "encoder.adaptor.audio_fbank.subsample.out.0.bias", "encoder.adaptor.audio_fbank.mask_emb",
                     "encoder.adaptor.audio_fbank.audio_rel_pos_table_list.1.weight",
                     "encoder.adaptor.audio_fbank.embed_audio_positions.weight"],
+    ),
+    # audio_fbank.mask_channel_prob > 0 (adaptor/audio.py:462-464): drawn channels zeroed over all frames AFTER the mask_emb rows
+    "tiny_audio_chmask": dict(
+        arch="tiny", active={"text", "audio_fbank"}, overrides={"dropout": 0.0},
+        adaptor_overrides={"audio_fbank": {"mask_channel_prob": 0.1}}, train=False,
+        slots=[("AUDIO", True, ("fbank", "audio", (2, 50, 80), [50, 37], [(0, 2), (0, 3), (1, 5)],
+                                [(0, 7), (0, 8), (0, 200), (1, 31), (1, 255)]), ["use_mask"]),
+               ("TEXT", True, ("tok", "src", (2, 4), [4, 3]), None),
+               ("TEXT", False, ("tok", "prev", (2, 6), [6, 5]), None)],
+        full_grads=["encoder.adaptor.audio_fbank.subsample.out.0.bias", "encoder.adaptor.audio_fbank.subsample.conv.2.bias",
+                    "encoder.adaptor.audio_fbank.mask_emb"],
     ),
     # cfg-5 family: OFA-large (D=1024, 16 heads, 12+12 layers, model/ofa.py:604-610), text + box-as-tokens -> text, short T
     "large_multislot": dict(
@@ -153,8 +180,8 @@ def make_value(spec, vocab):
     if spec[0] == "tok":
         _, key, shape, lengths = spec
         return recipe.tokens("input." + key, shape, vocab, lengths, bos=0 if key == "prev" else None)
-    if spec[0] == "fbank":                       # ("fbank", key, [B,T,80], lengths, [(row, subsampled frame) masked])
-        _, key, shape, lengths, masked = spec
+    if spec[0] == "fbank":           # ("fbank", key, [B,T,80], lengths, [(row, subsampled frame) masked][, [(row, channel) zeroed]])
+        _, key, shape, lengths, masked = spec[:5]
         v = recipe.floats("input." + key, shape)
         for r, n in enumerate(lengths):
             v[r, n:] = 0.0
@@ -162,7 +189,13 @@ def make_value(spec, vocab):
         mi = torch.zeros(shape[0], t2, dtype=torch.bool)
         for r, t in masked:
             mi[r, t] = True
-        return {"fbank": v, "fbank_lengths": torch.tensor(lengths, dtype=torch.long), "mask_indices": mi}
+        out = {"fbank": v, "fbank_lengths": torch.tensor(lengths, dtype=torch.long), "mask_indices": mi}
+        if len(spec) > 5:                        # [B, C] channel mask over the adaptor's embed_dim features (tiny: 256)
+            mc = torch.zeros(shape[0], AUDIO_EMBED_DIM, dtype=torch.bool)
+            for r, c in spec[5]:
+                mc[r, c] = True
+            out["mask_channel_indices"] = mc
+        return out
     if spec[0] == "vid":                         # ("vid", key, [B,3,F,H,W], [(row, frame) set to exactly zero])
         _, key, shape, zero_frames = spec
         v = recipe.floats("input." + key, shape)

@@ -80,6 +80,16 @@ def run_case(name, case):
                     blk_io[key] = (i[0], o)
                 hooks.append(blk.register_forward_hook(keep))
 
+    # stochastic depth (cases with "drop_seed"): the per-sample keep decisions of every active DropPath call are recorded in call
+    # order -- they are random INPUTS of the run, which the oracle and the HIP model replay
+    keep_rows = []
+    if "drop_seed" in case:
+        for m in model.modules():
+            if type(m).__name__ == "DropPath" and m.drop_prob > 0.0:
+                hooks.append(m.register_forward_hook(
+                    lambda m, i, o: keep_rows.append((o.detach().reshape(o.shape[0], -1).abs().amax(1) > 0).float())))
+        torch.manual_seed(case["drop_seed"])
+
     logits, extra, enc_out = model(slots, return_encoder_out=True)
     lprobs = model.get_normalized_probs((logits, extra), log_probs=True)
     loss = nll_loss(lprobs.view(-1, lprobs.size(-1)), target.view(-1), ignore_index=d.pad(), reduce=True)
@@ -113,6 +123,9 @@ def run_case(name, case):
     for k in case["full_grads"]:
         if params[k].grad is not None:     # (an unused parameter -- e.g. the shared fc1 of a modal_ffn layer -- has no gradient: norm -1 above)
             out["grad." + k] = params[k].grad.detach()
+    if keep_rows:
+        out["droppath_keep"] = torch.stack(keep_rows)
+        print("  drop-path keep draws:", [[int(v) for v in r] for r in keep_rows])
     for k in case.get("buffers", []):
         out["buffer." + k] = model.state_dict()[k].detach().clone()
     if blk_io:

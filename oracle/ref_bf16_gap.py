@@ -16,6 +16,10 @@ model, d = build_reference_model(case["arch"], VOCAB_EXTRA, case["active"], case
 recipe.fill_state(model.state_dict())
 model.eval()
 if case.get("train"): model.train()
+if "drop_seed" in case:                    # stochastic depth: both dtypes replay the golden's recorded draws
+    import numpy as np
+    from oracle.ref_import import force_drop_path_draws
+    force_drop_path_draws(model, np.load(f"/root/repo/tests/golden/{name}.npz")["droppath_keep"])
 def run(dtype):
     slots = []
     for mod, is_src, spec, attrs in case["slots"]:

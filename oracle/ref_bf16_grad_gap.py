@@ -22,6 +22,10 @@ def run(dtype):
     model.eval()
     if case.get("train"):
         model.train()
+    if "drop_seed" in case:                # stochastic depth: both dtypes replay the golden's recorded draws
+        import numpy as np
+        from oracle.ref_import import force_drop_path_draws
+        force_drop_path_draws(model, np.load(f"/root/repo/tests/golden/{name}.npz")["droppath_keep"])
     model.to(dtype)
     slots, prev = [], None
     for mod, is_src, spec, attrs in case["slots"]:

@@ -122,3 +122,22 @@ def build_reference_model(arch, vocab_extra, active_adaptors, overrides=None, ad
             setattr(getattr(m.cfg.adaptor, name), k, v)
     m.initialize(d)
     return m, d
+
+
+def force_drop_path_draws(model, keep_rows):
+    """Replay recorded per-sample keep decisions ([calls, B] of 0/1, tests/golden/<case>.npz "droppath_keep") in the reference's
+    active DropPath modules, in call order, instead of fresh torch.rand draws -- so that runs in different dtypes (the bf16 gap
+    scripts) take the same stochastic-depth decisions.  The reference divides its input by keep_prob IN PLACE before it multiplies
+    by the draw (module/droppath.py:57-59), so the hook only replaces the draw: output = (already divided) input * keep."""
+    import torch
+    rows = [torch.as_tensor(r) for r in keep_rows]
+    state = {"next": 0}
+
+    def hook(m, i, o):
+        x = i[0]
+        keep = rows[state["next"] % len(rows)].to(x.dtype)
+        state["next"] += 1
+        return x * keep.view([-1] + [1] * (x.ndim - 1))
+    for m in model.modules():
+        if type(m).__name__ == "DropPath" and m.drop_prob > 0.0:
+            m.register_forward_hook(hook)

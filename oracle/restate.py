@@ -78,6 +78,10 @@ class OConfig:
     training: bool = False                  # BatchNorm batch statistics (dropout must be 0 for a deterministic oracle)
     modal_ffn: bool = False                 # ofa.py:119-121: one FFN expert per ModalityType
     activation_fn: str = "gelu"             # module/utils.py get_activation_fn (ofa.py: activation_fn)
+    resnet_drop_path_rate: float = 0.0      # adaptor/image_resnet.py:49-52, module/resnet.py:114, 219-230
+    drop_keep: Optional[list] = None        # the per-sample keep draws (0/1, [B] each) of the DropPath calls, in call order: random
+                                            # INPUTS of a training-mode run, replayed (module/droppath.py:52-53)
+    audio_mask_channel: str = ""            # "" (mask_channel_prob == 0) | "after" | "before" (adaptor/audio.py:452-466)
 
 
 # --------------------------------------------------------------------------------------------
@@ -205,14 +209,16 @@ def _bn(state, p, x, cfg):
                         training=cfg.training, momentum=0.1, eps=1e-5)
 
 
-def _bottleneck(state, p, x, cfg, stride, has_down):
-    """module/resnet.py:112-137 (drop_path rate 0)."""
+def _bottleneck(state, p, x, cfg, stride, has_down, drop=0.0):
+    """module/resnet.py:112-137; drop > 0 in training: DropPath(drop, 0) on the residual branch (module/droppath.py:40-60)."""
     out = F.relu(_bn(state, p + ".bn1", F.conv2d(x, state[p + ".conv1.weight"]), cfg))
     out = F.relu(_bn(state, p + ".bn2", F.conv2d(out, state[p + ".conv2.weight"], stride=stride, padding=1), cfg))
     out = _bn(state, p + ".bn3", F.conv2d(out, state[p + ".conv3.weight"]), cfg)
     identity = x
     if has_down:
         identity = _bn(state, p + ".downsample.1", F.conv2d(x, state[p + ".downsample.0.weight"], stride=stride), cfg)
+    if drop > 0.0 and cfg.training:                                       # x.div_(keep_prob); x * floor(keep_prob + U)
+        out = out / (1.0 - drop) * cfg.drop_keep.pop(0).to(out.dtype).view(-1, 1, 1, 1)
     return F.relu(identity + out)
 
 
@@ -221,8 +227,9 @@ def resnet_backbone(state, p, x, cfg):
     x = F.relu(_bn(state, p + ".bn1", F.conv2d(x, state[p + ".conv1.weight"], stride=2, padding=3), cfg))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     for li, (blocks, stride) in enumerate(zip(cfg.resnet_layers, (1, 2, 2)), start=1):
+        dpr = [v.item() for v in torch.linspace(0, cfg.resnet_drop_path_rate, blocks)]    # :219; block 0 is built without it (:207-217)
         for b in range(blocks):
-            x = _bottleneck(state, f"{p}.layer{li}.{b}", x, cfg, stride if b == 0 else 1, b == 0)
+            x = _bottleneck(state, f"{p}.layer{li}.{b}", x, cfg, stride if b == 0 else 1, b == 0, dpr[b] if b else 0.0)
     return x
 
 
@@ -314,8 +321,13 @@ def audio_fbank_adaptor(state, cfg, side, slot):
             masks[i, diff:] = True
     pos_embed = F.embedding(torch.arange(t).unsqueeze(0).expand(b, t), state[p + ".embed_audio_positions.weight"])
     mi = slot.value.get("mask_indices")
-    if mi is not None and slot.get_attr("use_mask") is not None:                          # apply_mask, mask_prob > 0
+    if mi is not None and slot.get_attr("use_mask") is not None:                          # apply_mask (:452-466), mask_prob > 0
+        mch = slot.value["mask_channel_indices"].unsqueeze(1) if cfg.audio_mask_channel else None     # [B,1,C]: whole channels
+        if cfg.audio_mask_channel == "before":
+            x = x.masked_fill(mch, 0.0)
         x = torch.where(mi.unsqueeze(-1), state[p + ".mask_emb"].view(1, 1, -1), x)
+        if cfg.audio_mask_channel == "after":
+            x = x.masked_fill(mch, 0.0)
     embed, pos_embed = _post_hook(state, cfg, side, "audio_fbank", slot, x, pos_embed)
     rel = None
     if cfg.use_self_attn_bias:

@@ -62,7 +62,47 @@ def oracle_cfg(case):
                    entangle_position_embedding=ov.get("entangle_position_embedding", False), adaptor_entangle=ent,
                    adaptor_embed_scale=esc, adaptor_grad_scale=gsc,
                    resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)),
-                   activation_fn=ov.get("activation_fn", "gelu"))
+                   activation_fn=ov.get("activation_fn", "gelu"),
+                   resnet_drop_path_rate=float(case["adaptor_overrides"].get("image_resnet", {}).get("resnet_drop_path_rate", 0.0)),
+                   audio_mask_channel=_audio_mask_channel(case["adaptor_overrides"].get("audio_fbank", {})))
+
+
+def _audio_mask_channel(ov):
+    if ov.get("mask_channel_prob", 0.0) <= 0:
+        return ""
+    return "before" if ov.get("mask_channel_before", False) else "after"
+
+
+def drop_keep_rows(g):
+    """The recorded keep draws of a drop-path case, one [B] float tensor per DropPath call in call order."""
+    return [torch.from_numpy(r.copy()) for r in g["droppath_keep"]] if "droppath_keep" in g else None
+
+
+class replay_drop_path:
+    """Context: ofasys_amd's per-sample drop-path draw (ops._drop_path_uniform) answers with the recorded keep decisions instead
+    of fresh random numbers (u = 0.999 keeps a sample for any keep probability used here, u = 0 drops it)."""
+
+    def __init__(self, keep_rows):
+        self.rows = list(keep_rows or [])
+
+    def __enter__(self):
+        from ofasys_amd import ops
+        self.ops, self.orig = ops, ops._drop_path_uniform
+        if self.rows:
+            rows = self.rows
+
+            def replay(B, device):
+                r = rows.pop(0)
+                assert r.numel() == B
+                return (r.float() * 0.999).to(device)
+            ops._drop_path_uniform = replay
+        return self
+
+    def __exit__(self, *exc):
+        self.ops._drop_path_uniform = self.orig
+        if exc[0] is None:
+            assert not self.rows, f"{len(self.rows)} recorded drop-path draws were not consumed"
+        return False
 
 
 def case_inputs(case):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle.cases import CASES
-from tests.golden_util import case_inputs, load_golden, rel_err
+from tests.golden_util import case_inputs, drop_keep_rows, load_golden, rel_err, replay_drop_path
 from tests.model_util import build_model, make_slots
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,8 @@ BF16_TOL = 2e-2
 # 2x the reference's own bf16-vs-fp32 gap where that is larger (oracle/ref_bf16_gap.py: 4.7e-2 through the 50-layer
 # BatchNorm backbone of tiny_resnet, 3.0e-2 on tiny_video, 1.0e-2 on tiny_text)
 # ... and 2.1e-2 through the 24 layers of OFA-large (large_multislot)
-BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2, "large_multislot": 4.2e-2}
+# ... 4.2e-2 on tiny_resnet_droppath (same backbone, four images, the reference's recorded stochastic-depth draws replayed)
+BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_resnet_droppath": 1e-1, "tiny_video": 6e-2, "large_multislot": 4.2e-2}
 # fp32 gradients INSIDE the ResNet backbone: 16 bottlenecks of conv / BatchNorm over as few as 32 values per channel /
 # ReLU make the backward chain ill-conditioned -- torch's own CPU and GPU (MIOpen) fp32 implementations of this exact
 # backbone differ by 0.9% element-wise / 0.06% in norm (tools/bn_noise.py, run on the MI355X box); this build differs
@@ -25,7 +26,7 @@ BF16_TOL_CASE = {"tiny_resnet": 1e-1, "tiny_video": 6e-2, "large_multislot": 4.2
 # CPU) is 41.6% on tiny_resnet and 22.8% on tiny_video (worst parameter: the stem's bn1) -- a one-ulp change of a single
 # conv output (e.g. a different split-K plan) moves the stem gradients of THIS build by 10 points as well.  Bound = 1.25x that
 # gap; every parameter outside the backbone keeps 2.5 * tol.
-BF16_BACKBONE_GRAD_GAP = {"tiny_resnet": 0.416, "tiny_video": 0.228}
+BF16_BACKBONE_GRAD_GAP = {"tiny_resnet": 0.416, "tiny_video": 0.228, "tiny_resnet_droppath": 0.297}
 FP32_GRAD_TOL_DEEP = 5e-3
 FP32_GRAD_ELEM_TOL_DEEP = 4e-2
 
@@ -40,7 +41,8 @@ def _run(name, dtype):
         model.train()
     vals, target = case_inputs(case)
     slots = make_slots(vals, DEV, dtype)
-    logits, extra, enc = model(slots, return_encoder_out=True)
+    with replay_drop_path(drop_keep_rows(g)):          # stochastic-depth cases: the reference's recorded per-sample draws
+        logits, extra, enc = model(slots, return_encoder_out=True)
     loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
     model.zero_grad()
     loss.backward()

@@ -43,16 +43,24 @@ def _state_from_model(model):
     return state
 
 
-def _bf16_grad_check(got, want, tol):
+def _measured(what, value):
+    """`pytest -s` shows what a run actually measured next to the bound it is held to (DESIGN.md section 2 quotes these)."""
+    print(f"MEASURED {what}: {value:.3e}")
+
+
+def _bf16_grad_check(got, want, tol, what=""):
     scale = max(float(g.double().norm()) for g in want.values() if g is not None)
-    bad, checked = [], 0
+    bad, checked, worst = [], 0, 0.0
     for k, w in want.items():
         if k not in got or w is None:
             continue
         g, wn = float(got[k].double().norm()), float(w.double().norm())
+        if wn > 1e-2 * scale:
+            worst = max(worst, abs(g - wn) / wn)
         if abs(g - wn) > 2.5 * tol * wn + 2e-3 * scale:
             bad.append((k, g, wn))
         checked += 1
+    _measured(f"{what} worst gradient-norm deviation (parameters above 1% of the largest norm, {checked} checked)", worst)
     assert checked > 100 and not bad, bad[:8]
 
 
@@ -91,8 +99,10 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     assert int(out["stats"][0]) == n == sum(tlens)
     assert abs(float(out["stats"][1]) - float(ref_loss)) <= 2e-3 * float(ref_loss)
     got = _arena_grads(tr, model)
-    _bf16_grad_check(got, want, BF16_TOL)
+    _measured("cfg-2 packed graph step: loss deviation", abs(float(out["stats"][1]) - float(ref_loss)) / float(ref_loss))
+    _bf16_grad_check(got, want, BF16_TOL, "cfg-2 packed graph step:")
     gn = np.sqrt(sum(float(g.double().pow(2).sum()) for g in want.values() if g is not None)) / n
+    _measured("cfg-2 packed graph step: clip-norm deviation", abs(float(out["gnorm"]) - gn) / gn)
     assert abs(float(out["gnorm"]) - gn) <= 2e-2 * gn
     # 2) the logits of the packed forward at every non-pad decoder position
     model.train()
@@ -102,6 +112,7 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     rows = torch.nonzero(idx >= 0).squeeze(1)
     assert rows.numel() == sum(tlens)
     ref_rows = ref_logits.reshape(-1, ref_logits.shape[-1])[idx[rows]]
+    _measured("cfg-2 packed forward: logits max |diff| / max |logit|", rel_err(logits[0, rows], ref_rows))
     assert rel_err(logits[0, rows], ref_rows) < BF16_TOL
     filler = torch.nonzero(idx < 0).squeeze(1)
     assert bool(torch.isfinite(logits[0, filler]).all())

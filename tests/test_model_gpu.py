@@ -54,6 +54,8 @@ def _run(name, dtype):
 def test_fp32_matches_reference(name):
     g, model, logits, extra, enc, loss = _run(name, torch.float32)
     assert logits.shape == tuple(g["logits"].shape)
+    print(f"MEASURED {name} fp32: logits {rel_err(logits.detach().cpu(), g['logits']):.2e} (bound {FP32_TOL:.0e}), "
+          f"loss {rel_err(loss.detach().cpu(), g['loss'][0]):.2e}")                    # shown by pytest -s; quoted in DESIGN.md section 2
     assert rel_err(logits.detach().cpu(), g["logits"]) < FP32_TOL
     assert rel_err(loss.detach().cpu(), g["loss"][0]) < FP32_TOL
     assert rel_err(extra["attn"][0].cpu(), g["attn"]) < FP32_TOL
@@ -93,6 +95,8 @@ def test_bf16_matches_reference(name):
     g, model, logits, extra, enc, loss = _run(name, torch.bfloat16)
     assert logits.dtype == torch.bfloat16
     tol = BF16_TOL_CASE.get(name, BF16_TOL)
+    print(f"MEASURED {name} bf16: logits {rel_err(logits.detach().float().cpu(), g['logits']):.2e} (bound {tol:.1e}), "
+          f"loss {rel_err(loss.detach().float().cpu(), g['loss'][0]):.2e}")
     assert rel_err(logits.detach().float().cpu(), g["logits"]) < tol
     assert rel_err(loss.detach().float().cpu(), g["loss"][0]) < tol
     assert rel_err(extra["attn"][0].float().cpu(), g["attn"]) < 2 * tol

@@ -9,7 +9,8 @@ oracle (oracle/restate.py, pinned to the reference by tests/golden/*) on the SAM
   cfg-3   the two-task step with resnet101 (the BASELINE cfg-2b / cfg-3 trunk) instead of resnet50
 
 Tolerances: fp32 1e-3 (north_star) outside the ResNet trunk, the trunk's documented bounds inside (tests/test_model_gpu.py);
-bf16 2e-2 of max |logit| (2x the reference's own bf16-vs-fp32 gap) and 2.5x that on gradient norms."""
+bf16 2e-2 of max |logit| (2x the reference's own bf16-vs-fp32 gap) and 2.5x that on gradient norms; the cfg-2
+step (same bf16 weights on both sides) is held to 2x / 4x what it measured: logits 1.2e-2, gradient norms 1e-2, loss 1e-4."""
 import os
 import sys
 from types import SimpleNamespace
@@ -32,6 +33,12 @@ from tests.test_configs_gpu import _arena_grads, _check_grads, _oracle_step, _to
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="no GPU")]
 DEV = "cuda"
 BF16_TOL = 2e-2
+# cfg-2, the benchmarked step itself: the oracle runs on the model's OWN bf16 weights and inputs in fp32 arithmetic, so what is left
+# is the bf16 rounding of the activations between kernels and the MFMA accumulation order.  Measured on MI355X
+# (profiles/round3_parity_measured.txt): logits 6.1e-3 of max |logit|, loss 6.9e-6, worst gradient norm 2.4e-3, clip norm 4.7e-4.
+# Bounds = 2x (logits) / 4x (gradient norms: 2.5 * CFG2_GRAD_TOL = 1e-2) what was measured -- not the generic bf16 tier's 2e-2 / 5e-2.
+CFG2_LOGIT_TOL = 1.2e-2
+CFG2_GRAD_TOL = 4e-3
 
 
 def _state_from_model(model):
@@ -97,13 +104,13 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     torch.cuda.synchronize()
     assert any("graphs" in e for e in tr._graphs.values()), "the step was not captured"
     assert int(out["stats"][0]) == n == sum(tlens)
-    assert abs(float(out["stats"][1]) - float(ref_loss)) <= 2e-3 * float(ref_loss)
+    assert abs(float(out["stats"][1]) - float(ref_loss)) <= 1e-4 * float(ref_loss)          # measured 6.9e-6 (profiles/round3_parity_measured.txt)
     got = _arena_grads(tr, model)
     _measured("cfg-2 packed graph step: loss deviation", abs(float(out["stats"][1]) - float(ref_loss)) / float(ref_loss))
-    _bf16_grad_check(got, want, BF16_TOL, "cfg-2 packed graph step:")
+    _bf16_grad_check(got, want, CFG2_GRAD_TOL, "cfg-2 packed graph step:")
     gn = np.sqrt(sum(float(g.double().pow(2).sum()) for g in want.values() if g is not None)) / n
     _measured("cfg-2 packed graph step: clip-norm deviation", abs(float(out["gnorm"]) - gn) / gn)
-    assert abs(float(out["gnorm"]) - gn) <= 2e-2 * gn
+    assert abs(float(out["gnorm"]) - gn) <= 2e-3 * gn                                        # measured 4.7e-4
     # 2) the logits of the packed forward at every non-pad decoder position
     model.train()
     with torch.no_grad():
@@ -113,7 +120,7 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     assert rows.numel() == sum(tlens)
     ref_rows = ref_logits.reshape(-1, ref_logits.shape[-1])[idx[rows]]
     _measured("cfg-2 packed forward: logits max |diff| / max |logit|", rel_err(logits[0, rows], ref_rows))
-    assert rel_err(logits[0, rows], ref_rows) < BF16_TOL
+    assert rel_err(logits[0, rows], ref_rows) < CFG2_LOGIT_TOL
     filler = torch.nonzero(idx < 0).squeeze(1)
     assert bool(torch.isfinite(logits[0, filler]).all())
 
@@ -156,7 +163,7 @@ def test_cfg4_video_real_shape_vs_oracle(dtype):
         assert rel_err(logits.detach().float().cpu(), ref_logits) < tol
         assert abs(float(got_loss) - loss) <= tol * loss
         outside = {k: v for k, v in want.items() if ".embed_images." not in k}
-        _bf16_grad_check(got, outside, tol)
+        _bf16_grad_check(got, outside, tol, "cfg-4 real shape bf16 (outside the trunk):")
         for k, p in model.named_parameters():                           # the 101-layer trunk in bf16: finite, and alive at the stem
             if p.grad is not None:
                 assert bool(torch.isfinite(p.grad.float()).all()), k

@@ -90,6 +90,15 @@ class GeneralistModelConfig(BaseDataclass):
             return getattr(self.__dict__["decoder"], name[len("decoder_"):])
         raise AttributeError(name)
 
+    def __setattr__(self, name, value):
+        """module/transformer_config.py:186-192: a flat `encoder_x` / `decoder_x` write lands in the nested config (so that
+        `cfg.encoder_normalize_before = False` reaches the layers, which read `cfg.encoder.normalize_before`)."""
+        for side in ("encoder", "decoder"):
+            if name.startswith(side + "_") and name != side + "_" and side in self.__dict__:
+                setattr(self.__dict__[side], name[len(side) + 1:], value)
+                return
+        super().__setattr__(name, value)
+
 
 class OFAExecutor(ABC):      # model/ofa.py:125-154
     @abstractmethod

@@ -40,6 +40,27 @@ CASES = {
         full_grads=["encoder.layers.0.fc1.weight", "decoder.layers.3.ffn_layernorm.weight", "encoder.layers.2.fc2.bias",
                     "encoder.adaptor.embed_tokens.weight"],
     ),
+    # the layer's optional normalisations switched the other way: no attn_ln / ffn_layernorm / c_attn (scale_attn, scale_fc,
+    # scale_heads = False) and the FFN residual scaled per channel (scale_resids = True, w_resid; transformer_layer.py:60-69, 204-205)
+    "tiny_text_noscale": dict(
+        arch="tiny", active={"text"}, overrides={"scale_attn": False, "scale_fc": False, "scale_heads": False, "scale_resids": True},
+        adaptor_overrides={},
+        slots=[("TEXT", True, ("tok", "src", (2, 16), [16, 11]), None),
+               ("TEXT", False, ("tok", "prev", (2, 12), [9, 12]), None)],
+        full_grads=["encoder.layers.0.w_resid", "decoder.layers.3.w_resid", "encoder.layers.2.fc2.bias",
+                    "decoder.layers.1.encoder_attn.out_proj.weight", "encoder.adaptor.embed_tokens.weight"],
+    ),
+    # post-LN layers (encoder / decoder normalize_before = False: LayerNorm after each residual add, no final stack LayerNorm,
+    # transformer_layer.py:183-184, 207-208, 435-436, 468-469, 493-494; model/transformer.py:61-64, 255-258)
+    "tiny_text_postln": dict(
+        arch="tiny", active={"text"}, overrides={"encoder_normalize_before": False, "decoder_normalize_before": False},
+        adaptor_overrides={},
+        slots=[("TEXT", True, ("tok", "src", (2, 16), [16, 11]), None),
+               ("TEXT", False, ("tok", "prev", (2, 12), [9, 12]), None)],
+        full_grads=["encoder.layers.0.self_attn_layer_norm.weight", "decoder.layers.3.final_layer_norm.bias",
+                    "decoder.layers.0.encoder_attn_layer_norm.weight", "encoder.layers.3.fc1.weight",
+                    "encoder.adaptor.embed_tokens.weight"],
+    ),
     # three source slots incl. BOX-as-tokens: slot order != ModalityType order, block-diagonal rel-pos bias
     "tiny_multislot": dict(
         arch="tiny", active={"text"}, overrides={}, adaptor_overrides={},

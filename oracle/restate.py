@@ -82,6 +82,8 @@ class OConfig:
     drop_keep: Optional[list] = None        # the per-sample keep draws (0/1, [B] each) of the DropPath calls, in call order: random
                                             # INPUTS of a training-mode run, replayed (module/droppath.py:52-53)
     audio_mask_channel: str = ""            # "" (mask_channel_prob == 0) | "after" | "before" (adaptor/audio.py:452-466)
+    enc_normalize_before: bool = True       # cfg.encoder.normalize_before (config/default_model.yaml; transformer_layer.py:47)
+    dec_normalize_before: bool = True       # cfg.decoder.normalize_before (transformer_layer.py:265)
 
 
 # --------------------------------------------------------------------------------------------
@@ -469,22 +471,28 @@ def modal_for_ffn(state, p, modal_mask, x):
     return out.view(T, B, -1)
 
 
-def _ffn(state, p, cfg, x, modal_mask=None):
-    """transformer_layer.py:186-208 / :471-494 (pre-LN, scale_fc LayerNorm over F inside the FFN)."""
+def _ffn(state, p, cfg, x, modal_mask=None, pre=True):
+    """transformer_layer.py:186-208 / :471-494 (scale_fc LayerNorm over F inside the FFN; scale_resids: the residual is scaled
+    per channel by w_resid; post-LN layers normalise AFTER the residual add)."""
     r = x
-    x = layer_norm(state, p + ".final_layer_norm", x, cfg.eps)
+    if pre:
+        x = layer_norm(state, p + ".final_layer_norm", x, cfg.eps)
     act = {"gelu": gelu, "relu": F.relu, "linear": lambda t: t}[cfg.activation_fn]
     x = act(modal_for_ffn(state, p + ".experts_fc1", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc1", x))
     if (p + ".ffn_layernorm.weight") in state:
         x = layer_norm(state, p + ".ffn_layernorm", x, cfg.eps)
     x = modal_for_ffn(state, p + ".experts_fc2", modal_mask, x) if cfg.modal_ffn else linear(state, p + ".fc2", x)
-    return r + x
+    if (p + ".w_resid") in state:                                         # :204-205 / :490-491
+        r = state[p + ".w_resid"] * r
+    x = r + x
+    return x if pre else layer_norm(state, p + ".final_layer_norm", x, cfg.eps)       # :207-208 / :493-494
 
 
 def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias, modal_mask=None):
-    """transformer_layer.py:132-209 (normalize_before=True, dropout/droppath identity in eval)."""
+    """transformer_layer.py:132-209 (dropout/droppath identity in eval)."""
+    pre = cfg.enc_normalize_before
     r = x
-    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
+    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps) if pre else x
     if self_attn_bias is None:
         h = mha_fast(state, p + ".self_attn", cfg, h, padding_mask)
     else:
@@ -492,28 +500,35 @@ def encoder_layer(state, p, cfg, x, padding_mask, self_attn_bias, modal_mask=Non
     if (p + ".attn_ln.weight") in state:
         h = layer_norm(state, p + ".attn_ln", h, cfg.eps)                 # :179-180
     x = r + h
-    return _ffn(state, p, cfg, x, modal_mask)
+    if not pre:
+        x = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)    # :183-184
+    return _ffn(state, p, cfg, x, modal_mask, pre)
 
 
 def decoder_layer(state, p, cfg, x, enc, enc_padding_mask, self_attn_mask, self_attn_padding_mask,
                   self_attn_bias, cross_attn_bias, need_head_weights, modal_mask=None):
     """transformer_layer.py:351-495."""
+    pre = cfg.dec_normalize_before
     r = x
-    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)
+    h = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps) if pre else x
     h, _ = mha_slow(state, p + ".self_attn", cfg, h, h, self_attn_padding_mask, self_attn_mask, self_attn_bias)
     if (p + ".self_attn_ln.weight") in state:
         h = layer_norm(state, p + ".self_attn_ln", h, cfg.eps)            # :431-432
     x = r + h
+    if not pre:
+        x = layer_norm(state, p + ".self_attn_layer_norm", x, cfg.eps)    # :435-436
     r = x
-    h = layer_norm(state, p + ".encoder_attn_layer_norm", x, cfg.eps)     # :440-441
+    h = layer_norm(state, p + ".encoder_attn_layer_norm", x, cfg.eps) if pre else x   # :440-441
     h, cross_w = mha_slow(state, p + ".encoder_attn", cfg, h, enc, enc_padding_mask, None, cross_attn_bias,
                           need_head_weights=need_head_weights)            # :453-463 (static_kv -> slow path)
     if (p + ".cross_attn_ln.weight") in state:
         h = layer_norm(state, p + ".cross_attn_ln", h, cfg.eps)           # :464-465
     x = r + h
+    if not pre:
+        x = layer_norm(state, p + ".encoder_attn_layer_norm", x, cfg.eps)  # :468-469
     if modal_mask is not None:
         modal_mask = modal_mask[:x.shape[1], :x.shape[0]]                 # :477, 486
-    return _ffn(state, p, cfg, x, modal_mask), cross_w
+    return _ffn(state, p, cfg, x, modal_mask, pre), cross_w
 
 
 # --------------------------------------------------------------------------------------------
@@ -542,7 +557,8 @@ def encoder_forward(state, cfg, slots, record=None):
         x = encoder_layer(state, f"encoder.layers.{l}", cfg, x, masks if has_pad else None, b, modal_mask)
         if record is not None:
             record[f"enc_layer{l}"] = x
-    x = layer_norm(state, "encoder.layer_norm", x, cfg.eps)               # :142-143
+    if "encoder.layer_norm.weight" in state:                              # only a pre-LN stack has it (transformer.py:61-64)
+        x = layer_norm(state, "encoder.layer_norm", x, cfg.eps)           # :142-143
     return {"encoder_out": x, "encoder_padding_mask": masks, "position_embeddings": pos_embed}
 
 
@@ -576,7 +592,8 @@ def decoder_forward(state, cfg, slots, enc_out, record=None):
             record[f"dec_layer{l}"] = x
         if last:
             attn = cw.float().mean(dim=0)                                 # :498-506 (names swapped upstream: this IS cross-attn)
-    x = layer_norm(state, "decoder.layer_norm", x, cfg.eps)               # :508-509
+    if "decoder.layer_norm.weight" in state:                              # (transformer.py:255-258)
+        x = layer_norm(state, "decoder.layer_norm", x, cfg.eps)           # :508-509
     x = x.transpose(0, 1)
     logits = F.linear(x, state["decoder.adaptor.embed_tokens.weight"])    # adaptor/base.py:131
     return logits, {"attn": attn, "last_hidden_state": x}

@@ -71,6 +71,20 @@ CASES = {
         full_grads=["encoder.adaptor.text.token_rel_pos_table_list.0.weight", "decoder.layers.0.encoder_attn.c_attn",
                     "encoder.adaptor.text.type_embedding.weight"],
     ),
+    # one relative-position table for all layers (share_attn_bias), a non-default attention scale (attn_scale_factor, also the
+    # position-bias projections' scaling), and the text adaptor without type embedding / embedding LayerNorm / position LayerNorm
+    # (adaptor/base.py:59-66, 141-143, 172-180)
+    "tiny_multislot_shared": dict(
+        arch="tiny", active={"text"}, overrides={"share_attn_bias": True, "attn_scale_factor": 1.5},
+        adaptor_overrides={"text": {"add_type_embedding": False, "layernorm_embedding": False, "layernorm_position": False}},
+        slots=[("BOX", True, ("tok", "box", (3, 4), None), None),
+               ("TEXT", True, ("tok", "srcA", (3, 7), [7, 5, 3]), None),
+               ("STRUCT", True, ("tok", "srcB", (3, 5), None), None),
+               ("TEXT", False, ("tok", "prev", (3, 6), [6, 4, 6]), None)],
+        full_grads=["encoder.adaptor.text.token_rel_pos_table_list.0.weight", "decoder.adaptor.text.token_rel_pos_table_list.0.weight",
+                    "encoder.adaptor.pos_q_linear.weight", "decoder.cross_pos_k_linear.bias",
+                    "encoder.adaptor.text.embed_positions.weight"],
+    ),
     # modal_ffn (one FFN expert per modality).  The reference's modal_for_ffn ends in x.half() (transformer_layer.py:129), so it
     # only runs in an fp16 model: the fixture is a HALF-precision reference run on CPU ("half": True)
     "tiny_modal_ffn": dict(

@@ -155,9 +155,10 @@ def _post_hook(state, cfg, side, name, slot, embed, pos_embed):
     alpha = cfg.adaptor_grad_scale.get(name, 1.0)
     if alpha != 1.0:                                                      # base.py:174-176
         embed = embed * alpha + embed.detach() * (1 - alpha)
-    embed = layer_norm(state, p + ".layernorm_embedding", embed, cfg.eps)  # base.py:177-178
-    if pos_embed is not None:
-        pos_embed = layer_norm(state, p + ".layernorm_position", pos_embed, cfg.eps)  # base.py:179-180
+    if (p + ".layernorm_embedding.weight") in state:                      # base.py:177-178 (cfg.layernorm_embedding)
+        embed = layer_norm(state, p + ".layernorm_embedding", embed, cfg.eps)
+    if pos_embed is not None and (p + ".layernorm_position.weight") in state:          # base.py:179-180 (cfg.layernorm_position)
+        pos_embed = layer_norm(state, p + ".layernorm_position", pos_embed, cfg.eps)
     return embed, pos_embed   # dropout (base.py:181) is identity in eval
 
 

@@ -63,6 +63,7 @@ def oracle_cfg(case):
                    adaptor_embed_scale=esc, adaptor_grad_scale=gsc,
                    resnet_layers=layers, training=bool(case.get("train", False)), modal_ffn=bool(ov.get("modal_ffn", False)),
                    activation_fn=ov.get("activation_fn", "gelu"),
+                   share_attn_bias=ov.get("share_attn_bias", False), attn_scale_factor=float(ov.get("attn_scale_factor", 2.0)),
                    enc_normalize_before=ov.get("encoder_normalize_before", True),
                    dec_normalize_before=ov.get("decoder_normalize_before", True),
                    resnet_drop_path_rate=float(case["adaptor_overrides"].get("image_resnet", {}).get("resnet_drop_path_rate", 0.0)),

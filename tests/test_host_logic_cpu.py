@@ -14,7 +14,7 @@ from tests.model_util import build_model
 
 
 @pytest.mark.parametrize("name", ["tiny_text", "base_patch", "tiny_resnet", "tiny_video", "tiny_audio", "tiny_resnet_droppath",
-                                  "tiny_audio_chmask", "tiny_text_noscale", "tiny_text_postln"])
+                                  "tiny_audio_chmask", "tiny_text_noscale", "tiny_text_postln", "tiny_multislot_shared"])
 def test_state_dict_schema_matches_reference(name):
     g = load_golden(name)
     model, _ = build_model(CASES[name])

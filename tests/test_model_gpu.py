@@ -670,6 +670,78 @@ def test_layerdrop_keeps_the_reference_s_survivor_semantics(dtype):
             assert torch.isfinite(p.grad).all(), k
 
 
+@pytest.mark.parametrize("what", ["freeze_encoder", "freeze_embedding", "freeze_resnet"])
+def test_frozen_parameters_take_no_gradient_and_nothing_else_changes(what):
+    """freeze_encoder (model/ofa.py:382-383: encoder.requires_grad_(False) -- the tied embedding is a child of the encoder's adaptor,
+    so it freezes for the decoder too), freeze_encoder_embedding == freeze_decoder_embedding (adaptor/general.py:211, 218-219) and
+    image_resnet.freeze_resnet (adaptor/image_resnet.py:107-114: BatchNorm in eval mode, affine parameters frozen): the forward and
+    every remaining gradient equal the fixture of the unfrozen model; frozen tensors take no gradient and a train step (eager and
+    replayed graph) leaves them bit-identical while the others move."""
+    import copy
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import Trainer
+    name = "tiny_resnet" if what == "freeze_resnet" else "tiny_text"
+    case = copy.deepcopy(CASES[name])
+    if what == "freeze_encoder":
+        case["overrides"] = dict(case["overrides"], freeze_encoder=True)
+    elif what == "freeze_embedding":
+        case["overrides"] = dict(case["overrides"], freeze_encoder_embedding=True, freeze_decoder_embedding=True)
+    else:
+        case["adaptor_overrides"] = {"image_resnet": dict(case["adaptor_overrides"]["image_resnet"], freeze_resnet=True)}
+    g = load_golden(name)
+    model, d = build_model(case, DEV, torch.float32)
+    params = dict(model.named_parameters())
+    if what == "freeze_encoder":
+        frozen = {k for k in params if k.startswith("encoder.")} | {"decoder.adaptor.embed_tokens.weight"}
+    elif what == "freeze_embedding":
+        frozen = {"encoder.adaptor.embed_tokens.weight", "decoder.adaptor.embed_tokens.weight"}
+    else:
+        model.train()                                   # the adaptor's train() is what puts the trunk's BatchNorm into eval mode
+        frozen = {k for k, p in params.items() if not p.requires_grad}
+        assert frozen and all(".embed_images." in k and (".bn" in k or ".downsample.1." in k) for k in frozen), sorted(frozen)[:4]
+    assert {k for k, p in params.items() if not p.requires_grad} == {k for k in frozen if k in params}
+    vals, target = case_inputs(case)
+    if what != "freeze_resnet":                         # (a frozen trunk normalises with its running statistics: no fixture for that)
+        model.eval()
+        logits, _ = model(make_slots(vals, DEV))
+        loss = ops.cross_entropy_sum(logits, target.to(DEV), d.pad())
+        loss.backward()
+        assert rel_err(logits.detach().cpu(), g["logits"]) < FP32_TOL
+        gn = dict(zip([str(k) for k in g["grad_norm_keys"]], g["grad_norms"]))
+        scale = max(gn.values())
+        for k, p in params.items():
+            if k in frozen:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            elif gn[k] >= 0:
+                got = float(p.grad.double().norm())
+                assert abs(got - gn[k]) <= FP32_TOL * gn[k] + 1e-6 * scale, (k, got, gn[k])
+        model.zero_grad(set_to_none=True)
+    # the update loop: frozen tensors stay bit-identical, the rest moves; the replayed graph walks the eager trajectory
+    del model, params
+    runs = []
+    for use_graph in (False, True):
+        model, d = build_model(case, DEV, torch.float32)
+        model.train()
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        buffers0 = {k: v.detach().clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        tr = Trainer(model, lr=1e-3, clip_norm=1.0, use_graph=use_graph, graph_warmup=1)
+        batch = {"slots": make_slots(vals, DEV), "target": target.to(DEV)}
+        ops.manual_seed(5)
+        losses = [float(tr.train_step([batch])["stats"][1]) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert all(v == v and v < 1e6 for v in losses), losses
+        assert not use_graph or any("graphs" in e for e in tr._graphs.values())
+        for k, p in model.named_parameters():
+            same = torch.equal(p.detach(), before[k])
+            assert same == (k in frozen), (k, same)
+        if what == "freeze_resnet":                     # eval-mode BatchNorm: the running statistics do not move either
+            sd = model.state_dict()
+            assert buffers0 and all(torch.equal(sd[k], v) for k, v in buffers0.items())
+        runs.append(losses)
+        del tr, model
+    assert runs[0] == runs[1]
+
+
 def test_overfit_one_batch_loss_goes_down():
     """End-to-end sanity of the whole update loop (fused backward kernels + gradient arena + clip + Adam, captured step):
     40 steps on one tiny batch with dropout on must drive the per-token loss well below its starting value, with

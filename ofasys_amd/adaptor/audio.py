@@ -156,6 +156,9 @@ class AudioFbankAdaptor(BaseAdaptor):
         if (slot.has_attr("use_mask") or self.use_mask) and mask_indices is not None:      # apply_mask, :452-466
             mch = None
             if self.mask_channel_prob > 0:          # [B, C] channel draws of get_mask_indices: those channels are zeroed over all T
+                if slot.value.get("mask_channel_indices") is None:
+                    raise ValueError("audio_fbank.mask_channel_prob > 0: the slot value needs 'mask_channel_indices' ([B, C] bool, "
+                                     "adaptor/audio.py:433-446) next to 'mask_indices'")
                 mch = slot.value["mask_channel_indices"].to(feature.device).unsqueeze(1)
             if mch is not None and self.mask_channel_before:
                 feature = feature.masked_fill(mch, 0.0)

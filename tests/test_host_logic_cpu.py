@@ -54,6 +54,23 @@ def test_activation_checkpointing_flags_are_accepted_and_change_nothing():
     assert [type(m) for m in model.modules()] == [type(m) for m in plain.modules()]
 
 
+def test_layerdrop_survivors_match_the_reference_s_draws():
+    """model/transformer.kept_layers against the reference's LayerDropModuleList iterated on the same seeds (tests/golden/
+    layerdrop.json, oracle/gen_layerdrop_golden.py): same survivors, same number of random numbers consumed per iteration (the
+    second iteration of a seed matches too), every layer in evaluation mode."""
+    import json
+    from ofasys_amd.model.transformer import kept_layers
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "layerdrop.json")))
+    assert len(G["cases"]) >= 12
+    for c in G["cases"]:
+        layers = list(range(c["n"]))
+        torch.manual_seed(c["seed"])
+        assert kept_layers(layers, c["p"], True) == c["train_first"], c
+        if c["p"] > 0:                      # (p == 0 keeps everything without drawing; the reference draws and keeps everything)
+            assert kept_layers(layers, c["p"], True) == c["train_second"], c
+        assert kept_layers(layers, c["p"], False) == c["eval"] == layers
+
+
 def test_integer_paths_bit_exact():
     g = load_golden("tiny_text")
     model, d = build_model(CASES["tiny_text"])

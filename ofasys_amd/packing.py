@@ -11,9 +11,10 @@ The reference pads every sample of a micro-batch to the longest one, computes al
     attention takes the segment table {q_off, q_len, k_off, k_len} per sample (csrc/attention.hip, ragged mode).
 
 The default (biased-attention) configuration packs too since round 3: the position bias is no longer a dense [B,A,T,T] tensor laid
-out by padded position but computed inside the attention kernels from packed pos_q / pos_k rows and position-indexed bucket ids
-(ops.PosBias); the ids need packed row r of a sample to BE padded position r, i.e. each sample's valid positions must be a prefix of
-its padded row (one ragged slot, at the end -- image + text, video + text, text alone; `enc_prefix` / `dec_prefix`).  R is rounded up to `bucket` rows so that a
+out by padded position but ONE [A,T,T] matrix per layer shared by the batch (ops.SharedBias: batch-invariant positions), which the
+attention kernels index by the position INSIDE the sample; that needs packed row r of a sample to BE padded position r, i.e. each
+sample's valid positions must be a prefix of its padded row (one ragged slot, at the end -- image + text, video + text, text alone;
+`enc_prefix` / `dec_prefix`).  R is rounded up to `bucket` rows so that a
 handful of hipGraphs cover all batches of a length distribution.  Host side: the plan is built from HOST masks / lengths (no device
 sync), shipped with the batch, and is part of the step's static inputs.
 """

@@ -71,6 +71,44 @@ def test_layerdrop_survivors_match_the_reference_s_draws():
         assert kept_layers(layers, c["p"], False) == c["eval"] == layers
 
 
+def test_pack_plan_layout_is_a_bijection_on_the_non_pad_positions():
+    """packing.build_pack_plan (host logic of the ragged layout): every non-pad position of the padded batch appears exactly once in
+    the packed index, in order, each sample on an 8-row boundary; the inverse map undoes it; rows round up to the bucket; the segment
+    tables carry (offset, length) of queries and keys; `*_prefix` tells whether packed row r of a sample is padded position r."""
+    from ofasys_amd.packing import ALIGN, build_pack_plan
+    g = torch.Generator().manual_seed(3)
+    for trial in range(20):
+        B, Ts, Tt = int(torch.randint(1, 9, (1,), generator=g)), int(torch.randint(1, 70, (1,), generator=g)), int(torch.randint(1, 40, (1,), generator=g))
+        if trial % 2:                                  # right-padded rows (a prefix of every row is valid)
+            el = torch.randint(1, Ts + 1, (B,), generator=g)
+            enc = torch.arange(Ts)[None, :] >= el[:, None]
+        else:                                          # two ragged slots side by side: padding in the middle of a row
+            enc = torch.rand(B, Ts, generator=g) < 0.3
+            enc[:, 0] = False
+        dl = torch.randint(1, Tt + 1, (B,), generator=g)
+        dec = torch.arange(Tt)[None, :] >= dl[:, None]
+        plan = build_pack_plan(enc, dec, bucket=64, dec_bucket=32)
+        for mask, index, inverse, seg, bucket in ((enc, plan.enc_index, plan.enc_inverse, plan.enc_self, 64),
+                                                  (dec, plan.dec_index, plan.dec_inverse, plan.dec_self, 32)):
+            T = mask.shape[1]
+            want = torch.nonzero(~mask.reshape(-1)).squeeze(1)
+            got = index[index >= 0]
+            assert torch.equal(got, want)                                       # every valid position once, in (sample, position) order
+            assert index.numel() % bucket == 0 and index.numel() >= bucket
+            assert torch.equal(inverse[want], torch.nonzero(index >= 0).squeeze(1)) and int((inverse >= 0).sum()) == want.numel()
+            tab = seg.table
+            assert tab.dtype == torch.int32 and tab.shape == (B, 4)
+            for b in range(B):
+                off, n = int(tab[b, 0]), int(tab[b, 1])
+                assert off % ALIGN == 0 and n == int((~mask[b]).sum())
+                assert torch.equal(index[off:off + n] - b * T, torch.nonzero(~mask[b]).squeeze(1))
+                assert b + 1 == B or int(tab[b + 1, 0]) >= off + n
+            assert seg.max_q >= int(tab[:, 1].max()) and seg.max_q % 32 == 0
+        assert plan.enc_tokens == int((~enc).sum()) and plan.dec_tokens == int((~dec).sum())
+        assert torch.equal(plan.cross.table[:, :2], plan.dec_self.table[:, :2]) and torch.equal(plan.cross.table[:, 2:], plan.enc_self.table[:, 2:])
+        assert plan.dec_prefix and plan.enc_prefix == all(bool((~enc[b, :int((~enc[b]).sum())]).all()) for b in range(B))
+
+
 def test_integer_paths_bit_exact():
     g = load_golden("tiny_text")
     model, d = build_model(CASES["tiny_text"])

@@ -1,0 +1,59 @@
+"""CPU: the committed evidence hangs together -- the bench lines under profiles/ name the metric BASELINE.json names, point at
+profiler summaries that exist and agree with them, and the step times DESIGN.md / README.md quote are the ones in those lines.
+(A round whose documents quote one run and whose profiles hold another is caught here, not by a reader.)"""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest_round():
+    rounds = sorted({int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "round*_bench.json"))
+                     for m in [re.search(r"round(\d+)_bench\.json$", f)] if m})
+    assert rounds, "no profiles/roundN_bench.json"
+    return rounds[-1]
+
+
+def _line(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
+def test_bench_lines_follow_the_contract_and_their_profiles_exist():
+    r = _latest_round()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for suffix in ("", "_cfg2b", "_cfg4"):
+        d = _line(f"round{r}_bench{suffix}.json")
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in d, (suffix, key)
+        assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["higher_is_better"] is True and "synthetic" in d["data"]
+        assert "workload" in d["config"] and "model" not in d["config"]
+        assert "tokens/sec" in base["metric"] and d["metric"].startswith("multimodal tokens/sec") and d["unit"] == "tokens/s"
+        roof = d["roofline"]
+        assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.0 < roof["frac"] < 1.0
+        assert abs(d["value"] - d["config"]["nonpad_tokens_per_step"] / (d["ms_per_step"] * 1e-3)) <= 2e-3 * d["value"]
+        cpu = d["cpu_baseline"]
+        assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+        # the profiler's summary of the same command: committed, and the bench line quotes ITS total
+        src = roof["rocprof"]["source"]
+        assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), src
+        stats = json.load(open(os.path.join(ROOT, src)))
+        assert abs(stats["__meta__"]["total_ms_per_step"] - roof["rocprof"]["all_kernels_ms_per_step"]) < 1e-6
+        assert os.path.exists(os.path.join(ROOT, src.replace(".json", ".txt")))
+        # the profiler's per-launch time of the GEMM family agrees with the in-situ events within 10 %
+        assert abs(roof["rocprof"]["frac"] - roof["frac"]) <= 0.20 * roof["frac"], (suffix, roof["rocprof"]["frac"], roof["frac"])
+
+
+def test_documents_quote_the_committed_run():
+    r = _latest_round()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for suffix in ("", "_cfg2b", "_cfg4"):
+        ms = _line(f"round{r}_bench{suffix}.json")["ms_per_step"]
+        assert f"{ms:.2f} ms" in design, (suffix, f"{ms:.2f} ms is not in DESIGN.md")
+        assert f"{ms:.1f} ms" in readme, (suffix, f"{ms:.1f} ms is not in README.md")
+    head = _line(f"round{r}_bench.json")
+    assert f"{head['roofline']['frac'] * 100:.1f} %" in design

@@ -481,15 +481,12 @@ def test_maximum_positions_match_oracle():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,Ts,Tt,slen,tlen", [
-    (1, 1, 1, [1], [1]),                       # one source token, one target position (bos only)
-    (1, 33, 65, [33], [65]),                   # batch of one, lengths that are no multiple of any tile
-    (3, 5, 2, [5, 1, 3], [2, 1, 2]),           # rows with a single real token next to longer ones
-    (2, 129, 31, [129, 2], [31, 30]),          # one row almost entirely padding
-])
+@pytest.mark.parametrize("B,Ts,Tt,slen,tlen", __import__("oracle.edge_cases", fromlist=["SHAPES"]).SHAPES)
 def test_ragged_and_degenerate_shapes_match_oracle(B, Ts, Tt, slen, tlen, dtype):
-    """Edge shapes of the text path (tiny model, biased attention): logits, loss and every gradient norm against the CPU
-    oracle run on the same recipe weights and inputs."""
+    """Edge shapes of the text path (tiny model, biased attention; oracle/edge_cases.py: one token, a batch of one at odd lengths,
+    single-token rows, an almost entirely padded row): logits, loss and every gradient norm against the CPU oracle run on the same
+    recipe weights and inputs -- the oracle itself is pinned to the reference on exactly these inputs
+    (tests/test_oracle_golden.py::test_edge_shapes_match_reference)."""
     from oracle import recipe, restate
     from oracle.cases import VOCAB_EXTRA, make_target
     from oracle.restate import OSlot

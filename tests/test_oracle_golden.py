@@ -61,6 +61,40 @@ def test_forward_backward_matches_reference(name):
             assert rel_err(state[k[7:]].detach().double(), g[k].astype(np.float64)) < TOL, k
 
 
+@pytest.mark.parametrize("shape", __import__("oracle.edge_cases", fromlist=["SHAPES"]).SHAPES, ids=lambda s: f"b{s[0]}s{s[1]}t{s[2]}")
+def test_edge_shapes_match_reference(shape):
+    """The oracle on the degenerate / ragged shapes the HIP path is compared with it on (tests/test_model_gpu.py::
+    test_ragged_and_degenerate_shapes_match_oracle): one token, batch of one at odd lengths, single-token rows, an almost entirely
+    padded row -- against the reference run on the same inputs (tests/golden/edge_shapes.npz, oracle/gen_edge_golden.py)."""
+    from oracle import edge_cases as EC
+    torch.set_num_threads(8)
+    G = load_golden("edge_shapes")
+    case = CASES["tiny_text"]
+    state = state_from_golden(load_golden("tiny_text"))
+    params = {k: v.requires_grad_(True) for k, v in state.items() if v.is_floating_point() and not k.endswith("version")}
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    src, prev, target = EC.inputs(shape)
+    k = EC.key(shape)
+    assert np.array_equal(target.numpy(), G[k + ".target"])
+    logits, _ = restate.model_forward(state, oracle_cfg(case), [restate.OSlot("TEXT", True, src, None), restate.OSlot("TEXT", False, prev, None)])
+    loss, _ = restate.cross_entropy(logits, target)
+    assert rel_err(logits.detach(), G[k + ".logits"]) < TOL
+    assert rel_err(loss.detach(), G[k + ".loss"][0]) < TOL
+    loss.backward()
+    want = dict(zip([str(n) for n in G["grad_norm_keys"]], G[k + ".grad_norms"]))
+    scale = max(want.values())
+    checked = 0
+    for n, w in want.items():
+        g = params[n].grad
+        got = float(g.double().norm()) if g is not None else 0.0
+        if w < 0:
+            assert got == 0.0, n
+        else:
+            assert abs(got - w) <= 1e-4 * w + 1e-6 * scale, (n, got, w)
+            checked += 1
+    assert checked > 100
+
+
 def test_token_bucket_bit_exact():
     g = load_golden("tiny_text")
     b = restate.make_token_bucket_position(256, 1024)

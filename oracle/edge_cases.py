@@ -23,3 +23,14 @@ def inputs(shape):
     src = recipe.tokens(f"input.edge_src{B}{Ts}", (B, Ts), V, slen)
     prev = recipe.tokens(f"input.edge_prev{B}{Tt}", (B, Tt), V, tlen, bos=0)
     return src, prev, make_target(prev)
+
+
+MAX_POS_STRIDE = 53           # the 1024 x 1024 run keeps every 53rd logit / attention value: the file stays small
+
+
+def max_position_inputs():
+    """1024 source and 1024 target tokens: the edge of max_source_positions / max_target_positions and of the bucket tables."""
+    V = 4 + VOCAB_EXTRA
+    src = recipe.tokens("input.max_src", (1, 1024), V, [1024])
+    prev = recipe.tokens("input.max_prev", (1, 1024), V, [1024], bos=0)
+    return src, prev

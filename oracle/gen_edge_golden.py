@@ -42,6 +42,13 @@ def main():
         out[k + ".target"] = target.numpy()
         out[k + ".grad_norms"] = np.array([float(params[n].grad.double().norm()) if params[n].grad is not None else -1.0 for n in names])
         print(k, "loss", float(loss), "finite", bool(torch.isfinite(logits).all()))
+    src, prev = EC.max_position_inputs()                   # forward only, as the GPU test does
+    with torch.no_grad():
+        logits, extra = model([Slot(ModalityType.TEXT, True, src), Slot(ModalityType.TEXT, False, prev)])
+    out["maxpos.logits"] = logits.reshape(-1)[::EC.MAX_POS_STRIDE].numpy()
+    out["maxpos.attn"] = extra["attn"][0].reshape(-1)[::EC.MAX_POS_STRIDE].numpy()
+    out["maxpos.logits_absmax"] = np.array([float(logits.abs().max())])
+    print("maxpos", tuple(logits.shape), "finite", bool(torch.isfinite(logits).all()))
     path = os.path.join(ROOT, "tests", "golden", "edge_shapes.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KB")

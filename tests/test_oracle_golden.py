@@ -95,6 +95,24 @@ def test_edge_shapes_match_reference(shape):
     assert checked > 100
 
 
+def test_maximum_positions_match_reference():
+    """1024 source / 1024 target tokens (the edge of the position and bucket tables), forward: the oracle against the reference's run
+    (every 53rd logit and attention value of tests/golden/edge_shapes.npz) -- the GPU test compares the HIP path with the oracle there."""
+    from oracle import edge_cases as EC
+    torch.set_num_threads(8)
+    G = load_golden("edge_shapes")
+    state = state_from_golden(load_golden("tiny_text"))
+    state["decoder.adaptor.embed_tokens.weight"] = state["encoder.adaptor.embed_tokens.weight"]
+    src, prev = EC.max_position_inputs()
+    with torch.no_grad():
+        logits, extra = restate.model_forward(state, oracle_cfg(CASES["tiny_text"]),
+                                              [restate.OSlot("TEXT", True, src, None), restate.OSlot("TEXT", False, prev, None)])
+    assert abs(float(logits.abs().max()) - float(G["maxpos.logits_absmax"][0])) <= TOL * float(G["maxpos.logits_absmax"][0])
+    scale = float(G["maxpos.logits_absmax"][0])
+    assert float((logits.reshape(-1)[::EC.MAX_POS_STRIDE] - torch.from_numpy(G["maxpos.logits"])).abs().max()) < TOL * scale
+    assert rel_err(extra["attn"].reshape(-1)[::EC.MAX_POS_STRIDE], G["maxpos.attn"]) < TOL
+
+
 def test_token_bucket_bit_exact():
     g = load_golden("tiny_text")
     b = restate.make_token_bucket_position(256, 1024)

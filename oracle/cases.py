@@ -197,6 +197,25 @@ CASES = {
 }
 
 
+# Cases with a stored golden file that pin the ORACLE only (tests/test_oracle_golden.py, CPU): the HIP path meets the oracle on these
+# routes in tests/test_configs_gpu.py (cfg-5: struct / motion micro-batches) rather than through a fixture of its own.
+ORACLE_CASES = {
+    # every token-carrying modality the general adaptor routes to the text adaptor (adaptor/general.py:36-46): MOTION, PHONE, CATEGORY
+    # and STRUCT source slots next to TEXT, with modal_ffn so that each modality's OWN expert runs (half precision as tiny_modal_ffn)
+    "tiny_token_modalities": dict(
+        arch="tiny", active={"text"}, overrides={"modal_ffn": True}, adaptor_overrides={}, half=True,
+        slots=[("MOTION", True, ("tok", "motion", (2, 6), [6, 4]), None),
+               ("PHONE", True, ("tok", "phone", (2, 5), None), None),
+               ("CATEGORY", True, ("tok", "cat", (2, 2), None), None),
+               ("STRUCT", True, ("tok", "struct", (2, 4), [4, 3]), None),
+               ("TEXT", True, ("tok", "src", (2, 5), [5, 2]), None),
+               ("TEXT", False, ("tok", "prev", (2, 6), [6, 5]), None)],
+        full_grads=["encoder.layers.0.experts_fc1.4.weight", "encoder.layers.1.experts_fc2.5.bias",
+                    "encoder.layers.0.experts_fc1.8.bias", "encoder.adaptor.text.type_embedding.weight"],
+    ),
+}
+
+
 # Cases WITHOUT a stored golden file: the GPU test compares with the oracle directly (tests/test_bench_parity_gpu.py); listed here so
 # that oracle/ref_bf16_gap.py can measure the REFERENCE's own bf16-vs-fp32 gap on exactly these inputs (the bf16 tolerance's basis).
 EXTRA_CASES = {

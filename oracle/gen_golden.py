@@ -21,7 +21,7 @@ from oracle.ref_import import build_reference_model, install  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
-from oracle.cases import CASES, VOCAB_EXTRA, make_value, make_target  # noqa: E402
+from oracle.cases import CASES, ORACLE_CASES, VOCAB_EXTRA, make_value, make_target  # noqa: E402
 
 
 def run_case(name, case):
@@ -262,14 +262,14 @@ if __name__ == "__main__":
         softmax_bwd_vectors()
         sys.exit(0)
     if len(sys.argv) == 3 and sys.argv[1] == "--case":
-        run_case(sys.argv[2], CASES[sys.argv[2]])
+        run_case(sys.argv[2], {**CASES, **ORACLE_CASES}[sys.argv[2]])
         sys.exit(0)
     manifest_only = len(sys.argv) == 2 and sys.argv[1] == "--manifest"     # rewrite MANIFEST.json after single --case runs
     # one fresh process per case: the reference's dataclass defaults are shared mutable instances, so adaptor
     # configs (embed_dim, layers, ...) leak from one model to the next inside a process
     import subprocess
     if not manifest_only:
-        for name in CASES:
+        for name in {**CASES, **ORACLE_CASES}:
             subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
         softmax_vectors()
         softmax_bwd_vectors()
@@ -280,6 +280,6 @@ if __name__ == "__main__":
         "torch": torch.__version__, "numpy": np.__version__,
         "reference_tree_sha1": hashlib.sha1("".join(sorted(
             f"{r}/{f}" for r, _, fs in os.walk("/root/reference/ofasys") for f in fs if f.endswith(".py"))).encode()).hexdigest(),
-        "cases": {k: {kk: (sorted(vv) if isinstance(vv, set) else vv) for kk, vv in v.items() if kk != "slots"} for k, v in CASES.items()},
+        "cases": {k: {kk: (sorted(vv) if isinstance(vv, set) else vv) for kk, vv in v.items() if kk != "slots"} for k, v in {**CASES, **ORACLE_CASES}.items()},
     }
     json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, default=str)

@@ -5,16 +5,16 @@ import pytest
 import torch
 
 from oracle import restate
-from oracle.cases import CASES
+from oracle.cases import CASES, ORACLE_CASES
 from tests.golden_util import case_inputs, drop_keep_rows, load_golden, oracle_cfg, oracle_slots, rel_err, state_from_golden
 
 TOL = 2e-5   # fp32 vs fp32, different op order only (reference noise floor 2e-6)
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(CASES) + list(ORACLE_CASES))
 def test_forward_backward_matches_reference(name):
     torch.set_num_threads(8)
-    case = CASES[name]
+    case = {**CASES, **ORACLE_CASES}[name]
     # a "half" case is a reference run in fp16 (modal_ffn only exists there): the fp32 oracle meets it at fp16's rounding
     TOL, GTOL = (4e-3, 2e-2) if case.get("half") else (globals()["TOL"], 1e-4)
     g = load_golden(name)

@@ -137,7 +137,7 @@ class AudioFbankAdaptor(BaseAdaptor):
         if seq_length > self.audio_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.audio_rp_bucket.size(0)} positions of audio_rp_bucket")
         rp_bucket = ops.cached_index(self, ("audio", seq_length), lambda: self.audio_rp_bucket[:seq_length, :seq_length].contiguous())
-        return ops.embedding(rp_bucket, self.audio_rel_pos_table_list[idx].weight, plan_key=("audio", id(self)))
+        return ops.embedding(rp_bucket, self.audio_rel_pos_table_list[idx].weight, plan_key=("audio", ops.owner_token(self)))
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         assert slot.modality == ModalityType.AUDIO

@@ -40,6 +40,11 @@ class ImagePatchEmbedAdaptor(BaseAdaptor):
         # parameters named/shaped like nn.Conv2d(3, D, k=p, s=p) for checkpoint interchange
         self.proj = nn.Conv2d(3, cfg.embed_dim, kernel_size=patch_size, stride=patch_size)
 
+    def _ofa_plain_conv_weights(self):
+        """4-D weights the flat parameter arena must keep in torch's contiguous order (trainer.FlatParams._view): `proj.weight` is
+        read by ops.PatchEmbedFn as a [D, C*p*p] view, not by the im2col convolution."""
+        return (self.proj.weight,)
+
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         assert slot.modality == ModalityType.IMAGE
         image: torch.Tensor = slot.value

@@ -84,7 +84,7 @@ class ImageResnetAdaptor(BaseAdaptor):
         gather = lambda: self.image_rp_bucket[ids][:, ids].contiguous()        # noqa: E731   (and every step: ids come from (h, w))
         rp_bucket = ops.cached_index(self, ("image", hw, int(ids.numel())), gather) if hw is not None else gather()
         # (the position ids are arange-derived from the feature map's (h, w): with the shape, that identifies the lookup)
-        return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight, plan_key=("image", id(self), getattr(self, "_hw", None)))
+        return ops.embedding(rp_bucket, self.image_rel_pos_table_list[idx].weight, plan_key=("image", ops.owner_token(self), getattr(self, "_hw", None)))
 
     def get_patch_images_info(self, patch_images):
         """image_resnet.py:130-164 -> (embed rows [B, h*w, 1024], n, mask, position ids [T], pos_embed [B, T, D])."""

@@ -72,7 +72,7 @@ class TextAdaptor(BaseAdaptor):
         if seq_length > self.token_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.token_rp_bucket.size(0)} positions of token_rp_bucket")
         rp_bucket = ops.cached_index(self, ("text", seq_length), lambda: self.token_rp_bucket[:seq_length, :seq_length].contiguous())
-        return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight, plan_key=("text", id(self)))
+        return ops.embedding(rp_bucket, self.token_rel_pos_table_list[idx].weight, plan_key=("text", ops.owner_token(self)))
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         src_tokens = slot.value

@@ -58,7 +58,7 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         if seq_length > self.video_rp_bucket.size(0):                  # the reference fails on the size mismatch (slicing clamps)
             raise ValueError(f"sequence length {seq_length} exceeds the {self.video_rp_bucket.size(0)} positions of video_rp_bucket")
         rp_bucket = ops.cached_index(self, ("video", seq_length), lambda: self.video_rp_bucket[:seq_length, :seq_length].contiguous())
-        return ops.embedding(rp_bucket, self.video_rel_pos_table_list[idx].weight, plan_key=("video", id(self)))        # [F,F,A]
+        return ops.embedding(rp_bucket, self.video_rel_pos_table_list[idx].weight, plan_key=("video", ops.owner_token(self)))        # [F,F,A]
 
     def get_clip_videos_info(self, clip_videos: torch.Tensor):
         """video_image_sequence.py:111-154.  clip_videos: [B, 3, F, H, W]."""

@@ -71,9 +71,15 @@ class GradBucketReducer:
     def knows(self, signature):
         return signature is not None and signature in self._learned
 
-    def begin_step(self, signature=None):
+    def begin_step(self, signature=None, dynamic=False):
         """`signature` identifies the step's structure (trainer.sample_structure); early bucket launches are only armed for a
-        structure whose contribution counts were learned on an earlier, identical step (None: never armed, never learned)."""
+        structure whose contribution counts were learned on an earlier, identical step (None: never armed, never learned).
+        `dynamic`: the autograd graph of this step is NOT a function of the structure key (LayerDrop draws the kept layers per step
+        and per rank, module/layer_drop.py:37-41): nothing is armed and nothing is learned -- every bucket goes out at finish(),
+        in index order, dropped layers contributing zeros (the reference's DDP does the same through find_unused_parameters,
+        default_trainer.yaml:13-14)."""
+        if dynamic:
+            signature = None
         self._sig = signature
         self.expected = self._learned.get(signature) if (self.overlap and signature is not None) else None
         self._reset()

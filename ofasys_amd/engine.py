@@ -60,6 +60,31 @@ class OptimizerConfig:
 
 
 @dataclass
+class _SkipPoll:
+    """Host-side view of the device's skipped-update counter without a per-step sync: after every step the 2-element `skipped`
+    tensor is copied to pinned memory behind an event; a read returns the newest copy whose event has completed."""
+
+    def __init__(self):
+        self._host = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._ev = [torch.cuda.Event() for _ in range(2)]
+        self._busy = [False, False]
+        self._value = 0
+        self._turn = 0
+
+    def push_and_read(self, skipped_dev):
+        for i in range(2):
+            if self._busy[i] and self._ev[i].query():
+                self._value = max(self._value, int(self._host[i][1]))
+                self._busy[i] = False
+        i = self._turn
+        if not self._busy[i]:
+            self._host[i].copy_(skipped_dev, non_blocking=True)
+            self._ev[i].record()
+            self._busy[i] = True
+            self._turn ^= 1
+        return self._value
+
+
 class TrainerConfig:
     common: CommonConfig = field(default_factory=CommonConfig)
     optimization: OptimizationConfig = field(default_factory=OptimizationConfig)
@@ -184,20 +209,32 @@ class Trainer:
         cfg = self.cfg
         engine = self.setup(model, tasks)
         base_lr = cfg.optimization.lr[0]
-        skipped = 0                                                  # updates the device skipped (overflow): polled at log time
-        for update in range(1, cfg.optimization.max_update + 1):
-            engine.lr = polynomial_decay_lr(update - 1 - skipped, base_lr, cfg.optimization.max_update, cfg.optimization.warmup_ratio,
+        # The reference runs until num_updates -- which an overflow-skipped step does not advance -- reaches max_update
+        # (engine/trainer.py:447-452, 957-960), so skipped steps are made up.  The device counts them (`skipped`[1]); the host follows
+        # that counter through a pinned, event-guarded copy enqueued after every step (no sync: the schedule lags a skip by at most
+        # one step) and reads it exactly at log time and before leaving the loop.
+        poll = _SkipPoll() if self._device.type == "cuda" else None
+        skipped, attempts, max_update = 0, 0, cfg.optimization.max_update
+        while attempts - skipped < max_update:
+            attempts += 1
+            update = attempts - skipped                              # the update this attempt will be if it is not skipped
+            engine.lr = polynomial_decay_lr(update - 1, base_lr, max_update, cfg.optimization.warmup_ratio,
                                             cfg.optimization.end_learning_rate, cfg.optimization.power)
             out = engine.train_step(self._micro_batches(tasks))
-            if update % cfg.common.log_interval == 0 or update == cfg.optimization.max_update:
+            if poll is not None:
+                skipped = max(skipped, poll.push_and_read(out["skipped"]))
+            last = attempts - skipped >= max_update
+            if attempts % cfg.common.log_interval == 0 or last:
                 skipped = int(float(out["skipped"][1]))              # (one sync, with the log line's own)
                 engine.check()                                       # FloatingPointError on Nan/Inf gradients (trainer.py:866-876)
                 n, loss = float(out["stats"][0]), float(out["stats"][1])
-                rec = {"update": update, "loss": loss / max(n, 1.0) / 0.6931471805599453, "sample_size": n,
+                rec = {"update": attempts - skipped, "loss": loss / max(n, 1.0) / 0.6931471805599453, "sample_size": n,
                        "gnorm": float(out["gnorm"]), "lr": engine.lr}
                 self.history.append(rec)
                 if self._rank == 0:
                     logger.info("update %(update)d | loss %(loss).4f (base 2 per token) | sample_size %(sample_size)d | "
                                 "gnorm %(gnorm).3f | lr %(lr).3g", rec)
+            if attempts > 4 * max_update + 64:                       # every step skipped and no scaler floor to stop at
+                raise FloatingPointError(f"{skipped} of {attempts} updates were skipped on the device (non-finite gradients)")
         torch.cuda.synchronize()
         return self.history

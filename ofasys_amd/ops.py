@@ -579,6 +579,27 @@ def cached_index(owner, key, make):
     return t
 
 
+def owner_token(owner):
+    """A hashable identity of `owner` (a module) for process-wide caches.  NOT id(owner): ids are recycled after garbage collection,
+    and a later model whose adaptor lands on a freed address (another bucket table, the same T) would be handed the stale plan
+    (ADVICE r3).  The token object lives in the owner's __dict__ and in every cache key built from it, so its identity cannot be
+    reused while an entry exists; a copy.deepcopy / pickled module gets a fresh one."""
+    tok = owner.__dict__.get("_ofa_owner_token")
+    if tok is None or tok.owner_id != id(owner):
+        tok = owner.__dict__["_ofa_owner_token"] = _OwnerToken(id(owner))
+    return tok
+
+
+class _OwnerToken:
+    __slots__ = ("owner_id",)
+
+    def __init__(self, owner_id):
+        self.owner_id = owner_id
+
+    def __deepcopy__(self, memo):
+        return _OwnerToken(-1)                       # the copy's owner_token() replaces it on first use
+
+
 class SegmentPlan:
     """The positions of an id tensor sorted by id (stable) and cut into one segment per distinct id: what ofa_segment_rowsum needs to
     scatter-add a narrow table's gradient without scanning the id list per table row.  Built on the device (sort + unique) with ONE
@@ -1202,14 +1223,17 @@ def mul_rowvec(a, vec):
 class ScaleFn(torch.autograd.Function):
     """y = fwd * x, dx = bwd * dy (constants): `embed_scale * embed` and the gradient-only rescale
     `embed * a + embed.detach() * (1 - a)` of the adaptor post-hook (adaptor/base.py:168, 174-176) on the row-vector multiply kernel."""
-    _vecs = {}
+    _scalars = {}
 
     @classmethod
-    def _vec(cls, value, cols, like):
-        key = (float(value), cols, like.dtype, like.device)
-        v = cls._vecs.get(key)
+    def _scalar(cls, value, like):
+        """The factor as ONE fp32 element on the device: the multiply runs in fp32 and rounds once, as the reference's
+        `bf16 tensor * Python scalar` does (fp32 opmath).  A factor stored in the activation dtype would round first -- sqrt(768) =
+        27.7128 becomes 27.75 in bf16, +0.13 % on every embedding."""
+        key = (float(value), like.device)
+        v = cls._scalars.get(key)
         if v is None:
-            v = cls._vecs[key] = torch.full((cols,), float(value), dtype=like.dtype, device=like.device)
+            v = cls._scalars[key] = torch.full((1,), float(value), dtype=torch.float32, device=like.device)
         return v
 
     @staticmethod
@@ -1217,14 +1241,14 @@ class ScaleFn(torch.autograd.Function):
         ctx.bwd = bwd
         if fwd == 1.0:
             return x2d.view_as(x2d)
-        return K.mul_rowvec(x2d, ScaleFn._vec(fwd, x2d.shape[1], x2d))
+        return K.scale_row_groups(x2d, ScaleFn._scalar(fwd, x2d), max(x2d.shape[0], 1))
 
     @staticmethod
     def backward(ctx, dy):
         if ctx.bwd == 1.0:
             return dy, None, None
         dy = dy.contiguous()
-        return K.mul_rowvec(dy, ScaleFn._vec(ctx.bwd, dy.shape[1], dy)), None, None
+        return K.scale_row_groups(dy, ScaleFn._scalar(ctx.bwd, dy), max(dy.shape[0], 1)), None, None
 
 
 def scale(x, fwd=1.0, bwd=None):

@@ -70,6 +70,9 @@ class FlatParams:
                     params.append(g)
         assert params, "no trainable parameters"
         self.params = params
+        # 4-D weights NOT consumed by ops.Conv2dFn keep torch's contiguous layout (the patch-embedding projection: ops.PatchEmbedFn
+        # reshapes it to [D, C*p*p] as a view and its im2col emits columns in (c, ph, pw) order -- ADVICE r3)
+        self._plain4d = {id(w) for m in model.modules() for w in getattr(m, "_ofa_plain_conv_weights", lambda: ())()}
         dtype, device = params[0].dtype, params[0].device
         self.offsets, off = [], 0
         for p in params:
@@ -113,14 +116,15 @@ class FlatParams:
                 for i, m in enumerate(cross):
                     m._cross_all = (pack, i)
 
-    @staticmethod
-    def _view(buf, o, p):
+    def _view(self, buf, o, p):
         """Parameter p's window of an arena.  Spatial convolution weights ([Cout, Cin, kh, kw], kh * kw > 1) live in the arena in
         the order the im2col GEMM reads them -- [Cout][kh][kw][Cin], i.e. torch's channels_last strides for the same logical
         shape -- so the forward needs no permuted copy of the weight and the weight-gradient GEMM writes the arena directly
-        (state dicts hold values, not strides: checkpoints interchange unchanged)."""
+        (state dicts hold values, not strides: checkpoints interchange unchanged).  Only weights that ops.Conv2dFn consumes:
+        a module lists the others in `_ofa_plain_conv_weights()`."""
         n = p.numel()
-        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and (p.shape[1] * p.shape[2] * p.shape[3]) % 8 == 0:
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and (p.shape[1] * p.shape[2] * p.shape[3]) % 8 == 0 \
+                and id(p) not in self._plain4d:
             Cout, Cin, kh, kw = p.shape
             return buf[o:o + n].view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
         return buf[o:o + n].view(p.shape)
@@ -247,7 +251,10 @@ class TrainStep:
         self._sched = torch.zeros(5, dtype=torch.float32, device=dev)
         self._lr = float(lr)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
-        if self.use_graph and any(float(getattr(m, "layerdrop", 0.0) or 0.0) > 0.0 for m in model.modules()):
+        # LayerDrop: the kept layers -- hence the autograd graph and every parameter's contribution count -- change per step and
+        # per rank, so the step structure key says nothing about them: never captured, and the bucket reducer is never armed
+        self.dynamic_autograd = any(float(getattr(m, "layerdrop", 0.0) or 0.0) > 0.0 for m in model.modules())
+        if self.use_graph and self.dynamic_autograd:
             warnings.warn("ofasys_amd.TrainStep: LayerDrop draws the kept layers on the host every step; the step is not captured")
             self.use_graph = False
         self.graph_warmup = graph_warmup
@@ -301,7 +308,7 @@ class TrainStep:
         self.reducer.overlap = overlap_reduce
         # gradients are only read after backward unless buckets are all-reduced from inside it: fold lazily, in batches
         ops.defer_reductions(self.world == 1 or not overlap_reduce)
-        self.reducer.begin_step(structure)
+        self.reducer.begin_step(structure, dynamic=self.dynamic_autograd)
         for s in samples:
             plan = s.get("pack")
             target = s["target"]

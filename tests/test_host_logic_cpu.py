@@ -190,6 +190,34 @@ def test_flat_param_arena_keeps_spatial_conv_weights_in_gemm_order():
     assert w3.data_ptr() == fp.flat.data_ptr() + o3 * 4 and w3.permute(0, 2, 3, 1).is_contiguous()
 
 
+def test_flat_param_arena_leaves_the_patch_embedding_projection_contiguous():
+    """the [D, 3, p, p] projection of image_patch_embed is read by ops.PatchEmbedFn as a [D, 3*p*p] VIEW (columns in
+    (c, ph, pw) order), so the arena must not store it channels_last like the im2col convolutions' weights."""
+    from ofasys_amd.trainer import FlatParams
+    model, _ = build_model(CASES["base_patch"], "cpu", torch.float32)
+    FlatParams(model)
+    w = next(m for m in model.modules() if hasattr(m, "_ofa_plain_conv_weights")).proj.weight
+    assert w.dim() == 4 and w.is_contiguous() and w.grad.is_contiguous()
+    assert w.reshape(w.shape[0], -1).data_ptr() == w.data_ptr()               # a view, no copy
+
+
+def test_owner_token_is_not_reused_like_id():
+    """process-wide plan caches are keyed on a token object held by the owner, not on id(owner) (recycled after gc)."""
+    import copy
+    import gc
+    from ofasys_amd import ops
+    a = torch.nn.Linear(2, 2)
+    ta = ops.owner_token(a)
+    assert ops.owner_token(a) is ta and hash(ta) == hash(ops.owner_token(a))
+    b = copy.deepcopy(a)
+    assert ops.owner_token(b) is not ta and ops.owner_token(b) != ta
+    key = ("text", ta)
+    del a
+    gc.collect()
+    c = torch.nn.Linear(2, 2)                                                  # may land on a's address: its token still differs
+    assert ("text", ops.owner_token(c)) != key
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -303,6 +331,75 @@ def test_dp_collective_order_is_rank_invariant_across_modes():
         b(a(c(x))).sum().backward()
     want = torch.cat([p.grad.reshape(-1) for m in (a, b, c) for p in m.parameters()])
     assert torch.allclose(g0[: want.numel()], want, atol=1e-5)
+
+
+def _dp_layerdrop_worker(rank, world, port, q, dynamic):
+    """LayerDrop under DP: every rank keeps its OWN subset of layers each step, so a parameter's contribution count
+    changes from step to step under one structure key.  dynamic=True is what TrainStep passes for such a model."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd.distributed import GradBucketReducer
+    from ofasys_amd.trainer import FlatParams
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(4)])
+    fp = FlatParams(layers)
+    red = GradBucketReducer(fp.params, fp.grad, fp.offsets, None, bucket_bytes=512)
+    keep = [[(0, 2), (0, 1, 2, 3), (1, 2, 3)], [(1, 3), (0, 1, 2), (0, 3)]][rank]     # step 1 keeps layers the (learning) step 0 had dropped
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(7 + rank))
+    err, grads = None, []
+    try:
+        for step in range(3):
+            fp.zero_grad()
+            red.begin_step("same-structure", dynamic=dynamic)
+            h = x
+            for i in keep[step]:
+                h = layers[i](h)
+            h.sum().backward()
+            red.finish()
+            grads.append(fp.grad.clone().numpy())
+            assert red.last_launch_order == list(range(len(red.buckets)))
+            assert not dynamic or (red.expected is None and not red.knows("same-structure"))
+    except RuntimeError as e:
+        err = str(e)
+    q.put((rank, grads, err))
+    if err is None:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_dp_reducer_with_layerdrop_never_arms(dynamic):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 1000 + (0 if dynamic else 1)
+    procs = [ctx.Process(target=_dp_layerdrop_worker, args=(r, 2, port, q, dynamic)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():                              # the armed variant: one rank raised, its peer waits in a collective
+            p.terminate()
+    if not dynamic:                                   # what the advice describes: a kept layer the learned step had dropped
+        assert any(e and "were learned" in e for _, _, e in res)
+        return
+    assert all(e is None for _, _, e in res)
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(16, 16) for _ in range(4)]
+    keep = [[(0, 2), (0, 1, 2, 3), (1, 2, 3)], [(1, 3), (0, 1, 2), (0, 3)]]
+    for step in range(3):
+        for m in layers:
+            m.zero_grad()
+        for rank in range(2):
+            h = torch.randn(4, 16, generator=torch.Generator().manual_seed(7 + rank))
+            for i in keep[rank][step]:
+                h = layers[i](h)
+            h.sum().backward()
+        want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for m in layers for p in m.parameters()])
+        g0, g1 = torch.from_numpy(res[0][1][step]), torch.from_numpy(res[1][1][step])
+        assert torch.equal(g0, g1) and torch.allclose(g0[: want.numel()], want, atol=1e-5)
 
 
 def test_tool_scripts_compile():

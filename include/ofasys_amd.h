@@ -319,6 +319,11 @@ int ofa_bias_outer_grad(const void* dbias, void* d_frames, void* d_patches, int 
                         void* stream);
 int ofa_bias_block_add(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype, void* stream);
 int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
+/* A slot's OWN per-sample bias (an adaptor whose forward() fills AdaptorOutput.self_attn_bias, which the post-hook leaves alone:
+ * adaptor/base.py:183-189; summed into the layer bias at adaptor/general.py:276): bias [B,A,T,T][:, :, s:s+n, s:s+n] += values
+ * [B,A,n,n], and the gradient of `values` = that block of dbias, contiguous. */
+int ofa_bias_block_add_batch(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype, void* stream);
+int ofa_bias_block_slice(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
 
 /* ---- patch embedding (adaptor/image_patch_embed.py:59-73): im2col of non-overlapping p x p patches.
  * img [B,C,H,W] -> col [B*(H/p)*(W/p), Kpad] with K = C*p*p in (c,ph,pw) order (= Conv2d weight.view(D,-1)), zero pad. */
@@ -404,6 +409,24 @@ int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* beta, const 
 int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
                       void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int batch_stats,
                       int relu, int accumulate, const void* beta, int dtype, void* stream);
+/* SyncBatchNorm (adaptor/image_resnet.py:53-56, 87-90 `sync_bn` -> module/layer.py:26-27 nn.SyncBatchNorm): the same arithmetic in
+ * two phases each way, around the CALLER's all-reduce (SUM over the data-parallel ranks) of `sums`:
+ *   forward   fwd_stats: sums [2*C + 1] fp64 = this rank's (sum x, sum x^2, row count)  -> all-reduce -> fwd_apply: mean / rstd /
+ *             running buffers from the reduced sums (the row count is read on the device: no host sync, ranks may differ), y for
+ *             this rank's `rows` rows;
+ *   backward  bwd_stats: sums [2][C] fp32 = this rank's (sum g, sum g*xhat); dgamma / dbeta from them (rank-local, like every other
+ *             gradient before the gradient exchange) -> all-reduce -> bwd_dx: dx (and dres) with the reduced sums / *total_rows
+ *             (device pointer: element 2*C of the forward's reduced sums). */
+int ofa_batchnorm_fwd_stats(const void* x, double* sums, float* ws, int64_t rows, int C, int dtype, void* stream);
+int ofa_batchnorm_fwd_apply(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
+                            float* rstd, float* running_mean, float* running_var, const double* sums, int64_t rows, int C,
+                            float eps, float momentum, int relu, int dtype, void* stream);
+int ofa_batchnorm_bwd_stats(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                            float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate,
+                            const void* beta, int dtype, void* stream);
+int ofa_batchnorm_bwd_dx(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                         const float* sums, void* dx, void* dres, int64_t rows, const double* total_rows, int C, int relu,
+                         const void* beta, int dtype, void* stream);
 /* MaxPool2d(K, stride, pad) on NHWC; arg: one byte per output element (arg-max tap), consumed by the backward. */
 int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, int dtype,
                     void* stream);

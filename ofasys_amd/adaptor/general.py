@@ -38,8 +38,9 @@ class OFAGeneralAdaptor(torch.nn.Module):
         self.cfg = cfg
         self.is_src = is_src
         self.name2adaptor: Dict[str, BaseAdaptor] = {}
-        for config_field in fields(cfg.adaptor):
-            name = config_field.name
+        # the dataclass' own fields (reference order: state-dict order and the initial RNG stream), then adaptors a user registered
+        # after ofasys_amd was imported (their configs appear on first access: configure.ConfigStore.make_dataclass)
+        for name in [f.name for f in fields(cfg.adaptor)] + ConfigStore().late_plugins(cfg.adaptor):
             if name.startswith("_"):
                 continue
             if name == "image_vqgan" and is_src:                        # general.py:73-80
@@ -138,22 +139,23 @@ class OFAGeneralAdaptor(torch.nn.Module):
         # The position bias is the same for every sample when every slot's positions are (all built-in adaptors): it is then built
         # ONCE from row 0 -- [1, A, T, T] instead of general.py:223-282's [B, A, T, T], 154 MB per layer at cfg-2b -- and handed to
         # the attention kernels as an ops.SharedBias, which also sum its gradient over the batch in-kernel
-        shared = self.last_pos_shared
-        output.pos_shared = shared
-        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed[:1] if shared else output.pos_embed)
         num_layers = self.cfg.encoder.layers if self.is_src else self.cfg.decoder.layers
         num_rel_pos_tables = 1 if self.cfg.share_attn_bias else num_layers
+        # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values (take the values back), or -- an adaptor whose
+        # forward() fills `self_attn_bias` itself, which the post-hook leaves alone (adaptor/base.py:183-189) -- as a genuinely
+        # per-sample [B,A,n,n] tensor ("batch")
+        layer_values = [[_unexpand(mo.self_attn_bias[idx] if mo.self_attn_bias else None) for mo in modality_outputs]
+                        for idx in range(num_rel_pos_tables)]
+        per_sample = any(isinstance(v, _PerSample) for values in layer_values for v in values)
+        shared = self.last_pos_shared and not per_sample
+        output.pos_shared = shared
+        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed[:1] if shared else output.pos_embed)
         starts, s = [], 0
         for mo in modality_outputs:
             starts.append(s)
             s += mo.seq_length
         assert s == output.seq_length
-        for idx in range(num_rel_pos_tables):
-            values = []
-            for mo in modality_outputs:
-                b = mo.self_attn_bias[idx] if mo.self_attn_bias else None
-                # slot biases arrive as the reference's [B,A,T,T] expand view of [T,T,A] values; take the values back
-                values.append(_unexpand(b))
+        for values in layer_values:
             kinds, tensors = [], []
             for v in values:
                 if v is None:
@@ -161,6 +163,9 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 elif isinstance(v, ops.OuterRelPos):
                     kinds.append("outer")
                     tensors += [v.frames, v.patches]
+                elif isinstance(v, _PerSample):
+                    kinds.append("batch")
+                    tensors.append(v.t)
                 else:
                     kinds.append("dense")
                     tensors.append(v)
@@ -180,9 +185,18 @@ class OFAGeneralAdaptor(torch.nn.Module):
         return sample
 
 
+class _PerSample:
+    """A slot's own [B, A, n, n] attention bias (one matrix per sample): added block-wise to the dense [B, A, T, T] assembly."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
 def _unexpand(b):
-    """[B,A,T,T] batch-expanded view (stride 0 on batch) of [T,T,A] values -> the [T,T,A] values; a genuinely
-    per-sample bias (no adaptor in scope produces one) is rejected."""
+    """[B,A,T,T] batch-expanded view (stride 0 on batch) of [T,T,A] values -> the [T,T,A] values; a genuinely per-sample bias
+    (a custom adaptor's own `self_attn_bias`, adaptor/base.py:183-189) -> _PerSample: the whole layer bias is then assembled
+    densely, as the reference does (adaptor/general.py:265-280), and runs on the dense-bias attention kernels."""
     if b is None:
         return None
     if isinstance(b, ops.LazyRelPosBias):                             # (video: frame-level + patch-level tables, never materialised)
@@ -194,4 +208,6 @@ def _unexpand(b):
         return b[0].permute(1, 2, 0)
     if b.dim() == 3:
         return b
-    raise NotImplementedError("per-sample self_attn_bias from an adaptor is not supported yet")
+    if b.dim() == 4:
+        return _PerSample(b)
+    raise ValueError(f"self_attn_bias of an adaptor must be [B, A, n, n] (or [n, n, A] values), got shape {tuple(b.shape)}")

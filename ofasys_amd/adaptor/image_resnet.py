@@ -43,6 +43,13 @@ class ImageResnetAdaptorConfig(BaseAdaptorConfig):
     pretrained_ckpt_path: str = field(default="", metadata={"help": "path of pretrained ckpt"})
 
 
+def _sync_batch_norm_2d(out_chan, momentum=0.1, eps=1e-3):
+    """module/layer.py:26-27 SynBatchNorm2d."""
+    bn = nn.BatchNorm2d(out_chan, momentum=momentum, eps=eps)
+    bn._ofa_sync = True
+    return bn
+
+
 @register_config("ofasys.adaptor", "image_resnet", ImageResnetAdaptorConfig)
 class ImageResnetAdaptor(BaseAdaptor):
     pos_batch_invariant = True          # positions are arange- / grid-derived: identical for every batch row
@@ -50,13 +57,15 @@ class ImageResnetAdaptor(BaseAdaptor):
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: ImageResnetAdaptorConfig):
         super().__init__(embed_tokens, dictionary, is_src, general_adaptor, cfg)
-        if cfg.sync_bn:
-            raise NotImplementedError("sync_bn is not implemented (BatchNorm statistics stay per rank, the reference default)")
         if cfg.pretrained_ckpt_path:
             raise NotImplementedError("pretrained_ckpt_path: load the state dict through model.load_state_dict instead")
         self.embed_image_positions = Embedding(cfg.image_bucket_size ** 2 + 1, cfg.embed_dim)
         backbone = {"resnet50": resnet50_backbone, "resnet101": resnet101_backbone, "resnet152": resnet152_backbone}[cfg.resnet_type]
-        self.embed_images = backbone(norm_layer=None, drop_path_rate=cfg.resnet_drop_path_rate)
+        # image_resnet.py:87-90: norm_layer = SynBatchNorm2d when cfg.sync_bn (module/layer.py:26-27: nn.SyncBatchNorm converted from
+        # nn.BatchNorm2d(momentum=0.1, eps=1e-3) -- note the eps, 100x the plain layer's -- same parameters, buffers and state-dict
+        # keys).  Here the modules stay nn.BatchNorm2d holders carrying a flag: in training ops.batch_norm all-reduces each layer's
+        # per-channel sums over the default process group (ops.SyncBatchNormFn)
+        self.embed_images = backbone(norm_layer=_sync_batch_norm_2d if cfg.sync_bn else None, drop_path_rate=cfg.resnet_drop_path_rate)
         self.image_proj = Linear(1024, cfg.embed_dim)
         image_num_rel_dis = (2 * cfg.image_bucket_size - 1) * (2 * cfg.image_bucket_size - 1) + 3
         image_rp_bucket = make_image_bucket_position(cfg.image_bucket_size, image_num_rel_dis)

@@ -83,9 +83,28 @@ class ConfigStore:
         order = lambda kv: (prefix_names.index(kv[0]), "") if kv[0] in prefix_names else (len(prefix_names), kv[0])   # noqa: E731
         for name, node in sorted(self.repo.get(group, {}).items(), key=order):
             flds.append((name, node.config, field(default_factory=node.config)))
-        dc = dataclasses.make_dataclass(cls_name, flds, bases=(BaseDataclass,))
+        # A plugin registered AFTER this dataclass was synthesised (a user's own adaptor, `@register_config("ofasys.adaptor", name,
+        # Cfg)` in their script) still gets its config node: `cfg.adaptor.<name>` creates it on first access, and
+        # `late_plugins(cfg)` lists them for the owner (OFAGeneralAdaptor builds them after the built-in ones).
+        store = self
+
+        def _late_config(self_, name):
+            node = store.repo.get(group, {}).get(name) if not name.startswith("_") else None
+            if node is None or node.config is None:
+                raise AttributeError(f"{cls_name} has no field {name!r} (no plugin of that name is registered in {group!r})")
+            cfg = node.config()
+            object.__setattr__(self_, name, cfg)
+            return cfg
+
+        dc = dataclasses.make_dataclass(cls_name, flds, bases=(BaseDataclass,), namespace={"__getattr__": _late_config})
         dc.__module__ = module
+        dc.__config_group__ = group
         return dc
+
+    def late_plugins(self, cfg):
+        """Names registered in cfg's group that are not fields of its (earlier synthesised) dataclass, in registration order."""
+        have = {f.name for f in dataclasses.fields(cfg)}
+        return [n for n in self.names(getattr(type(cfg), "__config_group__", "")) if n not in have]
 
 
 def register_config(group, name, dataclass=None):

@@ -21,6 +21,23 @@ __global__ __launch_bounds__(256) void bias_block_add_kernel(T* __restrict__ bia
   }
 }
 
+// PER-SAMPLE block (a custom adaptor's own self_attn_bias, adaptor/base.py:183-189; adaptor/general.py:276):
+//   ADD:  bias[b][a][s+i][s+j] += values[b][a][i][j]        !ADD (gradient):  values[b][a][i][j] = bias[b][a][s+i][s+j]
+// one thread per (b,a,i,j), j fastest: coalesced on both sides
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void bias_block_batch_kernel(T* __restrict__ bias, T* __restrict__ values, int B, int A, int Tt,
+                                                               int s, int n) {
+  const int64_t total = (int64_t)B * A * n * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e % n);
+    const int i = (int)((e / n) % n);
+    const int64_t ba = e / ((int64_t)n * n);
+    T* p = bias + ((ba * Tt) + s + i) * Tt + s + j;
+    if (ADD) st1<T>(p, ld1<T>(p) + ld1<T>(values + e));
+    else values[e] = *p;
+  }
+}
+
 // dvalues[i][j][a] = sum_b dbias[b][a][s+i][s+j]; deterministic (b ascending).  One block per (row i, 64-column chunk): the A head
 // rows are read along j (coalesced on dbias), turned through LDS and written as the contiguous [64][A] run of dvalues -- the one
 // thread per (i, j, a) form wrote 2-byte elements A * 2 bytes apart (55 us for the 1568^2 video block of cfg-4, now HBM speed)
@@ -323,6 +340,35 @@ extern "C" int ofa_bias_block_add(void* bias, const void* values, int B, int A, 
     hipLaunchKernelGGL((bias_block_add_kernel<f16_t>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (f16_t*)bias, (const f16_t*)values, B, A, T, start, n);
   return check_launch("bias_block_add");
+}
+
+template <bool ADD>
+static int bias_block_batch_launch(void* bias, void* values, int B, int A, int T, int start, int n, int dtype, void* stream,
+                                   const char* what) {
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "%s: bad dtype %d", what, dtype);
+  OFA_REQUIRE(bias && values && B > 0 && A > 0 && n > 0 && start >= 0 && start + n <= T, OFA_ERR_INVALID,
+              "%s: bad argument (T=%d start=%d n=%d)", what, T, start, n);
+  const int64_t total = (int64_t)B * A * n * n;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((bias_block_batch_kernel<float, ADD>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (float*)bias, (float*)values, B, A, T, start, n);
+  else if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((bias_block_batch_kernel<bf16_t, ADD>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)bias, (bf16_t*)values, B, A, T, start, n);
+  else
+    hipLaunchKernelGGL((bias_block_batch_kernel<f16_t, ADD>), dim3(bias_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (f16_t*)bias, (f16_t*)values, B, A, T, start, n);
+  return check_launch(what);
+}
+
+extern "C" int ofa_bias_block_add_batch(void* bias, const void* values, int B, int A, int T, int start, int n, int dtype,
+                                        void* stream) {
+  return bias_block_batch_launch<true>(bias, const_cast<void*>(values), B, A, T, start, n, dtype, stream, "bias_block_add_batch");
+}
+
+extern "C" int ofa_bias_block_slice(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype,
+                                    void* stream) {
+  return bias_block_batch_launch<false>(const_cast<void*>(dbias), dvalues, B, A, T, start, n, dtype, stream, "bias_block_slice");
 }
 
 extern "C" int ofa_bias_block_grad(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype,

@@ -267,21 +267,36 @@ __device__ __forceinline__ void bn_fold_groups(const double* __restrict__ partia
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int groups, int C, int64_t rows,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var) {
+                                                          float* __restrict__ running_var,
+                                                          const double* __restrict__ rows_dev = nullptr) {
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), gl = threadIdx.x >> 4;
   double s, q;
   bn_fold_groups(partial, groups, C, c, gl, s, q);
   if (gl != 0 || c >= C) return;
-  const double m = s / (double)rows;
-  double var = q / (double)rows - m * m;
+  const double R = rows_dev ? *rows_dev : (double)rows;      // (SyncBatchNorm: the all-reduced row count lives on the device)
+  const double m = s / R;
+  double var = q / R - m * m;
   var = var < 0.0 ? 0.0 : var;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean) {
-    const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+    const double unbiased = R > 1.0 ? var * R / (R - 1.0) : var;
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
   }
+}
+
+// SyncBatchNorm forward: this rank's sums, [2][C] fp64 (sum x, sum x^2), for the all-reduce between ofa_batchnorm_fwd_stats and
+// ofa_batchnorm_fwd_apply
+__global__ __launch_bounds__(256) void bn_fold_sums_kernel(const double* __restrict__ partial, int groups, int C,
+                                                           double* __restrict__ sums, int64_t rows) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), gl = threadIdx.x >> 4;
+  double s, q;
+  bn_fold_groups(partial, groups, C, c, gl, s, q);
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = (double)rows;      // the row count travels with the sums
+  if (gl != 0 || c >= C) return;
+  sums[c] = s;
+  sums[C + c] = q;
 }
 
 // eval mode: statistics come from the running buffers
@@ -353,11 +368,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ sums, T* __restrict__ dx,
                                                         T* __restrict__ dres, int64_t rows, int C, int relu,
-                                                        int batch_stats, const T* __restrict__ beta = nullptr) {
+                                                        int batch_stats, const T* __restrict__ beta = nullptr,
+                                                        const double* __restrict__ stat_rows = nullptr) {
   constexpr int N = Vec<T>::N;
   const int vpr = C / N;
   const int64_t total = rows * vpr;
-  const float inv = 1.0f / (float)rows;
+  const float inv = (float)(1.0 / (stat_rows ? *stat_rows : (double)rows));   // (SyncBatchNorm: the statistics cover every rank's rows)
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     const int c = (int)(v % vpr) * N;
     float g[N], xx[N], gm[N], o[N], mu[N], rs[N], sg[N], sx[N];
@@ -550,6 +566,34 @@ static int bn_groups(int64_t rows) {
 }
 extern "C" int ofa_batchnorm_ws_floats(int C) { return 4 * 256 * C + 2 * C; }   // fp64 partials [256][2][C] + fp32 sums [2][C]
 
+// column statistics of x into ws (fp64 partials [groups][2][C]); returns the group count
+static int bn_fwd_colstat(const void* x, float* ws, int64_t rows, int C, int dtype, hipStream_t st) {
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  const int groups = bn_groups(rows);
+  const int cwl = bn_cw_log2(C / n);
+  dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
+  else if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
+  else
+    hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
+  return groups;
+}
+
+static int bn_apply_launch(const void* x, const void* gamma, const void* beta, const void* residual, void* y, const float* mean,
+                           const float* rstd, int64_t rows, int C, int relu, int dtype, hipStream_t st) {
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  dim3 grid(grid_1d(rows * (C / n))), block(256);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (const float*)residual, (float*)y, rows, C, relu);
+  else if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)mean, (const float*)rstd, (const bf16_t*)residual, (bf16_t*)y, rows, C, relu);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (const float*)mean, (const float*)rstd, (const f16_t*)residual, (f16_t*)y, rows, C, relu);
+  return check_launch("batchnorm_apply");
+}
+
 // training: batch statistics (+ running update when running_mean != NULL); eval (use_running != 0): running statistics.
 extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
                                  float* rstd, float* running_mean, float* running_var, float* ws, int64_t rows, int C,
@@ -563,43 +607,50 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
   if (use_running) {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, eps, C, mean, rstd);
   } else {
-    const int groups = bn_groups(rows);
-    const int cwl = bn_cw_log2(C / n);
-    dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
-    if (dtype == OFA_F32)
-      hipLaunchKernelGGL((bn_colstat_kernel<float, 0>), grid, block, 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
-    else if (dtype == OFA_BF16)
-      hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 0>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
-    else
-      hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 0>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)nullptr, (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)ws, rows, C, 0, cwl);
+    const int groups = bn_fwd_colstat(x, ws, rows, C, dtype, st);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
   if (rc) return rc;
-  dim3 grid(grid_1d(rows * (C / n))), block(256);
-  if (dtype == OFA_F32)
-    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (const float*)residual, (float*)y, rows, C, relu);
-  else if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)mean, (const float*)rstd, (const bf16_t*)residual, (bf16_t*)y, rows, C, relu);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<f16_t>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (const float*)mean, (const float*)rstd, (const f16_t*)residual, (f16_t*)y, rows, C, relu);
-  return check_launch("batchnorm_apply");
+  return bn_apply_launch(x, gamma, beta, residual, y, mean, rstd, rows, C, relu, dtype, st);
 }
 
-// dgamma/dbeta: [C] in `dtype` (accumulate != 0: added); dres (optional): gradient of the residual input (= gated dy).
-extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
-                                 const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows,
-                                 int C, int batch_stats, int relu, int accumulate, const void* beta, int dtype, void* stream) {
-  OFA_DT("batchnorm_bwd");
-  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && (!relu || y || beta), OFA_ERR_INVALID, "batchnorm_bwd: bad argument");
-  OFA_REQUIRE(!beta || (relu && !dres), OFA_ERR_INVALID, "batchnorm_bwd: the gate can be recomputed from x (beta != NULL) only for a ReLU layer without a residual input");
-  if (beta) relu = 2;
-  const int n = dtype == OFA_F32 ? 4 : 8;
-  OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
+// SyncBatchNorm, forward in two phases around the caller's all-reduce (SUM) of `sums` over the ranks:
+//   stats: sums [2*C + 1] fp64 = this rank's (sum x, sum x^2, row count);   apply: statistics from the reduced sums -- the row
+//   count is read from sums[2*C] on the device: ranks may hold different numbers of rows and nobody syncs to learn the total --,
+//   running buffers updated with them, y for this rank's rows.
+extern "C" int ofa_batchnorm_fwd_stats(const void* x, double* sums, float* ws, int64_t rows, int C, int dtype, void* stream) {
+  OFA_DT("batchnorm_fwd_stats");
+  OFA_REQUIRE(x && sums && ws && rows > 0 && C > 0, OFA_ERR_INVALID, "batchnorm_fwd_stats: bad argument");
+  OFA_REQUIRE(C % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d is not vectorizable", C);
   hipStream_t st = (hipStream_t)stream;
+  const int groups = bn_fwd_colstat(x, ws, rows, C, dtype, st);
+  hipLaunchKernelGGL(bn_fold_sums_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, rows);
+  return check_launch("batchnorm_fwd_stats");
+}
+
+extern "C" int ofa_batchnorm_fwd_apply(const void* x, const void* gamma, const void* beta, const void* residual, void* y,
+                                       float* mean, float* rstd, float* running_mean, float* running_var, const double* sums,
+                                       int64_t rows, int C, float eps, float momentum, int relu, int dtype, void* stream) {
+  OFA_DT("batchnorm_fwd_apply");
+  OFA_REQUIRE(x && gamma && beta && y && mean && rstd && sums && rows > 0 && C > 0, OFA_ERR_INVALID,
+              "batchnorm_fwd_apply: bad argument");
+  OFA_REQUIRE(C % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d is not vectorizable", C);
+  hipStream_t st = (hipStream_t)stream;
+  // the reduced sums are ONE group of partials over sums[2*C] rows
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, 1, C, rows, eps, momentum, mean, rstd, running_mean, running_var, sums + 2 * (int64_t)C);
+  int rc = check_launch("batchnorm_fwd_apply");
+  if (rc) return rc;
+  return bn_apply_launch(x, gamma, beta, residual, y, mean, rstd, rows, C, relu, dtype, st);
+}
+
+// backward statistics: sums [2][C] fp32 = (sum g, sum g*xhat) of this launch's rows, and the parameter gradients from them
+static int bn_bwd_stats_launch(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                               float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate,
+                               const void* beta, int dtype, hipStream_t st) {
+  const int n = dtype == OFA_F32 ? 4 : 8;
   const int groups = bn_groups(rows);
   const int cwl = bn_cw_log2(C / n);
-  float* sums = ws + (int64_t)4 * 256 * C;
   dim3 grid(cdiv(C / n, 1 << cwl), groups), block(256);
   if (dtype == OFA_F32) {
     if (beta) hipLaunchKernelGGL((bn_colstat_kernel<float, 2>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const float*)gamma, (const float*)beta);
@@ -615,16 +666,63 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
     else hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
   }
-  int rc = check_launch("batchnorm_bwd_stats");
-  if (rc) return rc;
-  dim3 g2(grid_1d(rows * (C / n)));
+  return check_launch("batchnorm_bwd_stats");
+}
+
+static int bn_bwd_dx_launch(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                            const float* sums, void* dx, void* dres, int64_t rows, const double* stat_rows, int C, int batch_stats,
+                            int relu, const void* beta, int dtype, hipStream_t st) {
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  dim3 g2(grid_1d(rows * (C / n))), block(256);
   if (dtype == OFA_F32)
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats, (const float*)beta);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), g2, block, 0, st, (const float*)dy, (const float*)y, (const float*)x, (const float*)gamma, mean, rstd, (const float*)sums, (float*)dx, (float*)dres, rows, C, relu, batch_stats, (const float*)beta, stat_rows);
   else if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats, (const bf16_t*)beta);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), g2, block, 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)gamma, mean, rstd, (const float*)sums, (bf16_t*)dx, (bf16_t*)dres, rows, C, relu, batch_stats, (const bf16_t*)beta, stat_rows);
   else
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<f16_t>), g2, block, 0, st, (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, (const f16_t*)gamma, mean, rstd, (const float*)sums, (f16_t*)dx, (f16_t*)dres, rows, C, relu, batch_stats, (const f16_t*)beta);
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<f16_t>), g2, block, 0, st, (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, (const f16_t*)gamma, mean, rstd, (const float*)sums, (f16_t*)dx, (f16_t*)dres, rows, C, relu, batch_stats, (const f16_t*)beta, stat_rows);
   return check_launch("batchnorm_bwd_dx");
+}
+
+// dgamma/dbeta: [C] in `dtype` (accumulate != 0: added); dres (optional): gradient of the residual input (= gated dy).
+extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
+                                 const float* rstd, void* dx, void* dres, void* dgamma, void* dbeta, float* ws, int64_t rows,
+                                 int C, int batch_stats, int relu, int accumulate, const void* beta, int dtype, void* stream) {
+  OFA_DT("batchnorm_bwd");
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && dx && ws && rows > 0 && C > 0 && (!relu || y || beta), OFA_ERR_INVALID, "batchnorm_bwd: bad argument");
+  OFA_REQUIRE(!beta || (relu && !dres), OFA_ERR_INVALID, "batchnorm_bwd: the gate can be recomputed from x (beta != NULL) only for a ReLU layer without a residual input");
+  if (beta) relu = 2;
+  const int n = dtype == OFA_F32 ? 4 : 8;
+  OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
+  hipStream_t st = (hipStream_t)stream;
+  float* sums = ws + (int64_t)4 * 256 * C;
+  int rc = bn_bwd_stats_launch(dy, y, x, gamma, mean, rstd, sums, dgamma, dbeta, ws, rows, C, relu, accumulate, beta, dtype, st);
+  if (rc) return rc;
+  return bn_bwd_dx_launch(dy, y, x, gamma, mean, rstd, sums, dx, dres, rows, nullptr, C, batch_stats, relu, beta, dtype, st);
+}
+
+// SyncBatchNorm, backward in two phases around the caller's all-reduce (SUM) of `sums` [2][C] fp32 over the ranks: the parameter
+// gradients are this rank's own sums (the data-parallel gradient exchange adds them up like every other gradient), the input
+// gradient uses the reduced sums over total_rows rows (torch.nn.SyncBatchNorm's backward: batch_norm_backward_reduce -> all_reduce
+// -> batch_norm_backward_elemt).  total_rows: DEVICE pointer to the reduced row count (element 2*C of the forward's sums).
+extern "C" int ofa_batchnorm_bwd_stats(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
+                                       const float* rstd, float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C,
+                                       int relu, int accumulate, const void* beta, int dtype, void* stream) {
+  OFA_DT("batchnorm_bwd_stats");
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && sums && ws && rows > 0 && C > 0 && (!relu || y || beta), OFA_ERR_INVALID, "batchnorm_bwd_stats: bad argument");
+  if (beta) relu = 2;
+  OFA_REQUIRE(C % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d is not vectorizable", C);
+  return bn_bwd_stats_launch(dy, y, x, gamma, mean, rstd, sums, dgamma, dbeta, ws, rows, C, relu, accumulate, beta, dtype, (hipStream_t)stream);
+}
+
+extern "C" int ofa_batchnorm_bwd_dx(const void* dy, const void* y, const void* x, const void* gamma, const float* mean,
+                                    const float* rstd, const float* sums, void* dx, void* dres, int64_t rows,
+                                    const double* total_rows, int C, int relu, const void* beta, int dtype, void* stream) {
+  OFA_DT("batchnorm_bwd_dx");
+  OFA_REQUIRE(dy && x && gamma && mean && rstd && sums && dx && rows > 0 && total_rows && C > 0 && (!relu || y || beta), OFA_ERR_INVALID, "batchnorm_bwd_dx: bad argument");
+  OFA_REQUIRE(!beta || (relu && !dres), OFA_ERR_INVALID, "batchnorm_bwd_dx: the gate can be recomputed from x (beta != NULL) only for a ReLU layer without a residual input");
+  if (beta) relu = 2;
+  OFA_REQUIRE(C % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d is not vectorizable", C);
+  return bn_bwd_dx_launch(dy, y, x, gamma, mean, rstd, sums, dx, dres, rows, total_rows, C, 1, relu, beta, dtype, (hipStream_t)stream);
 }
 
 extern "C" int ofa_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad,

@@ -876,6 +876,25 @@ def bias_block_add_(bias, values, start):
     return bias
 
 
+def bias_block_add_batch_(bias, values, start):
+    """In place: bias[B,A,T,T][:, :, s:s+n, s:s+n] += values[B,A,n,n] (one matrix per sample and head)."""
+    B, A, T, _ = bias.shape
+    n = values.shape[-1]
+    values = values.contiguous()
+    assert bias.is_contiguous() and values.dtype == bias.dtype and tuple(values.shape) == (B, A, n, n)
+    lib().call("ofa_bias_block_add_batch", ptr(bias), ptr(values), B, A, T, start, n, dtype_code(bias), stream())
+    return bias
+
+
+def bias_block_slice(dbias, start, n):
+    """dbias[B,A,T,T][:, :, s:s+n, s:s+n] as a contiguous [B,A,n,n] tensor (the gradient of bias_block_add_batch_'s values)."""
+    dbias = dbias.contiguous()
+    B, A, T, _ = dbias.shape
+    out = torch.empty(B, A, n, n, dtype=dbias.dtype, device=dbias.device)
+    lib().call("ofa_bias_block_slice", ptr(dbias), ptr(out), B, A, T, start, n, dtype_code(dbias), stream())
+    return out
+
+
 def bias_outer_grad(dbias, start, F, P):
     """dbias [1|.., A, T, T] (one matrix) -> (d_frames [F,F,A], d_patches [P,P,A]) of an OUTER slot at `start` (ofa_bias_outer_grad)."""
     dbias = dbias.contiguous()
@@ -965,6 +984,58 @@ def batchnorm_bwd(dy, y, x, gamma, mean, rstd, batch_stats, relu, want_dres=Fals
                ptr(dbeta), ptr(ws), rows, C, int(batch_stats), int(relu), int(acc), ptr(beta) if (relu and not want_dres) else None,
                dtype_code(x), stream())
     return dx, dres, dgamma, dbeta
+
+
+def batchnorm_fwd_stats(x):
+    """SyncBatchNorm, forward phase 1: this rank's [2*C + 1] fp64 sums (sum x, sum x^2, row count) -- to be all-reduced."""
+    x = x.contiguous()
+    rows, C = x.shape
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+    ws = workspace(lib().cdll.ofa_batchnorm_ws_floats(C) * 4, x.device, "bn")
+    lib().call("ofa_batchnorm_fwd_stats", ptr(x), ptr(sums), ptr(ws), rows, C, dtype_code(x), stream())
+    return sums
+
+
+def batchnorm_fwd_apply(x, gamma, beta, running_mean, running_var, sums, momentum, eps, relu=False, residual=None):
+    """SyncBatchNorm, forward phase 2: statistics from the all-reduced sums; returns y, mean, rstd."""
+    x = x.contiguous()
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = residual.contiguous()
+    lib().call("ofa_batchnorm_fwd_apply", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(rstd),
+               ptr(running_mean), ptr(running_var), ptr(sums), rows, C, float(eps), float(momentum), int(relu), dtype_code(x), stream())
+    return y, mean, rstd
+
+
+def batchnorm_bwd_stats(dy, y, x, gamma, mean, rstd, relu, regate_beta=None, dgamma=None, dbeta=None):
+    """SyncBatchNorm, backward phase 1: this rank's [2, C] fp32 sums (sum g, sum g*xhat) -- to be all-reduced -- and the rank-local
+    parameter gradients (accumulated into dgamma / dbeta when given)."""
+    dy = dy.contiguous()
+    rows, C = x.shape
+    acc = dgamma is not None
+    if not acc:
+        dgamma = torch.empty(C, dtype=gamma.dtype, device=x.device)
+        dbeta = torch.empty(C, dtype=gamma.dtype, device=x.device)
+    sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().cdll.ofa_batchnorm_ws_floats(C) * 4, x.device, "bn")
+    lib().call("ofa_batchnorm_bwd_stats", ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dgamma), ptr(dbeta),
+               ptr(ws), rows, C, int(relu), int(acc), ptr(regate_beta), dtype_code(x), stream())
+    return sums, dgamma, dbeta
+
+
+def batchnorm_bwd_dx(dy, y, x, gamma, mean, rstd, sums, total_rows, relu, want_dres=False, regate_beta=None):
+    """SyncBatchNorm, backward phase 2 (sums all-reduced; total_rows: 1-element fp64 device tensor)."""
+    dy = dy.contiguous()
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    assert total_rows.dtype == torch.float64 and total_rows.numel() == 1
+    lib().call("ofa_batchnorm_bwd_dx", ptr(dy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(sums), ptr(dx), ptr(dres), rows,
+               ptr(total_rows), C, int(relu), ptr(regate_beta), dtype_code(x), stream())
+    return dx, dres
 
 
 def maxpool_fwd(x, B, H, W, C, k, stride, pad):

@@ -1157,39 +1157,58 @@ class LazyRelPosBias:
 
 class BiasAssembleFn(torch.autograd.Function):
     """bias_l = abs.clone(); bias_l[:, :, s:e, s:e] += values_k for each slot k (adaptor/general.py:270-280).
-    kinds[k]: None (no values), "dense" (one tensor [n_k, n_k, A]: the un-expanded rel-pos values) or "outer" (two tensors, frames
-    [F,F,A] and patches [P,P,A]: an OuterRelPos); `tensors` holds them in slot order."""
+    kinds[k]: None (no values), "dense" (one tensor [n_k, n_k, A]: the un-expanded rel-pos values), "outer" (two tensors, frames
+    [F,F,A] and patches [P,P,A]: an OuterRelPos) or "batch" (one tensor [B, A, n_k, n_k]: a custom adaptor's own per-sample bias,
+    adaptor/base.py:183-189 -- only in the dense [B, A, T, T] form); `tensors` holds them in slot order."""
 
     @staticmethod
     def forward(ctx, abs_bias, starts, kinds, *tensors):
         it = iter(tensors)
-        values = [None if k is None else (next(it) if k == "dense" else (next(it), next(it))) for k in kinds]
-        ctx.blocks = [None if v is None else ((s, v[0].shape[0], v[1].shape[0], v[0].dtype) if isinstance(v, tuple) else (s, v.shape[0], v.dtype))
-                      for s, v in zip(starts, values)]
+        values = [None if k is None else ((next(it), next(it)) if k == "outer" else next(it)) for k in kinds]
+        blocks = []
+        for s, k, v in zip(starts, kinds, values):
+            if k is None:
+                blocks.append(None)
+            elif k == "outer":
+                blocks.append((s, v[0].shape[0], v[1].shape[0], v[0].dtype))
+            elif k == "batch":
+                blocks.append(("batch", s, v.shape[-1], v.dtype))
+            else:
+                blocks.append((s, v.shape[0], v.dtype))
+        ctx.blocks = blocks
         ctx.set_materialize_grads(False)         # (the two image outputs never carry a gradient: no zero tensors for them)
-        if abs_bias.shape[0] == 1 and abs_bias.is_cuda and abs_bias.dtype in (torch.bfloat16, torch.float16):
+        if abs_bias.shape[0] == 1 and abs_bias.is_cuda and abs_bias.dtype in (torch.bfloat16, torch.float16) and "batch" not in kinds:
             # the batch-shared form: ONE launch assembles the layer's matrix and writes the two swizzled images the fused attention
             # kernels read (ofa_bias_build) -- was a clone + one block add per slot
             out, swz = K.bias_build(abs_bias[0], starts, values)
             ctx.mark_non_differentiable(*swz)
             return out.unsqueeze(0), swz[0], swz[1]
         out = abs_bias.clone(memory_format=torch.contiguous_format)
-        for s, v in zip(starts, values):
-            if v is not None:
-                if isinstance(v, tuple):
-                    v = OuterRelPos(*v).dense()
-                K.bias_block_add_(out, v.to(out.dtype), s)
+        for s, k, v in zip(starts, kinds, values):
+            if v is None:
+                continue
+            if k == "batch":
+                assert v.shape[0] == out.shape[0] and v.shape[1] == out.shape[1] and v.shape[2] == v.shape[3], \
+                    f"per-sample self_attn_bias {tuple(v.shape)} does not fit the layer bias {tuple(out.shape)}"
+                K.bias_block_add_batch_(out, v.to(out.dtype), s)
+                continue
+            if k == "outer":
+                v = OuterRelPos(*v).dense()
+            K.bias_block_add_(out, v.to(out.dtype), s)
         return out, None, None
 
     @staticmethod
     def backward(ctx, dout, _dr=None, _dc=None):
         if dout is None:
-            return (None, None, None) + (None,) * sum(0 if b is None else (2 if len(b) == 4 else 1) for b in ctx.blocks)
+            return (None, None, None) + (None,) * sum(0 if b is None else (2 if (len(b) == 4 and b[0] != "batch") else 1) for b in ctx.blocks)
         grads = []
         for blk in ctx.blocks:
             if blk is None:
                 continue
-            if len(blk) == 4:                                   # outer slot: sum the block straight into the two tables
+            if blk[0] == "batch":                               # per-sample slot: its block of the gradient, as it is
+                _, s, n, dt = blk
+                grads.append(K.bias_block_slice(dout, s, n).to(dt))
+            elif len(blk) == 4:                                 # outer slot: sum the block straight into the two tables
                 s, Fr, P, dt = blk
                 if dout.shape[0] == 1 and dout.is_cuda:
                     dvf, dvi = K.bias_outer_grad(dout, s, Fr, P)
@@ -1559,6 +1578,65 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dres, dg, db, None, None, None, None, None, None, None
 
 
+def _bn_all_reduce(t, group):
+    """SUM of a statistics tensor over the data-parallel ranks (the one exchange of a SyncBatchNorm layer, each way)."""
+    import torch.distributed as dist
+    if t.is_cuda and torch.cuda.is_current_stream_capturing() and dist.get_backend(group) != "nccl":
+        raise NotImplementedError("sync_bn inside a captured step needs the nccl (RCCL) backend: host-side collectives cannot be captured")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class SyncBatchNormFn(torch.autograd.Function):
+    """nn.SyncBatchNorm (module/layer.py:26-27, adaptor/image_resnet.py:87-90 `sync_bn`) on NHWC rows, training mode: the batch
+    statistics cover every rank's rows.  Same kernels as BatchNormFn, cut in two phases each way around ONE all-reduce of the
+    per-channel sums ([2C + 1] fp64 forward -- the row count rides along, so ranks may hold different batch sizes and nobody
+    syncs --, [2, C] fp32 backward); the parameter gradients stay rank-local sums, which the gradient exchange adds up like every
+    other gradient (torch's own SyncBatchNorm backward does the same)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, momentum, eps, relu, group, mailbox=None):
+        sums = _bn_all_reduce(K.batchnorm_fwd_stats(x), group)
+        y, mean, rstd = K.batchnorm_fwd_apply(x, weight, bias, running_mean, running_var, sums, momentum, eps, relu, residual)
+        ctx.save_for_backward(x, y, weight, mean, rstd, sums)
+        ctx.mailbox, ctx.group = mailbox, group
+        ctx.cfg = (relu, residual is not None)
+        ctx.bias_ref = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd, fsums = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        regate = ctx.bias_ref if (relu and not has_res) else None
+        gw, gb = _sink(weight), _sink(ctx.bias_ref)
+        sink = gw is not None and gb is not None and weight.requires_grad
+        sums, dg, db = K.batchnorm_bwd_stats(dy, y, x, weight, mean, rstd, relu, regate, gw if sink else None, gb if sink else None)
+        if sink:
+            _sink_done(weight)
+            _sink_done(ctx.bias_ref)
+            dg = db = None
+        _bn_all_reduce(sums, ctx.group)
+        dx, dres = K.batchnorm_bwd_dx(dy, y, x, weight, mean, rstd, sums, fsums[-1:], relu, has_res, regate)
+        if ctx.mailbox is not None and dres is not None:
+            ctx.mailbox.append(dres)
+            dres = None
+        return dx, dres, dg, db, None, None, None, None, None, None, None
+
+
+def _bn_sync_group(bn):
+    """The process group a BatchNorm layer synchronises its training statistics over, or None: `bn._ofa_sync` is set by the owner
+    (ImageResnetAdaptor with cfg.sync_bn) to True (default group) or a group; a single-rank job needs no exchange."""
+    sync = getattr(bn, "_ofa_sync", None)
+    if sync is None or sync is False:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if sync is True else sync
+    return (group,) if dist.get_world_size(group) > 1 else None
+
+
 def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mailbox=None):
     """bn holds torch's parameters / buffers (state-dict parity); statistics follow bn.training like nn.BatchNorm2d.
     grad_mailbox (a list shared with ONE conv2d call on the same tensor `residual`): in backward the residual's gradient is not
@@ -1576,7 +1654,11 @@ def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mail
     cast = rm is not None and rm.dtype != torch.float32       # model.bfloat16() casts the buffers too: keep the update in fp32
     if cast:
         rm, rv = rm.float(), rv.float()
-    y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, grad_mailbox)
+    sync = _bn_sync_group(bn) if training else None
+    if sync is not None:
+        y = SyncBatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, sync[0], grad_mailbox)
+    else:
+        y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, grad_mailbox)
     if cast and training:
         bn.running_mean.copy_(rm)
         bn.running_var.copy_(rv)

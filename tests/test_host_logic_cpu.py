@@ -402,6 +402,47 @@ def test_dp_reducer_with_layerdrop_never_arms(dynamic):
         assert torch.equal(g0, g1) and torch.allclose(g0[: want.numel()], want, atol=1e-5)
 
 
+def _bn_exchange_worker(rank, world, port, q):
+    """The one exchange of a SyncBatchNorm layer, over CPU-hosted partials: [2C + 1] fp64 (sum x, sum x^2, row count) per rank."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd import ops
+    x = torch.randn(40, 8, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    mine = x[:13] if rank == 0 else x[13:]                          # uneven row blocks
+    sums = torch.cat([mine.sum(0), (mine * mine).sum(0), torch.tensor([float(mine.shape[0])], dtype=torch.float64)])
+    ops._bn_all_reduce(sums, None)
+    q.put((rank, sums.numpy()))
+    dist.destroy_process_group()
+
+
+def test_sync_bn_exchange_over_two_gloo_ranks_gives_whole_batch_statistics():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_bn_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0], res[1])
+    s = torch.from_numpy(res[0])
+    C = 8
+    R = float(s[2 * C])
+    assert R == 40.0
+    mean, var = s[:C] / R, s[C:2 * C] / R - (s[:C] / R) ** 2          # what bn_finalize_kernel computes from the reduced sums
+    x = torch.randn(40, 8, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1, eps=1e-3).double().train()
+    y = bn(x)
+    assert torch.allclose(mean, x.mean(0)) and torch.allclose(var, x.var(0, unbiased=False))
+    assert torch.allclose(bn.running_mean, 0.1 * mean) and torch.allclose(bn.running_var, 0.9 + 0.1 * var * R / (R - 1))
+    assert torch.allclose(y, (x - mean) / torch.sqrt(var + 1e-3))
+
+
 def test_tool_scripts_compile():
     """tools/*.py (profiling / analysis helpers referenced by DESIGN.md) must at least parse."""
     import glob

@@ -51,11 +51,15 @@ def build(args, device):
     m = GeneralistModel()
     m.cfg.arch = args.arch
     m.__init__(m.cfg)
-    if getattr(args, "workload", "cfg2") in ("cfg2b", "cfg4"):
-        # cfg-2b / cfg-4: the default IMAGE / VIDEO adaptors (ResNet backbone) with the default biased attention
-        for name in ("text", "image_resnet") + (("video_image_sequence",) if args.workload == "cfg4" else ()):
+    wl = getattr(args, "workload", "cfg2")
+    if wl in ("cfg2b", "cfg3", "cfg4", "cfg5"):
+        # cfg-2b / cfg-3 / cfg-4 / cfg-5: the default IMAGE / VIDEO / AUDIO adaptors (ResNet backbone) with the default
+        # biased attention; the trunk is the arch's own (model/ofa.py:557-610: resnet101 for base, resnet152 for large)
+        for name in ("text", "image_resnet") + (("video_image_sequence",) if wl in ("cfg4", "cfg5") else ()) + \
+                (("audio_fbank",) if wl == "cfg5" else ()):
             getattr(m.cfg.adaptor, name).is_active = True
-        m.cfg.adaptor.image_resnet.resnet_type = "resnet101"
+        if args.arch == "base":
+            m.cfg.adaptor.image_resnet.resnet_type = "resnet101"
     else:
         m.cfg.use_self_attn_bias = False                  # the image_patch_embed adaptor's only working corner,
         m.cfg.entangle_position_embedding = True
@@ -114,7 +118,119 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2", pack=False):
     return sample, ntok, (slen.tolist(), tlen.tolist())
 
 
-CPU_SAMPLE = {"cfg2": (8, 6), "cfg2b": (4, 4), "cfg4": (1, 4)}      # workload -> (batch, timed steps) of the CPU leg: 10-30 s of host work
+def _ragged_tokens(d, B, T, g, lo_frac, bos=False, vocab_lo=4, vocab_hi=None):
+    V = vocab_hi or len(d)
+    t = torch.randint(vocab_lo, V, (B, T), generator=g)
+    n = torch.randint(max(int(T * lo_frac), 1), T + 1, (B,), generator=g)
+    n[0] = T
+    if bos:
+        t[:, 0] = d.bos()
+    for b in range(B):
+        t[b, n[b]:] = d.pad()
+    return t, n
+
+
+def _target_of(d, prev, tlen):
+    target = torch.full_like(prev, d.pad())
+    for b in range(prev.shape[0]):
+        n = int(tlen[b])
+        target[b, :n - 1] = prev[b, 1:n]
+        target[b, n - 1] = d.eos()
+    return target
+
+
+def make_micro(d, kind, B, seed, device):
+    """One micro-batch of a multi-task step (cfg-3 / cfg-5): (sample, non-pad tokens, forward-FLOP descriptor).  Kinds:
+      text    [TEXT] -> [TEXT], 128 / 128 (cfg-1's text_infilling shapes)
+      image   = the cfg-2b batch ([IMAGE via image_resnet][TEXT <= 252] -> [TEXT <= 64]), packed rows
+      box     [IMAGE][BOX: 4 <bin> tokens][TEXT <= 32] -> [TEXT <= 32]   (boxes are vocabulary tokens, preprocessor/default/box.py)
+      video   = the cfg-4 batch ([VIDEO 8 x 224 x 224][TEXT <= 32] -> [TEXT <= 32])
+      audio   [AUDIO fbank [B, 400, 80], ragged lengths][TEXT <= 32] -> [TEXT <= 32]
+      struct / motion   [STRUCT | MOTION as tokens, <= 64][TEXT <= 32] -> [TEXT <= 64]   (adaptor/general.py:36-46: the text adaptor)
+    The descriptor is (visual tokens, trunk frames, audio frames, per-sample (encoder text+token length, target length) list)."""
+    from ofasys_amd import ModalityType, Slot
+    if kind == "image":
+        s, ntok, (sls, tls) = make_batch(d, B, 252, 64, seed, device, "cfg2b", pack=True)
+        return s, ntok, dict(nvis=196, frames=1, audio=0, lens=list(zip(sls, tls)), Ts=252, Tt=64)
+    if kind == "video":
+        s, ntok, (sls, tls) = make_batch(d, B, 32, 32, seed, device, "cfg4")
+        return s, ntok, dict(nvis=1568, frames=8, audio=0, lens=[(32, 32)] * B, Ts=32, Tt=32)       # runs padded
+    g = torch.Generator().manual_seed(4321 + seed)
+    half = _HALF_NOW[0]
+    if kind == "text":
+        src, slen = _ragged_tokens(d, B, 128, g, 0.875)
+        prev, tlen = _ragged_tokens(d, B, 128, g, 0.875, bos=True)
+        slots = [Slot(ModalityType.TEXT, True, src.to(device)), Slot(ModalityType.TEXT, False, prev.to(device))]
+        desc = dict(nvis=0, frames=0, audio=0, lens=[(128, 128)] * B, Ts=128, Tt=128)
+        ntok = int(slen.sum()) + int(tlen.sum())
+    elif kind == "box":
+        img = torch.randn(B, 3, 224, 224, generator=g).to(half)
+        first_bin = d.index("<bin>_0")
+        box = torch.randint(first_bin, first_bin + 1000, (B, 4), generator=g)
+        src, slen = _ragged_tokens(d, B, 32, g, 0.5)
+        prev, tlen = _ragged_tokens(d, B, 32, g, 0.25, bos=True)
+        slots = [Slot(ModalityType.IMAGE, True, img.to(device)), Slot(ModalityType.BOX, True, box.to(device)),
+                 Slot(ModalityType.TEXT, True, src.to(device)), Slot(ModalityType.TEXT, False, prev.to(device))]
+        desc = dict(nvis=196, frames=1, audio=0, lens=[(4 + 32, 32)] * B, Ts=36, Tt=32)
+        ntok = B * (196 + 4) + int(slen.sum()) + int(tlen.sum())
+    elif kind == "audio":
+        T = 400
+        flen = torch.randint(T // 2, T + 1, (B,), generator=g)
+        flen[0] = T
+        fb = torch.randn(B, T, 80, generator=g)
+        for b in range(B):
+            fb[b, flen[b]:] = 0.0
+        t2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
+        value = {"fbank": fb.to(half).to(device), "fbank_lengths": flen.to(device),
+                 "mask_indices": torch.zeros(B, t2, dtype=torch.bool, device=device)}
+        src, slen = _ragged_tokens(d, B, 32, g, 0.5)
+        prev, tlen = _ragged_tokens(d, B, 32, g, 0.25, bos=True)
+        slots = [Slot(ModalityType.AUDIO, True, value), Slot(ModalityType.TEXT, True, src.to(device)),
+                 Slot(ModalityType.TEXT, False, prev.to(device))]
+        desc = dict(nvis=t2, frames=0, audio=1, lens=[(32, 32)] * B, Ts=32, Tt=32)
+        alen = (((flen - 3) // 2 + 1) - 3) // 2 + 1
+        ntok = int(alen.sum()) + int(slen.sum()) + int(tlen.sum())
+    elif kind in ("struct", "motion"):
+        mod = ModalityType.STRUCT if kind == "struct" else ModalityType.MOTION
+        tok, mlen = _ragged_tokens(d, B, 64, g, 0.5)
+        src, slen = _ragged_tokens(d, B, 32, g, 0.5)
+        prev, tlen = _ragged_tokens(d, B, 64, g, 0.25, bos=True)
+        slots = [Slot(mod, True, tok.to(device)), Slot(ModalityType.TEXT, True, src.to(device)),
+                 Slot(ModalityType.TEXT, False, prev.to(device))]
+        desc = dict(nvis=0, frames=0, audio=0, lens=[(64 + 32, 64)] * B, Ts=96, Tt=64)
+        ntok = int(mlen.sum()) + int(slen.sum()) + int(tlen.sum())
+    else:
+        raise ValueError(kind)
+    return {"slots": slots, "target": _target_of(d, prev, tlen).to(device), "task": kind}, ntok, desc
+
+
+STEP_MICRO = {      # multi-task workloads: the micro-batches of ONE update (engine/trainer.py:747-884: every task's micro-batch, every step)
+    "cfg3": ("image", "text"),
+    "cfg5": ("text", "image", "box", "video", "audio", "struct", "motion"),
+}
+TRUNK_GMAC = {"resnet50": 4.1 * 0.75, "resnet101": 6.9, "resnet152": 10.7}     # stride-16 trunk (3 stages) per 224 x 224 frame, GMAC
+
+
+def micro_fwd_flops(dims, V, desc, trunk_gmac, executed):
+    """Forward FLOPs of one micro-batch by SURVEY 8d's formulas (+ the ResNet trunk, + the audio subsampling convolutions);
+    executed: at every sample's own lengths where rows are packed, and the position-bias products once per batch (ops.SharedBias)."""
+    D = dims[0]
+    vis = desc["nvis"]
+    per = 0.0
+    if desc["frames"]:
+        per += desc["frames"] * (2 * trunk_gmac * 1e9 + 2 * 196 * 1024 * D)
+    if desc["audio"]:
+        # Conv2d(1, D, 3, 2) on [400, 80] -> [199, 39]; Conv2d(D, D, 3, 2) -> [99, 19]; Linear(D * 19, D)   (module/subsample.py:11-63)
+        per += 2 * 199 * 39 * 9 * D + 2 * 99 * 19 * 9 * D * D + 2 * 99 * 19 * D * D
+    lens = desc["lens"] if executed else [(desc["Ts"], desc["Tt"])] * len(desc["lens"])
+    tot = sum(fwd_flops_per_sample(*dims, vis + sl, tl, V, patch_tokens=0, bias=not executed) + per for sl, tl in lens)
+    if executed:
+        tot += fwd_flops_per_sample(*dims, vis + desc["Ts"], desc["Tt"], V, patch_tokens=0, bias=True) - \
+            fwd_flops_per_sample(*dims, vis + desc["Ts"], desc["Tt"], V, patch_tokens=0, bias=False)
+    return tot
+
+
+CPU_SAMPLE = {"cfg2": (8, 6), "cfg2b": (4, 4), "cfg4": (1, 4), "cfg3": (2, 2), "cfg5": (1, 1)}      # workload -> (batch, timed steps) of the CPU leg: 10-30 s of host work
 
 
 def cpu_baseline(args, model, d):
@@ -131,8 +247,9 @@ def cpu_baseline(args, model, d):
     if args.workload == "cfg2":
         cfg = OConfig(**dims, use_self_attn_bias=False, entangle_position_embedding=True,
                       adaptor_entangle={"text": True, "image_patch_embed": True})
-    else:
-        cfg = OConfig(**dims, resnet_layers=(3, 4, 23), training=True)      # resnet101, BatchNorm on batch statistics
+    else:                                                                   # BatchNorm on batch statistics (train mode)
+        rl = {"resnet50": (3, 4, 6), "resnet101": (3, 4, 23), "resnet152": (3, 8, 36)}[cfgm.adaptor.image_resnet.resnet_type]
+        cfg = OConfig(**dims, resnet_layers=rl, training=True)
     st = {}
     for k, v in model.state_dict().items():
         v = v.detach().cpu()
@@ -142,28 +259,53 @@ def cpu_baseline(args, model, d):
     B, steps = CPU_SAMPLE[args.workload]
     B = args.cpu_batch or B
     steps = args.cpu_steps or steps
-    Ts_text, Tt, nvis, _ = WORKLOADS[args.workload]
-    sample, ntok, _ = make_batch(d, B, Ts_text, Tt, 0, torch.device("cpu"), args.workload)
-    slots = [OSlot(sl.modality.name, sl.is_src, sl.value.float() if sl.value.is_floating_point() else sl.value, sl.attributes)
-             for sl in sample["slots"]]
-    target = sample["target"]
+    samples, ntok, _ = make_step(d, args, B, 0, torch.device("cpu"), packed=False)
+
+    def oslots(sample):
+        out = []
+        for sl in sample["slots"]:
+            v = sl.value
+            if isinstance(v, dict):
+                v = {k: (t.float() if t.is_floating_point() else t) for k, t in v.items()}
+            elif v.is_floating_point():
+                v = v.float()
+            out.append(OSlot(sl.modality.name, sl.is_src, v, sl.attributes))
+        return out
+    work = [(oslots(sm), sm["target"]) for sm in samples]
     params = [v for v in st.values() if v.requires_grad]
 
     def step():
         for p in params:
             p.grad = None
-        logits, _ = restate.model_forward(st, cfg, slots)
-        loss, _ = restate.cross_entropy(logits, target)
-        loss.backward()
+        for slots, target in work:                      # gradient accumulation over the step's micro-batches
+            logits, _ = restate.model_forward(st, cfg, slots)
+            loss, _ = restate.cross_entropy(logits, target)
+            loss.backward()
     step()
     t0 = time.time()
     for _ in range(steps):
         step()
     dt = (time.time() - t0) / steps
+    shape = WORKLOADS[args.workload][3]
     return {"value": ntok / dt, "unit": "tokens/s", "cores": cores, "kind": "port", "batch": B, "gpu_batch": args.batch,
-            "sample": f"oracle/restate.py fp32, {args.workload}, batch {B} (the GPU line runs batch {args.batch}), the padded shape "
-                      f"{nvis}+{Ts_text} -> {Tt} computed in full as the reference does, non-pad tokens counted like `value`; "
-                      f"fwd+CE+bwd, {steps} timed steps after 1 warm-up, torch.set_num_threads({cores})", "s_per_step": dt}
+            "s_per_sample": dt / (B * len(work)),
+            "sample": f"oracle/restate.py fp32, {args.workload}, micro-batch {B} x {len(work)} micro-batch(es) (the GPU line runs "
+                      f"micro-batch {args.batch}), the padded shapes computed in full as the reference does ({shape}), non-pad tokens "
+                      f"counted like `value`; fwd+CE+bwd, {steps} timed step(s) after 1 warm-up, torch.set_num_threads({cores})",
+            "s_per_step": dt}
+
+
+def make_step(d, args, B, seed, device, packed):
+    """The micro-batches of ONE update of the workload: (samples, non-pad tokens, descriptors)."""
+    if args.workload in STEP_MICRO:
+        parts = [make_micro(d, kind, B, seed + 1009 * i, device) for i, kind in enumerate(STEP_MICRO[args.workload])]
+        if not packed:
+            for p in parts:
+                p[0].pop("pack", None)
+        return [p[0] for p in parts], sum(p[1] for p in parts), [p[2] for p in parts]
+    Ts_text, Tt, _, _ = WORKLOADS[args.workload]
+    s1, ntok, lens = make_batch(d, B, Ts_text, Tt, seed, device, args.workload, pack=packed)
+    return [s1], ntok, lens
 
 
 def pmc_traffic():
@@ -194,7 +336,7 @@ def rocprof_gemm_ms(workload):
     events around relaunches (tools/collect_profiles.sh -> tools/prof_summary.py --json)."""
     here = os.path.dirname(os.path.abspath(__file__))
     name = {"cfg2": "round3_rocprof_kernel_stats.json", "cfg2b": "round3_rocprof_cfg2b_kernel_stats.json",
-            "cfg4": "round3_rocprof_cfg4_kernel_stats.json"}[workload]
+            "cfg4": "round3_rocprof_cfg4_kernel_stats.json"}.get(workload, "none")
     try:
         rows = json.load(open(os.path.join(here, "profiles", name)))
     except (OSError, ValueError):
@@ -210,6 +352,12 @@ WORKLOADS = {   # name -> (source text length, target length, visual tokens per 
     "cfg2b": (252, 64, 196, "cfg-2b image_caption: image_resnet101 224x224 (196 tok, rel-pos biased attention) + text<=252 -> text<=64"),
     "cfg4": (32, 32, 1568, "cfg-4 video_caption: 8 frames 224x224 through image_resnet101 (1568 tok, frame+image rel-pos bias) + "
                            "text<=32 -> text<=32"),
+    # multi-task steps (STEP_MICRO): every micro-batch has its own shapes; the three numbers are the largest micro-batch's
+    "cfg3": (252, 128, 196, "cfg-3 two-task step (scripts/trainer_api.py:22-27): caption micro-batch = cfg-2b (image_resnet101 196 tok + "
+                            "text<=252 -> text<=64, packed rows) + text_infilling micro-batch 128 -> 128, both every update"),
+    "cfg5": (96, 128, 1568, "cfg-5 seven-modality step on OFA-large (resnet152 trunk): 7 micro-batches per update -- text 128->128, image "
+                            "(196+<=252 -> <=64), image+box tokens, video 8x224x224 (1568 tok), audio fbank [400,80] (99 tok), "
+                            "struct-as-tokens, motion-as-tokens -- gradient accumulation over all of them, ragged slot collation"),
 }
 
 
@@ -232,8 +380,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--arch", default="base")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 4 for cfg4)")
+    ap.add_argument("--arch", default=None, help="model size (default: base; large for cfg5)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU (micro-)batch (default 32; 8 for cfg3; 4 for cfg4 / cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="CPU-leg batch (0: per workload, CPU_SAMPLE)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU-leg timed steps (0: per workload)")
@@ -241,8 +389,9 @@ def main():
     ap.add_argument("--profile-park-cycles", type=float, default=1.5e8,
                     help="spin-kernel cycles in front of the instrumented step (the host must finish enqueueing before the GPU starts)")
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS),
-                    help="cfg2 (headline: image_patch_embed, bias-free), cfg2b (image_resnet101 + biased attention, 196+252 -> 64) "
-                         "or cfg4 (video 8x224x224 -> 1568 tokens + 32 text -> 32, micro-batch 4)")
+                    help="cfg2 (headline: image_patch_embed, bias-free), cfg2b (image_resnet101 + biased attention, 196+252 -> 64), "
+                         "cfg4 (video 8x224x224 -> 1568 tokens + 32 text -> 32, micro-batch 4), cfg3 (two-task step: cfg2b + text "
+                         "128/128, micro-batch 8 each) or cfg5 (OFA-large, seven modality micro-batches of 4 per update)")
     ap.add_argument("--no-pack", action="store_true",
                     help="cfg2 only: run the padded batch (every sample computed at 448 + 64 positions, as the reference does) instead "
                          "of packing the non-pad positions")
@@ -261,7 +410,9 @@ def main():
     args = ap.parse_args()
     _HALF_NOW[0] = HALF[args.dtype]
     if args.batch is None:
-        args.batch = 4 if args.workload == "cfg4" else 32
+        args.batch = {"cfg4": 4, "cfg5": 4, "cfg3": 8}.get(args.workload, 32)
+    if args.arch is None:
+        args.arch = "large" if args.workload == "cfg5" else "base"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -308,8 +459,8 @@ def main():
     # ragged row packing: cfg-2 and (since round 3: the position bias lives inside the attention kernels) the default biased
     # configuration cfg-2b; cfg-4's padding sits in the MIDDLE of a row (all-zero frames), which the position-indexed rel-pos ids
     # of a packed row cannot express -- it runs padded
-    packed = args.workload in ("cfg2", "cfg2b") and not args.no_pack
-    batches = [make_batch(d, args.batch, Ts_text, Tt, rank + 97 * i, device, args.workload, pack=packed) for i in range(4)]
+    packed = args.workload in ("cfg2", "cfg2b", "cfg3", "cfg5") and not args.no_pack      # (cfg3 / cfg5: their cfg-2b-shaped micro-batch)
+    batches = [make_step(d, args, args.batch, rank + 97 * i, device, packed) for i in range(4)]
     ntok = sum(b[1] for b in batches) / len(batches)
 
     def barrier():
@@ -321,13 +472,13 @@ def main():
 
     def step():
         nonlocal step_i
-        trainer.train_step([batches[step_i % len(batches)][0]])
+        trainer.train_step(batches[step_i % len(batches)][0])
         step_i += 1
 
     if trainer.use_graph:                   # setup: eager priming steps + the one-time graph capture of every batch STRUCTURE
         for b in batches:                   # (packed batches fall into a few row-count buckets, each with its own hipGraph)
             for _ in range(trainer.graph_warmup + 1):
-                trainer.train_step([b[0]])
+                trainer.train_step(b[0])
     for _ in range(args.warmup):
         step()
     barrier()
@@ -358,7 +509,7 @@ def main():
         alone = red.time_buckets_alone()
         red.profile, red.exposed_events = True, []
         for _ in range(3):
-            trainer.train_step([batches[0][0]], eager=True)
+            trainer.train_step(batches[0][0], eager=True)
         torch.cuda.synchronize()
         exposed = [a.elapsed_time(b) for a, b in red.exposed_events]
         red.profile = False
@@ -388,7 +539,7 @@ def main():
             # two events are QUEUED when the GPU reaches them -- the kernels then run back to back exactly as in the replayed graph
             # and each event pair brackets one kernel, not the host's dispatch gap
             torch.cuda._sleep(int(args.profile_park_cycles))
-            trainer.train_step([batches[0][0]], eager=True)        # HIP events around each launch: not inside a graph
+            trainer.train_step(batches[0][0], eager=True)          # HIP events around each launch: not inside a graph
         torch.cuda.synchronize()
         prof = K.gemm_profile_end()
         # what an event pair costs by itself in this regime (dispatch of ONE kernel between two queued events): the same bracket around
@@ -410,7 +561,12 @@ def main():
         cfg = model.cfg
         dims = (cfg.encoder.embed_dim, cfg.encoder.attention_heads, cfg.encoder.ffn_embed_dim, cfg.encoder.layers, cfg.decoder.layers)
         fwd_exec = None
-        if args.workload == "cfg2":
+        if args.workload in STEP_MICRO:
+            gm = TRUNK_GMAC[cfg.adaptor.image_resnet.resnet_type]
+            fwd_step_padded = sum(micro_fwd_flops(dims, len(d), ds, gm, executed=False) for ds in batches[0][2])
+            fwd_exec = sum(sum(micro_fwd_flops(dims, len(d), ds, gm, executed=True) for ds in b[2]) for b in batches) / len(batches)
+            fwd = fwd_step_padded / args.batch               # (per "sample" = one row of every micro-batch)
+        elif args.workload == "cfg2":
             fwd = fwd_flops_per_sample(*dims, 257 + Ts_text, Tt, len(d))
             # the same formulas at every sample's OWN lengths: what a ragged (packed) step actually has to compute
             fwd_exec = sum(fwd_flops_per_sample(*dims, 257 + sl, tl, len(d)) for _, _, (sls, tls) in batches
@@ -482,7 +638,8 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tokens_per_sec_per_gpu": total_tokens * args.steps / dt / world,
-            "config": {"workload": desc + ", OFA-base enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
+            "config": {"workload": desc + f", OFA-{args.arch} enc-dec train step (fwd+CE+bwd+allreduce+clip+Adam)",
+                       "micro_batches_per_step": len(batches[0][0]),
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "padded_positions_per_sample": nvis + Ts_text + Tt, "nonpad_tokens_per_step": total_tokens,
                        "vocab": len(d), "parallelism": f"dp{world}", "random_init": True, "step_mode": graph_mode, "ragged_row_packing": packed,

@@ -71,14 +71,17 @@ def _bf16_grad_check(got, want, tol, what=""):
     assert checked > 100 and not bad, bad[:8]
 
 
-def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
-    """bench.py's headline configuration, exactly as the bench builds and steps it, against the oracle."""
+@pytest.mark.parametrize("B", [8, 32])
+def test_cfg2_benchmarked_step_packed_graph_vs_oracle(B):
+    """bench.py's headline configuration, exactly as the bench builds and steps it, against the oracle.  B = 32 is the benchmarked
+    batch itself: its 13 312-row encoder bucket, the 216-workgroup grouped weight-gradient launches and the eight-wave 192 x 256 /
+    256 x 256 tile plans; the oracle walks it as four shards of 8 rows (the loss and the gradients of a batch
+    are sums over its rows), which bounds the CPU leg to ~15 s."""
     import bench
     from ofasys_amd.trainer import TrainStep
     args = SimpleNamespace(arch="base", workload="cfg2", dtype="bf16", dropout=0.0)      # dropout 0: the oracle has none
     bench._HALF_NOW[0] = torch.bfloat16
     model, d = bench.build(args, torch.device(DEV))
-    B = 8
     sample, ntok, (slens, tlens) = bench.make_batch(d, B, 191, 64, 0, torch.device(DEV), "cfg2", pack=True)
     plan = sample["pack"]
     assert plan.enc_index.numel() % 512 == 0 and plan.dec_index.numel() % 256 == 0          # the bench's row buckets
@@ -87,15 +90,21 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     cfg = OConfig(**ARCH["base"], use_self_attn_bias=False, entangle_position_embedding=True,
                   adaptor_entangle={"text": True, "image_patch_embed": True})
     img, src, prev = (s.value.detach().cpu() for s in sample["slots"])
-    oslots = [OSlot("IMAGE", True, img.float(), ["adaptor=image_patch_embed"]), OSlot("TEXT", True, src), OSlot("TEXT", False, prev)]
     target = sample["target"].cpu()
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     params = oracle_params(state)
-    ref_logits, _ = restate.model_forward(state, cfg, oslots)
-    ref_loss, n = restate.cross_entropy(ref_logits, target)
-    ref_loss.backward()
+    ref_loss, n, shards = 0.0, 0, []
+    for r0 in range(0, B, 8):                                    # (gradients accumulate in the parameters' .grad across the shards)
+        rows = slice(r0, r0 + 8)
+        oslots = [OSlot("IMAGE", True, img[rows].float(), ["adaptor=image_patch_embed"]), OSlot("TEXT", True, src[rows]),
+                  OSlot("TEXT", False, prev[rows])]
+        lg, _ = restate.model_forward(state, cfg, oslots)
+        ls, ns = restate.cross_entropy(lg, target[rows])
+        ls.backward()
+        ref_loss, n = ref_loss + float(ls), n + int(ns)
+        shards.append(lg.detach())
     want = {k: (None if p.grad is None else p.grad.detach()) for k, p in params.items()}
-    ref_logits = ref_logits.detach()
+    ref_logits = torch.cat(shards, 0)
 
     # 1) the step: three train_steps -> the third one is a REPLAY of the captured graph (lr 0: same weights, same gradients)
     tr = TrainStep(model, lr=0.0, clip_norm=0.0, use_graph=True, graph_warmup=1)
@@ -106,10 +115,10 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     assert int(out["stats"][0]) == n == sum(tlens)
     assert abs(float(out["stats"][1]) - float(ref_loss)) <= 1e-4 * float(ref_loss)          # measured 6.9e-6 (profiles/round3_parity_measured.txt)
     got = _arena_grads(tr, model)
-    _measured("cfg-2 packed graph step: loss deviation", abs(float(out["stats"][1]) - float(ref_loss)) / float(ref_loss))
-    _bf16_grad_check(got, want, CFG2_GRAD_TOL, "cfg-2 packed graph step:")
+    _measured(f"cfg-2 packed graph step (B = {B}): loss deviation", abs(float(out["stats"][1]) - float(ref_loss)) / float(ref_loss))
+    _bf16_grad_check(got, want, CFG2_GRAD_TOL, f"cfg-2 packed graph step (B = {B}):")
     gn = np.sqrt(sum(float(g.double().pow(2).sum()) for g in want.values() if g is not None)) / n
-    _measured("cfg-2 packed graph step: clip-norm deviation", abs(float(out["gnorm"]) - gn) / gn)
+    _measured(f"cfg-2 packed graph step (B = {B}): clip-norm deviation", abs(float(out["gnorm"]) - gn) / gn)
     assert abs(float(out["gnorm"]) - gn) <= 2e-3 * gn                                        # measured 4.7e-4
     # 2) the logits of the packed forward at every non-pad decoder position
     model.train()
@@ -119,7 +128,7 @@ def test_cfg2_benchmarked_step_packed_graph_vs_oracle():
     rows = torch.nonzero(idx >= 0).squeeze(1)
     assert rows.numel() == sum(tlens)
     ref_rows = ref_logits.reshape(-1, ref_logits.shape[-1])[idx[rows]]
-    _measured("cfg-2 packed forward: logits max |diff| / max |logit|", rel_err(logits[0, rows], ref_rows))
+    _measured(f"cfg-2 packed forward (B = {B}): logits max |diff| / max |logit|", rel_err(logits[0, rows], ref_rows))
     assert rel_err(logits[0, rows], ref_rows) < CFG2_LOGIT_TOL
     filler = torch.nonzero(idx < 0).squeeze(1)
     assert bool(torch.isfinite(logits[0, filler]).all())
@@ -208,6 +217,42 @@ def test_large_with_default_image_adaptor_vs_oracle(dtype):
         for k, p in model.named_parameters():
             if p.grad is not None:
                 assert bool(torch.isfinite(p.grad.float()).all()), k
+
+
+LARGE_AV = {"arch": "large", "active": {"text", "video_image_sequence", "audio_fbank"}, "overrides": {"dropout": 0.0},
+            "adaptor_overrides": {}}
+
+
+def test_large_with_video_and_audio_slots_vs_oracle():
+    """OFA-large had only ever run token and image slots.  One update over two micro-batches -- a VIDEO slot (3
+    frames of 64 x 64 through the default trunk resnet152, one all-zero padding frame, frame + patch rel-pos bias) and an AUDIO slot
+    (fbank with ragged lengths and mask_emb rows) -- each with ragged text, fp32, against the oracle: loss, sample_size, every
+    gradient norm (north-star 1e-3 tier outside the trunk; the 152-layer train-mode BatchNorm trunk at batch 2 keeps its
+    documented 5e-2 on gradient norms, tests/test_model_gpu.py)."""
+    from ofasys_amd.trainer import TrainStep
+    from tests.golden_util import case_inputs
+    video = dict(slots=[("VIDEO", True, ("vid", "large_av.video", (2, 3, 3, 64, 64), [(1, 1)]), None),
+                        ("TEXT", True, ("tok", "large_av.vsrc", (2, 6), [6, 4]), None),
+                        ("TEXT", False, ("tok", "prev", (2, 7), [7, 5]), None)])
+    audio = dict(slots=[("AUDIO", True, ("fbank", "large_av.audio", (2, 50, 80), [50, 37], [(0, 2), (0, 3), (1, 5)]), ["use_mask"]),
+                        ("TEXT", True, ("tok", "large_av.asrc", (2, 4), [4, 3]), None),
+                        ("TEXT", False, ("tok", "prev", (2, 6), [6, 5]), None)])
+    mbs = [case_inputs(video), case_inputs(audio)]
+    model, d = build_model(LARGE_AV, DEV, torch.float32)
+    cfg = OConfig(**ARCH["large"], resnet_layers=(3, 8, 36), training=True)
+    loss, n, want = _oracle_step(oracle_state_for(model), cfg, mbs)
+    tr = TrainStep(model, lr=0.0, clip_norm=0.0)
+    samples = [{"slots": make_slots(v, DEV), "target": t.to(DEV), "task": name} for (v, t), name in zip(mbs, ("video", "audio"))]
+    out = tr.train_step(samples)
+    torch.cuda.synchronize()
+    assert int(out["stats"][0]) == n
+    _measured("OFA-large video + audio step fp32: loss deviation", abs(float(out["stats"][1]) - loss) / loss)
+    assert abs(float(out["stats"][1]) - loss) <= 1e-3 * loss
+    got = _arena_grads(tr, model)
+    _check_grads(got, want, backbone_tol=5e-2)
+    for k in ("encoder.adaptor.video_image_sequence.embed_frame_positions.weight", "encoder.adaptor.audio_fbank.mask_emb",
+              "encoder.adaptor.audio_fbank.subsample.conv.0.weight"):
+        assert float(got[k].abs().max()) > 0.0, k
 
 
 def test_cfg3_two_task_step_resnet101():

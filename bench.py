@@ -313,7 +313,7 @@ def pmc_traffic():
     passes (profiles/, produced by tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on
     gfx950, tools/pmc_traffic.py)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         try:
             rows = json.load(open(os.path.join(here, "profiles", name)))
         except (OSError, ValueError):
@@ -335,11 +335,17 @@ def rocprof_gemm_ms(workload):
     committed rocprofv3 kernel trace of this very command -- the REPLAYED hipGraph's kernels, timed by the profiler, not by HIP
     events around relaunches (tools/collect_profiles.sh -> tools/prof_summary.py --json)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    name = {"cfg2": "round3_rocprof_kernel_stats.json", "cfg2b": "round3_rocprof_cfg2b_kernel_stats.json",
-            "cfg4": "round3_rocprof_cfg4_kernel_stats.json"}.get(workload, "none")
-    try:
-        rows = json.load(open(os.path.join(here, "profiles", name)))
-    except (OSError, ValueError):
+    stem = {"cfg2": "rocprof_kernel_stats.json", "cfg2b": "rocprof_cfg2b_kernel_stats.json", "cfg4": "rocprof_cfg4_kernel_stats.json",
+            "cfg3": "rocprof_cfg3_kernel_stats.json", "cfg5": "rocprof_cfg5_kernel_stats.json"}[workload]
+    rows = name = None
+    for rnd in ("round4_", "round3_"):                               # the newest committed trace of this command
+        try:
+            rows = json.load(open(os.path.join(here, "profiles", rnd + stem)))
+            name = rnd + stem
+            break
+        except (OSError, ValueError):
+            continue
+    if rows is None:
         return None, None, None
     meta = rows.pop("__meta__", {})
     fam = sum(r["ms_per_step"] for k, r in rows.items()

@@ -59,7 +59,6 @@ class OptimizerConfig:
     weight_decay: float = 0.01
 
 
-@dataclass
 class _SkipPoll:
     """Host-side view of the device's skipped-update counter without a per-step sync: after every step the 2-element `skipped`
     tensor is copied to pinned memory behind an event; a read returns the newest copy whose event has completed."""
@@ -85,6 +84,7 @@ class _SkipPoll:
         return self._value
 
 
+@dataclass
 class TrainerConfig:
     common: CommonConfig = field(default_factory=CommonConfig)
     optimization: OptimizationConfig = field(default_factory=OptimizationConfig)

@@ -178,10 +178,11 @@ def test_resnet_block_backward_bf16_pinned_per_bottleneck():
 
       matched  dL/d(input) against the ORACLE's fp32 bottleneck (oracle/restate.py:_bottleneck) fed THE SAME bf16 input, bf16-valued
                weights and gradient: only the block's own bf16 arithmetic (conv GEMMs, BatchNorm statistics over 32-512 values per
-               channel, ReLU gates) separates the two.  Bound: 3 x what the REFERENCE's bf16 block pays in the same experiment
+               channel, ReLU gates) separates the two.  Bound: 2 x what the REFERENCE's bf16 block pays in the same experiment
                (tests/golden/resnet_block_bf16_gap.json, oracle/ref_bf16_block_gap.py: 4-9 % in norm);
-      chain    against the golden fp32 dL/d(input) itself (the block input then carries the bf16 forward's drift too): 1.5 x the
-               reference's own figure for that.
+      chain    against the golden fp32 dL/d(input) itself (the block input then carries the bf16 forward's drift too): 1.25 x the
+               reference's own figure for that.  Measured on MI355X (round 4): matched 0.94 / 1.42 / 1.07 / 0.89 x the reference's own
+               figure (layer3.5 / 3.0 / 2.0 / 1.0), chain 0.95 / 0.94 / 0.95 / 0.96 x.
     Printed next to the bounds (`pytest -s`)."""
     import json
     import os
@@ -226,10 +227,10 @@ def test_resnet_block_backward_bf16_pinned_per_bottleneck():
         (dx4,) = torch.autograd.grad(y4, x4, dy4.to(torch.bfloat16).float())
         ref = dx4.permute(0, 2, 3, 1).reshape(-1, dx4.shape[1]).double()
         matched = float((dx - ref).norm() / ref.norm())
-        print(f"MEASURED bf16 bottleneck {k}: matched {matched:.3e} (reference's own {gap[k]['matched_norm_rel']:.3e}, bound 3x); "
-              f"chain {chain:.3e} (reference's own {gap[k]['norm_rel']:.3e}, bound 1.5x)")
-        assert matched <= 3.0 * gap[k]["matched_norm_rel"], (k, matched, gap[k])
-        assert chain <= 1.5 * gap[k]["norm_rel"], (k, chain, gap[k])
+        print(f"MEASURED bf16 bottleneck {k}: matched {matched:.3e} (reference's own {gap[k]['matched_norm_rel']:.3e}, bound 2x); "
+              f"chain {chain:.3e} (reference's own {gap[k]['norm_rel']:.3e}, bound 1.25x)")
+        assert matched <= 2.0 * gap[k]["matched_norm_rel"], (k, matched, gap[k])
+        assert chain <= 1.25 * gap[k]["norm_rel"], (k, chain, gap[k])
 
 
 def test_token_bucket_buffer_bit_exact():

@@ -76,15 +76,17 @@ def test_custom_adaptor_with_its_own_per_sample_attention_bias(dtype, tol):
         assert e < tol, (b, e)
     assert abs(both[1] - (alone[0][1] + alone[1][1])) <= tol * abs(both[1])
     worst = 0.0
+    sums = {k: alone[0][2].get(k, 0) + alone[1][2].get(k, 0) for k in both[2]}
+    scale = max(float(r.norm()) for r in sums.values() if torch.is_tensor(r))
     for k, g in both[2].items():
-        ref = alone[0][2].get(k, 0) + alone[1][2].get(k, 0)
+        ref = sums[k]
         if not torch.is_tensor(ref):
             continue
         denom = float(ref.norm())
-        if denom < 1e-6:
-            continue
-        worst = max(worst, float((g - ref).norm()) / denom)
-        assert float((g - ref).norm()) <= (5 * tol) * denom + 1e-6, (k, float((g - ref).norm()) / denom)
+        if denom > 1e-2 * scale:
+            worst = max(worst, float((g - ref).norm()) / denom)
+        # (parameters whose gradient is mathematically ~0 -- a key-side position bias shifts every score of a row alike -- hold noise)
+        assert float((g - ref).norm()) <= (5 * tol) * denom + 2e-3 * scale, (k, float((g - ref).norm()) / max(denom, 1e-30))
     print(f"MEASURED per-sample bias {dtype}: worst gradient deviation (batch vs sum of singles) {worst:.2e}")
     # the per-sample term is live: its table rows get a gradient through the custom adaptor
     k0 = "encoder.adaptor.text_own_bias.token_rel_pos_table_list.0.weight"

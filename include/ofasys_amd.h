@@ -122,10 +122,6 @@ typedef struct ofa_gemm_group_item {
 /* host only: validates the items and fills `splits` (one K-slice length for the group: <= 256 workgroups in total) */
 int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype);
 int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dtype, void* stream);
-/* The same group launched in pieces of at most max_wgs workgroups (a multiple of 8; 0 = one launch): each piece occupies at most
- * max_wgs of the 256 compute units, so a group running on a side stream leaves the rest to the kernels of the caller's main stream
- * (the latency-bound decoder-side chain of the backward pass: ofasys_amd/ops.py, `_Wgrads.side`). */
-int ofa_gemm_group_tn_part(const ofa_gemm_group_item* items, int n, int dtype, int max_wgs, void* stream);
 
 /* ---- the reference's fused softmax extensions, wave64 re-derivations.
  * x,y: [b, np, sq, sk]; softmax over sk of scale*x, fp32 accumulate.  sk <= 4096 (scaled_masked_softmax_cuda.cu:47-52). */

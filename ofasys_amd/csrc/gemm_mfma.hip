@@ -1116,15 +1116,12 @@ struct GroupItem {
   int64_t lda, ldb;
   int M, N, K, ksplit, splits, tiles_m, tiles_n, first;   // first: index of the item's first workgroup
 };
-struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total, wg0, count; };   // this launch: workgroups wg0 .. wg0 + count - 1 of `total`
+struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total; };
 
 template <bool F16>
 __global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
-  // XCD chunks over the flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2.
-  // A group can be launched in several pieces of at most `max_wgs` workgroups (ofa_gemm_group_tn_part): a launch that deliberately
-  // occupies only part of the chip, so that a weight-gradient group on a side stream leaves compute units to the latency-bound
-  // kernels of the main stream (ops.py: _Wgrads.side)
-  const int id = ga.wg0 + xcd_remap((int)blockIdx.x, ga.count);
+  // XCD chunks over the flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2
+  const int id = xcd_remap((int)blockIdx.x, ga.total);
   int p = 0;
   for (int q = 1; q < ga.n; ++q)
     if (id >= ga.it[q].first) p = q;
@@ -1427,10 +1424,9 @@ extern "C" int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype)
   return 0;
 }
 
-extern "C" int ofa_gemm_group_tn_part(const ofa_gemm_group_item* items, int n, int dtype, int max_wgs, void* stream) {
+extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dtype, void* stream) {
   OFA_REQUIRE(dtype == OFA_BF16 || dtype == OFA_F16, OFA_ERR_INVALID, "gemm_group: 16-bit operands only (dtype %d)", dtype);
   OFA_REQUIRE(items && n >= 1 && n <= GROUP_MAX, OFA_ERR_INVALID, "gemm_group: 1..%d products per launch (got %d)", GROUP_MAX, n);
-  OFA_REQUIRE(max_wgs == 0 || (max_wgs >= 8 && max_wgs % 8 == 0), OFA_ERR_INVALID, "gemm_group: max_wgs %d must be 0 (no limit) or a multiple of 8", max_wgs);
   GroupArgs ga;
   int first = 0;
   for (int p = 0; p < n; ++p) {
@@ -1457,18 +1453,9 @@ extern "C" int ofa_gemm_group_tn_part(const ofa_gemm_group_item* items, int n, i
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int piece = max_wgs > 0 ? max_wgs : first;
-  for (int wg0 = 0; wg0 < first; wg0 += piece) {
-    ga.wg0 = wg0;
-    ga.count = first - wg0 < piece ? first - wg0 : piece;
-    if (dtype == OFA_F16) hipLaunchKernelGGL(gemm_group_tn_kernel<true>, dim3(ga.count), dim3(512), lds, st, ga);
-    else hipLaunchKernelGGL(gemm_group_tn_kernel<false>, dim3(ga.count), dim3(512), lds, st, ga);
-  }
+  if (dtype == OFA_F16) hipLaunchKernelGGL(gemm_group_tn_kernel<true>, dim3(ga.total), dim3(512), lds, st, ga);
+  else hipLaunchKernelGGL(gemm_group_tn_kernel<false>, dim3(ga.total), dim3(512), lds, st, ga);
   return check_launch("gemm_group_tn");
-}
-
-extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dtype, void* stream) {
-  return ofa_gemm_group_tn_part(items, n, dtype, 0, stream);
 }
 
 extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA,

@@ -245,10 +245,10 @@ def gemm_group_ok(dy, x, out):
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.is_contiguous())
 
 
-def gemm_group_tn(products, fold, max_wgs=0):
+def gemm_group_tn(products, fold):
     """products: [(dy [K,M], x [K,N], out [M,N], alpha)], each passing gemm_group_ok: out += alpha * dy^T x for all of them in
     ONE launch of 256 x 256 tiles (fp32 K-slice slabs) + the FoldQueue's batched reduce (`fold`: the queue to register the
-    slabs with; the caller flushes it).  max_wgs > 0: in pieces of at most that many workgroups (ofa_gemm_group_tn_part)."""
+    slabs with; the caller flushes it)."""
     assert 1 <= len(products) <= GROUP_MAX
     arr = (_GroupItem * len(products))()
     for it, (dy, x, out, alpha) in zip(arr, products):
@@ -265,13 +265,13 @@ def gemm_group_tn(products, fold, max_wgs=0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib().call("ofa_gemm_group_tn_part", ctypes.addressof(arr), len(products), dt, int(max_wgs), stream())
+        lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
         e1.record()
         es = products[0][0].element_size()
         _prof.append((sum(2.0 * it.m * it.n * it.k for it in arr), e0, e1,
                       sum((it.m + it.n) * it.k * es + it.splits * it.m * it.n * 4 for it in arr)))
     else:
-        lib().call("ofa_gemm_group_tn_part", ctypes.addressof(arr), len(products), dt, int(max_wgs), stream())
+        lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
     for it, sl, (dy, x, out, alpha) in zip(arr, slabs, products):   # (registered after the launch: add() may flush the queue)
         fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
 

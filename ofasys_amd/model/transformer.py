@@ -241,8 +241,6 @@ class TransformerDecoder(nn.Module):
         if encoder_out is not None and len(encoder_out["encoder_out"]) > 0:
             enc = encoder_out["encoder_out"][0]
             assert enc.size()[1] == bsz, f"Expected enc.shape == (t, {bsz}, c) got {enc.shape}"
-            if self.training and incremental_state is None:
-                enc = ops.side_phase_end(enc)       # backward: the decoder's weight-gradient side phase ends where its gradient is complete
         if encoder_out is not None and len(encoder_out["encoder_padding_mask"]) > 0:
             padding_mask = encoder_out["encoder_padding_mask"][0]
         if encoder_out is not None and len(encoder_out["position_embeddings"]) > 0:
@@ -325,8 +323,6 @@ class TransformerDecoder(nn.Module):
         _check_packable(self.cfg, wants_extras or incremental_state is not None or full_context_alignment)
         from ..packing import causal_tag
         enc = encoder_out["encoder_out"][0]                           # [enc rows, 1, C]
-        if self.training:
-            enc = ops.side_phase_end(enc)           # backward: the decoder's weight-gradient side phase ends where its gradient is complete
         x = ops.pack_rows(adaptor_output.embed, pack.dec_index, pack.dec_inverse).transpose(0, 1)       # [dec rows, 1, C]
         tag = causal_tag(x.device)
         self_bias = cross_bias = None

@@ -123,10 +123,6 @@ def drop_pending():
     """Forget queued weight gradients and folds without launching them: the start of a step, so that what a backward pass that
     raised left behind is not added to the next step's gradients."""
     _Wgrads.items, _Wgrads.queued, _Fold.queued = [], False, False
-    if _Wgrads.side is not None:                    # (a side phase a failed backward left open: its launches are on their stream)
-        if _Wgrads.side["used"]:
-            torch.cuda.current_stream().wait_stream(_Wgrads.side["stream"])
-        _Wgrads.side = None
     if _Fold.queue is not None:
         _Fold.queue.__init__()
 
@@ -158,56 +154,6 @@ class _Wgrads:
     enabled = os.environ.get("OFA_WGRAD_GROUP", "1") != "0"
     items = []           # (dy, x2d, out, alpha, weight)
     queued = False       # an end-of-backward flush is registered with the autograd engine
-    # Side phase (wgrad_side_begin .. side_phase_end): while the backward pass walks the DECODER -- a chain of small, latency-bound
-    # kernels (2048-row GEMMs on a third of the chip, 64-position attention) -- the layers' grouped weight-gradient launches, which
-    # nothing in that chain waits for, go to a second stream in pieces of at most `side_wgs` workgroups: they fill the compute units
-    # the chain leaves idle instead of queueing full-chip launches into it.  The main stream joins at the phase's end (the
-    # encoder output's gradient), where the reducer notifications of those weights fire.
-    side_wgs = int(os.environ.get("OFA_WGRAD_SIDE", "128"))      # 0: off
-    side = None          # {"stream", "keep", "pending"} while a side phase is active
-    side_stream = None
-
-
-def wgrad_side_begin():
-    """Start of a backward pass whose first phase is the decoder's (trainer.TrainStep): grouped weight gradients go to the side
-    stream until side_phase_end()'s node runs.  No effect without a GPU, with OFA_WGRAD_SIDE=0, or when grouping is off."""
-    if not (_Wgrads.enabled and _Wgrads.side_wgs > 0 and torch.cuda.is_available()):
-        return
-    if _Wgrads.side_stream is None:
-        _Wgrads.side_stream = torch.cuda.Stream()
-    _Wgrads.side = {"stream": _Wgrads.side_stream, "keep": [], "pending": [], "used": False}
-
-
-def _side_join():
-    """The main stream waits for the side stream's weight gradients; their reducer notifications fire; operands are released."""
-    st, _Wgrads.side = _Wgrads.side, None
-    if st is None:
-        return
-    if st["used"]:
-        torch.cuda.current_stream().wait_stream(st["stream"])
-    for w in st["pending"]:
-        _sink_done(w)
-    st["keep"].clear()
-
-
-class _SidePhaseEndFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dy):
-        flush_wgrads()
-        _side_join()
-        return dy
-
-
-def side_phase_end(x):
-    """Identity on the encoder output handed to the decoder; in backward -- when every decoder layer has produced its gradients -- the
-    side phase of the weight gradients ends (see _Wgrads.side)."""
-    if _Wgrads.enabled and _Wgrads.side_wgs > 0 and torch.is_grad_enabled() and x.requires_grad and x.is_cuda:
-        return _SidePhaseEndFn.apply(x)
-    return x
 
 
 def _wgrad(dy, x2d, gw, alpha, *weights):
@@ -237,24 +183,11 @@ def _flush_at_end_of_backward():
 def _end_of_backward():
     _Wgrads.queued = False
     flush_wgrads()
-    _side_join()                                  # (a backward pass without a side_phase_end node: join here)
 
 
 def flush_wgrads():
     items, _Wgrads.items = _Wgrads.items, []
     if not items:
-        return
-    st = _Wgrads.side
-    if st is not None and len(items) > 1:
-        cur, side = torch.cuda.current_stream(), st["stream"]
-        side.wait_stream(cur)                        # fork: dy / x were produced on the main stream
-        with torch.cuda.stream(side):
-            q = K.FoldQueue()
-            K.gemm_group_tn([it[:4] for it in items], q, max_wgs=_Wgrads.side_wgs)
-            q.flush()                                # the slab fold runs behind the GEMM, on the side stream, into the arena
-        st["used"] = True
-        st["keep"].append(items)                     # dy / x stay allocated until the join (the main stream must not reuse them)
-        st["pending"].extend(w for it in items for w in it[4])
         return
     if len(items) == 1:
         dy, x2d, gw, alpha, _ = items[0]

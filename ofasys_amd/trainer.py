@@ -329,7 +329,6 @@ class TrainStep:
             else:
                 loss = ops.cross_entropy_sum(logits, target, self.pad)
                 n = target.ne(self.pad).sum()
-            ops.wgrad_side_begin()                   # the decoder's weight gradients run beside its backward chain (ops._Wgrads.side)
             if self.loss_scale_cfg is None:
                 loss.backward()
             else:                                    # FP16Optimizer.backward: loss * loss_scale (fp16_optimizer.py:92-102)

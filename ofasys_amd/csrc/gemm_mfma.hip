@@ -697,10 +697,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
 // while tile kt multiplies; the wait in front of the stage barrier is `vmcnt(2 * pieces)` -- only the OLDEST tile has to
 // have landed.  Same tile geometry, swizzle, fragment reads and epilogue as gemm_mfma_kernel (LDS-DMA path: whole K
 // tiles); the stage select is an add on the fragment address registers instead of an offset immediate.
-template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int S = 4, bool F16 = false>
+// TMW x TNW: MFMA tiles (32 x 32) per wave.  2 x 2 is the 64 x 64 wave block of the other kernels.  Round 4: the 64 x 64 and 64 x 128
+// WORKGROUP tiles of the decoder-side products run as FOUR waves of 32 x 32 / 32 x 64 (1 x 1 / 1 x 2) instead of one / two waves of
+// 64 x 64: a K-step's LDS-DMA pieces (16 KiB = 16 wave-instructions at ~60 issue cycles each for a 64 x 64 tile) were all issued
+// by ONE wave -- ~1000 cycles per K-step beside 512 MFMA-cycles; four waves issue four pieces each.
+template <int WM, int WN, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, int S = 4, bool F16 = false, int TMW = 2, int TNW = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit,
                                                                float* __restrict__ ws) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+  constexpr int BM = 32 * TMW * WM, BN = 32 * TNW * WN, NT = 64 * WM * WN;
   static_assert(S == 3 || S == 4, "ring depth");
   typedef TileGeom<BM, A_KMAJ> GA;
   typedef TileGeom<BN, B_KMAJ> GB;
@@ -727,11 +731,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
   const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
   const int nk = (kend - kbeg) / BK;                                   // launcher guarantees whole K tiles
 
-  f32x16 acc[2][2];
+  f32x16 acc[TMW][TNW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -754,13 +758,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
   for (; issued < S - 1 && issued < nk; ++issued) dma(issued);
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
-  FragAddr<BM, A_KMAJ> fax[2];
-  FragAddr<BN, B_KMAJ> faw[2];
+  FragAddr<BM, A_KMAJ> fax[TMW];
+  FragAddr<BN, B_KMAJ> faw[TNW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    fax[i].init(lds0, wm * 64 + i * 32, lane);
-    faw[i].init(lds0 + (uint32_t)EA * 2u, wn * 64 + i * 32, lane);
-  }
+  for (int i = 0; i < TMW; ++i) fax[i].init(lds0, wm * 32 * TMW + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < TNW; ++j) faw[j].init(lds0 + (uint32_t)EA * 2u, wn * 32 * TNW + j * 32, lane);
   constexpr int NA = A_KMAJ ? 4 : 1, NB = B_KMAJ ? 4 : 1;
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -782,15 +785,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
     bf16_t* rst = reinterpret_cast<bf16_t*>(smem_raw + (size_t)((stage + S - 1) % S) * STG);
     if (refill && !B_KMAJ && knext + BK > g.b_krows)
       glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
-    u64x2 x0[2], w0[2], x1[2], w1[2];
-#define RING_ISSUE(KK, X, W)                        \
-    frag_issue<BM, A_KMAJ, KK, 0>(X[0], fax[0]);    \
-    frag_issue<BM, A_KMAJ, KK, 0>(X[1], fax[1]);    \
-    frag_issue<BN, B_KMAJ, KK, 0>(W[0], faw[0]);    \
-    frag_issue<BN, B_KMAJ, KK, 0>(W[1], faw[1])
-#define RING_WAIT(X, W) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(W[0]), "+v"(W[1]))
+    u64x2 x0[TMW], w0[TNW], x1[TMW], w1[TNW];
+#define RING_ISSUE(KK, X, W)                                                                                           \
+    static_for<0, TMW>([&](auto ic) { frag_issue<BM, A_KMAJ, KK, 0>(X[decltype(ic)::value], fax[decltype(ic)::value]); }); \
+    static_for<0, TNW>([&](auto jc) { frag_issue<BN, B_KMAJ, KK, 0>(W[decltype(jc)::value], faw[decltype(jc)::value]); })
+    // (the wait statement names every fragment register: that is what orders the MFMAs behind it)
+#define RING_WAIT(X, W)                                                                                                \
+    if constexpr (TMW == 2 && TNW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[TMW - 1]), "+v"(W[0]), "+v"(W[TNW - 1])); \
+    else if constexpr (TMW == 1 && TNW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(W[0]), "+v"(W[TNW - 1]));            \
+    else if constexpr (TMW == 2 && TNW == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[TMW - 1]), "+v"(W[0]));            \
+    else { static_assert(TMW <= 2 && TNW <= 2, "RING_WAIT names every fragment register: add the shape");              \
+           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(W[0])); }
 #define RING_MMA(X, W)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+    _Pragma("unroll") for (int i = 0; i < TMW; ++i) _Pragma("unroll") for (int j = 0; j < TNW; ++j)                    \
         acc[i][j] = mfma16<F16>(W[j], X[i], acc[i][j])
 #define RING_DMA(Q)                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
@@ -835,12 +842,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
     const bool wrap = stage == S - 1;
     const uint32_t delta = wrap ? (uint32_t)(0u - (uint32_t)(S - 1) * STG) : STG;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int q = 0; q < NA; ++q) fax[i].a[q] += delta;
 #pragma unroll
-      for (int q = 0; q < NB; ++q) faw[i].a[q] += delta;
-    }
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+      for (int q = 0; q < NB; ++q) faw[j].a[q] += delta;
     stage = wrap ? 0 : stage + 1;
   }
   __syncthreads();                                     // every wave is done with the fragment reads
@@ -848,15 +856,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
     const bool split = gridDim.y > 1;
     constexpr int REGION = ((int)(S * STG) / (WM * WN)) & ~1023;
     unsigned char* wl = smem_raw + wave * REGION;
-    const int m_w = m0 + wm * 64, n_w = n0 + wn * 64;
+    const int m_w = m0 + wm * 32 * TMW, n_w = n0 + wn * 32 * TNW;
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * gridDim.y + ks) * g.M * n4;
-      epilogue_lds<2, 2, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
+      epilogue_lds<TMW, TNW, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
       void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
-      epilogue_lds<2, 2, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
+      epilogue_lds<TMW, TNW, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
   }
 }
@@ -1189,12 +1197,12 @@ static void launch_cfg2(const GemmArgs& g, int batch, int splits, int ksplit, fl
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-template <int WM, int WN, bool AK, bool BKM, bool OF, int S = 4, bool F16 = false>
+template <int WM, int WN, bool AK, bool BKM, bool OF, int S = 4, bool F16 = false, int TMW = 2, int TNW = 2>
 static void launch_ring(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 32 * TMW * WM, BN = 32 * TNW * WN;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const size_t lds = S * (size_t)(BM + BN) * BK * sizeof(bf16_t);
-  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF, S, F16>;
+  auto kern = gemm_ring_kernel<WM, WN, AK, BKM, OF, S, F16, TMW, TNW>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1214,7 +1222,11 @@ static bool use_ring(const GemmArgs& g, int wm, int wn, int64_t blocks, int kspl
 template <int WM, int WN, bool AK, bool BKM, bool OF, bool F16 = false>
 static void launch_cfg(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   if (use_ring(g, WM, WN, (int64_t)cdiv(g.M, 64 * WM) * cdiv(g.N, 64 * WN) * splits * batch, ksplit)) {
-    launch_ring<WM, WN, AK, BKM, OF, 4, F16>(g, batch, splits, ksplit, ws, st);
+    // the 64 x 64 / 64 x 128 workgroup tiles run as FOUR waves of 32 x 32 / 32 x 64 (see gemm_ring_kernel): in the replayed steps
+    // cfg-2 12.18 -> 12.07 ms, cfg-5 (every product is a small grid) 135.6 -> 130.5 ms, same box (profiles/round4_ring_waves_ab.txt)
+    if constexpr (WM == 1 && WN == 1) launch_ring<2, 2, AK, BKM, OF, 4, F16, 1, 1>(g, batch, splits, ksplit, ws, st);
+    else if constexpr (WM == 1 && WN == 2) launch_ring<2, 2, AK, BKM, OF, 4, F16, 1, 2>(g, batch, splits, ksplit, ws, st);
+    else launch_ring<WM, WN, AK, BKM, OF, 4, F16>(g, batch, splits, ksplit, ws, st);
     return;
   }
   // LDS-DMA staging needs full K tiles (no zero fill); anything else takes the register-staged loop
@@ -1274,7 +1286,15 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   // Round 3 (tools/gemm_split_check.py, the ResNet trunk's 1 x 1 / 3 x 3 products): at K = 1024 the split loses too (18432 x 256 x 1024:
   // 31.7 us in two slices + reduce vs 20.2 us as 64 x 128 tiles; 6272 x 256 x 1024: 22.4 vs 14.0 us as 64 x 64 tiles), and so does any
   // split of a product whose 128 x 128 tiles already fill a round of the 256 CUs (18432 x 256 x 2304: 46.6 vs 37.6 us)
-  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 2048;   // (tools/gemm_timeline.py)
+  // Planner overrides for experiments (tools/gemm_tile_sweep.py, gemm_split_check.py, gemm_timeline.py, the forced-tile test) exist in
+  // the DEBUG library only (make -C ofasys_amd/csrc debug -> libofasys_amd_dbg.so, -DOFA_DEBUG_SWITCHES); the shipped library has
+  // one code path and reads no environment variable.
+#ifdef OFA_DEBUG_SWITCHES
+  static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 2048;
+  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // 22 / 12 / 11 / 44 (= 84) / 34 (= 83)
+#else
+  constexpr int split_min_k = 2048, force_tile = 0;
+#endif
   if (g.K < split_min_k || t22 >= 256) maxs = 1;
   const int64_t want = 384;
   int wm, wn;
@@ -1282,7 +1302,6 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   if (t22 * maxs >= want && g.M > 64 && g.N >= 128) { wm = 2; wn = 2; tiles = t22; }
   else if (t12 * maxs >= want && g.N >= 128) { wm = 1; wn = 2; tiles = t12; }
   else { wm = 1; wn = 1; tiles = t11; }
-  static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // experiments: 22 / 12 / 11 / 44 (= 84) / 34 (= 83)
   if (force_tile == 22) { wm = 2; wn = 2; tiles = t22; }
   else if (force_tile == 12) { wm = 1; wn = 2; tiles = t12; }
   else if (force_tile == 11) { wm = 1; wn = 1; tiles = t11; }

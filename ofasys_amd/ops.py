@@ -5,7 +5,6 @@ activation is a dense [rows, C] matrix in batch-major order ([B,T,C] storage); f
 boundary are transposed *views* of that storage, so no layout copies happen between ops.
 """
 import math
-import os
 
 import torch
 
@@ -151,7 +150,7 @@ def _fold():
 # one launch of 256 x 256 tiles with ~2 long K-slices per product instead of one launch of 3-7 short slices each
 # (kernels.gemm_group_tn).  The queue holds dY and X until then.
 class _Wgrads:
-    enabled = os.environ.get("OFA_WGRAD_GROUP", "1") != "0"
+    enabled = True       # (tests / A-B tools may clear it: every weight gradient is then its own product)
     items = []           # (dy, x2d, out, alpha, weight)
     queued = False       # an end-of-backward flush is registered with the autograd engine
 

@@ -116,13 +116,15 @@ print("forced tiles ok")
 @pytest.mark.parametrize("tile", ["83", "84"])
 def test_gemm_eight_wave_tiles_forced(K, tile):
     """Every product of the list on the eight-wave 192 x 256 / 256 x 256 kernels (gemm_big_kernel<3|4, 2, .., 2, 4>): ragged edges in M
-    and N, all four operand layouts, column / row bias, alpha, fp32 output, accumulation, ldc > N.  OFA_GEMM_TILE is read once
-    per process, hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile."""
+    and N, all four operand layouts, column / row bias, alpha, fp32 output, accumulation, ldc > N.  OFA_GEMM_TILE exists in the DEBUG library only
+    (libofasys_amd_dbg.so, OFASYS_AMD_LIB) and is read once per process, hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OFA_GEMM_TILE=tile)
+    dbg = os.path.join(root, "ofasys_amd", "libofasys_amd_dbg.so")            # (make -C ofasys_amd/csrc debug; built by __graft_entry__.build)
+    assert os.path.exists(dbg), "the debug library (planner overrides compiled in) is not built: make -C ofasys_amd/csrc debug"
+    env = dict(os.environ, OFA_GEMM_TILE=tile, OFASYS_AMD_LIB=dbg)
     r = subprocess.run([sys.executable, "-c", _FORCED_TILE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced tiles ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

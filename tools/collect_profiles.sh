@@ -38,4 +38,4 @@ python tools/attn_bench.py > $O/round${N}_attn_bench.txt 2>&1
 for w in cfg2b cfg4 dec cross; do python tools/attn_sbias_bench.py $w 2>&1 | grep -v amdgpu.ids >> $O/round${N}_attn_sbias_bench.txt; done
 for w in cfg2 cfg2b cfg4; do python tools/native_glue_trace.py $w 2>&1 | grep -v amdgpu.ids > $O/round${N}_native_glue_$w.txt; done
 timeout 300 tools/experiments/_build/adam_stream_bench > $O/round${N}_adam_stream_bench.txt 2>&1 || true
-(python tools/gemm_split_check.py; OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_split_check.txt
+(python tools/gemm_split_check.py; OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_split_check.txt

@@ -1,6 +1,8 @@
 """Tile choice on the ResNet trunk's convolution products (forward NT: [rows, K] x [N, K]^T; input gradient NN: [rows, N] x [N, K]):
     for t in 0 22 12 11; do OFA_GEMM_TILE=$t python tools/gemm_conv_sweep.py [cfg2b|cfg4]; done
-prints one line per shape: the planner's choice (OFA_GEMM_TILE unset / 0) or the forced 128x128 / 64x128 / 64x64 tile."""
+prints one line per shape: the planner's choice (OFA_GEMM_TILE unset / 0) or the forced 128x128 / 64x128 / 64x64 tile.
+(The OFA_GEMM_* planner overrides exist in the DEBUG library only: make -C ofasys_amd/csrc debug, then run with
+OFASYS_AMD_LIB=ofasys_amd/libofasys_amd_dbg.so; the shipped library ignores them.)"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from ofasys_amd import kernels as K

@@ -1,7 +1,9 @@
 """Split-K (+ reduce launch) vs an unsplit launch of smaller tiles on the ResNet trunk's skinny products (cfg-2b / cfg-4:
 B = 32 images of 384^2 -> layer2 rows 73728, layer3 rows 18432; conv as [rows, K] x [N, K]^T).  Run twice:
     python tools/gemm_split_check.py                       # the planner's choice (split when K >= 1024 and tiles < 384)
-    OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py    # never split"""
+    OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py    # never split
+(The OFA_GEMM_* planner overrides exist in the DEBUG library only: make -C ofasys_amd/csrc debug, then run with
+OFASYS_AMD_LIB=ofasys_amd/libofasys_amd_dbg.so; the shipped library ignores them.)"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from ofasys_amd import kernels as K

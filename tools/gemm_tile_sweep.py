@@ -1,5 +1,7 @@
 """Time the train step's GEMM shapes under one forced tile configuration (OFA_GEMM_TILE is read once per process):
-  OFA_GEMM_TILE=0|22|12|34|44 python tools/gemm_tile_sweep.py [M ...]      -> lines "kind M N K us TF" """
+  OFA_GEMM_TILE=0|22|12|34|44 python tools/gemm_tile_sweep.py [M ...]      -> lines "kind M N K us TF" 
+(The OFA_GEMM_* planner overrides exist in the DEBUG library only: make -C ofasys_amd/csrc debug, then run with
+OFASYS_AMD_LIB=ofasys_amd/libofasys_amd_dbg.so; the shipped library ignores them.)"""
 import os
 import sys
 import torch

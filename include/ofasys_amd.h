@@ -109,8 +109,9 @@ int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int
  * launch (256 x 256 eight-wave tiles).  The nn.Linear weight gradients of one Transformer layer (dW = dY^T X, what autograd
  * computes for transformer_layer.py:194,202 and multihead_attention.py:199-217,346) are 9-36 such tiles each: launched alone
  * each has to be cut into 3-7 short K-slices to occupy the chip; together they fill it with ~2 long slices each.
- * The slabs are finished by ofa_fold_batched (out (+)= alpha * sum_s slabs[s]).  16-bit operands; k % 64 == 0, m, n, lda,
- * ldb % 8 == 0, 16-byte aligned pointers.  `items` is a HOST array. */
+ * The slabs are finished by ofa_fold_batched (out (+)= alpha * sum_s slabs[s]).  16-bit operands; any k >= 1 (a row count that
+ * is not a multiple of the 64-row K tile is completed with zero rows inside the kernel), m, n, lda, ldb % 8 == 0, 16-byte aligned
+ * pointers.  `items` is a HOST array. */
 typedef struct ofa_gemm_group_item {
   const void* a;     /* [k, m] rows (lda >= m): output-gradient rows dY */
   const void* b;     /* [k, n] rows (ldb >= n): layer-input rows X */

@@ -211,8 +211,15 @@ __device__ __forceinline__ void frag_issue(u64x2& d, const FragAddr<R, KMAJ>& fa
   }
 }
 
+// 16 zero bytes: the LDS-DMA source of the contraction rows past the end of an m-major A (glds_ptrs<.., ZERO>).  A weight gradient
+// dW = dY^T X contracts over the ROWS; when their number is not a multiple of the 64-row K tile (1568 = 8 x 14 x 14 positions of the
+// ResNet trunk at micro-batch 8; any ragged batch), the last tile's missing rows of A are fetched from here -- the DMA source
+// address is per lane and arbitrary -- and B's are clamped to its last row: 0 x finite = 0.  Such products used to take the
+// register-staged loop (46 us for a product the DMA loop does in ~10: 14 % of the cfg-3 step, round 4 profile).
+__device__ uint4 ofa_zero16 = {0u, 0u, 0u, 0u};
+
 // DMA source pointers of one operand tile, advanced by a constant stride per K-step.
-template <int R, bool KMAJ, int NT, int NV>
+template <int R, bool KMAJ, int NT, int NV, bool ZERO = false>
 __device__ __forceinline__ void glds_ptrs(const bf16_t* (&ptr)[NV], const bf16_t* __restrict__ base, int64_t ld, int r0,
                                           int rmax, int k0, int tid, int krows = 0x7fffffff) {
 #pragma unroll
@@ -230,8 +237,10 @@ __device__ __forceinline__ void glds_ptrs(const bf16_t* (&ptr)[NV], const bf16_t
       const int last = ((rmax + 7) & ~7) - 8;
       col = col < last ? col : last;
       int kr = k0 + k;
-      kr = kr < krows ? kr : krows - 1;       // rows past the operand's end (zero-padded contraction tail) are clamped
+      const bool past = kr >= krows;
+      kr = past ? krows - 1 : kr;             // rows past the operand's end (zero-padded contraction tail) are clamped ...
       ptr[i] = base + (int64_t)kr * ld + col;
+      if (ZERO && past) ptr[i] = reinterpret_cast<const bf16_t*>(&ofa_zero16);      // ... or, for A, read as zeros
     }
   }
 }
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     // K (and every split) is a multiple of BK: all tiles are full, rows/columns outside M/N are clamped reads
     const bf16_t* pa[NVA];
     const bf16_t* pb[NVB];
-    glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+    glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, kbeg, tid, g.a_krows);
     glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
     const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
     int knext = kbeg;
@@ -539,6 +548,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
     __syncthreads();
     OFA_TL(1);
     if (nk > 1) {                      // tile 1 travels under the whole of K-step 0
+      if (!A_KMAJ && knext + BK > g.a_krows)     // ragged contraction tail: A's missing k rows read as zeros
+        glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);
       if (!B_KMAJ && knext + BK > g.b_krows)     // zero-padded contraction tail: clamp B's k rows
         glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
       glds_issue<NT, NVA>(pa, stepA, sA[1], wave_u);
@@ -596,6 +607,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmArgs g, int 
         __syncthreads();               /* ... for every wave, and every wave is done reading this stage */ \
       }                                                                                                \
       const bool more2 = (MORE2);                                                                      \
+      if (more2 && !A_KMAJ && knext + BK > g.a_krows)   /* ragged contraction tail: A's missing k rows read as zeros */ \
+        glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);            \
       if (more2 && !B_KMAJ && knext + BK > g.b_krows)   /* zero-padded contraction tail: clamp B's k rows */ \
         glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);                  \
       OFA_SB;                                                                                          \
@@ -742,11 +755,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* pa[NVA];
   const bf16_t* pb[NVB];
-  glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, kbeg, tid, g.a_krows);
   glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
   const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
   int knext = kbeg;
   auto dma = [&](int stage) {
+    if (!A_KMAJ && knext + BK > g.a_krows)                            // ragged contraction tail: A's missing k rows read as zeros
+      glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);
     if (!B_KMAJ && knext + BK > g.b_krows)                            // zero-padded contraction tail: clamp B's k rows
       glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
     bf16_t* st = reinterpret_cast<bf16_t*>(smem_raw + (size_t)stage * STG);
@@ -783,6 +798,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ring_kernel(GemmArgs g, int 
     // MFMAs is as long as the MFMAs themselves (the ring tolerates the later issue: the tile is not needed for 3 steps)
     const bool refill = issued < nk;
     bf16_t* rst = reinterpret_cast<bf16_t*>(smem_raw + (size_t)((stage + S - 1) % S) * STG);
+    if (refill && !A_KMAJ && knext + BK > g.a_krows)
+      glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);
     if (refill && !B_KMAJ && knext + BK > g.b_krows)
       glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
     u64x2 x0[TMW], w0[TNW], x1[TMW], w1[TNW];
@@ -961,11 +978,13 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* pa[NVA];
   const bf16_t* pb[NVB];
-  glds_ptrs<BM, A_KMAJ, NT, NVA>(pa, A, g.lda, m0, g.M, kbeg, tid);
+  glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, kbeg, tid, g.a_krows);
   glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
   const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
   int knext = kbeg;
   auto dma = [&](bf16_t* da, bf16_t* db) {
+    if (!A_KMAJ && knext + BK > g.a_krows)                  // ragged contraction tail: A's missing k rows read as zeros
+      glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);
     if (!B_KMAJ && knext + BK > g.b_krows)                  // zero-padded contraction tail: clamp B's k rows
       glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
     glds_issue<NT, NVA>(pa, stepA, da, wave_u);
@@ -1040,6 +1059,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
         __syncthreads();
       }
       const bool more2 = kt + 2 < nk;     // refill the retired stage with tile kt+2 ...
+      if (more2 && !A_KMAJ && knext + BK > g.a_krows)          // ragged contraction tail: A's missing k rows read as zeros
+        glds_ptrs<BM, A_KMAJ, NT, NVA, true>(pa, A, g.lda, m0, g.M, knext, tid, g.a_krows);
       if (more2 && !B_KMAJ && knext + BK > g.b_krows)          // zero-padded contraction tail: clamp B's k rows
         glds_ptrs<BN, B_KMAJ, NT, NVB>(pb, B, g.ldb, n0, g.N, knext, tid, g.b_krows);
 #pragma unroll
@@ -1122,7 +1143,7 @@ constexpr int GROUP_MAX = 8;
 struct GroupItem {
   const void* A; const void* B; float* ws;
   int64_t lda, ldb;
-  int M, N, K, ksplit, splits, tiles_m, tiles_n, first;   // first: index of the item's first workgroup
+  int M, N, K, krows, ksplit, splits, tiles_m, tiles_n, first;   // K: rounded up to whole K tiles, krows: the real row count; first: index of the item's first workgroup
 };
 struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total; };
 
@@ -1138,7 +1159,7 @@ __global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
   g.A = it.A; g.B = it.B; g.C = nullptr; g.bias = nullptr;
   g.M = it.M; g.N = it.N; g.K = it.K; g.transA = 1; g.transB = 0;
   g.lda = it.lda; g.ldb = it.ldb; g.ldc = 0; g.strideA = g.strideB = g.strideC = 0;
-  g.alpha = 1.f; g.flags = 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.b_krows = it.K;
+  g.alpha = 1.f; g.flags = 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.a_krows = g.b_krows = it.krows;
   const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
   const int ks = local / ntiles, t = local - ks * ntiles;
   gemm_big_body<4, 2, false, false, true, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, true);
@@ -1274,6 +1295,9 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
   // padded K; A's tail columns are zeros, B's rows past K are clamped reads
   if ((g.flags & OFA_GEMM_A_KPAD_ZERO) && !g.transA && !g.transB && (g.K % BK) != 0 && ((g.K + BK - 1) / BK) * BK <= g.lda)
     g.K = ((g.K + BK - 1) / BK) * BK;
+  // weight gradients over a row count that is not a multiple of 64 (both operands m-major): the LDS-DMA loop over the rounded-up K,
+  // A's missing rows read as zeros, B's clamped (a_krows / b_krows = the real count, set by the launcher)
+  if (g.transA && !g.transB && (g.K % BK) != 0 && !(g.flags & OFA_GEMM_NO_LDS_DMA)) g.K = ((g.K + BK - 1) / BK) * BK;
   // tile choice: the biggest tile that, together with split-K (when a workspace is given and K is long), still puts
   // >= ~1.5 workgroups on every CU; 128x128 tiles halve the LDS traffic per flop of 64-wide ones.
   const int64_t t22 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
@@ -1359,7 +1383,7 @@ int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes) { return ge
 
 int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool f16) {
   GemmArgs g = g_in;
-  g.b_krows = g.K;
+  g.a_krows = g.b_krows = g.K;
   const GemmPlan pl = gemm_plan(g, batch, ws != nullptr, ws_bytes);
   g.K = pl.K;
   const int wm = pl.wm, wn = pl.wn, big_tm = pl.big_tm, splits = pl.splits, ksplit = pl.ksplit;
@@ -1406,7 +1430,7 @@ extern "C" int ofa_gemm_splits(int M, int N, int K, int transA, int transB, int 
 // ---- grouped weight-gradient products
 static bool group_item_ok(const ofa_gemm_group_item& it) {
   if (it.m <= 0 || it.n <= 0 || it.k <= 0 || !it.a || !it.b) return false;
-  if ((it.k % BK) || (it.m & 7) || (it.n & 7)) return false;          // whole LDS-DMA K tiles; 16-byte vectors along m and n
+  if ((it.m & 7) || (it.n & 7)) return false;                         // 16-byte vectors along m and n (k: any row count, see ofa_zero16)
   if (it.lda < it.m || it.ldb < it.n || (it.lda & 7) || (it.ldb & 7)) return false;
   if (((uintptr_t)it.a & 15) || ((uintptr_t)it.b & 15)) return false;
   return true;
@@ -1418,6 +1442,7 @@ static bool group_item_ok(const ofa_gemm_group_item& it) {
 static void group_plan(ofa_gemm_group_item* items, int n) {
   int kmax = 0;
   for (int p = 0; p < n; ++p) kmax = items[p].k > kmax ? items[p].k : kmax;
+  kmax = cdiv(kmax, BK) * BK;
   int len = kmax;
   for (int l = 4 * BK; l < kmax; l += BK) {
     int64_t wgs = 0;
@@ -1437,7 +1462,7 @@ extern "C" int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype)
   OFA_REQUIRE(items && n >= 1 && n <= GROUP_MAX, OFA_ERR_INVALID, "gemm_group: 1..%d products per launch (got %d)", GROUP_MAX, n);
   for (int p = 0; p < n; ++p)
     OFA_REQUIRE(group_item_ok(items[p]), OFA_ERR_INVALID,
-                "gemm_group: product %d (m=%d n=%d k=%d lda=%lld ldb=%lld) needs k %% 64 == 0, m, n, lda, ldb %% 8 == 0 and 16-byte aligned operands",
+                "gemm_group: product %d (m=%d n=%d k=%d lda=%lld ldb=%lld) needs m, n, lda, ldb %% 8 == 0 and 16-byte aligned operands",
                 p, items[p].m, items[p].n, items[p].k, (long long)items[p].lda, (long long)items[p].ldb);
   group_plan(items, n);
   return 0;
@@ -1454,7 +1479,7 @@ extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dt
     OFA_REQUIRE(it.splits >= 1 && it.splits <= 32, OFA_ERR_INVALID, "gemm_group: product %d: splits %d (run ofa_gemm_group_plan)", p, it.splits);
     GroupItem& d = ga.it[p];
     d.A = it.a; d.B = it.b; d.ws = it.slabs; d.lda = it.lda; d.ldb = it.ldb;
-    d.M = it.m; d.N = it.n; d.K = it.k;
+    d.M = it.m; d.N = it.n; d.K = cdiv(it.k, BK) * BK; d.krows = it.k;
     d.ksplit = cdiv(cdiv(it.k, BK), it.splits) * BK;
     d.splits = it.splits;
     OFA_REQUIRE(cdiv(it.k, d.ksplit) == it.splits, OFA_ERR_INVALID, "gemm_group: product %d: %d slices leave an empty one", p, it.splits);

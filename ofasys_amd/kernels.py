@@ -240,7 +240,7 @@ GROUP_MAX = 8
 def gemm_group_ok(dy, x, out):
     """Can out[M,N] (+)= dy[K,M]^T x[K,N] ride in a grouped launch (ofa_gemm_group_tn)?"""
     return (dy.dim() == 2 and x.dim() == 2 and dy.dtype in (torch.bfloat16, torch.float16) and x.dtype == dy.dtype
-            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0] and dy.shape[0] % 64 == 0
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0] and dy.shape[0] >= 1
             and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.is_contiguous())
 

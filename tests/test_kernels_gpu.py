@@ -64,7 +64,7 @@ def test_layernorm(K, dtype, rows, cols, gelu):
 
 
 GEMM_SHAPES = [(64, 64, 64), (128, 128, 128), (200, 136, 72), (130, 768, 256), (534, 264, 768), (77, 64, 1032),
-               (256, 3072, 768), (1000, 208, 264)]
+               (256, 3072, 768), (1000, 208, 264), (1024, 256, 1568), (256, 2304, 40)]      # (the last two: ragged-K weight-gradient shapes)
 
 
 @pytest.mark.parametrize("M,N,K_", [(3584, 4096, 4096), (3320, 3848, 4160), (4032, 3072, 256), (13312, 768, 768)])
@@ -159,6 +159,9 @@ def test_gemm(K, dtype, M, N, K_, ta, tb):
     [(768, 3072, 1024), (3072, 768, 1024), (2304, 768, 1024), (768, 768, 1024)],          # one encoder layer's four products
     [(768, 768, 512), (1536, 768, 2048), (200, 776, 512), (8, 8, 64), (264, 256, 1088)],   # unequal K, ragged M / N, a tiny one
     [(256, 256, 64)] * 8,                                                                  # the most one launch takes
+    # row counts that are not a multiple of the 64-row K tile (round 4: A's missing rows are read as zeros inside the kernel):
+    # 1568 = 8 x 14 x 14 positions of the ResNet trunk at micro-batch 8, a contraction shorter than one tile, 64 k + 1 rows
+    [(256, 1024, 1568), (1024, 256, 1568), (256, 2304, 1568), (768, 768, 40), (264, 200, 1025)],
 ])
 def test_gemm_group_tn(K, dtype, shapes):
     """ofa_gemm_group_tn + ofa_fold_batched: out_p += alpha_p * dy_p^T x_p for a group of weight-gradient products, against fp32
@@ -183,8 +186,8 @@ def test_gemm_group_tn(K, dtype, shapes):
     q.flush()
     dy, x, out, alpha = prods[0]
     assert rel(out, refs[0] + alpha * (dy.float().t() @ x.float())) < 1e-4
-    # not eligible: ragged contraction, fp32 operands
-    assert not K.gemm_group_ok(dy[:40], x[:40], out)
+    # a ragged contraction is eligible (since round 4); fp32 operands are not
+    assert K.gemm_group_ok(dy[:40], x[:40], out)
     assert not K.gemm_group_ok(dy.float(), x.float(), out)
 
 

@@ -105,6 +105,15 @@ int ofa_gemm(const void* A, const void* B, void* C, const void* bias, int M, int
              int batch_inner, int64_t strideA2, int64_t strideB2, int64_t strideC2,
              float alpha, int flags, int dtype, void* ws, int64_t ws_bytes, void* stream);
 
+/* ofa_gemm (one product, no batch) that ALSO leaves the per-column (sum, sum of squares) of its rounded 16-bit output as partial rows
+ * [groups][2][N] fp64, one per wave block of rows, written by the kernel's epilogue from the tile it holds anyway -- the statistics
+ * pass of a BatchNorm behind a convolution (module/resnet.py:105-128) for free.  *groups (HOST int, set before the call returns) is
+ * the number of partial rows written, or 0 when the selected plan cannot produce them (split-K, fp32 output, accumulation, N % 8,
+ * more than max_groups rows): the product is computed either way and the caller then runs its own statistics pass. */
+int ofa_gemm_colstat(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA, int transB,
+                     int64_t lda, int64_t ldb, int64_t ldc, float alpha, int flags, int dtype, void* ws, int64_t ws_bytes,
+                     double* partial, int max_groups, int* groups, void* stream);
+
 /* ---- grouped weight-gradient products: up to 8 independent  slabs_p[s][m][n] = sum over K-slice s of a_p^T b_p  in ONE
  * launch (256 x 256 eight-wave tiles).  The nn.Linear weight gradients of one Transformer layer (dW = dY^T X, what autograd
  * computes for transformer_layer.py:194,202 and multihead_attention.py:199-217,346) are 9-36 such tiles each: launched alone
@@ -417,11 +426,13 @@ int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, const void* 
  *             this rank's `rows` rows;
  *   backward  bwd_stats: sums [2][C] fp32 = this rank's (sum g, sum g*xhat); dgamma / dbeta from them (rank-local, like every other
  *             gradient before the gradient exchange) -> all-reduce -> bwd_dx: dx (and dres) with the reduced sums / *total_rows
- *             (device pointer: element 2*C of the forward's reduced sums). */
+ *             (device pointer: element 2*C of the forward's reduced sums).
+ * fwd_apply with groups > 0 is also the BatchNorm forward BEHIND A CONVOLUTION whose GEMM left the column statistics of its output
+ * as `groups` partial rows [groups][2][C] fp64 (ofa_gemm_colstat): no statistics pass over the activation at all. */
 int ofa_batchnorm_fwd_stats(const void* x, double* sums, float* ws, int64_t rows, int C, int dtype, void* stream);
 int ofa_batchnorm_fwd_apply(const void* x, const void* gamma, const void* beta, const void* residual, void* y, float* mean,
-                            float* rstd, float* running_mean, float* running_var, const double* sums, int64_t rows, int C,
-                            float eps, float momentum, int relu, int dtype, void* stream);
+                            float* rstd, float* running_mean, float* running_var, const double* sums, int groups, int64_t rows,
+                            int C, float eps, float momentum, int relu, int dtype, void* stream);
 int ofa_batchnorm_bwd_stats(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
                             float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate,
                             const void* beta, int dtype, void* stream);

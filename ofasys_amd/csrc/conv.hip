@@ -244,17 +244,21 @@ __global__ __launch_bounds__(256) void bn_colstat_kernel(const T* __restrict__ x
 __device__ __forceinline__ void bn_fold_groups(const double* __restrict__ partial, int groups, int C, int c, int gl, double& s,
                                                double& q) {
   __shared__ double red[2][16][16];
-  double a[16], b[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int g = gl + 16 * i;
-    const bool ok = c < C && g < groups;                    // groups <= 256 (bn_groups)
-    a[i] = ok ? partial[((int64_t)g * 2) * C + c] : 0.0;
-    b[i] = ok ? partial[((int64_t)g * 2 + 1) * C + c] : 0.0;
-  }
   double sa = 0.0, sb = 0.0;
+  // 256 groups per trip (the statistics kernels write at most 256; the partial rows a convolution's GEMM epilogue leaves -- one per
+  // wave block of 32 .. 128 rows -- can be more)
+  for (int g0 = 0; g0 < groups; g0 += 256) {
+    double a[16], b[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { sa += a[i]; sb += b[i]; }
+    for (int i = 0; i < 16; ++i) {
+      const int g = g0 + gl + 16 * i;
+      const bool ok = c < C && g < groups;
+      a[i] = ok ? partial[((int64_t)g * 2) * C + c] : 0.0;
+      b[i] = ok ? partial[((int64_t)g * 2 + 1) * C + c] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sa += a[i]; sb += b[i]; }
+  }
   red[0][gl][threadIdx.x & 15] = sa;
   red[1][gl][threadIdx.x & 15] = sb;
   __syncthreads();
@@ -631,14 +635,17 @@ extern "C" int ofa_batchnorm_fwd_stats(const void* x, double* sums, float* ws, i
 
 extern "C" int ofa_batchnorm_fwd_apply(const void* x, const void* gamma, const void* beta, const void* residual, void* y,
                                        float* mean, float* rstd, float* running_mean, float* running_var, const double* sums,
-                                       int64_t rows, int C, float eps, float momentum, int relu, int dtype, void* stream) {
+                                       int groups, int64_t rows, int C, float eps, float momentum, int relu, int dtype,
+                                       void* stream) {
   OFA_DT("batchnorm_fwd_apply");
-  OFA_REQUIRE(x && gamma && beta && y && mean && rstd && sums && rows > 0 && C > 0, OFA_ERR_INVALID,
+  OFA_REQUIRE(x && gamma && beta && y && mean && rstd && sums && groups >= 0 && rows > 0 && C > 0, OFA_ERR_INVALID,
               "batchnorm_fwd_apply: bad argument");
   OFA_REQUIRE(C % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d is not vectorizable", C);
   hipStream_t st = (hipStream_t)stream;
-  // the reduced sums are ONE group of partials over sums[2*C] rows
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, 1, C, rows, eps, momentum, mean, rstd, running_mean, running_var, sums + 2 * (int64_t)C);
+  if (groups == 0)   // SyncBatchNorm: the reduced sums are ONE group of partials over sums[2*C] rows (the count lives on the device)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, 1, C, rows, eps, momentum, mean, rstd, running_mean, running_var, sums + 2 * (int64_t)C);
+  else               // `groups` partial rows [groups][2][C] over this launch's `rows` rows, e.g. left by ofa_gemm_colstat's epilogue
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var, (const double*)nullptr);
   int rc = check_launch("batchnorm_fwd_apply");
   if (rc) return rc;
   return bn_apply_launch(x, gamma, beta, residual, y, mean, rstd, rows, C, relu, dtype, st);

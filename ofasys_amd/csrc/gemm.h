@@ -11,6 +11,9 @@ struct GemmArgs {
   int batch_inner;                       // batch index z -> (z / batch_inner, z % batch_inner)
   int64_t strideA2, strideB2, strideC2;  // outer strides (elements)
   int b_krows;                           // valid k rows of an m-major B (== K unless the contraction is zero-padded)
+  double* colstat;                       // optional: per-column (sum, sum of squares) of the ROUNDED output, one partial row per wave
+                                         // block of rows -- [groups][2][N] fp64, groups = ceil(M / colstat_rows) (epilogue_lds; BatchNorm)
+  int colstat_rows;                      // rows per partial row (the launcher fills it: 32 * accumulator tiles per wave along M)
   int a_krows;                           // valid k rows of an m-major A (weight gradients over a row count that is not a multiple of 64)
 };
 __host__ __device__ inline int64_t batch_off(int z, int inner, int64_t s_in, int64_t s_out) {

@@ -355,6 +355,23 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
         for (int e = 0; e < 4; ++e) bcol[j][q][e] = 0.f;
   }
   const float alpha = RAW ? 1.0f : g.alpha;
+  // Column statistics of the rounded tile (g.colstat, 16-bit outputs): the 16-byte row segments this lane reads back are 8 columns of
+  // rows lane / LPR, + RPI, ...: their sums and sums of squares ride in 16 registers, are folded over the RPI row lanes at the end and
+  // land in ONE partial row per wave block -- the statistics pass of the BatchNorm that follows a convolution (csrc/conv.hip) reads
+  // nothing but these partial rows (module/resnet.py:105-128: every convolution of the trunk is followed by a BatchNorm).
+  const bool stats = !F32 && !RAW && g.colstat != nullptr;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+  auto stat8 = [&](const uint4& u) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = lo16<F16>(w[j]), hi = hi16<F16>(w[j]);
+      cs[2 * j] += lo; cq[2 * j] += lo * lo;
+      cs[2 * j + 1] += hi; cq[2 * j + 1] += hi * hi;
+    }
+  };
   for (int ip0 = 0; ip0 < TM; ip0 += ipass) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -396,6 +413,17 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
       const int rows_full = (TM - ip0 < ipass ? TM - ip0 : ipass) * 32;
       unsigned char* p = (unsigned char*)Cb + ((int64_t)(m_w + ip0 * 32 + lane / LPR) * ldc + n) * E;
       const int64_t pstep = (int64_t)RPI * ldc * E;
+      if (stats) {
+#pragma unroll 8
+        for (int r0 = 0; r0 < rows_full; r0 += RPI) {
+          const int mloc = r0 + lane / LPR;
+          const uint4 u = *reinterpret_cast<const uint4*>(wl + mloc * ROWB + ((c ^ ((mloc >> SH) & (CH - 1))) << 4));
+          *reinterpret_cast<uint4*>(p) = u;
+          stat8(u);
+          p += pstep;
+        }
+        continue;
+      }
 #pragma unroll 8
       for (int r0 = 0; r0 < rows_full; r0 += RPI) {
         const int mloc = r0 + lane / LPR;
@@ -411,6 +439,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
       const int m = m_w + ip0 * 32 + mloc;
       const uint4 u = *reinterpret_cast<const uint4*>(wl + mloc * ROWB + ((c ^ ((mloc >> SH) & (CH - 1))) << 4));
       if (m >= g.M || n >= g.N) continue;
+      if (stats) stat8(u);                             // (N % 8 == 0 when statistics are requested: the whole chunk is inside the row)
       if (F32) {
         float* p = (float*)Cb + (int64_t)m * ldc + n;
         float4 o = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
@@ -441,6 +470,27 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
           *reinterpret_cast<uint2*>(p) = make_uint2(o.x, o.y);
           if (second) *reinterpret_cast<uint2*>(p + 4) = make_uint2(o.z, o.w);
         }
+      }
+    }
+  }
+  if (stats) {
+    // fold over the RPI lanes that hold the same 8 columns (lane % LPR), then lanes 0 .. LPR - 1 write the wave block's partial row
+#pragma unroll
+    for (int mask = LPR; mask < 64; mask <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cs[j] += __shfl_xor(cs[j], mask, 64);
+        cq[j] += __shfl_xor(cq[j], mask, 64);
+      }
+    }
+    const int grp = m_w / (TM * 32);
+    const int n = n_w + (lane % LPR) * 8;
+    if (lane < LPR && m_w < g.M && n < g.N) {
+      double* ps = g.colstat + ((int64_t)grp * 2) * g.N + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ps[j] = (double)cs[j];
+        ps[g.N + j] = (double)cq[j];
       }
     }
   }
@@ -1160,6 +1210,7 @@ __global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
   g.M = it.M; g.N = it.N; g.K = it.K; g.transA = 1; g.transB = 0;
   g.lda = it.lda; g.ldb = it.ldb; g.ldc = 0; g.strideA = g.strideB = g.strideC = 0;
   g.alpha = 1.f; g.flags = 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.a_krows = g.b_krows = it.krows;
+  g.colstat = nullptr; g.colstat_rows = 0;
   const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
   const int ks = local / ntiles, t = local - ks * ntiles;
   gemm_big_body<4, 2, false, false, true, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, true);
@@ -1381,10 +1432,30 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
 
 int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes) { return gemm_plan(g, batch, ws_bytes > 0, ws_bytes).splits; }
 
+// rows per column-statistics partial row of the kernel the plan selects (0: that kernel cannot produce them): the accumulator
+// rows of one wave, 32 * TM (epilogue_lds)
+static int plan_colstat_rows(const GemmArgs& g, const GemmPlan& pl, int batch) {
+  if (pl.splits > 1 || batch != 1) return 0;
+  if (pl.big_tm) return pl.big_tm * 32;
+  GemmArgs gp = g;
+  gp.K = pl.K;
+  const int64_t blocks = (int64_t)cdiv(g.M, 64 * pl.wm) * cdiv(g.N, 64 * pl.wn) * pl.splits * batch;
+  return (use_ring(gp, pl.wm, pl.wn, blocks, pl.ksplit) && pl.wm == 1) ? 32 : 64;      // (the four-wave ring forms: 32-row wave blocks)
+}
+
+int gemm_mfma_colstat_groups(const GemmArgs& g_in, void* ws, int64_t ws_bytes) {
+  GemmArgs g = g_in;
+  if ((g.flags & (OFA_GEMM_OUT_F32 | OFA_GEMM_ACCUM)) || (g.N & 7)) return 0;
+  const GemmPlan pl = gemm_plan(g, 1, ws != nullptr, ws_bytes);
+  const int rows = plan_colstat_rows(g, pl, 1);
+  return rows ? cdiv(g.M, rows) : 0;
+}
+
 int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool f16) {
   GemmArgs g = g_in;
   g.a_krows = g.b_krows = g.K;
   const GemmPlan pl = gemm_plan(g, batch, ws != nullptr, ws_bytes);
+  if (g.colstat) g.colstat_rows = plan_colstat_rows(g, pl, batch);
   g.K = pl.K;
   const int wm = pl.wm, wn = pl.wn, big_tm = pl.big_tm, splits = pl.splits, ksplit = pl.ksplit;
   const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
@@ -1522,4 +1593,26 @@ extern "C" int ofa_gemm(const void* A, const void* B, void* C, const void* bias,
   if (dtype != OFA_F32 && !(flags & OFA_GEMM_FORCE_SIMPLE) && K > 0 && gemm_mfma_supported(g))
     return gemm_mfma_launch(g, batch, ws, ws_bytes, st, dtype == OFA_F16);
   return gemm_simple_launch(g, batch, dtype, st);
+}
+
+extern "C" int ofa_gemm_colstat(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int transA, int transB,
+                                int64_t lda, int64_t ldb, int64_t ldc, float alpha, int flags, int dtype, void* ws, int64_t ws_bytes,
+                                double* partial, int max_groups, int* groups, void* stream) {
+  OFA_REQUIRE(groups, OFA_ERR_INVALID, "gemm_colstat: groups must not be NULL");
+  *groups = 0;
+  OFA_REQUIRE(OFA_DT_OK(dtype), OFA_ERR_INVALID, "gemm_colstat: bad dtype %d", dtype);
+  OFA_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, OFA_ERR_INVALID, "gemm_colstat: bad argument");
+  OFA_REQUIRE(!(flags & (OFA_GEMM_BIAS_COL | OFA_GEMM_BIAS_ROW)) || bias, OFA_ERR_INVALID, "gemm_colstat: bias flag without bias");
+  OFA_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, OFA_ERR_INVALID, "gemm_colstat: leading dimension too small");
+  GemmArgs g{A, B, C, bias, M, N, K, transA, transB, lda, ldb, ldc, 0, 0, 0, alpha, flags, 1, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype != OFA_F32 && !(flags & OFA_GEMM_FORCE_SIMPLE) && gemm_mfma_supported(g)) {
+    const int ng = partial ? gemm_mfma_colstat_groups(g, ws, ws_bytes) : 0;
+    if (ng > 0 && ng <= max_groups) {
+      g.colstat = partial;
+      *groups = ng;
+    }
+    return gemm_mfma_launch(g, 1, ws, ws_bytes, st, dtype == OFA_F16);
+  }
+  return gemm_simple_launch(g, 1, dtype, st);
 }

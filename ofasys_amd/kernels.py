@@ -228,6 +228,37 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, bias_row=False, alpha=1.
     return out
 
 
+def gemm_colstat(a, b, bias=None, max_groups=512):
+    """out = a @ b^T (+ bias) like gemm(a, b, False, True), plus the per-column (sum, sum of squares) of the rounded output as partial
+    rows [groups, 2, N] fp64 left by the kernel's epilogue (ofa_gemm_colstat), or None when the selected plan cannot produce them."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    M, Kd, N = a.shape[0], a.shape[1], b.shape[0]
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if a.dtype == torch.float32 or N % 8:
+        return gemm(a, b, False, True, bias=bias, out=out), None
+    flags = GEMM_BIAS_COL if bias is not None else 0
+    ws = workspace(256 << 20, a.device, "gemm")
+    cap = min(max_groups, (M + 31) // 32)
+    partial = torch.empty(cap, 2, N, dtype=torch.float64, device=a.device)
+    groups = ctypes.c_int(0)
+    args = ("ofa_gemm_colstat", ptr(a), ptr(b), ptr(out), ptr(bias), M, N, Kd, 0, 1, a.stride(0), b.stride(0), out.stride(0), 1.0,
+            flags, dtype_code(a), ptr(ws), ws.numel() * 4, ptr(partial), cap, ctypes.addressof(groups), stream())
+    if _prof is not None:                        # roofline timing in situ (see gemm)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib().call(*args)
+        e1.record()
+        _prof.append((2.0 * M * N * Kd, e0, e1, (M * Kd + Kd * N + M * N) * a.element_size()))
+    else:
+        lib().call(*args)
+    return out, (partial[:groups.value] if groups.value > 0 else None)
+
+
 class _GroupItem(ctypes.Structure):     # ofa_gemm_group_item
     _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("lda", ctypes.c_int64),
                 ("ldb", ctypes.c_int64), ("m", ctypes.c_int32), ("n", ctypes.c_int32), ("k", ctypes.c_int32),
@@ -996,8 +1027,9 @@ def batchnorm_fwd_stats(x):
     return sums
 
 
-def batchnorm_fwd_apply(x, gamma, beta, running_mean, running_var, sums, momentum, eps, relu=False, residual=None):
-    """SyncBatchNorm, forward phase 2: statistics from the all-reduced sums; returns y, mean, rstd."""
+def batchnorm_fwd_apply(x, gamma, beta, running_mean, running_var, sums, momentum, eps, relu=False, residual=None, groups=0):
+    """Forward from statistics that exist already; returns y, mean, rstd.  groups = 0: SyncBatchNorm phase 2 (`sums` = the
+    all-reduced [2C + 1] sums); groups > 0: `sums` = [groups, 2, C] partial rows over x's rows (a convolution's GEMM epilogue)."""
     x = x.contiguous()
     rows, C = x.shape
     y = torch.empty_like(x)
@@ -1006,7 +1038,8 @@ def batchnorm_fwd_apply(x, gamma, beta, running_mean, running_var, sums, momentu
     if residual is not None:
         residual = residual.contiguous()
     lib().call("ofa_batchnorm_fwd_apply", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(rstd),
-               ptr(running_mean), ptr(running_var), ptr(sums), rows, C, float(eps), float(momentum), int(relu), dtype_code(x), stream())
+               ptr(running_mean), ptr(running_var), ptr(sums), int(groups), rows, C, float(eps), float(momentum), int(relu),
+               dtype_code(x), stream())
     return y, mean, rstd
 
 

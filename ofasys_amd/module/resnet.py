@@ -24,10 +24,6 @@ def conv1x1(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
 
 
-def _conv(x, conv: nn.Conv2d, B, H, W, nchw=False):
-    return ops.conv2d(x, conv.weight, conv.bias, B, H, W, conv.stride[0], conv.padding[0], nchw)
-
-
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -55,21 +51,17 @@ class Bottleneck(nn.Module):
         # GEMM, which accumulates onto it, instead of a separate add of two [B*H*W, C] tensors per block (ops.batch_norm)
         dropping = self.training and self.drop_path.drop_prob > 0.0
         mailbox = [] if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad and not dropping) else None
-        out, _, _ = ops.conv2d(x, self.conv1.weight, self.conv1.bias, B, H, W, self.conv1.stride[0], self.conv1.padding[0],
-                               grad_mailbox=mailbox)
-        out = ops.batch_norm(out, self.bn1, relu=True)
-        out, Ho, Wo = _conv(out, self.conv2, B, H, W)
-        out = ops.batch_norm(out, self.bn2, relu=True)
-        out, _, _ = _conv(out, self.conv3, B, Ho, Wo)
+        # conv_bn: in training the BatchNorm's statistics come out of the convolution's GEMM epilogue (no pass over its output)
+        out, _, _ = ops.conv_bn(x, self.conv1, self.bn1, B, H, W, relu=True, conv_mailbox=mailbox)
+        out, Ho, Wo = ops.conv_bn(out, self.conv2, self.bn2, B, H, W, relu=True)
         identity = x
         if self.downsample is not None:
-            identity, _, _ = _conv(x, self.downsample[0], B, H, W)
-            identity = ops.batch_norm(identity, self.downsample[1])
+            identity, _, _ = ops.conv_bn(x, self.downsample[0], self.downsample[1], B, H, W)
         if dropping:                                          # relu(identity + drop_path(bn3(out))), module/resnet.py:127-135
-            out = ops.batch_norm(out, self.bn3)
+            out, _, _ = ops.conv_bn(out, self.conv3, self.bn3, B, Ho, Wo)
             out = self.drop_path(out.view(B, Ho * Wo, out.shape[1])).reshape(B * Ho * Wo, out.shape[1])
             return ops.relu(ops.dropout_add(out, identity, 0.0, False)), B, Ho, Wo
-        out = ops.batch_norm(out, self.bn3, relu=True, residual=identity, grad_mailbox=mailbox)   # relu(identity + bn3(out))
+        out, _, _ = ops.conv_bn(out, self.conv3, self.bn3, B, Ho, Wo, relu=True, residual=identity, bn_mailbox=mailbox)   # relu(identity + bn3(out))
         return out, B, Ho, Wo
 
 
@@ -135,8 +127,7 @@ class ResNet(nn.Module):
         its caller immediately flattens to [B, h*w, 1024] (adaptor/image_resnet.py:159) -- the same rows."""
         B, _, H, W = x.shape
         with ops.bn_scope():
-            out, H, W = _conv(x, self.conv1, B, H, W, nchw=True)
-            out = ops.batch_norm(out, self.bn1, relu=True)
+            out, H, W = ops.conv_bn(x, self.conv1, self.bn1, B, H, W, relu=True, nchw=True)
             out, H, W = ops.max_pool(out, B, H, W, self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding)
             fm = (out, B, H, W)
             for layer in (self.layer1, self.layer2, self.layer3):

@@ -1463,7 +1463,9 @@ class Conv2dFn(torch.autograd.Function):
     (module/resnet.py:22-38, module/subsample.py:29-35).  weight keeps torch's [Cout, Cin, kh, kw] layout (state dict)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, mailbox=None):
+    def forward(ctx, x, weight, bias, geom, mailbox=None, want_stats=False):
+        """-> (y, stats): stats = the column statistics of y as partial rows [groups, 2, Cout] fp64 left by the GEMM's epilogue when
+        `want_stats` (a BatchNorm follows: conv_bn) and the selected kernel can produce them, else an empty tensor."""
         B, H, W, stride, pad, nchw = geom
         ctx.mailbox = mailbox
         Cout, Cin, kh, kw = weight.shape
@@ -1479,14 +1481,21 @@ class Conv2dFn(torch.autograd.Function):
             if col.shape[1] != w2.shape[1]:
                 w2 = torch.nn.functional.pad(w2, (0, col.shape[1] - w2.shape[1]))
             w2 = w2.contiguous()
-        y = K.gemm(col, w2, False, True, bias=bias)
+        stats = None
+        if want_stats:
+            y, stats = K.gemm_colstat(col, w2, bias=bias)
+        else:
+            y = K.gemm(col, w2, False, True, bias=bias)
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float64, device=y.device)
+        ctx.mark_non_differentiable(stats)
         ctx.save_for_backward(col, w2)
         ctx.geom = (B, H, W, Cin, kh, kw, stride, pad, nchw, direct)
         ctx.refs = (weight, bias)
-        return y
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         col, w2 = ctx.saved_tensors
         B, H, W, Cin, kh, kw, stride, pad, nchw, direct = ctx.geom
         weight, bias = ctx.refs
@@ -1516,14 +1525,35 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw = dw2[:, :kh * kw * Cin].reshape(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
         db = K.colsum(dy, out_dtype=weight.dtype) if bias is not None else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv2d(x, weight, bias, B, H, W, stride=1, pad=0, nchw=False, grad_mailbox=None):
     """-> (rows [B*Ho*Wo, Cout], Ho, Wo).  grad_mailbox: see batch_norm."""
     kh, kw = weight.shape[2], weight.shape[3]
-    y = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw), grad_mailbox)
+    y, _ = Conv2dFn.apply(x, weight, bias, (B, H, W, stride, pad, nchw), grad_mailbox, False)
     return y, K.conv_out_size(H, kh, stride, pad), K.conv_out_size(W, kw, stride, pad)
+
+
+class _ConvBn:
+    epilogue_stats = True    # (tests / A-B tools may clear it: every BatchNorm then runs its own statistics pass)
+
+
+def conv_bn(x, conv, bn, B, H, W, relu=False, residual=None, nchw=False, conv_mailbox=None, bn_mailbox=None):
+    """BatchNorm(conv(x)) [+ residual] [ReLU] -- every convolution of the ResNet trunk is followed by a BatchNorm (module/resnet.py:
+    105-128, 232-246).  In training the statistics pass over the convolution's output does not exist: the GEMM's epilogue leaves the
+    per-channel (sum, sum of squares) of the rounded tile it holds as partial rows (ofa_gemm_colstat) and the BatchNorm finalises
+    from those.  Falls back to the separate statistics kernel when the GEMM plan cannot produce them (split-K, fp32), for
+    SyncBatchNorm layers and in eval mode.  -> (rows, Ho, Wo)."""
+    weight = conv.weight
+    kh, kw = weight.shape[2], weight.shape[3]
+    stride, pad = conv.stride[0], conv.padding[0]
+    training = bn.training or bn.running_mean is None
+    want = (_ConvBn.epilogue_stats and training and x.is_cuda and weight.dtype in (torch.bfloat16, torch.float16)
+            and _bn_sync_group(bn) is None)
+    y, stats = Conv2dFn.apply(x, weight, conv.bias, (B, H, W, stride, pad, nchw), conv_mailbox, want)
+    out = batch_norm(y, bn, relu=relu, residual=residual, grad_mailbox=bn_mailbox, stats=stats if stats.numel() else None)
+    return out, K.conv_out_size(H, kh, stride, pad), K.conv_out_size(W, kw, stride, pad)
 
 
 class _BnScope:
@@ -1550,8 +1580,12 @@ class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm2d (+ optional residual add and ReLU fused, module/resnet.py:105-128) on NHWC rows."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, mailbox=None):
-        y, mean, rstd = K.batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual)
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, mailbox=None, stats=None):
+        if stats is not None and training:       # the producing convolution's GEMM left the column statistics (conv_bn)
+            y, mean, rstd = K.batchnorm_fwd_apply(x, weight, bias, running_mean, running_var, stats, momentum, eps, relu, residual,
+                                                  groups=stats.shape[0])
+        else:
+            y, mean, rstd = K.batchnorm_fwd(x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual)
         ctx.save_for_backward(x, y, weight, mean, rstd)
         ctx.mailbox = mailbox
         ctx.cfg = (training, relu, residual is not None)
@@ -1657,7 +1691,7 @@ def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mail
     if sync is not None:
         y = SyncBatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu, sync[0], grad_mailbox)
     else:
-        y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, grad_mailbox)
+        y = BatchNormFn.apply(x, residual, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, grad_mailbox, stats)
     if cast and training:
         bn.running_mean.copy_(rm)
         bn.running_var.copy_(rv)

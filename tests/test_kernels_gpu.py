@@ -191,6 +191,67 @@ def test_gemm_group_tn(K, dtype, shapes):
     assert not K.gemm_group_ok(dy.float(), x.float(), out)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K_,bias", [
+    (6272, 256, 1024, False), (6272, 1024, 256, False), (1568, 256, 2304, False),      # ResNet layer3 products (B = 32 / 8), 1 x 1 and 3 x 3
+    (25088, 128, 1152, False), (784, 1024, 256, True), (200, 136, 72, True),           # layer2; micro-batch 4; ragged M / N / K
+    (13312, 768, 768, True), (13312, 2304, 768, False), (2048, 768, 768, True),        # the eight-wave tiles, the four-wave ring tiles
+    (100352, 64, 64, False),                                                            # more wave blocks than max_groups: no statistics
+])
+def test_gemm_colstat(K, dtype, M, N, K_, bias):
+    """ofa_gemm_colstat: the product is bit-identical to ofa_gemm's, and the partial rows its epilogue leaves sum to the column sums /
+    sums of squares of the ROUNDED output (what the BatchNorm statistics kernel would read back from memory)."""
+    torch.manual_seed(3)
+    a = (torch.randn(M, K_, device=DEV) * 0.5).to(dtype)
+    b = (torch.randn(N, K_, device=DEV) * 0.5).to(dtype)
+    bv = torch.randn(N, device=DEV).to(dtype) if bias else None
+    out, part = K.gemm_colstat(a, b, bias=bv)
+    ref = K.gemm(a, b, False, True, bias=bv)
+    assert torch.equal(out, ref)
+    if M >= 100000:
+        assert part is None
+        return
+    assert part is not None and part.dtype == torch.float64 and part.shape[1:] == (2, N) and part.shape[0] <= 512
+    got = part.sum(0)
+    o = out.double()
+    want = torch.stack([o.sum(0), (o * o).sum(0)])
+    scale = torch.stack([o.abs().sum(0), (o * o).sum(0)]).clamp_min(1e-30)
+    assert float(((got - want).abs() / scale).max()) < 2e-6, float(((got - want).abs() / scale).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(8, 14, 14, 256, 1024, 1, 1, 0), (8, 28, 28, 128, 128, 3, 2, 1), (2, 56, 56, 64, 64, 3, 1, 1)])
+def test_conv_bn_statistics_from_the_gemm_epilogue(K, dtype, shape):
+    """ops.conv_bn (BatchNorm statistics from the convolution's GEMM epilogue) against conv2d + batch_norm (statistics kernel over the
+    stored output): same outputs to a rounding of the 16-bit type, same running statistics, same gradients."""
+    from ofasys_amd import ops
+    B, H, W, Cin, Cout, k, stride, pad = shape
+    torch.manual_seed(4)
+    x0 = torch.randn(B * H * W, Cin, device=DEV).to(dtype)
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride, pad, bias=False).to(DEV).to(dtype)
+    res = {}
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm2d(Cout).to(DEV).to(dtype).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cout))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, Cout))
+        conv.weight.grad = None
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y, Ho, Wo = ops.conv_bn(x, conv, bn, B, H, W, relu=True)
+        else:
+            t, Ho, Wo = ops.conv2d(x, conv.weight, None, B, H, W, stride, pad)
+            y = ops.batch_norm(t, bn, relu=True)
+        dy = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9)).to(dtype)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[fused] = (y.detach().float(), bn.running_mean.float().clone(), bn.running_var.float().clone(), x.grad.float(),
+                      conv.weight.grad.float().clone(), bn.weight.grad.float().clone())
+    tol = 1.6e-2 if dtype == torch.bfloat16 else 2e-3
+    for a, b, t in zip(res[True], res[False], (tol, 1e-4, 1e-4, 4 * tol, 4 * tol, 4 * tol)):
+        assert rel(a, b) < t, (rel(a, b), t)
+
+
 def test_gemm_splitk_and_batched(K):
     torch.manual_seed(2)
     # wgrad shape: skinny output, long contraction -> split-K path

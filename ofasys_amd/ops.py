@@ -1608,7 +1608,7 @@ class BatchNormFn(torch.autograd.Function):
         if ctx.mailbox is not None and dres is not None:
             ctx.mailbox.append(dres)             # handed to the consumer named at forward time, which adds it inside its own kernel
             dres = None
-        return dx, dres, dg, db, None, None, None, None, None, None, None
+        return dx, dres, dg, db, None, None, None, None, None, None, None, None
 
 
 def _bn_all_reduce(t, group):
@@ -1670,7 +1670,7 @@ def _bn_sync_group(bn):
     return (group,) if dist.get_world_size(group) > 1 else None
 
 
-def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mailbox=None):
+def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mailbox=None, stats=None):
     """bn holds torch's parameters / buffers (state-dict parity); statistics follow bn.training like nn.BatchNorm2d.
     grad_mailbox (a list shared with ONE conv2d call on the same tensor `residual`): in backward the residual's gradient is not
     returned to autograd (which would add it to the other consumer's gradient with a separate elementwise kernel) but left in the

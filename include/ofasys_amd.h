@@ -128,6 +128,9 @@ typedef struct ofa_gemm_group_item {
   int64_t lda, ldb;
   int32_t m, n, k;
   int32_t splits;    /* filled by ofa_gemm_group_plan */
+  void* out;         /* optional, with out_alpha / ldo: when the plan leaves this product ONE K-slice (splits == 1) the kernel adds */
+  int64_t ldo;       /* out_alpha * a^T b straight onto out [m, n] (16-bit, row stride ldo, 16-byte aligned) in its epilogue -- no slab, */
+  float out_alpha;   /* no fold launch (the weight gradients of a small micro-batch: every product is one slice).  NULL: always slabs */
 } ofa_gemm_group_item;
 /* host only: validates the items and fills `splits` (one K-slice length for the group: <= 256 workgroups in total) */
 int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype);

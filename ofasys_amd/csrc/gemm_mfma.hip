@@ -407,12 +407,29 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, const f32x16 (&a
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int c = lane % LPR;
     const int n = n_w + c * (16 / E);
-    if (vec16 && m_w + TM * 32 <= g.M && n_w + TN * 32 <= g.N && (RAW || !(g.flags & OFA_GEMM_ACCUM))) {
+    const bool acc16 = !RAW && !F32 && (g.flags & OFA_GEMM_ACCUM);     // C += tile, 16-bit: one extra 16-byte load per store
+    if (vec16 && m_w + TM * 32 <= g.M && n_w + TN * 32 <= g.N && (RAW || !(g.flags & OFA_GEMM_ACCUM) || acc16)) {
       // interior tile, plain store: straight-line, 8 LDS reads in flight per batch (the guarded loop below pays an LDS
       // round trip plus ~10 branches per 16-byte store -- ~8 us for a 256x256 tile, measured with the K loop removed)
       const int rows_full = (TM - ip0 < ipass ? TM - ip0 : ipass) * 32;
       unsigned char* p = (unsigned char*)Cb + ((int64_t)(m_w + ip0 * 32 + lane / LPR) * ldc + n) * E;
       const int64_t pstep = (int64_t)RPI * ldc * E;
+      if (acc16) {
+#pragma unroll 8
+        for (int r0 = 0; r0 < rows_full; r0 += RPI) {
+          const int mloc = r0 + lane / LPR;
+          const uint4 u = *reinterpret_cast<const uint4*>(wl + mloc * ROWB + ((c ^ ((mloc >> SH) & (CH - 1))) << 4));
+          const uint4 old = *reinterpret_cast<const uint4*>(p);
+          uint4 o;
+          o.x = enc2<F16>(lo16<F16>(u.x) + lo16<F16>(old.x), hi16<F16>(u.x) + hi16<F16>(old.x));
+          o.y = enc2<F16>(lo16<F16>(u.y) + lo16<F16>(old.y), hi16<F16>(u.y) + hi16<F16>(old.y));
+          o.z = enc2<F16>(lo16<F16>(u.z) + lo16<F16>(old.z), hi16<F16>(u.z) + hi16<F16>(old.z));
+          o.w = enc2<F16>(lo16<F16>(u.w) + lo16<F16>(old.w), hi16<F16>(u.w) + hi16<F16>(old.w));
+          *reinterpret_cast<uint4*>(p) = o;
+          p += pstep;
+        }
+        continue;
+      }
       if (stats) {
 #pragma unroll 8
         for (int r0 = 0; r0 < rows_full; r0 += RPI) {
@@ -1192,6 +1209,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
 constexpr int GROUP_MAX = 8;
 struct GroupItem {
   const void* A; const void* B; float* ws;
+  void* out; int64_t ldo; float alpha;     // out != nullptr: ONE K-slice, accumulated straight onto out (16-bit) in the epilogue
   int64_t lda, ldb;
   int M, N, K, krows, ksplit, splits, tiles_m, tiles_n, first;   // K: rounded up to whole K tiles, krows: the real row count; first: index of the item's first workgroup
 };
@@ -1206,14 +1224,15 @@ __global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
     if (id >= ga.it[q].first) p = q;
   const GroupItem& it = ga.it[p];
   GemmArgs g;
-  g.A = it.A; g.B = it.B; g.C = nullptr; g.bias = nullptr;
+  g.A = it.A; g.B = it.B; g.C = it.out; g.bias = nullptr;
   g.M = it.M; g.N = it.N; g.K = it.K; g.transA = 1; g.transB = 0;
-  g.lda = it.lda; g.ldb = it.ldb; g.ldc = 0; g.strideA = g.strideB = g.strideC = 0;
-  g.alpha = 1.f; g.flags = 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.a_krows = g.b_krows = it.krows;
+  g.lda = it.lda; g.ldb = it.ldb; g.ldc = it.ldo; g.strideA = g.strideB = g.strideC = 0;
+  g.alpha = it.out ? it.alpha : 1.f; g.flags = it.out ? OFA_GEMM_ACCUM : 0; g.batch_inner = 1; g.strideA2 = g.strideB2 = g.strideC2 = 0; g.a_krows = g.b_krows = it.krows;
   g.colstat = nullptr; g.colstat_rows = 0;
   const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
   const int ks = local / ntiles, t = local - ks * ntiles;
-  gemm_big_body<4, 2, false, false, true, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, true);
+  // (OUT_F32 = false: the non-slab epilogue of this instantiation is the 16-bit accumulate of a one-slice product)
+  gemm_big_body<4, 2, false, false, false, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
 }
 
 template <bool OUT_F32, bool F16 = false>
@@ -1546,10 +1565,14 @@ extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dt
   int first = 0;
   for (int p = 0; p < n; ++p) {
     const ofa_gemm_group_item& it = items[p];
-    OFA_REQUIRE(group_item_ok(it) && it.slabs && !((uintptr_t)it.slabs & 15), OFA_ERR_INVALID, "gemm_group: product %d is not eligible", p);
+    const bool direct = it.out != nullptr && it.splits == 1;
+    OFA_REQUIRE(group_item_ok(it) && (direct || (it.slabs && !((uintptr_t)it.slabs & 15))), OFA_ERR_INVALID, "gemm_group: product %d is not eligible", p);
+    OFA_REQUIRE(!direct || (!((uintptr_t)it.out & 15) && it.ldo >= it.n && !(it.ldo & 7)), OFA_ERR_INVALID,
+                "gemm_group: product %d: out must be 16-byte aligned with a row stride that is a multiple of 8 elements", p);
     OFA_REQUIRE(it.splits >= 1 && it.splits <= 32, OFA_ERR_INVALID, "gemm_group: product %d: splits %d (run ofa_gemm_group_plan)", p, it.splits);
     GroupItem& d = ga.it[p];
     d.A = it.a; d.B = it.b; d.ws = it.slabs; d.lda = it.lda; d.ldb = it.ldb;
+    d.out = direct ? it.out : nullptr; d.ldo = it.ldo; d.alpha = it.out_alpha;
     d.M = it.m; d.N = it.n; d.K = cdiv(it.k, BK) * BK; d.krows = it.k;
     d.ksplit = cdiv(cdiv(it.k, BK), it.splits) * BK;
     d.splits = it.splits;

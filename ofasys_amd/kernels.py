@@ -262,10 +262,11 @@ def gemm_colstat(a, b, bias=None, max_groups=512):
 class _GroupItem(ctypes.Structure):     # ofa_gemm_group_item
     _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("lda", ctypes.c_int64),
                 ("ldb", ctypes.c_int64), ("m", ctypes.c_int32), ("n", ctypes.c_int32), ("k", ctypes.c_int32),
-                ("splits", ctypes.c_int32)]
+                ("splits", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64), ("out_alpha", ctypes.c_float)]
 
 
 GROUP_MAX = 8
+GROUP_DIRECT = True      # (tests / A-B tools may clear it: every grouped product then goes through an fp32 slab and the fold)
 
 
 def gemm_group_ok(dy, x, out):
@@ -287,9 +288,20 @@ def gemm_group_tn(products, fold):
         it.m, it.n, it.k = dy.shape[1], x.shape[1], dy.shape[0]
     dt = dtype_code(products[0][0])
     lib().call("ofa_gemm_group_plan", ctypes.addressof(arr), len(products), dt)
-    slabs = [torch.empty(it.splits * it.m * it.n, dtype=torch.float32, device=products[0][0].device) for it in arr]
-    for it, sl in zip(arr, slabs):
-        it.slabs = sl.data_ptr()
+    # a product the plan leaves ONE K-slice (a small micro-batch's weight gradients) is accumulated straight onto its 16-bit arena
+    # gradient in the kernel's epilogue: no fp32 slab, no fold launch (the fold of a one-slab job only rounds and accumulates)
+    slabs, direct_outs = [], set()
+    for it, (dy, x, out, alpha) in zip(arr, products):
+        direct = (GROUP_DIRECT and it.splits == 1 and out.dtype == dy.dtype and out.dim() == 2 and out.stride(1) == 1 and out.stride(0) % 8 == 0
+                  and out.data_ptr() % 16 == 0 and out.data_ptr() not in direct_outs)     # (two read-modify-writes of one output
+        if direct:                                                                         #  must not share a launch)
+            direct_outs.add(out.data_ptr())
+            it.out, it.ldo, it.out_alpha = out.data_ptr(), out.stride(0), float(alpha)
+            slabs.append(None)
+        else:
+            sl = torch.empty(it.splits * it.m * it.n, dtype=torch.float32, device=dy.device)
+            it.slabs = sl.data_ptr()
+            slabs.append(sl)
     if _prof is not None:
         # roofline timing in situ (see gemm): the grouped launch alone; the fold of its K-slice slabs is a FoldQueue launch later on
         # and is accounted for in bench.py from the fold kernel's own share (rocprof), not here
@@ -300,11 +312,13 @@ def gemm_group_tn(products, fold):
         e1.record()
         es = products[0][0].element_size()
         _prof.append((sum(2.0 * it.m * it.n * it.k for it in arr), e0, e1,
-                      sum((it.m + it.n) * it.k * es + it.splits * it.m * it.n * 4 for it in arr)))
+                      sum((it.m + it.n) * it.k * es + (it.splits * it.m * it.n * 4 if sl is not None else 2 * it.m * it.n * es)
+                          for it, sl in zip(arr, slabs))))
     else:
         lib().call("ofa_gemm_group_tn", ctypes.addressof(arr), len(products), dt, stream())
     for it, sl, (dy, x, out, alpha) in zip(arr, slabs, products):   # (registered after the launch: add() may flush the queue)
-        fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
+        if sl is not None:
+            fold.add(sl, 0, out, it.m * it.n, it.m * it.n, it.splits, alpha, True)
 
 
 # ---- optional per-launch timing of the GEMM kernel family (bench.py roofline): HIP events on the launch stream

@@ -254,6 +254,34 @@ def test_conv_bn_statistics_from_the_gemm_epilogue(K, dtype, shape):
         assert rel(a, b) < t, (rel(a, b), t)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_group_tn_one_slice_products_accumulate_without_slabs(K, dtype):
+    """A grouped weight-gradient launch whose products are ONE K-slice each (a small micro-batch: few rows) adds alpha * dy^T x straight
+    onto the 16-bit gradient in the kernel's epilogue -- no fp32 slab, nothing queued for the fold -- also on top of an earlier
+    contribution, with ragged M / N tiles, a row count that is not a multiple of 64, and the same output twice in one group (the
+    second contribution then takes the slab path: two read-modify-writes of one output must not share a launch)."""
+    torch.manual_seed(6)
+    shapes = [(1024, 1024, 512), (3072, 1024, 512), (264, 200, 136), (1024, 4096, 448)]
+    prods, refs = [], []
+    for i, (M, N, Kk) in enumerate(shapes):
+        dy = (torch.randn(Kk, M, device=DEV) * 0.2).to(dtype)
+        x = (torch.randn(Kk, N, device=DEV) * 0.2).to(dtype)
+        out = (torch.randn(M, N, device=DEV)).to(dtype)
+        alpha = 1.0 if i % 2 == 0 else 0.5
+        refs.append(out.float() + alpha * (dy.float().t() @ x.float()))
+        prods.append((dy, x, out, alpha))
+    dy0, x0, out0, a0 = prods[0]
+    prods.append((dy0, x0, out0, a0))                       # the same output again
+    refs[0] = refs[0] + a0 * (dy0.float().t() @ x0.float())
+    q = K.FoldQueue()
+    K.gemm_group_tn(prods, q)
+    assert len(q.jobs) == 1                                 # only the duplicate went through a slab
+    q.flush()
+    tol = 1.6e-2 if dtype == torch.bfloat16 else 2e-3
+    for (dy, x, out, alpha), ref in zip(prods[:4], refs):
+        assert rel(out.float(), ref) < tol, (tuple(out.shape), rel(out.float(), ref))
+
+
 def test_gemm_splitk_and_batched(K):
     torch.manual_seed(2)
     # wgrad shape: skinny output, long contraction -> split-K path

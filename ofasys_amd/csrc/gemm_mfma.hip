@@ -1386,10 +1386,16 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
 #ifdef OFA_DEBUG_SWITCHES
   static const int split_min_k = getenv("OFA_GEMM_SPLIT_MIN_K") ? atoi(getenv("OFA_GEMM_SPLIT_MIN_K")) : 2048;
   static const int force_tile = getenv("OFA_GEMM_TILE") ? atoi(getenv("OFA_GEMM_TILE")) : 0;   // 22 / 12 / 11 / 44 (= 84) / 34 (= 83)
+  static const int64_t nosplit_t11 = getenv("OFA_GEMM_NOSPLIT_T11") ? atoll(getenv("OFA_GEMM_NOSPLIT_T11")) : 256;
 #else
   constexpr int split_min_k = 2048, force_tile = 0;
+  constexpr int64_t nosplit_t11 = 256;
 #endif
   if (g.K < split_min_k || t22 >= 256) maxs = 1;
+  // Round 4: a forward / input-gradient product whose 64 x 64 tiles alone put a four-wave workgroup on every compute unit is not split
+  // either (the decoder-side K = 2304 / 3072 input gradients: 1536 x 768 x 3072 ran as 72 tiles x 5 slices + a reduce launch, 26 + 6.5 us;
+  // as 288 ring-staged 64 x 64 tiles it needs no second launch)
+  if (!g.transA && g.K <= 4096 && t11 >= nosplit_t11) maxs = 1;
   const int64_t want = 384;
   int wm, wn;
   int64_t tiles;

@@ -13,6 +13,11 @@ for w in cfg2b cfg4; do
   rocprofv3 --kernel-trace --stats -d /tmp/r${N}stats_$w -o p -- python $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --profile-gemm 0 > $O/stats_${w}_run.log 2>&1
   python $R/tools/prof_summary.py /tmp/r${N}stats_$w/p_results.db 24 90 --json $O/round${N}_rocprof_${w}_kernel_stats.json > $O/round${N}_rocprof_${w}_kernel_stats.txt 2>&1
 done
+# the two multi-task workloads: 4 batches x 3 set-up steps + 2 warm-up + 6 timed = 20 train steps in the trace
+for w in cfg3 cfg5; do
+  rocprofv3 --kernel-trace --stats -d /tmp/r${N}stats_$w -o p -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --profile-gemm 0 > $O/stats_${w}_run.log 2>&1
+  python $R/tools/prof_summary.py /tmp/r${N}stats_$w/p_results.db 20 90 --json $O/round${N}_rocprof_${w}_kernel_stats.json > $O/round${N}_rocprof_${w}_kernel_stats.txt 2>&1
+done
 # HBM traffic: separate PMC passes (eager: 3 + 1 = 4 train steps each)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/r${N}fetch -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/fetch_run.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/r${N}write -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/write_run.log 2>&1
@@ -26,7 +31,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
  python $R/tools/pmc_dump.py /tmp/r${N}mfma/p_results.db) > $O/round${N}_pmc_mfma_lds.txt 2>&1
 cd $R
 # the bench lines below quote the kernel-trace / PMC summaries of THIS run (bench.py reads them from profiles/)
-cp $O/round${N}_rocprof_kernel_stats.json $O/round${N}_rocprof_cfg2b_kernel_stats.json $O/round${N}_rocprof_cfg4_kernel_stats.json $O/round${N}_pmc_traffic.json $R/profiles/
+cp $O/round${N}_rocprof_kernel_stats.json $O/round${N}_rocprof_cfg2b_kernel_stats.json $O/round${N}_rocprof_cfg4_kernel_stats.json $O/round${N}_rocprof_cfg3_kernel_stats.json $O/round${N}_rocprof_cfg5_kernel_stats.json $O/round${N}_pmc_traffic.json $R/profiles/
 python bench.py > $O/round${N}_bench.json 2> $O/bench_run.log
 tail -c 1200 $O/round${N}_bench.json
 python bench.py --workload cfg2b --steps 30 --warmup 5 > $O/round${N}_bench_cfg2b.json 2> $O/bench_cfg2b_run.log
@@ -39,3 +44,5 @@ for w in cfg2b cfg4 dec cross; do python tools/attn_sbias_bench.py $w 2>&1 | gre
 for w in cfg2 cfg2b cfg4; do python tools/native_glue_trace.py $w 2>&1 | grep -v amdgpu.ids > $O/round${N}_native_glue_$w.txt; done
 timeout 300 tools/experiments/_build/adam_stream_bench > $O/round${N}_adam_stream_bench.txt 2>&1 || true
 (python tools/gemm_split_check.py; OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_split_check.txt
+# what every parity test measures next to its bound (pytest -s prints MEASURED lines)
+python -m pytest tests -m gpu -q -s 2>&1 | grep -E "MEASURED|passed|failed" > $O/round${N}_parity_measured.txt

@@ -412,134 +412,6 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ dy
   }
 }
 
-// ---------------------------------------------------------------------------------------------- small layers: no finalize launch
-// A BatchNorm layer of the trunk's late stages (6272 rows x 256 / 1024 channels: 3-13 MB) is six kernels at the ~5 us latency floor of
-// a launch -- statistics, finalize, apply; statistics, finalize, dx -- and none of it is bandwidth.  For such layers the statistics
-// kernels write FEW partial rows (<= 16 row groups, bn_groups) and the consumer folds them itself: a workgroup owns a slab of
-// `cw` column vectors x a row range, first folds the slab's columns of the partial rows (<= 64 rows x 4 KiB, L2-resident and shared
-// by every row range of the column chunk) into mean / rstd (forward) or sum g / sum g*xhat (backward) in LDS, then streams its rows.
-// The row range 0 of each column chunk also writes what the finalize kernel wrote: mean / rstd / running statistics, or
-// dgamma / dbeta.  MODE 0: y = [relu]((x - mean) * rstd * gamma + beta [+ residual]);  MODE 1: dx (and dres), see bn_bwd_dx_kernel.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_slab_kernel(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                      const T* __restrict__ residual_or_dy, const T* __restrict__ y_in,
-                                                      T* __restrict__ out, T* __restrict__ dres, const double* __restrict__ partial,
-                                                      int groups, int64_t rows, int C, int cw_log2, int relu, float eps,
-                                                      float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                      T* __restrict__ dgamma, T* __restrict__ dbeta, int accumulate) {
-  constexpr int N = Vec<T>::N;
-  __shared__ double raw[2][32 * N];            // the slab's columns of the folded partial rows
-  __shared__ float st[2][32 * N];              // forward: mean, rstd;  backward: sum g, sum g*xhat
-  const int cw = 1 << cw_log2, rl = 256 >> cw_log2;
-  const int ncol = cw * N;                     // channels of this slab
-  const int c0 = blockIdx.x * ncol;
-  for (int v = threadIdx.x; v < 2 * ncol; v += 256) {
-    const int q = v / ncol, ch = v - q * ncol;
-    double t = 0.0;
-    if (c0 + ch < C)
-      for (int g = 0; g < groups; ++g) t += partial[((int64_t)g * 2 + q) * C + c0 + ch];
-    raw[q][ch] = t;
-  }
-  __syncthreads();
-  for (int ch = threadIdx.x; ch < ncol; ch += 256) {
-    const int c = c0 + ch;
-    if (c >= C) continue;
-    const double s = raw[0][ch], q = raw[1][ch];
-    if (MODE == 0) {
-      const double R = (double)rows;
-      const double m = s / R;
-      double var = q / R - m * m;
-      var = var < 0.0 ? 0.0 : var;
-      const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
-      st[0][ch] = mu;
-      st[1][ch] = rs;
-      if (blockIdx.y == 0) {
-        mean[c] = mu;
-        rstd[c] = rs;
-        if (running_mean) {
-          const double unbiased = R > 1.0 ? var * R / (R - 1.0) : var;
-          running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-          running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-        }
-      }
-    } else {
-      st[0][ch] = (float)s;
-      st[1][ch] = (float)q;
-      if (blockIdx.y == 0 && dgamma) {
-        st1<T>(dgamma + c, (accumulate ? ld1<T>(dgamma + c) : 0.f) + (float)q);
-        st1<T>(dbeta + c, (accumulate ? ld1<T>(dbeta + c) : 0.f) + (float)s);
-      }
-    }
-  }
-  __syncthreads();
-  const int cx = threadIdx.x & (cw - 1), ry = threadIdx.x >> cw_log2;
-  const int c = c0 + cx * N;
-  if (c >= C) return;
-  float a0[N], a1[N], gm[N], bt[N], mu[N], rs[N];
-  load_vec<T>(gamma + c, gm);
-#pragma unroll
-  for (int j = 0; j < N; ++j) { bt[j] = 0.f; a0[j] = st[0][cx * N + j]; a1[j] = st[1][cx * N + j]; }
-  if (MODE == 0) {
-    load_vec<T>(beta + c, bt);
-#pragma unroll
-    for (int j = 0; j < N; ++j) { mu[j] = a0[j]; rs[j] = a1[j]; }
-  } else {
-    if (relu == 2) load_vec<T>(beta + c, bt);
-#pragma unroll
-    for (int j = 0; j < N; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; }
-  }
-  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
-  const int64_t r_lo = (int64_t)blockIdx.y * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
-  const float inv = 1.0f / (float)rows;
-  auto one = [&](int64_t r, const float (&xx)[N], const float (&second)[N], const float (&yy)[N]) {
-    float o[N];
-    if (MODE == 0) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        float t = (xx[j] - mu[j]) * rs[j] * gm[j] + bt[j];
-        if (residual_or_dy) t += second[j];
-        o[j] = relu ? fmaxf(t, 0.f) : t;
-      }
-      store_vec<T>(out + r * C + c, o);
-    } else {
-      float g[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const bool on = relu == 2 ? ((xx[j] - mu[j]) * rs[j] * gm[j] + bt[j] > 0.f) : (!relu || yy[j] > 0.f);
-        g[j] = on ? second[j] : 0.f;
-        const float xh = (xx[j] - mu[j]) * rs[j];
-        o[j] = gm[j] * rs[j] * (g[j] - (a0[j] + xh * a1[j]) * inv);
-      }
-      store_vec<T>(out + r * C + c, o);
-      if (dres) store_vec<T>(dres + r * C + c, g);
-    }
-  };
-  int64_t r = r_lo + ry;
-  for (; r + rl < r_hi; r += 2 * rl) {          // two rows per trip: the loads of both are in flight before the arithmetic
-    float x0[N], x1[N], s0[N], s1[N], y0[N], y1[N];
-    load_vec<T>(x + r * C + c, x0);
-    load_vec<T>(x + (r + rl) * C + c, x1);
-    if (residual_or_dy) {
-      load_vec<T>(residual_or_dy + r * C + c, s0);
-      load_vec<T>(residual_or_dy + (r + rl) * C + c, s1);
-    }
-    if (MODE == 1 && relu == 1) {
-      load_vec<T>(y_in + r * C + c, y0);
-      load_vec<T>(y_in + (r + rl) * C + c, y1);
-    }
-    one(r, x0, s0, y0);
-    one(r + rl, x1, s1, y1);
-  }
-  if (r < r_hi) {
-    float x0[N], s0[N], y0[N];
-    load_vec<T>(x + r * C + c, x0);
-    if (residual_or_dy) load_vec<T>(residual_or_dy + r * C + c, s0);
-    if (MODE == 1 && relu == 1) load_vec<T>(y_in + r * C + c, y0);
-    one(r, x0, s0, y0);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- MaxPool2d(k, s, p), NHWC
 // One thread per (position, channel vector of N): 16-byte accesses on the activations, N bytes on the arg-max taps (the one
 // element per thread form ran the backward at 1.2 TB/s: 233 us for the 32 x 192 x 192 x 64 stem of cfg-2b).
@@ -692,35 +564,9 @@ static int bn_cw_log2(int vec_cols) {
   while (l > 0 && (1 << l) > vec_cols) --l;
   return l;
 }
-constexpr int64_t BN_SMALL_ROWS = 8192;     // layers up to this many rows take the no-finalize form (bn_slab_kernel)
-constexpr int BN_SLAB_MAX_GROUPS = 64;      // ... whose consumers fold at most this many partial rows themselves
 static int bn_groups(int64_t rows) {
-  if (rows <= BN_SMALL_ROWS) {              // few partial rows: the consumer folds them (<= 16 x 4 KiB per slab)
-    const int64_t g = (rows + 511) / 512;
-    return (int)(g < 1 ? 1 : g);
-  }
   int64_t g = (rows + 127) / 128;
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
-}
-// row ranges per column chunk of bn_slab_kernel: ~400 rows each (a slab of 256 channels then moves ~400 KB), at least 1
-static int bn_slab_row_chunks(int64_t rows) {
-  const int64_t n = (rows + 391) / 392;
-  return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
-}
-template <int MODE>
-static void bn_slab_launch(const void* x, const void* gamma, const void* beta, const void* second, const void* y_in, void* out,
-                           void* dres, const double* partial, int groups, int64_t rows, int C, int relu, float eps, float momentum,
-                           float* mean, float* rstd, float* running_mean, float* running_var, void* dgamma, void* dbeta,
-                           int accumulate, int dtype, hipStream_t st) {
-  const int n = dtype == OFA_F32 ? 4 : 8;
-  const int cwl = bn_cw_log2(C / n);
-  dim3 grid(cdiv(C / n, 1 << cwl), bn_slab_row_chunks(rows)), block(256);
-  if (dtype == OFA_F32)
-    hipLaunchKernelGGL((bn_slab_kernel<float, MODE>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta, (const float*)second, (const float*)y_in, (float*)out, (float*)dres, partial, groups, rows, C, cwl, relu, eps, momentum, mean, rstd, running_mean, running_var, (float*)dgamma, (float*)dbeta, accumulate);
-  else if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bn_slab_kernel<bf16_t, MODE>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)second, (const bf16_t*)y_in, (bf16_t*)out, (bf16_t*)dres, partial, groups, rows, C, cwl, relu, eps, momentum, mean, rstd, running_mean, running_var, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
-  else
-    hipLaunchKernelGGL((bn_slab_kernel<f16_t, MODE>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)gamma, (const f16_t*)beta, (const f16_t*)second, (const f16_t*)y_in, (f16_t*)out, (f16_t*)dres, partial, groups, rows, C, cwl, relu, eps, momentum, mean, rstd, running_mean, running_var, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
 }
 extern "C" int ofa_batchnorm_ws_floats(int C) { return 4 * 256 * C + 2 * C; }   // fp64 partials [256][2][C] + fp32 sums [2][C]
 
@@ -766,11 +612,6 @@ extern "C" int ofa_batchnorm_fwd(const void* x, const void* gamma, const void* b
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, eps, C, mean, rstd);
   } else {
     const int groups = bn_fwd_colstat(x, ws, rows, C, dtype, st);
-    if (rows <= BN_SMALL_ROWS) {                 // small layer: statistics -> fold + finalize + apply in ONE launch (bn_slab_kernel)
-      bn_slab_launch<0>(x, gamma, beta, residual, nullptr, y, nullptr, (const double*)ws, groups, rows, C, relu, eps, momentum, mean, rstd,
-                        running_mean, running_var, nullptr, nullptr, 0, dtype, st);
-      return check_launch("batchnorm_fwd_slab");
-    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   int rc = check_launch("batchnorm_stats");
@@ -803,20 +644,17 @@ extern "C" int ofa_batchnorm_fwd_apply(const void* x, const void* gamma, const v
   hipStream_t st = (hipStream_t)stream;
   if (groups == 0)   // SyncBatchNorm: the reduced sums are ONE group of partials over sums[2*C] rows (the count lives on the device)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, 1, C, rows, eps, momentum, mean, rstd, running_mean, running_var, sums + 2 * (int64_t)C);
-  else if (groups <= BN_SLAB_MAX_GROUPS && rows <= BN_SMALL_ROWS) {   // few partial rows of a small layer: the apply kernel folds them itself
-    bn_slab_launch<0>(x, gamma, beta, residual, nullptr, y, nullptr, sums, groups, rows, C, relu, eps, momentum, mean, rstd, running_mean,
-                      running_var, nullptr, nullptr, 0, dtype, st);
-    return check_launch("batchnorm_fwd_apply_slab");
-  } else             // `groups` partial rows [groups][2][C] over this launch's `rows` rows, e.g. left by ofa_gemm_colstat's epilogue
+  else               // `groups` partial rows [groups][2][C] over this launch's `rows` rows, e.g. left by ofa_gemm_colstat's epilogue
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, sums, groups, C, rows, eps, momentum, mean, rstd, running_mean, running_var, (const double*)nullptr);
   int rc = check_launch("batchnorm_fwd_apply");
   if (rc) return rc;
   return bn_apply_launch(x, gamma, beta, residual, y, mean, rstd, rows, C, relu, dtype, st);
 }
 
-// backward column statistics into ws (fp64 partials [groups][2][C]: sum g, sum g*xhat); returns the group count
-static int bn_bwd_colstat(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
-                          float* ws, int64_t rows, int C, int relu, const void* beta, int dtype, hipStream_t st) {
+// backward statistics: sums [2][C] fp32 = (sum g, sum g*xhat) of this launch's rows, and the parameter gradients from them
+static int bn_bwd_stats_launch(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
+                               float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate,
+                               const void* beta, int dtype, hipStream_t st) {
   const int n = dtype == OFA_F32 ? 4 : 8;
   const int groups = bn_groups(rows);
   const int cwl = bn_cw_log2(C / n);
@@ -824,27 +662,17 @@ static int bn_bwd_colstat(const void* dy, const void* y, const void* x, const vo
   if (dtype == OFA_F32) {
     if (beta) hipLaunchKernelGGL((bn_colstat_kernel<float, 2>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const float*)gamma, (const float*)beta);
     else hipLaunchKernelGGL((bn_colstat_kernel<float, 1>), grid, block, 0, st, (const float*)x, (const float*)dy, (const float*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
   } else if (dtype == OFA_BF16) {
     if (beta) hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const bf16_t*)gamma, (const bf16_t*)beta);
     else hipLaunchKernelGGL((bn_colstat_kernel<bf16_t, 1>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
-  } else {
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
+  }
+  else {
     if (beta) hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 2>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl, (const f16_t*)gamma, (const f16_t*)beta);
     else hipLaunchKernelGGL((bn_colstat_kernel<f16_t, 1>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)dy, (const f16_t*)y, mean, rstd, (double*)ws, rows, C, relu, cwl);
-  }
-  return groups;
-}
-
-// backward statistics: sums [2][C] fp32 = (sum g, sum g*xhat) of this launch's rows, and the parameter gradients from them
-static int bn_bwd_stats_launch(const void* dy, const void* y, const void* x, const void* gamma, const float* mean, const float* rstd,
-                               float* sums, void* dgamma, void* dbeta, float* ws, int64_t rows, int C, int relu, int accumulate,
-                               const void* beta, int dtype, hipStream_t st) {
-  const int groups = bn_bwd_colstat(dy, y, x, gamma, mean, rstd, ws, rows, C, relu, beta, dtype, st);
-  if (dtype == OFA_F32)
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (float*)dgamma, (float*)dbeta, accumulate);
-  else if (dtype == OFA_BF16)
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<bf16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (bf16_t*)dgamma, (bf16_t*)dbeta, accumulate);
-  else
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<f16_t>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)ws, groups, C, sums, (f16_t*)dgamma, (f16_t*)dbeta, accumulate);
+  }
   return check_launch("batchnorm_bwd_stats");
 }
 
@@ -873,12 +701,6 @@ extern "C" int ofa_batchnorm_bwd(const void* dy, const void* y, const void* x, c
   const int n = dtype == OFA_F32 ? 4 : 8;
   OFA_REQUIRE(C % n == 0, OFA_ERR_UNSUPPORTED, "batchnorm: C=%d must be a multiple of %d", C, n);
   hipStream_t st = (hipStream_t)stream;
-  if (batch_stats && rows <= BN_SMALL_ROWS) {    // small layer: statistics -> fold + parameter gradients + dx in ONE launch (bn_slab_kernel)
-    const int groups = bn_bwd_colstat(dy, y, x, gamma, mean, rstd, ws, rows, C, relu, beta, dtype, st);
-    bn_slab_launch<1>(x, gamma, beta, dy, y, dx, dres, (const double*)ws, groups, rows, C, relu, 0.f, 0.f, const_cast<float*>(mean),
-                      const_cast<float*>(rstd), nullptr, nullptr, dgamma, dbeta, accumulate, dtype, st);
-    return check_launch("batchnorm_bwd_slab");
-  }
   float* sums = ws + (int64_t)4 * 256 * C;
   int rc = bn_bwd_stats_launch(dy, y, x, gamma, mean, rstd, sums, dgamma, dbeta, ws, rows, C, relu, accumulate, beta, dtype, st);
   if (rc) return rc;

@@ -696,10 +696,12 @@ def test_conv2d(K, dtype, Cin, Cout, k, stride, pad, H, W, nchw):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("training,relu,with_res", [(True, True, True), (True, False, False), (False, True, False), (True, True, False)])
-def test_batchnorm(K, dtype, training, relu, with_res):
+# one and several row groups / column chunks of the statistics kernels, a channel count that is not a multiple of the 256-channel block
+@pytest.mark.parametrize("shape", [(3, 64, 7, 5), (8, 256, 28, 28), (2, 1032, 20, 21), (2, 64, 96, 96)])
+def test_batchnorm(K, dtype, training, relu, with_res, shape):
     from ofasys_amd import ops
     torch.manual_seed(32)
-    B, C, H, W = 3, 64, 7, 5
+    B, C, H, W = shape
     x = (1.5 * torch.randn(B, C, H, W, device=DEV) + 0.3).to(dtype)
     res = torch.randn(B, C, H, W, device=DEV).to(dtype) if with_res else None
     bn = torch.nn.BatchNorm2d(C).to(DEV)

@@ -52,8 +52,9 @@ def test_gemm_group_plan_is_host_only():
     assert sum(t * s for t, s in zip(tiles, sp)) <= 256 and sp[2] > sp[0] >= 1        # the long contraction gets more slices
     assert plan([(256, 256, 64)]) == [1]
     assert plan([(4096, 4096, 1024), (4096, 4096, 512)]) == [1, 1]                     # more than one round already: no slicing
+    assert plan([(768, 768, 100)]) == [1]                                              # any row count (round 4: zero rows inside the kernel)
     with pytest.raises(L.OfaError, match="gemm_group"):
-        plan([(768, 768, 100)])                                                        # k % 64
+        plan([(772, 768, 128)])                                                        # m % 8
     with pytest.raises(L.OfaError, match="gemm_group"):
         plan([(768, 768, 128)], L.F32)
     with pytest.raises(L.OfaError, match="gemm_group"):

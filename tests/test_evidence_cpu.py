@@ -23,7 +23,7 @@ def _line(name):
 def test_bench_lines_follow_the_contract_and_their_profiles_exist():
     r = _latest_round()
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    for suffix in ("", "_cfg2b", "_cfg4"):
+    for suffix in ("", "_cfg2b", "_cfg4") + (("_cfg3", "_cfg5") if r >= 4 else ()):
         d = _line(f"round{r}_bench{suffix}.json")
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                     "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -43,15 +43,18 @@ def test_bench_lines_follow_the_contract_and_their_profiles_exist():
         stats = json.load(open(os.path.join(ROOT, src)))
         assert abs(stats["__meta__"]["total_ms_per_step"] - roof["rocprof"]["all_kernels_ms_per_step"]) < 1e-6
         assert os.path.exists(os.path.join(ROOT, src.replace(".json", ".txt")))
-        # the profiler's per-launch time of the GEMM family agrees with the in-situ events within 10 %
-        assert abs(roof["rocprof"]["frac"] - roof["frac"]) <= 0.20 * roof["frac"], (suffix, roof["rocprof"]["frac"], roof["frac"])
+        # the profiler's time of the GEMM family (which also holds the split-K reduces and slab folds) agrees with the in-situ events
+        # (which bracket the GEMM launches alone) within 20 %; 30 % for the multi-task steps, whose small micro-batches put a larger
+        # share of the family time into folds and reduces (cfg-3: 1.28 of 8.98 ms)
+        tol = 0.30 if suffix in ("_cfg3", "_cfg5") else 0.20
+        assert abs(roof["rocprof"]["frac"] - roof["frac"]) <= tol * roof["frac"], (suffix, roof["rocprof"]["frac"], roof["frac"])
 
 
 def test_documents_quote_the_committed_run():
     r = _latest_round()
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     readme = open(os.path.join(ROOT, "README.md")).read()
-    for suffix in ("", "_cfg2b", "_cfg4"):
+    for suffix in ("", "_cfg2b", "_cfg4") + (("_cfg3", "_cfg5") if r >= 4 else ()):      # (round 4 on: all five BASELINE configurations)
         ms = _line(f"round{r}_bench{suffix}.json")["ms_per_step"]
         assert f"{ms:.2f} ms" in design, (suffix, f"{ms:.2f} ms is not in DESIGN.md")
         assert f"{ms:.1f} ms" in readme, (suffix, f"{ms:.1f} ms is not in README.md")

@@ -308,12 +308,14 @@ def make_step(d, args, B, seed, device, packed):
     return [s1], ntok, lens
 
 
-def pmc_traffic():
+def pmc_traffic(workload="cfg2"):
     """(HBM bytes per launch of the MFMA GEMM kernels, HBM bytes of one whole step, source) from the committed rocprofv3 PMC
-    passes (profiles/, produced by tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled on
-    gfx950, tools/pmc_traffic.py)."""
+    passes of THIS workload's eager step (profiles/, produced by tools/collect_profiles.sh: separate FETCH_SIZE and WRITE_SIZE passes,
+    FETCH_SIZE doubled on gfx950, tools/pmc_traffic.py); (None, None, reason) when no pass of the workload is committed."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    tag = "" if workload == "cfg2" else "_" + workload
+    rounds = ("round4", "round3", "round2", "round1") if workload == "cfg2" else ("round4",)
+    for name in [f"{r}_pmc_traffic{tag}.json" for r in rounds]:
         try:
             rows = json.load(open(os.path.join(here, "profiles", name)))
         except (OSError, ValueError):
@@ -326,8 +328,8 @@ def pmc_traffic():
                 tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
         if n:
             return tot / n, meta.get("bytes_per_step"), (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per launch, all MFMA "
-                                                         "GEMM instantiations of the eager cfg-2 step)")
-    return None, None, None
+                                                         f"GEMM instantiations of the eager {workload} step)")
+    return None, None, f"none (no PMC pass of the {workload} step is committed under profiles/)"
 
 
 def rocprof_gemm_ms(workload):
@@ -593,9 +595,7 @@ def main():
         # a packed step is priced at the flops of the positions it computes (never at the padded count it skips)
         step_flops = 3 * fwd_exec if fwd_exec and (packed or args.workload != "cfg2") else step_flops_padded
         step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
-        traffic, step_bytes, traffic_src = pmc_traffic()
-        if args.workload != "cfg2":              # the committed PMC passes are of the cfg-2 step: no per-launch traffic figure for the others
-            traffic, traffic_src = None, "none (the PMC passes under profiles/ cover the cfg-2 step only)"
+        traffic, step_bytes, traffic_src = pmc_traffic(args.workload)
         roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "ofa::gemm_mfma_kernel + ofa::gemm_big_kernel + ofa::gemm_ring_kernel (" + ("bf16 v_mfma_f32_32x32x16_bf16" if args.dtype == "bf16" else "fp16 v_mfma_f32_32x32x16_f16") + ", all instantiations)",
                 "step_achieved": step_tflops, "step_frac": step_tflops / PEAK_BF16_TFLOPS, "step_flops": step_flops,
@@ -604,7 +604,7 @@ def main():
                                       "padded shape (every sample at the longest lengths)") +
                                      ("" if args.workload == "cfg2" else "; position-bias products counted once per batch (they are "
                                       "computed once: ops.SharedBias), SURVEY 8d counts them per sample"))}
-        if step_bytes and args.workload == "cfg2":
+        if step_bytes:
             roof["hbm"] = {"step_bytes": step_bytes, "achieved_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                            "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                            "how": "sum over every kernel of the step of rocprofv3 PMC FETCH_SIZE + WRITE_SIZE bytes (committed profile, "

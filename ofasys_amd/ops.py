@@ -1257,16 +1257,16 @@ class ScaleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, fwd, bwd):
         ctx.bwd = bwd
-        if fwd == 1.0:
+        if fwd == 1.0 or x2d.shape[0] == 0:
             return x2d.view_as(x2d)
-        return K.scale_row_groups(x2d, ScaleFn._scalar(fwd, x2d), max(x2d.shape[0], 1))
+        return K.scale_row_groups(x2d, ScaleFn._scalar(fwd, x2d), x2d.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.bwd == 1.0:
+        if ctx.bwd == 1.0 or dy.shape[0] == 0:
             return dy, None, None
         dy = dy.contiguous()
-        return K.scale_row_groups(dy, ScaleFn._scalar(ctx.bwd, dy), max(dy.shape[0], 1)), None, None
+        return K.scale_row_groups(dy, ScaleFn._scalar(ctx.bwd, dy), dy.shape[0]), None, None
 
 
 def scale(x, fwd=1.0, bwd=None):

@@ -22,6 +22,10 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/r${N}fetch -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/fetch_run.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/r${N}write -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/write_run.log 2>&1
 python $R/tools/pmc_traffic.py /tmp/r${N}fetch/p_results.db /tmp/r${N}write/p_results.db $O/round${N}_pmc_traffic.json 4 > $O/round${N}_pmc_traffic.txt 2>&1
+# ... and of the reference's default configuration (cfg-2b)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/r${N}fetch_cfg2b -o p -- python $R/bench.py --workload cfg2b --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/fetch_cfg2b_run.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/r${N}write_cfg2b -o p -- python $R/bench.py --workload cfg2b --steps 3 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/write_cfg2b_run.log 2>&1
+python $R/tools/pmc_traffic.py /tmp/r${N}fetch_cfg2b/p_results.db /tmp/r${N}write_cfg2b/p_results.db $O/round${N}_pmc_traffic_cfg2b.json 4 > $O/round${N}_pmc_traffic_cfg2b.txt 2>&1
 # MFMA busy / LDS activity / bank conflicts per kernel
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d /tmp/r${N}mfma -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-gemm 0 --no-graph > $O/mfma_run.log 2>&1
 (set +x; echo "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
@@ -31,7 +35,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
  python $R/tools/pmc_dump.py /tmp/r${N}mfma/p_results.db) > $O/round${N}_pmc_mfma_lds.txt 2>&1
 cd $R
 # the bench lines below quote the kernel-trace / PMC summaries of THIS run (bench.py reads them from profiles/)
-cp $O/round${N}_rocprof_kernel_stats.json $O/round${N}_rocprof_cfg2b_kernel_stats.json $O/round${N}_rocprof_cfg4_kernel_stats.json $O/round${N}_rocprof_cfg3_kernel_stats.json $O/round${N}_rocprof_cfg5_kernel_stats.json $O/round${N}_pmc_traffic.json $R/profiles/
+cp $O/round${N}_rocprof_kernel_stats.json $O/round${N}_rocprof_cfg2b_kernel_stats.json $O/round${N}_rocprof_cfg4_kernel_stats.json $O/round${N}_rocprof_cfg3_kernel_stats.json $O/round${N}_rocprof_cfg5_kernel_stats.json $O/round${N}_pmc_traffic.json $O/round${N}_pmc_traffic_cfg2b.json $R/profiles/
 python bench.py > $O/round${N}_bench.json 2> $O/bench_run.log
 tail -c 1200 $O/round${N}_bench.json
 python bench.py --workload cfg2b --steps 30 --warmup 5 > $O/round${N}_bench_cfg2b.json 2> $O/bench_cfg2b_run.log

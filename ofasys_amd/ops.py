@@ -1489,6 +1489,7 @@ class Conv2dFn(torch.autograd.Function):
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=y.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)         # (no zero-filled fp64 "gradient" of the statistics output: it was one fill launch per layer)
         ctx.save_for_backward(col, w2)
         ctx.geom = (B, H, W, Cin, kh, kw, stride, pad, nchw, direct)
         ctx.refs = (weight, bias)
@@ -1496,6 +1497,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:
+            return None, None, None, None, None, None
         col, w2 = ctx.saved_tensors
         B, H, W, Cin, kh, kw, stride, pad, nchw, direct = ctx.geom
         weight, bias = ctx.refs

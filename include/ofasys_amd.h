@@ -294,6 +294,11 @@ int ofa_colsum_ws_floats(int cols);
 int ofa_colsum(const void* x, void* out, float* ws, int64_t rows, int cols, int64_t ld, float alpha, int accumulate,
                int dtype, int out_dtype, void* stream);
 
+/* out[i] = sum_{k < n} inputs[k][i] (n <= 16 tensors of `numel` elements; `inputs` is a HOST array of device pointers; fp32
+ * accumulation, one rounding): the gradient of a tensor several consumers read -- the abs-position bias that every layer of a stack
+ * builds its attention bias from (adaptor/general.py:265-270, model/transformer.py:280-299) -- which autograd would sum with n - 1
+ * pairwise adds. */
+int ofa_add_n(const void* const* inputs, int n, void* out, int64_t numel, int dtype, void* stream);
 /* y = a * b, b either [rows,cols] or a [cols] row vector (c_attn head scale, multihead_attention.py:342-345). */
 int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream);
 /* y[r, :] = x[r, :] * scale[r / group] (fp32 scale per group of `group` consecutive rows): DropPath (module/droppath.py:

@@ -155,7 +155,8 @@ class OFAGeneralAdaptor(torch.nn.Module):
             starts.append(s)
             s += mo.seq_length
         assert s == output.seq_length
-        for values in layer_values:
+        abs_fan = ops.fan_out(abs_pos_bias, num_rel_pos_tables)      # one view per layer: their gradients are summed in one launch
+        for idx, values in enumerate(layer_values):
             kinds, tensors = [], []
             for v in values:
                 if v is None:
@@ -169,7 +170,7 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 else:
                     kinds.append("dense")
                     tensors.append(v)
-            b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_pos_bias, starts, kinds, *tensors)
+            b, swz_row, swz_col = ops.BiasAssembleFn.apply(abs_fan[idx], starts, kinds, *tensors)
             # (squeeze, not b[0]: a select's backward zero-fills a whole [1, A, T, T] tensor and copies the gradient into it, per layer)
             output.self_attn_bias.append(ops.SharedBias(b.squeeze(0), (swz_row, swz_col) if swz_row is not None else None) if shared else b)
         return output

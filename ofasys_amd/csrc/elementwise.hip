@@ -724,7 +724,51 @@ __global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) out[h] = sw[0] + sw[1] + sw[2] + sw[3];
 }
+// out[i] = sum_{k < n} in_k[i]   (fp32 accumulation, one rounding): the gradient of a tensor that n consumers read (ops.fan_out: the
+// abs-position bias every layer of a stack assembles its attention bias from) in ONE launch instead of autograd's n - 1 pairwise adds
+struct AddNArgs { const void* in[16]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs a, T* __restrict__ out, int64_t numel) {
+  constexpr int N = Vec<T>::N;
+  const int64_t nvec = numel / N;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    for (int k = 0; k < a.n; ++k) {
+      float t[N];
+      load_vec<T>((const T*)a.in[k] + v * N, t);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += t[j];
+    }
+    store_vec<T>(out + v * N, acc);
+  }
+  if (blockIdx.x == 0) {                                   // the tail that is not a whole 16-byte vector
+    for (int64_t i = nvec * N + threadIdx.x; i < numel; i += 256) {
+      float t = 0.f;
+      for (int k = 0; k < a.n; ++k) t += ld1<T>((const T*)a.in[k] + i);
+      st1<T>(out + i, t);
+    }
+  }
+}
 }  // namespace ofa
+
+extern "C" int ofa_add_n(const void* const* inputs, int n, void* out, int64_t numel, int dtype, void* stream) {
+  OFA_DT_CHECK("add_n");
+  OFA_REQUIRE(inputs && out && n >= 1 && n <= 16 && numel >= 0, OFA_ERR_INVALID, "add_n: 1..16 inputs (got %d)", n);
+  if (numel == 0) return 0;
+  AddNArgs a;
+  for (int k = 0; k < 16; ++k) a.in[k] = inputs[k < n ? k : 0];
+  for (int k = 0; k < n; ++k) OFA_REQUIRE(inputs[k] && !((uintptr_t)inputs[k] & 15), OFA_ERR_INVALID, "add_n: input %d is NULL or not 16-byte aligned", k);
+  OFA_REQUIRE(!((uintptr_t)out & 15), OFA_ERR_INVALID, "add_n: out is not 16-byte aligned");
+  a.n = n;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t work = numel / (dtype == OFA_F32 ? 4 : 8) + 1;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((add_n_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, a, (float*)out, numel);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, a, (bf16_t*)out, numel);
+  else hipLaunchKernelGGL((add_n_kernel<f16_t>), dim3(grid_for(work)), dim3(256), 0, st, a, (f16_t*)out, numel);
+  return check_launch("add_n");
+}
 
 extern "C" int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream) {
   OFA_DT_CHECK("mul");

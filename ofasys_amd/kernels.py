@@ -886,6 +886,18 @@ def mul(a, b):
     return y
 
 
+def add_n(tensors):
+    """sum of up to 16 same-shaped tensors in one launch (fp32 accumulation, one rounding)."""
+    ts = [t.contiguous() for t in tensors]
+    assert 1 <= len(ts) <= 16 and all(t.shape == ts[0].shape and t.dtype == ts[0].dtype for t in ts)
+    if len(ts) == 1:
+        return ts[0]
+    out = torch.empty_like(ts[0])
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    lib().call("ofa_add_n", ctypes.addressof(arr), len(ts), ptr(out), out.numel(), dtype_code(out), stream())
+    return out
+
+
 def mul_rowvec(a, vec):
     a, vec = a.contiguous(), vec.contiguous()
     rows, cols = _rows_cols(a)

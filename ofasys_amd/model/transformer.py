@@ -269,6 +269,7 @@ class TransformerDecoder(nn.Module):
         chain = LayerChain()
         layers = kept_layers(self.layers, self.layerdrop, self.training)
         cross_kv = self._cross_kv(enc, incremental_state) if len(layers) == len(self.layers) else None   # (dropped layers: own projections)
+        cross_biases = ops.fan_out_bias(cross_abs_pos_bias, len(layers))    # one view per layer: their gradients are summed in one launch
         for idx, layer in enumerate(layers):
             chain.next_ln = layers[idx + 1].self_attn_layer_norm if idx + 1 < len(layers) else self.layer_norm
             self_attn_mask = (self.buffered_future_mask(x) if incremental_state is None and not full_context_alignment
@@ -290,7 +291,7 @@ class TransformerDecoder(nn.Module):
                 self_attn_padding_mask=self_attn_padding_mask,
                 need_attn=bool((idx == alignment_layer) or return_all_attention_weights),
                 need_head_weights=bool(idx == alignment_layer), self_attn_bias=self_attn_bias,
-                cross_attn_bias=cross_abs_pos_bias, modal_mask=adaptor_output.modal_mask, chain=chain, cross_kv=cross_kv)
+                cross_attn_bias=cross_biases[idx], modal_mask=adaptor_output.modal_mask, chain=chain, cross_kv=cross_kv)
             if return_all_attention_weights:
                 decoder_attentions.append(layer_self_attn)
                 cross_attentions.append(layer_cross_attn)
@@ -337,11 +338,12 @@ class TransformerDecoder(nn.Module):
         chain = LayerChain()
         layers = kept_layers(self.layers, self.layerdrop, self.training)
         cross_kv = self._cross_kv(enc, incremental_state) if len(layers) == len(self.layers) else None
+        cross_biases = ops.fan_out_bias(cross_bias, len(layers))
         for idx, layer in enumerate(layers):
             chain.next_ln = layers[idx + 1].self_attn_layer_norm if idx + 1 < len(layers) else self.layer_norm
             sb = self_bias[0 if self.cfg.share_attn_bias else idx] if self_bias is not None else False
             x, _, _ = layer(x, enc, pack.cross, None, self_attn_mask=tag, self_attn_padding_mask=pack.dec_self, need_attn=False,
-                            need_head_weights=False, self_attn_bias=sb, cross_attn_bias=cross_bias,
+                            need_head_weights=False, self_attn_bias=sb, cross_attn_bias=cross_biases[idx],
                             modal_mask=adaptor_output.modal_mask, chain=chain, cross_kv=cross_kv)
         normed = chain.take()
         if normed is not None:

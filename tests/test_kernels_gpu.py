@@ -282,6 +282,25 @@ def test_gemm_group_tn_one_slice_products_accumulate_without_slabs(K, dtype):
         assert rel(out.float(), ref) < tol, (tuple(out.shape), rel(out.float(), ref))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,shape", [(2, (12, 64, 64)), (6, (4, 7, 7)), (12, (16, 33, 41)), (16, (1, 5))])
+def test_add_n_and_fan_out(K, dtype, n, shape):
+    """ofa_add_n: the sum of n tensors in one launch (fp32 accumulation, one rounding; a tail that is not a whole 16-byte vector), and
+    ops.fan_out: n consumers of one tensor get their gradients summed by it."""
+    from ofasys_amd import ops
+    torch.manual_seed(8)
+    ts = [torch.randn(*shape, device=DEV).to(dtype) for _ in range(n)]
+    got = K.add_n(ts)
+    want = torch.stack([t.float() for t in ts]).sum(0)
+    assert got.dtype == dtype and rel(got.float(), want) < (1e-6 if dtype == torch.float32 else 8e-3)
+    x = torch.randn(*shape, device=DEV).to(dtype).requires_grad_(True)
+    views = ops.fan_out(x, n + 3)                                      # (19 consumers with n = 16: two launches)
+    loss = sum((i + 1) * (v.float() * ts[i % n].float()).sum() for i, v in enumerate(views[:-1]))      # the last view stays unused
+    loss.backward()
+    wantg = sum((i + 1) * ts[i % n].float() for i in range(n + 2))
+    assert rel(x.grad.float(), wantg) < (1e-6 if dtype == torch.float32 else 1.6e-2)
+
+
 def test_gemm_splitk_and_batched(K):
     torch.manual_seed(2)
     # wgrad shape: skinny output, long contraction -> split-K path

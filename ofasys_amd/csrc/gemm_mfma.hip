@@ -1083,6 +1083,9 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& g, int tiles_m, in
   else if constexpr (TM == 3 && TN == 2)                                               \
     asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]),                     \
                  "+v"(wb[SET][0]), "+v"(wb[SET][TN - 1]));                                                          \
+  else if constexpr (TM == 4 && TN == 4)                                               \
+    asm volatile(BIG_WAITCNT : "+v"(xa[SET][0]), "+v"(xa[SET][1]), "+v"(xa[SET][2]), "+v"(xa[SET][3]),   \
+                 "+v"(wb[SET][0]), "+v"(wb[SET][1]), "+v"(wb[SET][2]), "+v"(wb[SET][TN - 1]));                      \
   else                                                                                 \
     static_assert(TM == 4 && TN == 2, "BIG_WAIT names every fragment register: add the shape")
   // One k-slice: TM*TN MFMAs on fragment set SET, with the NEXT slice's fragment reads (k-slice KKN into the other set)
@@ -1215,8 +1218,8 @@ struct GroupItem {
 };
 struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total; };
 
-template <bool F16>
-__global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
+template <bool F16, bool W4 = false>
+__global__ __launch_bounds__(W4 ? 256 : 512) void gemm_group_tn_kernel(GroupArgs ga) {
   // XCD chunks over the flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2
   const int id = xcd_remap((int)blockIdx.x, ga.total);
   int p = 0;
@@ -1232,7 +1235,8 @@ __global__ __launch_bounds__(512) void gemm_group_tn_kernel(GroupArgs ga) {
   const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
   const int ks = local / ntiles, t = local - ks * ntiles;
   // (OUT_F32 = false: the non-slab epilogue of this instantiation is the 16-bit accumulate of a one-slice product)
-  gemm_big_body<4, 2, false, false, false, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
+  if constexpr (W4) gemm_big_body<4, 4, false, false, false, 2, 2, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
+  else gemm_big_body<4, 2, false, false, false, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
 }
 
 template <bool OUT_F32, bool F16 = false>
@@ -1597,6 +1601,18 @@ extern "C" int ofa_gemm_group_tn(const ofa_gemm_group_item* items, int n, int dt
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
+#ifdef OFA_DEBUG_SWITCHES
+  static const bool w4 = getenv("OFA_GROUP_W4") && atoi(getenv("OFA_GROUP_W4"));     // experiment: four waves of 128 x 128
+  if (w4 && dtype != OFA_F16) {
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute((const void*)gemm_group_tn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL((gemm_group_tn_kernel<false, true>), dim3(ga.total), dim3(256), lds, st, ga);
+    return check_launch("gemm_group_tn_w4");
+  }
+#endif
   if (dtype == OFA_F16) hipLaunchKernelGGL(gemm_group_tn_kernel<true>, dim3(ga.total), dim3(512), lds, st, ga);
   else hipLaunchKernelGGL(gemm_group_tn_kernel<false>, dim3(ga.total), dim3(512), lds, st, ga);
   return check_launch("gemm_group_tn");

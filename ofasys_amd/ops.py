@@ -1168,10 +1168,10 @@ class FanOutFn(torch.autograd.Function):
         gs = [g for g in grads if g is not None]
         if not gs:
             return None, None
-        out = gs[0]
-        for i in range(0, len(gs), 16):                     # (16 inputs per launch)
-            chunk = gs[i:i + 16] if i == 0 else [out] + gs[i:i + 15]
-            out = K.add_n(chunk) if len(chunk) > 1 else chunk[0]
+        out, i = gs[0], 1
+        while i < len(gs):                                  # (16 inputs per launch: the running sum + the next 15)
+            out = K.add_n([out] + gs[i:i + 15])
+            i += 15
         return out, None
 
 

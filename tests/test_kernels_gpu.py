@@ -301,6 +301,18 @@ def test_add_n_and_fan_out(K, dtype, n, shape):
     assert rel(x.grad.float(), wantg) < (1e-6 if dtype == torch.float32 else 1.6e-2)
 
 
+def test_fan_out_of_a_deep_stack(K):
+    """More consumers than two launches of ofa_add_n hold (16 + 15 = 31): every gradient is in the sum exactly once."""
+    from ofasys_amd import ops
+    torch.manual_seed(9)
+    x = torch.randn(3, 17, device=DEV).requires_grad_(True)
+    for n in (31, 32, 47):
+        x.grad = None
+        ws = [torch.randn(3, 17, device=DEV) for _ in range(n)]
+        sum((v * w).sum() for v, w in zip(ops.fan_out(x, n), ws)).backward()
+        assert rel(x.grad, torch.stack(ws).sum(0)) < 1e-6, n
+
+
 def test_gemm_splitk_and_batched(K):
     torch.manual_seed(2)
     # wgrad shape: skinny output, long contraction -> split-K path

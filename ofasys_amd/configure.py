@@ -3,10 +3,9 @@ registry that adaptors register themselves in (reference: configure/config_store
 
 Only what the path needs is here (no argparse/omegaconf bridge -- out of scope).
 """
-import copy
 import dataclasses
-from dataclasses import dataclass, field, fields, is_dataclass
-from typing import Any, Dict
+from dataclasses import dataclass, field, is_dataclass
+from typing import Any
 
 
 def ChoiceEnum(choices):

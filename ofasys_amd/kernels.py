@@ -4,7 +4,6 @@ Each wrapper allocates outputs with torch (plumbing: device memory + streams), c
 kernel on torch's current stream.  Everything here requires GPU tensors; nothing falls back to torch math.
 """
 import ctypes
-import os
 
 import torch
 

@@ -3,7 +3,7 @@ forward signatures, arch presets and state-dict keys; the encoder/decoder run on
 import logging
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 from torch import Tensor

@@ -4,7 +4,6 @@ These are the building blocks the mirrored modules (ofasys_amd/module, adaptor, 
 activation is a dense [rows, C] matrix in batch-major order ([B,T,C] storage); fairseq's [T,B,C] tensors at the module
 boundary are transposed *views* of that storage, so no layout copies happen between ops.
 """
-import math
 
 import torch
 

@@ -14,7 +14,7 @@ sync anywhere in the step).
 """
 import os
 import warnings
-from typing import List, Optional
+from typing import List
 
 import torch
 

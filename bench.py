@@ -114,7 +114,12 @@ def make_batch(d, B, Ts_text, Tt, rank, device, workload="cfg2", pack=False):
     if pack:        # ragged row packing (ofasys_amd/packing.py): only the non-pad positions go through the stack
         from ofasys_amd.packing import build_pack_plan
         enc_mask = torch.cat([torch.zeros(B, 257 if patch else 196, dtype=torch.bool), src.eq(d.pad())], 1)
-        sample["pack"] = build_pack_plan(enc_mask, prev.eq(d.pad()), bucket=512, dec_bucket=256).to(device)
+        plan = build_pack_plan(enc_mask, prev.eq(d.pad()), bucket=512, dec_bucket=256)
+        # the targets by packed decoder row: collation work, done once per batch on the host (TrainStep gathers them on the device
+        # every step when the sample does not bring them)
+        idx = plan.dec_index
+        sample["target_packed"] = target.reshape(-1)[idx.clamp_min(0)].masked_fill(idx < 0, d.pad()).view(1, -1).to(device)
+        sample["pack"] = plan.to(device)
     return sample, ntok, (slen.tolist(), tlen.tolist())
 
 

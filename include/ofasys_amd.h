@@ -387,6 +387,10 @@ int ofa_sumsq(const void* x, float* out /* fp32[1], accumulated into */, float* 
  * otherwise sched[3] = 0. */
 int ofa_step_schedule(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
                       float* gnorm, float clip_norm, double beta1, double beta2, void* stream);
+/* stats [3] fp64 += [count of target != pad, loss[0], the same count]: one micro-batch's share of the update's logging sums
+ * [sample_size, loss_sum, ntokens] (engine/trainer.py:842-860, criterion/cross_entropy.py:55-67 with sentence_avg = False); loss: a
+ * device fp32 scalar; target: int64 [n].  One launch, nothing on the host. */
+int ofa_step_stats_add(double* stats, const float* loss, const int64_t* target, int64_t n, int64_t pad, void* stream);
 /* The same with a DYNAMIC LOSS SCALE (engine/optim/fp16_optimizer.py:170-204 clip_grad_norm / step, dynamic_loss_scaler.py:9-70):
  * the arena holds loss_scale * (sum of gradients); loss_scaler: device fp64[8] = [loss_scale, iter, last_overflow_iter,
  * last_rescale_iter, overflows_since_rescale, fatal, -, -].  sched[0] = 1 / (loss_scale * sample_size), times clip_norm / gnorm when

@@ -594,6 +594,32 @@ extern "C" int ofa_adam_step(float* master, float* exp_avg, float* exp_avg_sq, c
   return check_launch("adam_step");
 }
 
+// One micro-batch's contribution to the step statistics [sample_size, loss_sum, ntokens] (engine/trainer.py:842-860: the criterion's
+// logging outputs summed over the micro-batches of an update): the count of non-pad targets, the loss sum (a device scalar) and the
+// count again, in ONE single-block launch -- was target.ne(pad).sum() plus three read-modify-writes of a fp64 element, nine launches.
+__global__ __launch_bounds__(256) void step_stats_add_kernel(double* __restrict__ stats, const float* __restrict__ loss,
+                                                             const int64_t* __restrict__ target, int64_t n, int64_t pad) {
+  __shared__ int red[4];
+  int cnt = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) cnt += target[i] != pad;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double c = (double)(red[0] + red[1] + red[2] + red[3]);
+    stats[0] += c;
+    stats[1] += (double)loss[0];
+    stats[2] += c;
+  }
+}
+
+extern "C" int ofa_step_stats_add(double* stats, const float* loss, const int64_t* target, int64_t n, int64_t pad, void* stream) {
+  OFA_REQUIRE(stats && loss && (target || n == 0) && n >= 0, OFA_ERR_INVALID, "step_stats_add: bad argument");
+  hipLaunchKernelGGL(step_stats_add_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, loss, target, n, pad);
+  return check_launch("step_stats_add");
+}
+
 extern "C" int ofa_step_schedule_scaled(const float* gsq, const double* sample_size, double* step, const double* lr, float* sched,
                                         float* gnorm, double* loss_scaler, float clip_norm, double beta1, double beta2,
                                         double scale_factor, double scale_window, double tolerance, double threshold,

@@ -768,6 +768,14 @@ def im2col_patch(img, p, Kpad):
 
 
 # ------------------------------------------------------------------ criterion / optimizer
+def step_stats_add(stats, loss, target, pad):
+    """stats (fp64 [3]: sample_size, loss_sum, ntokens) += (non-pad targets, loss, non-pad targets): one launch."""
+    assert stats.dtype == torch.float64 and stats.numel() >= 3 and loss.dtype == torch.float32 and loss.numel() == 1
+    t = target.reshape(-1)
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    lib().call("ofa_step_stats_add", ptr(stats), ptr(loss), ptr(t), t.numel(), int(pad), stream())
+
+
 def cross_entropy_fwd(logits2d, target, V, ignore_index):
     """logits2d: [rows, ld] storage (ld >= V, multiple of the vector width); returns lse [rows], row_loss [rows]."""
     rows, ld = logits2d.shape[0], logits2d.stride(0)

@@ -286,6 +286,7 @@ class TrainStep:
         self._pool = None
         self._warned_cap = False
         self._skipped_seen = 0.0
+        self._seed = torch.ones((), dtype=torch.float32, device=dev)   # the backward seed of a micro-batch's loss (autograd's default: one fill per call)
         self.last = {}
 
     # ------------------------------------------------------------------ learning rate (host -> device scalar)
@@ -323,19 +324,29 @@ class TrainStep:
             cm = s.get("constraint_masks")
             if plan is not None and cm is not None:
                 raise NotImplementedError("constraint masks are laid out by padded position: run such samples without a pack plan")
+            counted = False
             if self.label_smoothing > 0 or self.constraint_range is not None or self.drop_worst_ratio > 0 or cm is not None:
                 loss, _, n = ops.label_smoothed_cross_entropy(logits, target, self.pad, self.label_smoothing,
                                                               self.constraint_range, cm, self.drop_worst_ratio)
             else:
                 loss = ops.cross_entropy_sum(logits, target, self.pad)
-                n = target.ne(self.pad).sum()
+                n = None
+                if loss.is_cuda and loss.dtype == torch.float32 and target.is_contiguous():
+                    # [sample_size, loss_sum, ntokens] += (non-pad targets, loss, non-pad targets) in one launch
+                    K.step_stats_add(self._stats, loss.detach(), target, self.pad)
+                    counted = True
+                else:
+                    n = target.ne(self.pad).sum()
             if self.loss_scale_cfg is None:
-                loss.backward()
+                if self._seed is None or self._seed.shape != loss.shape or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
+                    self._seed = torch.ones_like(loss)
+                loss.backward(self._seed)
             else:                                    # FP16Optimizer.backward: loss * loss_scale (fp16_optimizer.py:92-102)
                 loss.backward(self._ls[0].to(loss.dtype))
-            self._stats[0] += n
-            self._stats[1] += loss.detach().double()
-            self._stats[2] += n
+            if not counted:
+                self._stats[0] += n
+                self._stats[1] += loss.detach().double()
+                self._stats[2] += n
         ops.flush_folds()
         ops.rng_advance()
 

@@ -301,6 +301,20 @@ def test_add_n_and_fan_out(K, dtype, n, shape):
     assert rel(x.grad.float(), wantg) < (1e-6 if dtype == torch.float32 else 1.6e-2)
 
 
+def test_step_stats_add(K):
+    """ofa_step_stats_add: [sample_size, loss_sum, ntokens] += (non-pad targets, loss, non-pad targets), accumulated over calls."""
+    torch.manual_seed(10)
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    want = torch.zeros(3, dtype=torch.float64)
+    for n in (1, 255, 256, 2048, 5000):
+        t = torch.randint(0, 7, (n,), device=DEV)
+        loss = torch.rand((), device=DEV) * 1000
+        K.step_stats_add(stats, loss, t, 1)
+        c = float((t != 1).sum())
+        want += torch.tensor([c, float(loss), c], dtype=torch.float64)
+    assert torch.equal(stats.cpu()[[0, 2]], want[[0, 2]]) and abs(float(stats[1]) - float(want[1])) < 1e-9 * float(want[1])
+
+
 def test_fan_out_of_a_deep_stack(K):
     """More consumers than two launches of ofa_add_n hold (16 + 15 = 31): every gradient is in the sum exactly once."""
     from ofasys_amd import ops

@@ -23,4 +23,6 @@ int gemm_simple_launch(const GemmArgs& g, int batch, int dtype, hipStream_t st);
 int gemm_mfma_launch(const GemmArgs& g, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool f16 = false);
 bool gemm_mfma_supported(const GemmArgs& g);
 int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes);
+// gemm_pp.hip: the ping-pong main loop on the 256 x 256 / 192 x 256 tile (tm = 4 / 3); false: shape or variant not built
+bool gemm_pp_launch(int variant, const GemmArgs& g, int batch, int tm, int splits, int ksplit, float* ws, hipStream_t st, bool f16);
 }  // namespace ofa

@@ -113,20 +113,35 @@ print("forced tiles ok")
 """
 
 
+@pytest.mark.parametrize("pp", ["0", "21"])
 @pytest.mark.parametrize("tile", ["83", "84"])
-def test_gemm_eight_wave_tiles_forced(K, tile):
+def test_gemm_eight_wave_tiles_forced(K, tile, pp):
     """Every product of the list on the eight-wave 192 x 256 / 256 x 256 kernels (gemm_big_kernel<3|4, 2, .., 2, 4>): ragged edges in M
     and N, all four operand layouts, column / row bias, alpha, fp32 output, accumulation, ldc > N.  OFA_GEMM_TILE exists in the DEBUG library only
-    (libofasys_amd_dbg.so, OFASYS_AMD_LIB) and is read once per process, hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile."""
+    (libofasys_amd_dbg.so, OFASYS_AMD_LIB), hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile.
+    pp = 21: the same products through the ping-pong main loop (csrc/gemm_pp.hip) in every layout it is built for -- the shipped planner
+    sends it the m-major-operand products only; pp = 0 forces the lockstep loop for all of them."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dbg = os.path.join(root, "ofasys_amd", "libofasys_amd_dbg.so")            # (make -C ofasys_amd/csrc debug; built by __graft_entry__.build)
     assert os.path.exists(dbg), "the debug library (planner overrides compiled in) is not built: make -C ofasys_amd/csrc debug"
-    env = dict(os.environ, OFA_GEMM_TILE=tile, OFASYS_AMD_LIB=dbg)
+    env = dict(os.environ, OFA_GEMM_TILE=tile, OFASYS_AMD_LIB=dbg, OFA_GEMM_PP=pp)
     r = subprocess.run([sys.executable, "-c", _FORCED_TILE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced tiles ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_gemm_ping_pong_loop_bit_identical_to_lockstep_loop():
+    """tools/gemm_pp_check.py: every product (K = 1 .. 7 tiles and long, ragged M / N, NT / NN / TN, bias / alpha / accumulate, batched, ragged
+    weight-gradient row counts, the grouped launch) through the ping-pong loop and through the lockstep loop on the same tile, compared bit
+    for bit, repeatedly (a missing LDS-DMA wait or a too-early buffer refill shows as a rare mismatch); plus one fp32 reference per layout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_check.py"), "21"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 mismatching products" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -57,22 +57,29 @@ class BaseAdaptorConfig(BaseDataclass):
     use_self_attn_bias: bool = None
     share_attn_bias: bool = None
 
+    # adaptor field -> where an unset (None) value is inherited from in the model config (adaptor/base.py:83-101).
+    # entangle_position_embedding is in the table for parity with the reference, but its dataclass default is False, never None:
+    # it is NOT inherited from the model -- an adaptor entangles positions only when its own config says so.
+    _INHERITED = {
+        "dropout": "dropout",
+        "embed_dim": "encoder.embed_dim",
+        "num_attention_heads": "encoder.attention_heads",
+        "encoder_layers": "encoder.layers",
+        "decoder_layers": "decoder.layers",
+        "max_position": "max_source_positions",
+        "use_self_attn_bias": "use_self_attn_bias",
+        "share_attn_bias": "share_attn_bias",
+        "entangle_position_embedding": "entangle_position_embedding",
+    }
+
     def parse_from_model_cfg(self, model_cfg):
-        """adaptor/base.py:83-101: fill unset fields from the model config (entangle_position_embedding defaults to
-        False, i.e. it is NOT inherited)."""
-        self.dropout = model_cfg.dropout if self.dropout is None else self.dropout
-        self.embed_dim = model_cfg.encoder.embed_dim if self.embed_dim is None else self.embed_dim
-        self.num_attention_heads = (model_cfg.encoder.attention_heads if self.num_attention_heads is None
-                                    else self.num_attention_heads)
-        self.encoder_layers = model_cfg.encoder.layers if self.encoder_layers is None else self.encoder_layers
-        self.decoder_layers = model_cfg.decoder.layers if self.decoder_layers is None else self.decoder_layers
-        self.max_position = model_cfg.max_source_positions if self.max_position is None else self.max_position
-        self.use_self_attn_bias = (model_cfg.use_self_attn_bias if self.use_self_attn_bias is None
-                                   else self.use_self_attn_bias)
-        self.share_attn_bias = model_cfg.share_attn_bias if self.share_attn_bias is None else self.share_attn_bias
-        self.entangle_position_embedding = (model_cfg.entangle_position_embedding
-                                            if self.entangle_position_embedding is None
-                                            else self.entangle_position_embedding)
+        """Fill every field the adaptor's own config left unset from the model config (table above)."""
+        for name, path in self._INHERITED.items():
+            if getattr(self, name) is None:
+                node = model_cfg
+                for part in path.split("."):
+                    node = getattr(node, part)
+                setattr(self, name, node)
 
 
 class BaseAdaptor(torch.nn.Module):
@@ -85,19 +92,22 @@ class BaseAdaptor(torch.nn.Module):
     def __init__(self, embed_tokens: Embedding, dictionary: Dictionary, is_src: bool, general_adaptor,
                  cfg: BaseAdaptorConfig):
         super().__init__()
-        # not registered as child modules, exactly like the reference (adaptor/base.py:128-136)
-        self.embed_tokens = lambda x: embed_tokens(x)
-        self.embed_tokens_T = lambda x: ops.linear(x, embed_tokens.weight)
-        self.dictionary = dictionary
-        self.is_src = is_src
-        self._general_adaptor = [general_adaptor]
-        self.cfg = cfg
+        D = cfg.embed_dim
+        # the shared token embedding is reached through closures, NOT registered as a child module: the state dict must list it once,
+        # under the general adaptor (adaptor/base.py:128-136)
+        self.embed_tokens = lambda ids: embed_tokens(ids)
+        self.embed_tokens_T = lambda rows: ops.linear(rows, embed_tokens.weight)      # tied output projection
+        self.cfg, self.dictionary, self.is_src = cfg, dictionary, is_src
+        self._general_adaptor = [general_adaptor]                                      # (a list: not a child module either)
         self.num_layers = cfg.encoder_layers if is_src else cfg.decoder_layers
-        self.dropout_module = Dropout(cfg.dropout, module_name=self.__class__.__name__)
-        self.layernorm_embedding = LayerNorm(cfg.embed_dim) if cfg.layernorm_embedding else None
-        self.layernorm_position = LayerNorm(cfg.embed_dim) if cfg.layernorm_position else None
-        self.type_embedding = Embedding(1, cfg.embed_dim) if cfg.add_type_embedding else None
-        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
+        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(D)
+        # optional post-hook pieces.  Attribute names are state-dict keys and the REGISTRATION ORDER is part of the contract too: it is
+        # the key order of the state dict and the order the initialiser draws its random numbers in (tests/test_init_cpu.py compares both
+        # with the reference build) -- dropout, the two LayerNorms, then the type embedding.
+        self.dropout_module = Dropout(cfg.dropout, module_name=type(self).__name__)
+        self.layernorm_embedding = LayerNorm(D) if cfg.layernorm_embedding else None
+        self.layernorm_position = LayerNorm(D) if cfg.layernorm_position else None
+        self.type_embedding = Embedding(1, D) if cfg.add_type_embedding else None
         self.register_forward_hook(BaseAdaptor.forward_hook_fn)
 
     @property

@@ -3,6 +3,7 @@ stride-16 features -> Linear(1024, D); 2-D position ids `w + h*bucket + 1`; 2-D 
 into the integer table `image_rp_bucket` and one Embedding table per layer."""
 from dataclasses import dataclass, field
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -15,22 +16,21 @@ from .base import AdaptorOutput, BaseAdaptor, BaseAdaptorConfig
 
 
 def make_image_bucket_position(bucket_size, num_relative_distance):
-    """Integer table, bit-exact with adaptor/image_resnet.py:25-40 (built once on the host)."""
-    coords_h = torch.arange(bucket_size)
-    coords_w = torch.arange(bucket_size)
-    coords = torch.stack(torch.meshgrid([coords_h, coords_w], indexing="ij"))
-    coords_flatten = torch.flatten(coords, 1)
-    relative_coords = coords_flatten[:, :, None] - coords_flatten[:, None, :]
-    relative_coords = relative_coords.permute(1, 2, 0).contiguous()
-    relative_coords[:, :, 0] += bucket_size - 1
-    relative_coords[:, :, 1] += bucket_size - 1
-    relative_coords[:, :, 0] *= 2 * bucket_size - 1
-    relative_position_index = torch.zeros(size=(bucket_size * bucket_size + 1,) * 2, dtype=relative_coords.dtype)
-    relative_position_index[1:, 1:] = relative_coords.sum(-1)
-    relative_position_index[0, 0:] = num_relative_distance - 3
-    relative_position_index[0:, 0] = num_relative_distance - 2
-    relative_position_index[0, 0] = num_relative_distance - 1
-    return relative_position_index
+    """The reference's [bucket_size^2 + 1, bucket_size^2 + 1] int64 table of 2-D relative-position ids (adaptor/image_resnet.py:25-40; a
+    state-dict buffer, pinned by the CRC in tests/golden/base_resnet*.npz).  Written from its meaning: grid cell p = (y, x) has id
+    1 + y * bucket_size + x; the entry for a pair of cells is the row-major index of their offset (dy, dx) in the
+    (2 * bucket_size - 1)^2 window of possible offsets; id 0 is the reserved class-token slot, whose row, column and corner take the
+    last three ids of the table."""
+    span = 2 * bucket_size - 1
+    ys, xs = np.divmod(np.arange(bucket_size * bucket_size, dtype=np.int64), bucket_size)
+    dy = ys[:, None] - ys[None, :] + (bucket_size - 1)
+    dx = xs[:, None] - xs[None, :] + (bucket_size - 1)
+    table = np.empty((bucket_size * bucket_size + 1,) * 2, dtype=np.int64)
+    table[1:, 1:] = dy * span + dx
+    table[0, :] = num_relative_distance - 3
+    table[:, 0] = num_relative_distance - 2
+    table[0, 0] = num_relative_distance - 1
+    return torch.from_numpy(table)
 
 
 @dataclass

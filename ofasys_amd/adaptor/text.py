@@ -17,17 +17,22 @@ from .base import AdaptorOutput, BaseAdaptor, BaseAdaptorConfig
 
 
 def make_token_bucket_position(bucket_size, max_position):
-    """Integer bucket table, bit-exact with adaptor/text.py:20-30 (built once on the host at construction)."""
-    context_pos = torch.arange(max_position, dtype=torch.long)[:, None]
-    memory_pos = torch.arange(max_position, dtype=torch.long)[None, :]
-    relative_pos = context_pos - memory_pos
-    sign = torch.sign(relative_pos)
+    """The reference's [max_position, max_position] int64 table of 1-D relative-position buckets (adaptor/text.py:20-30; the table is a
+    buffer of the state dict, so it has to come out bit for bit -- pinned by the CRC in tests/golden/tiny_text.npz and, at the audio
+    adaptor's sizes, against the recorded state dict).  Built from what the table IS rather than as the reference's 2-D tensor
+    expression: the bucket of (i, j) depends on the distance d = i - j alone; distances up to mid = bucket_size / 2 keep their own
+    bucket, beyond that bucket mid + n covers the geometric band
+        mid * r^((n-1)/(mid-1)) < |d| <= mid * r^(n/(mid-1)),   r = (max_position - 1) / mid,   n = ceil((mid-1) * ln(|d|/mid) / ln r),
+    mirrored for negative d and shifted by bucket_size - 1 (indices 0 .. 2 * bucket_size - 2): ONE 1-D lookup over |d|, gathered by
+    |i - j|.  The band index is evaluated in float32 in the reference's operation order, because the table is DEFINED by that rounding:
+    at (1024, 4096), the audio adaptor's sizes, d = 3396 has (mid-1) * ln(d/mid) / ln r = 465.0000008 -- float32 rounds it to 465.0 and
+    the reference's table says band 465, exact arithmetic would say 466."""
     mid = bucket_size // 2
-    abs_pos = torch.where((relative_pos < mid) & (relative_pos > -mid), mid - 1, torch.abs(relative_pos))
-    log_pos = torch.ceil(torch.log(abs_pos / mid) / math.log((max_position - 1) / mid) * (mid - 1)) + mid
-    log_pos = log_pos.int()
-    bucket_pos = torch.where(abs_pos.le(mid), relative_pos, log_pos * sign).long()
-    return bucket_pos + bucket_size - 1
+    dist = torch.arange(max_position, dtype=torch.long)
+    band = torch.ceil(torch.log(dist.clamp_min(1) / mid) / math.log((max_position - 1) / mid) * (mid - 1)).long()
+    magnitude = torch.where(dist <= mid, dist, mid + band)                       # |bucket| by distance
+    rel = dist[:, None] - dist[None, :]
+    return torch.sign(rel) * magnitude[rel.abs()] + (bucket_size - 1)
 
 
 @dataclass

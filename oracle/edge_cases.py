@@ -9,6 +9,7 @@ SHAPES = [
     (1, 33, 65, [33], [65]),                   # batch of one, lengths that are no multiple of any tile
     (3, 5, 2, [5, 1, 3], [2, 1, 2]),           # rows with a single real token next to longer ones
     (2, 129, 31, [129, 2], [31, 30]),          # one row almost entirely padding
+    (2, 128, 128, [128, 116], [128, 119]),     # BASELINE.json configs[0]'s own shape: tiny arch, bsz 2, seq_len 128 / 128 (row 1 padded)
 ]
 
 

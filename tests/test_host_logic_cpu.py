@@ -121,6 +121,27 @@ def test_integer_paths_bit_exact():
         assert [t - d.bin_start for t in d.box_to_tokens(row, int(gb["max_image_size"][0]))] == list(want)
 
 
+def test_bucket_tables_bit_exact_at_every_adaptor_size():
+    """make_token_bucket_position / make_image_bucket_position (re-derived as 1-D distance / 2-D offset lookups, adaptor/text.py and
+    adaptor/image_resnet.py here) against the CRC-32 of the tables the REFERENCE's own builders return (tests/golden/bucket_tables.json,
+    oracle/gen_bucket_crc.py): text 256 / 1024, the audio adaptor's 1024 / 4096 -- where one band edge is decided by float32 rounding --
+    and a few more sizes; the oracle's restatement is held to the same CRCs."""
+    import json
+    import os
+    from ofasys_amd.adaptor.image_resnet import make_image_bucket_position
+    from ofasys_amd.adaptor.text import make_token_bucket_position
+    from oracle import restate
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bucket_tables.json")))
+    for e in G["token"]:
+        for fn in (make_token_bucket_position, restate.make_token_bucket_position):
+            t = fn(e["bucket_size"], e["max_position"])
+            assert str(t.dtype) == e["dtype"] and zlib.crc32(t.contiguous().numpy().tobytes()) == e["crc32"], (fn.__module__, e)
+    for e in G["image"]:
+        for fn in (make_image_bucket_position, restate.make_image_bucket_position):
+            t = fn(e["bucket_size"], e["num_relative_distance"])
+            assert str(t.dtype) == e["dtype"] and zlib.crc32(t.contiguous().numpy().tobytes()) == e["crc32"], (fn.__module__, e)
+
+
 def test_slot_attributes_and_adaptor_routing():
     from ofasys_amd import ModalityType, Slot
     model, _ = build_model(CASES["base_patch"])

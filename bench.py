@@ -319,7 +319,7 @@ def pmc_traffic(workload="cfg2"):
     FETCH_SIZE doubled on gfx950, tools/pmc_traffic.py); (None, None, reason) when no pass of the workload is committed."""
     here = os.path.dirname(os.path.abspath(__file__))
     tag = "" if workload == "cfg2" else "_" + workload
-    rounds = ("round4", "round3", "round2", "round1") if workload == "cfg2" else ("round4",)
+    rounds = ("round5", "round4", "round3", "round2", "round1") if workload == "cfg2" else ("round5", "round4")
     for name in [f"{r}_pmc_traffic{tag}.json" for r in rounds]:
         try:
             rows = json.load(open(os.path.join(here, "profiles", name)))
@@ -345,7 +345,7 @@ def rocprof_gemm_ms(workload):
     stem = {"cfg2": "rocprof_kernel_stats.json", "cfg2b": "rocprof_cfg2b_kernel_stats.json", "cfg4": "rocprof_cfg4_kernel_stats.json",
             "cfg3": "rocprof_cfg3_kernel_stats.json", "cfg5": "rocprof_cfg5_kernel_stats.json"}[workload]
     rows = name = None
-    for rnd in ("round4_", "round3_"):                               # the newest committed trace of this command
+    for rnd in ("round5_", "round4_", "round3_"):                    # the newest committed trace of this command
         try:
             rows = json.load(open(os.path.join(here, "profiles", rnd + stem)))
             name = rnd + stem
@@ -616,15 +616,18 @@ def main():
                                   "same command) / this run's step time"}
         if prof and prof["time_ms"] > 0:
             raw_ms = prof["time_ms"]
-            # the bracket of a kernel that does nothing (~1 us of work) is dispatch + event cost, not kernel time: taken off every launch
+            # `achieved` / `frac`: the RAW in-situ brackets (what the contract asks for: algorithmic flops / HIP-event time of the launches,
+            # measured live).  A bracket also holds dispatch + event cost (~5 us per launch: the same two events around a kernel that does
+            # nothing measure it), so the raw figure is a LOWER bound; the committed rocprofv3 trace of this command (roofline.rocprof:
+            # kernel durations only) sits a few % above it, and the bracket-calibrated figure (side fields) above that.  VERDICT r4 item 9.
             cal_ms = max(raw_ms - prof["launches"] * max(prof["null_bracket_us"] - 1.0, 0.0) * 1e-3, 0.5 * raw_ms)
-            prof["time_ms"] = cal_ms
-            ach = prof["flops"] / (prof["time_ms"] * 1e-3) / 1e12
+            ach = prof["flops"] / (raw_ms * 1e-3) / 1e12
+            ach_cal = prof["flops"] / (cal_ms * 1e-3) / 1e12
             roof.update({"achieved": ach, "frac": ach / PEAK_BF16_TFLOPS, "launches_per_step": prof["launches"] // args.profile_gemm,
-                         "gemm_ms_per_step_raw_events": raw_ms / args.profile_gemm, "event_bracket_overhead_us": prof["null_bracket_us"],
-                         "frac_raw_events": prof["flops"] / (raw_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         "avg_launch_us": prof["time_ms"] * 1e3 / max(prof["launches"], 1),
-                         "gemm_ms_per_step": prof["time_ms"] / args.profile_gemm,
+                         "gemm_ms_per_step": raw_ms / args.profile_gemm, "event_bracket_overhead_us": prof["null_bracket_us"],
+                         "achieved_events_calibrated": ach_cal, "frac_events_calibrated": ach_cal / PEAK_BF16_TFLOPS,
+                         "gemm_ms_per_step_events_calibrated": cal_ms / args.profile_gemm,
+                         "avg_launch_us": raw_ms * 1e3 / max(prof["launches"], 1),
                          "gemm_flops_per_step": prof["flops"] / args.profile_gemm,
                          "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1),
                          "how": "instrumented eager step right after the timed region, the stream parked behind a spin kernel "
@@ -632,9 +635,9 @@ def main():
                                 "by two HIP events on its launch stream (one launch each, no relaunch, caches as the step leaves "
                                 "them; includes the split-K reduce where ofa_gemm runs one; a layer's grouped weight-gradient "
                                 "launch is one launch, its slab fold is a FoldQueue kernel outside this family time -- see "
-                                "roofline.rocprof for the profiler's figure incl. reduces and folds).  `achieved` / `frac` use the "
-                                "bracketed times minus the measured cost of an EMPTY bracket per launch (event_bracket_overhead_us - 1 us: "
-                                "the same two events around a one-element kernel); frac_raw_events is without that correction"})
+                                "roofline.rocprof for the profiler's figure incl. reduces and folds).  `achieved` / `frac` are the raw "
+                                "bracketed times; *_events_calibrated subtract the measured cost of an EMPTY bracket per launch "
+                                "(event_bracket_overhead_us - 1 us: the same two events around a one-element kernel)"})
             fam_ms, all_ms, src = rocprof_gemm_ms(args.workload)
             if fam_ms:
                 f = prof["flops"] / args.profile_gemm / (fam_ms * 1e-3) / 1e12

@@ -288,7 +288,12 @@ def gemm_group_tn(products, fold):
     dt = dtype_code(products[0][0])
     lib().call("ofa_gemm_group_plan", ctypes.addressof(arr), len(products), dt)
     # a product the plan leaves ONE K-slice (a small micro-batch's weight gradients) is accumulated straight onto its 16-bit arena
-    # gradient in the kernel's epilogue: no fp32 slab, no fold launch (the fold of a one-slab job only rounds and accumulates)
+    # gradient in the kernel's epilogue: no fp32 slab, no fold launch (the fold of a one-slab job only rounds and accumulates).
+    # Arithmetic: round(alpha * dY^T X) to 16 bits, add the old 16-bit gradient, round again -- that is the REFERENCE's accumulation
+    # over micro-batches (autograd hands AccumulateGrad a 16-bit gradient, `p.grad += g` adds in 16 bits: engine/trainer.py:766-784
+    # under model.half() / bfloat16()); the slab + fold path (fp32 sum of the slices and the old gradient, ONE rounding) is tighter than
+    # the reference, not the other way round.  tests/test_kernels_gpu.py::test_gemm_group_tn_direct_accumulation_over_micro_batches
+    # bounds both against an fp64 sum.
     slabs, direct_outs = [], set()
     for it, (dy, x, out, alpha) in zip(arr, products):
         direct = (GROUP_DIRECT and it.splits == 1 and out.dtype == dy.dtype and out.dim() == 2 and out.stride(1) == 1 and out.stride(0) % 8 == 0

@@ -5,6 +5,8 @@ activation is a dense [rows, C] matrix in batch-major order ([B,T,C] storage); f
 boundary are transposed *views* of that storage, so no layout copies happen between ops.
 """
 
+import weakref
+
 import torch
 
 from . import kernels as K
@@ -585,7 +587,21 @@ def owner_token(owner):
     tok = owner.__dict__.get("_ofa_owner_token")
     if tok is None or tok.owner_id != id(owner):
         tok = owner.__dict__["_ofa_owner_token"] = _OwnerToken(id(owner))
+        # entries keyed by the token go when the owner does (a process that builds many models -- tests, sweeps -- would otherwise keep
+        # every dead model's plan tensors on the device: ADVICE r4).  The finalizer holds the token, not the owner.
+        weakref.finalize(owner, _purge_owner_entries, tok)
     return tok
+
+
+def _purge_owner_entries(tok):
+    def mentions(key):
+        return key is tok or (isinstance(key, tuple) and any(mentions(k) for k in key))
+    for cache in _TOKEN_KEYED_CACHES:
+        for key in [k for k in cache if mentions(k)]:
+            del cache[key]
+
+
+_TOKEN_KEYED_CACHES = []        # process-wide caches whose keys contain owner tokens (SegmentPlan._cache registers itself below)
 
 
 class _OwnerToken:
@@ -629,6 +645,9 @@ class SegmentPlan:
                 cls._cache.clear()
             plan = cls._cache[key] = cls(ids)
         return plan
+
+
+_TOKEN_KEYED_CACHES.append(SegmentPlan._cache)
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -1167,6 +1186,15 @@ class FanOutFn(torch.autograd.Function):
         gs = [g for g in grads if g is not None]
         if not gs:
             return None, None
+        # ofa_add_n takes contiguous, 16-byte aligned inputs of ONE dtype; a gradient that is a view at an odd offset, strided, or of
+        # another dtype (an fp32 gradient from the exact-tier attention path) takes autograd's own pairwise adds instead of raising
+        # in the middle of backward
+        fast = all(g.dtype == gs[0].dtype and g.is_contiguous() and g.data_ptr() % 16 == 0 and g.shape == gs[0].shape for g in gs)
+        if not fast:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g.to(out.dtype) if g.dtype != out.dtype else out + g
+            return out, None
         out, i = gs[0], 1
         while i < len(gs):                                  # (16 inputs per launch: the running sum + the next 15)
             out = K.add_n([out] + gs[i:i + 15])
@@ -1696,17 +1724,35 @@ class SyncBatchNormFn(torch.autograd.Function):
         return dx, dres, dg, db, None, None, None, None, None, None, None
 
 
+_SYNC_BN_GROUP = []      # the SyncBatchNorm layers' own communicator (created collectively, once per process)
+
+
+def sync_bn_process_group():
+    """The default `sync_bn` exchange runs on its OWN communicator, never on the group the gradient buckets use: a communicator
+    matches collectives by issue order, and the bucket reducer issues its all-reduces at rank-local points of backward (a rank whose
+    step structure is already learned launches buckets from inside backward, a rank that still learns launches all of them at
+    finish()), so SyncBatchNorm's backward exchange would land between different buckets on different ranks.  Created on
+    first use by a collective `new_group` -- every rank reaches its first SyncBatchNorm layer in the same (eager, warm-up) step -- or
+    up front by TrainStep."""
+    import torch.distributed as dist
+    if not _SYNC_BN_GROUP:
+        _SYNC_BN_GROUP.append(dist.new_group())
+    return _SYNC_BN_GROUP[0]
+
+
 def _bn_sync_group(bn):
     """The process group a BatchNorm layer synchronises its training statistics over, or None: `bn._ofa_sync` is set by the owner
-    (ImageResnetAdaptor with cfg.sync_bn) to True (default group) or a group; a single-rank job needs no exchange."""
+    (ImageResnetAdaptor with cfg.sync_bn) to True (all ranks, on the layers' dedicated communicator) or to a group; a single-rank job
+    needs no exchange."""
     sync = getattr(bn, "_ofa_sync", None)
     if sync is None or sync is False:
         return None
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return None
-    group = None if sync is True else sync
-    return (group,) if dist.get_world_size(group) > 1 else None
+    if sync is True:
+        return (sync_bn_process_group(),) if dist.get_world_size() > 1 else None
+    return (sync,) if dist.get_world_size(sync) > 1 else None
 
 
 def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, grad_mailbox=None, stats=None):

@@ -257,6 +257,15 @@ class TrainStep:
         if self.use_graph and self.dynamic_autograd:
             warnings.warn("ofasys_amd.TrainStep: LayerDrop draws the kept layers on the host every step; the step is not captured")
             self.use_graph = False
+        # SyncBatchNorm layers exchange statistics in the middle of forward AND backward.  They do so on their own communicator
+        # (ops.sync_bn_process_group, created here while every rank is at the same point), and with them in the model the bucket
+        # reducer is never armed: ranks learn step structures at different times (padded lengths are part of the key), and a rank
+        # that launches buckets from inside backward next to one that launches them at finish() would interleave the two kinds of
+        # collectives differently -- harmless across communicators only as long as nobody's stream waits on both.  Every bucket
+        # goes out at finish(), in index order, on every rank.
+        self.sync_collectives = any(getattr(m, "_ofa_sync", None) not in (None, False) for m in model.modules())
+        if self.sync_collectives and self.world > 1 and any(getattr(m, "_ofa_sync", None) is True for m in model.modules()):
+            ops.sync_bn_process_group()
         self.graph_warmup = graph_warmup
         default_dp = "full"
         if self.world > 1:
@@ -309,7 +318,7 @@ class TrainStep:
         self.reducer.overlap = overlap_reduce
         # gradients are only read after backward unless buckets are all-reduced from inside it: fold lazily, in batches
         ops.defer_reductions(self.world == 1 or not overlap_reduce)
-        self.reducer.begin_step(structure, dynamic=self.dynamic_autograd)
+        self.reducer.begin_step(structure, dynamic=self.dynamic_autograd or self.sync_collectives)
         for s in samples:
             plan = s.get("pack")
             target = s["target"]
@@ -331,7 +340,7 @@ class TrainStep:
             else:
                 loss = ops.cross_entropy_sum(logits, target, self.pad)
                 n = None
-                if loss.is_cuda and loss.dtype == torch.float32 and target.is_contiguous():
+                if loss.is_cuda and loss.dtype == torch.float32 and target.is_contiguous() and target.dtype == torch.int64:
                     # [sample_size, loss_sum, ntokens] += (non-pad targets, loss, non-pad targets) in one launch
                     K.step_stats_add(self._stats, loss.detach(), target, self.pad)
                     counted = True

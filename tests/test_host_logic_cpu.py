@@ -494,3 +494,126 @@ def test_bench_self_launches_ranks_when_no_launcher_started_it():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world"] == 2
 
+
+class _SyncProbe(torch.autograd.Function):
+    """Stands in for a SyncBatchNorm layer: one all-reduce on the layers' communicator in forward and one in backward."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        ctx.group = group
+        s = x.detach().sum().reshape(1).clone()
+        dist.all_reduce(s, group=group)
+        return x + 0.0 * s
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        s = dy.sum().reshape(1).clone()
+        dist.all_reduce(s, group=ctx.group)
+        return dy + 0.0 * s, None
+
+
+def _dp_syncbn_worker(rank, world, port, q, dynamic):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd import ops
+    from ofasys_amd.distributed import GradBucketReducer
+    from ofasys_amd.trainer import FlatParams
+    bn = torch.nn.BatchNorm2d(4)
+    bn._ofa_sync = True
+    (group,) = ops._bn_sync_group(bn)
+    own = group is not None and group is not dist.group.WORLD and ops._bn_sync_group(bn)[0] is group     # dedicated, created once
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(4)])
+    fp = FlatParams(layers)
+    red = GradBucketReducer(fp.params, fp.grad, fp.offsets, None, bucket_bytes=512)
+    grads, early = [], []
+    for step in range(3):
+        # rank 0 sees ONE structure (armed from step 1 on), rank 1 a new one every step (padded lengths differ): never armed
+        sig = "same" if rank == 0 else f"len{step}"
+        fp.zero_grad()
+        red.begin_step(sig, dynamic=dynamic)
+        h = torch.randn(4, 16, generator=torch.Generator().manual_seed(7 + rank + 10 * step))
+        for i, lin in enumerate(layers):
+            h = lin(h)
+            if i == 1:
+                h = _SyncProbe.apply(h, group)
+        h.sum().backward()
+        red.finish()
+        grads.append(fp.grad.clone().numpy())
+        early.append(red.last_early)
+    q.put((rank, grads, early, own))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_sync_bn_collectives_next_to_bucket_reducer_with_ranks_in_different_modes(dynamic):
+    """SyncBatchNorm's exchanges run on their OWN communicator (ops.sync_bn_process_group), so a rank that launches gradient
+    buckets from inside backward (structure learned) next to a rank that launches them at finish() (still learning: its padded lengths
+    changed) interleaves the two kinds of collectives differently without mismatching either sequence; TrainStep additionally never
+    arms the reducer when the model holds such layers (dynamic = True).  Both settings must give the summed gradients on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34500 + os.getpid() % 1000 + (0 if dynamic else 1)
+    procs = [ctx.Process(target=_dp_syncbn_worker, args=(r, 2, port, q, dynamic)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][3] and res[1][3]                                    # the dedicated group, the same object on every call
+    if dynamic:
+        assert res[0][2] == [0, 0, 0] and res[1][2] == [0, 0, 0]      # nobody launched from inside backward
+    else:
+        assert res[0][2][1] > 0 and res[1][2] == [0, 0, 0]            # rank 0 armed, rank 1 not: the situation of the advice
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(16, 16) for _ in range(4)]
+    for step in range(3):
+        for m in layers:
+            m.zero_grad()
+        for rank in range(2):
+            h = torch.randn(4, 16, generator=torch.Generator().manual_seed(7 + rank + 10 * step))
+            for lin in layers:
+                h = lin(h)
+            h.sum().backward()
+        want = torch.cat([p.grad.reshape(-1) for m in layers for p in m.parameters()])
+        g0, g1 = torch.from_numpy(res[0][1][step]), torch.from_numpy(res[1][1][step])
+        assert torch.equal(g0, g1) and torch.allclose(g0[: want.numel()], want, atol=1e-5)
+
+
+def test_owner_token_entries_leave_the_plan_cache_with_their_owner():
+    """process-wide caches keyed by an owner token drop the entries of a collected module (weakref.finalize)."""
+    import gc
+    from ofasys_amd import ops
+    m = torch.nn.Linear(2, 2)
+    key = ("text", ops.owner_token(m))
+    other = ("text", ops.owner_token(torch.nn.Linear(2, 2)))          # (its owner is already gone: purged on collection)
+    gc.collect()
+    ops.SegmentPlan._cache[key] = object()
+    keep = torch.nn.Linear(2, 2)
+    key2 = ("image", ops.owner_token(keep), (3, 4))
+    ops.SegmentPlan._cache[key2] = object()
+    assert key in ops.SegmentPlan._cache and other not in ops.SegmentPlan._cache
+    del m
+    gc.collect()
+    assert key not in ops.SegmentPlan._cache and key2 in ops.SegmentPlan._cache
+    del ops.SegmentPlan._cache[key2]
+
+
+def test_fan_out_backward_takes_the_pairwise_path_for_gradients_add_n_would_refuse():
+    """FanOutFn.backward hands strided / mixed-dtype gradients to plain adds instead of ofa_add_n (contiguous, aligned, one dtype)."""
+    from ofasys_amd import ops
+    x = torch.randn(6, 8, requires_grad=True)
+    a, b, c = ops.FanOutFn.apply(x, 3)
+    ga = torch.randn(8, 6).t()                                         # not contiguous
+    gb = torch.randn(6, 8, dtype=torch.float64)                        # another dtype
+    (a * ga).sum().backward(retain_graph=True, inputs=[x])
+    g1 = x.grad.clone()
+    x.grad = None
+    ((a * ga).sum() + (b.double() * gb).sum() + c.sum()).backward(inputs=[x])
+    assert torch.allclose(g1, ga) and torch.allclose(x.grad, ga + gb.float() + 1.0, atol=1e-6)

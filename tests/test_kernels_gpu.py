@@ -207,6 +207,32 @@ def test_gemm_group_tn(K, dtype, shapes):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_group_tn_direct_accumulation_over_micro_batches(K, dtype):
+    """update_freq > 1 with small micro-batches: every micro-batch's one-slice weight gradient lands on the 16-bit arena gradient in the
+    kernel's epilogue (round the product, add, round -- the reference's `p.grad += g` in 16 bits).  Four accumulations against the fp64
+    sum: within the four half-ulp roundings of the 16-bit format, and no worse than torch's own 16-bit `+=` of the same four products."""
+    torch.manual_seed(9)
+    M, N, Kk, steps = 768, 1024, 256, 4
+    out = torch.zeros(M, N, device=DEV, dtype=dtype)
+    emul = torch.zeros(M, N, device=DEV, dtype=dtype)
+    ref = torch.zeros(M, N, device=DEV, dtype=torch.float64)
+    for _ in range(steps):
+        dy = torch.randn(Kk, M, device=DEV).to(dtype)
+        x = torch.randn(Kk, N, device=DEV).to(dtype)
+        q = K.FoldQueue()
+        K.gemm_group_tn([(dy, x, out, 0.5)], q)
+        q.flush()
+        prod = 0.5 * (dy.double().t() @ x.double())
+        ref += prod
+        emul += prod.to(dtype)                        # what the reference does: a 16-bit gradient added in 16 bits
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    scale = float(ref.abs().max())
+    err, err_emul = float((out.double() - ref).abs().max()) / scale, float((emul.double() - ref).abs().max()) / scale
+    print(f"MEASURED direct 16-bit accumulation over {steps} micro-batches ({dtype}): max err {err:.2e} of the largest entry (torch 16-bit += : {err_emul:.2e})")
+    assert err <= steps * eps and err <= 1.5 * err_emul + eps / 4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K_,bias", [
     (6272, 256, 1024, False), (6272, 1024, 256, False), (1568, 256, 2304, False),      # ResNet layer3 products (B = 32 / 8), 1 x 1 and 3 x 3
     (25088, 128, 1152, False), (784, 1024, 256, True), (200, 136, 72, True),           # layer2; micro-batch 4; ragged M / N / K

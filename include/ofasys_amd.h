@@ -262,8 +262,10 @@ int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, 
  * with the inverse index, scatters gradients back. */
 int ofa_gather_rows(const void* src, const int64_t* index, void* out, int64_t n, int D, int64_t src_rows, int dtype,
                     void* stream);
-int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
-                      void* stream);
+/* out[r, :] = weight[ids[r], :]  (F.embedding, adaptor/text.py:124-125); is_pad (optional, n bytes): is_pad[r] = ids[r] == pad_id -- the
+ * padding mask the text adaptor derives from the same ids (adaptor/text.py:108-111), written by the same pass. */
+int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, uint8_t* is_pad, int64_t pad_id,
+                      int dtype, void* stream);
 /* dweight[seg_row[s], :] (+)= sum over p in [seg_off[s], seg_off[s+1]) of dout[order[p], :]   (D <= 64 columns).
  * The embedding gradient of a lookup whose ids are the same every step -- the rel-pos bias `table[bucket[i][j]]` (adaptor/text.py:
  * 101-104, image_resnet.py:116-128): order = positions sorted by id (stable), one segment per distinct id, built once per lookup
@@ -284,10 +286,13 @@ int ofa_dropout_add_fwd(const void* x, const void* residual, void* y, int64_t n,
                         uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
 int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t offset,
                     const int64_t* offset_base, int dtype, void* stream);
-/* y[r][c] = (a[r][c] + (b? b[r][c]:0) + (vec? vec[c]:0)) * (rowmask && rowmask[r] ? 0 : 1)  -- adaptor/base.py:168-173,
- * model/transformer.py:110-112 */
+/* y[r][c] = (a[r][c] + (b? b[rb][c]:0) + (vec? vec[c]:0)) * (rowmask && rowmask[r] ? 0 : 1)  -- adaptor/base.py:168-173,
+ * model/transformer.py:110-112.  rb = r, or r % b_period when b_period > 0: b then holds ONE sample's rows (position embeddings are the
+ * same for every sample of a batch: adaptor/text.py:124 `embed_positions(arange)`) and is never expanded to [B, T, D]. */
 int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y, int64_t rows,
-                        int cols, int dtype, void* stream);
+                        int cols, int64_t b_period, int dtype, void* stream);
+/* out[i] (+)= sum_{b < batch} x[b * n + i]  (fp32 accumulation, one rounding): the gradient of such a batch-shared tensor. */
+int ofa_batch_sum(const void* x, void* out, int batch, int64_t n, int accumulate, int dtype, void* stream);
 
 /* out[c] (out_dtype) (+)= alpha * sum_r x[r][c]  -- bias gradients of nn.Linear (autograd of multihead_attention.py:199-217). */
 int ofa_colsum_ws_floats(int cols);

@@ -151,8 +151,8 @@ class AudioFbankAdaptor(BaseAdaptor):
         # adaptor/audio.py:303-310 builds this row by row on the host (one device sync per row); same mask, no sync:
         # positions >= the subsampled length are padding
         padding_mask = torch.arange(T2, device=feature.device)[None, :] >= feature_length[:, None]
-        pos = torch.arange(T2, device=feature.device)[None, :].expand(feature.shape[0], T2)
-        pos_embed = self.embed_audio_positions(pos)
+        pos = torch.arange(T2, device=feature.device)[None, :]
+        pos_embed = self.embed_audio_positions(pos).expand(feature.shape[0], -1, -1)       # one lookup, batch-shared (ops.shared_rows)
         if (slot.has_attr("use_mask") or self.use_mask) and mask_indices is not None:      # apply_mask, :452-466
             mch = None
             if self.mask_channel_prob > 0:          # [B, C] channel draws of get_mask_indices: those channels are zeroed over all T

@@ -97,6 +97,8 @@ class BaseAdaptor(torch.nn.Module):
         # under the general adaptor (adaptor/base.py:128-136)
         self.embed_tokens = lambda ids: embed_tokens(ids)
         self.embed_tokens_T = lambda rows: ops.linear(rows, embed_tokens.weight)      # tied output projection
+        # (embedding rows, ids == pad) from one launch (adaptor/text.py:108-125 computes the two separately)
+        self.embed_tokens_and_pad_mask = lambda ids, pad: ops.embedding_with_pad_mask(ids, embed_tokens.weight, embed_tokens.padding_idx, pad)
         self.cfg, self.dictionary, self.is_src = cfg, dictionary, is_src
         self._general_adaptor = [general_adaptor]                                      # (a list: not a child module either)
         self.num_layers = cfg.encoder_layers if is_src else cfg.decoder_layers
@@ -129,7 +131,13 @@ class BaseAdaptor(torch.nn.Module):
         if self.layernorm_embedding is not None:
             embed = self.layernorm_embedding(embed)
         if self.layernorm_position is not None and output.pos_embed is not None:
-            output.pos_embed = self.layernorm_position(output.pos_embed)
+            base = ops.shared_rows(output.pos_embed)
+            if base is not None:
+                # positions shared by the batch (every built-in adaptor: a stride-0 expand of [1, T, D]): normalise the T rows once; the
+                # [B, T, D] the contract promises stays a view, and the gradient arrives summed over the batch through the expand
+                output.pos_embed = self.layernorm_position(base).expand_as(output.pos_embed)
+            else:
+                output.pos_embed = self.layernorm_position(output.pos_embed)
         output.embed = self.dropout_module(embed)
         output.pos_shared = bool(self.pos_batch_invariant)
         if not output.self_attn_bias and self.cfg.use_self_attn_bias:

@@ -126,10 +126,17 @@ class OFAGeneralAdaptor(torch.nn.Module):
             o = modality_outputs[0]
             output = AdaptorOutput(o.embed, o.masks, o.pos_embed, None)
         else:
+            pos_parts = [x.pos_embed for x in modality_outputs]
+            bases = [ops.shared_rows(t) for t in pos_parts]
+            if all(b is not None for b in bases):
+                # every slot's positions are shared by the batch: concatenate the [1, n, D] copies, expand the result (stride 0)
+                pos_embed = torch.cat(bases, dim=1).expand(pos_parts[0].shape[0], -1, -1)
+            else:
+                pos_embed = torch.cat(tuple(pos_parts), dim=1)
             output = AdaptorOutput(
                 torch.cat(tuple(x.embed for x in modality_outputs), dim=1),
                 torch.cat(tuple(x.masks for x in modality_outputs), dim=1),
-                torch.cat(tuple(x.pos_embed for x in modality_outputs), dim=1),
+                pos_embed,
                 None,
             )
         self.last_pos_shared = all(getattr(mo, "pos_shared", False) for mo in modality_outputs)    # (read by the stacks)

@@ -55,6 +55,7 @@ class ImagePatchEmbedAdaptor(BaseAdaptor):
         if self.cfg.add_cls_token:
             x = torch.cat((self.cls_token.expand(batch_size, -1, -1).to(x.dtype), x), dim=1)
         n = x.size(1)
-        mask = torch.zeros((batch_size, n), dtype=torch.bool, device=image.device)
-        pos = torch.arange(n, dtype=torch.long, device=image.device).unsqueeze(0).expand(batch_size, -1)
-        return AdaptorOutput(x, mask, self.embed_image_positions(pos), None)
+        mask = ops.cached_index(self, ("nomask", batch_size, n), lambda: torch.zeros((batch_size, n), dtype=torch.bool, device=image.device))
+        pos = ops.cached_index(self, ("arange", n), lambda: torch.arange(n, dtype=torch.long, device=image.device).unsqueeze(0))
+        # one lookup of the n positions, expanded (stride 0) to the batch: ops.shared_rows
+        return AdaptorOutput(x, mask, self.embed_image_positions(pos).expand(batch_size, -1, -1), None)

@@ -106,7 +106,7 @@ class ImageResnetAdaptor(BaseAdaptor):
         image_padding_mask = torch.zeros((B, n), dtype=torch.bool, device=device)
         idx = (torch.arange(w, device=device).unsqueeze(0).expand(h, w)
                + torch.arange(h, device=device).unsqueeze(1) * self.cfg.image_bucket_size + 1).view(-1)
-        image_pos_embed = self.embed_image_positions(idx[None, :].expand(B, n))
+        image_pos_embed = self.embed_image_positions(idx[None, :]).expand(B, -1, -1)        # one lookup, batch-shared (ops.shared_rows)
         return image_embed, n, image_padding_mask, idx, image_pos_embed
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:

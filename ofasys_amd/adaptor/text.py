@@ -81,14 +81,18 @@ class TextAdaptor(BaseAdaptor):
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:
         src_tokens = slot.value
-        if self.dictionary.pad() is not None:
-            padding_masks = src_tokens.eq(self.dictionary.pad())
-        else:
-            padding_masks = torch.zeros_like(src_tokens, dtype=torch.bool)
         bsz, seq_len = src_tokens.shape
-        positions = torch.arange(seq_len, device=src_tokens.device).unsqueeze(0).expand(bsz, seq_len)   # utils.py:623-630
-        pos_embed = self.embed_positions(positions)
-        token_embedding = self.embed_tokens(src_tokens)
+        pad = self.dictionary.pad()
+        if pad is not None and src_tokens.is_cuda:
+            token_embedding, padding_masks = self.embed_tokens_and_pad_mask(src_tokens, pad)      # one launch for both
+        else:
+            token_embedding = self.embed_tokens(src_tokens)
+            padding_masks = src_tokens.eq(pad) if pad is not None else torch.zeros_like(src_tokens, dtype=torch.bool)
+        # positions are arange(T) for every row regardless of padding (utils.py:623-630): looked up ONCE, [1, T, D], and handed on as
+        # the [B, T, D] the contract names through a stride-0 expand (ops.shared_rows: the post-hook, the entangled add and the
+        # position bias read the one copy)
+        positions = ops.cached_index(self, ("arange", seq_len), lambda: torch.arange(seq_len, device=src_tokens.device).unsqueeze(0))
+        pos_embed = self.embed_positions(positions).expand(bsz, -1, -1)
         return AdaptorOutput(token_embedding, padding_masks, pos_embed, [])
 
     def forward_output(self, x: Tensor, extra: Dict[str, Any], slot: Slot, **kwargs):

@@ -76,9 +76,10 @@ class VideoImageSequenceAdaptor(BaseAdaptor):
         image_position_idx = (torch.arange(w, device=device).unsqueeze(0).expand(h, w)
                               + torch.arange(h, device=device).unsqueeze(1) * ira.cfg.image_bucket_size + 1).view(-1)
         frame_position_idx = torch.arange(Fr, device=device) + 1
-        image_pos_embed = ira.embed_image_positions(image_position_idx[None, :].expand(B, P))
-        frame_pos_embed = self.embed_frame_positions(frame_position_idx[None, :].expand(B, Fr))
-        video_pos_embed = (image_pos_embed.unsqueeze(1) + frame_pos_embed.unsqueeze(2)).reshape(B, T, -1)
+        # positions are the same for every clip: [1, ...] lookups, the sum built once and expanded (stride 0) to the batch
+        image_pos_embed = ira.embed_image_positions(image_position_idx[None, :])
+        frame_pos_embed = self.embed_frame_positions(frame_position_idx[None, :])
+        video_pos_embed = (image_pos_embed.unsqueeze(1) + frame_pos_embed.unsqueeze(2)).reshape(1, T, -1).expand(B, -1, -1)
         return video_embed, T, video_padding_mask, image_position_idx, video_pos_embed
 
     def forward(self, slot: Slot, **kwargs) -> AdaptorOutput:

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
 template <typename T>
 __global__ __launch_bounds__(256) void add_rowvec_mask_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                               const T* __restrict__ vec, const uint8_t* __restrict__ rowmask,
-                                                              T* __restrict__ y, int64_t rows, int cols) {
+                                                              T* __restrict__ y, int64_t rows, int cols, int64_t b_period) {
   constexpr int N = Vec<T>::N;
   const int vpr = cols / N;
   const int64_t total = rows * vpr;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void add_rowvec_mask_kernel(const T* __restric
     float x[N], t[N];
     load_vec<T>(a + r * cols + c, x);
     if (b) {
-      load_vec<T>(b + r * cols + c, t);
+      load_vec<T>(b + (b_period ? r % b_period : r) * cols + c, t);     // b_period rows of b serve every sample (shared positions)
 #pragma unroll
       for (int j = 0; j < N; ++j) x[j] += t[j];
     }
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void add_rowvec_mask_kernel(const T* __restric
 
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict__ w, const int64_t* __restrict__ ids,
-                                                            T* __restrict__ out, int64_t n, int D, int64_t V) {
+                                                            T* __restrict__ out, int64_t n, int D, int64_t V,
+                                                            uint8_t* __restrict__ is_pad, int64_t pad_id) {
   constexpr int N = Vec<T>::N;
   const int vpr = D / N;
   const int64_t total = n * vpr;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict_
     const int64_t r = v / vpr;
     const int c = (int)(v % vpr) * N;
     int64_t id = ids[r];
+    if (is_pad && c == 0) is_pad[r] = id == pad_id;         // the padding mask of the same ids (adaptor/text.py:108-111), one byte per row
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     *reinterpret_cast<typename Vec<T>::type*>(out + r * D + c) =
         *reinterpret_cast<const typename Vec<T>::type*>(w + id * D + c);
@@ -414,27 +416,28 @@ extern "C" int ofa_dropout_bwd(const void* dy, void* dx, int64_t n, float p, uin
 }
 
 extern "C" int ofa_add_rowvec_mask(const void* a, const void* b, const void* vec, const uint8_t* rowmask, void* y,
-                                   int64_t rows, int cols, int dtype, void* stream) {
+                                   int64_t rows, int cols, int64_t b_period, int dtype, void* stream) {
   OFA_DT_CHECK("add_rowvec_mask");
-  OFA_REQUIRE(rows >= 0 && cols > 0 && a && y, OFA_ERR_INVALID, "add_rowvec_mask: bad argument");
+  OFA_REQUIRE(rows >= 0 && cols > 0 && a && y && b_period >= 0, OFA_ERR_INVALID, "add_rowvec_mask: bad argument");
   OFA_REQUIRE(cols % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "add_rowvec_mask: cols=%d not vectorizable", cols);
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((add_rowvec_mask_kernel<float>), dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, (const float*)a,
-                       (const float*)b, (const float*)vec, rowmask, (float*)y, rows, cols);
+                       (const float*)b, (const float*)vec, rowmask, (float*)y, rows, cols, b_period);
   else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((add_rowvec_mask_kernel<bf16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st,
-                       (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)vec, rowmask, (bf16_t*)y, rows, cols);
+                       (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)vec, rowmask, (bf16_t*)y, rows, cols, b_period);
   else
     hipLaunchKernelGGL((add_rowvec_mask_kernel<f16_t>), dim3(grid_for(rows * cols / 8)), dim3(256), 0, st,
-                       (const f16_t*)a, (const f16_t*)b, (const f16_t*)vec, rowmask, (f16_t*)y, rows, cols);
+                       (const f16_t*)a, (const f16_t*)b, (const f16_t*)vec, rowmask, (f16_t*)y, rows, cols, b_period);
   return check_launch("add_rowvec_mask");
 }
 
-extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, int dtype,
-                                 void* stream) {
+extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, uint8_t* is_pad,
+                                 int64_t pad_id, int dtype, void* stream) {
   OFA_DT_CHECK("embedding_fwd");
+  OFA_REQUIRE(!is_pad || D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "embedding_fwd: the pad mask rides with the vector kernel (D = %d)", D);
   OFA_REQUIRE(n >= 0 && D > 0 && V > 0 && weight && ids && out, OFA_ERR_INVALID, "embedding_fwd: bad argument");
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -452,13 +455,13 @@ extern "C" int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* o
   }
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((embedding_fwd_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, (const float*)weight, ids,
-                       (float*)out, n, D, V);
+                       (float*)out, n, D, V, is_pad, pad_id);
   else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const bf16_t*)weight,
-                       ids, (bf16_t*)out, n, D, V);
+                       ids, (bf16_t*)out, n, D, V, is_pad, pad_id);
   else
     hipLaunchKernelGGL((embedding_fwd_kernel<f16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, (const f16_t*)weight,
-                       ids, (f16_t*)out, n, D, V);
+                       ids, (f16_t*)out, n, D, V, is_pad, pad_id);
   return check_launch("embedding_fwd");
 }
 
@@ -768,6 +771,37 @@ extern "C" int ofa_add_n(const void* const* inputs, int n, void* out, int64_t nu
   else if (dtype == OFA_BF16) hipLaunchKernelGGL((add_n_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, a, (bf16_t*)out, numel);
   else hipLaunchKernelGGL((add_n_kernel<f16_t>), dim3(grid_for(work)), dim3(256), 0, st, a, (f16_t*)out, numel);
   return check_launch("add_n");
+}
+
+// out[i] (+)= sum_b x[b * n + i]: the gradient of a tensor every sample of the batch read (batch-invariant position embeddings)
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int batch, int64_t n, int accumulate) {
+  constexpr int N = Vec<T>::N;
+  const int64_t total = n / N;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    float acc[N], t[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    if (accumulate) load_vec<T>(out + v * N, acc);
+    for (int b = 0; b < batch; ++b) {
+      load_vec<T>(x + (int64_t)b * n + v * N, t);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += t[j];
+    }
+    store_vec<T>(out + v * N, acc);
+  }
+}
+
+extern "C" int ofa_batch_sum(const void* x, void* out, int batch, int64_t n, int accumulate, int dtype, void* stream) {
+  OFA_DT_CHECK("batch_sum");
+  OFA_REQUIRE(x && out && batch >= 1 && n >= 0, OFA_ERR_INVALID, "batch_sum: bad argument");
+  OFA_REQUIRE(n % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "batch_sum: n=%lld not vectorizable", (long long)n);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32) hipLaunchKernelGGL((batch_sum_kernel<float>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (float*)out, batch, n, accumulate);
+  else if (dtype == OFA_BF16) hipLaunchKernelGGL((batch_sum_kernel<bf16_t>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, batch, n, accumulate);
+  else hipLaunchKernelGGL((batch_sum_kernel<f16_t>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const f16_t*)x, (f16_t*)out, batch, n, accumulate);
+  return check_launch("batch_sum");
 }
 
 extern "C" int ofa_mul(const void* a, const void* b, void* y, int64_t rows, int cols, int b_rowvec, int dtype, void* stream) {

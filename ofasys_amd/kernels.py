@@ -714,23 +714,47 @@ def dropout_bwd(dy, p, seed, offset, offset_base=None):
 
 
 def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+    """b: same rows as a, or the rows of ONE sample (a's row count a multiple of b's: positions shared by the batch)."""
     a = a.contiguous()
     rows, cols = _rows_cols(a)
+    period = 0
     if b is not None:
         b = b.contiguous()
+        brows = b.numel() // cols
+        if brows != rows:
+            assert brows > 0 and rows % brows == 0, (rows, brows)
+            period = brows
     if rowmask is not None:
         rowmask = _u8(rowmask)
     y = torch.empty_like(a)
-    lib().call("ofa_add_rowvec_mask", ptr(a), ptr(b), ptr(vec), ptr(rowmask), ptr(y), rows, cols, dtype_code(a), stream())
+    lib().call("ofa_add_rowvec_mask", ptr(a), ptr(b), ptr(vec), ptr(rowmask), ptr(y), rows, cols, period, dtype_code(a), stream())
     return y
 
 
-def embedding_fwd(weight, ids):
+def batch_sum(x, batch, out=None, accumulate=False):
+    """x [batch * n] (contiguous) -> out [n] = sum over the batch (fp32 accumulation)."""
+    x = x.contiguous()
+    n = x.numel() // batch
+    if out is None:
+        out = torch.empty(n, dtype=x.dtype, device=x.device)
+        accumulate = False
+    lib().call("ofa_batch_sum", ptr(x), ptr(out), int(batch), n, int(bool(accumulate)), dtype_code(x), stream())
+    return out
+
+
+def embedding_fwd(weight, ids, pad_mask_of=None):
+    """pad_mask_of: a token id -- also returns the bool mask ids == pad_mask_of, written by the same kernel."""
     ids = ids.contiguous()
     V, D = weight.shape
     out = torch.empty(*ids.shape, D, dtype=weight.dtype, device=weight.device)
-    lib().call("ofa_embedding_fwd", ptr(weight), ptr(ids), ptr(out), ids.numel(), D, V, dtype_code(weight), stream())
-    return out
+    mask = None
+    if pad_mask_of is not None and D % (4 if weight.dtype == torch.float32 else 8) == 0:
+        mask = torch.empty(ids.shape, dtype=torch.bool, device=weight.device)
+    lib().call("ofa_embedding_fwd", ptr(weight), ptr(ids), ptr(out), ids.numel(), D, V, ptr(mask), int(pad_mask_of) if mask is not None else 0,
+               dtype_code(weight), stream())
+    if pad_mask_of is None:
+        return out
+    return out, (mask if mask is not None else ids.eq(pad_mask_of))
 
 
 def gather_rows(src2d, index):

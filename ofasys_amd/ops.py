@@ -486,13 +486,15 @@ class DropoutAddFn(torch.autograd.Function):
 
 
 class AddFn(torch.autograd.Function):
-    """a + b + vec (row broadcast) with rows where rowmask is set forced to zero."""
+    """a + b + vec (row broadcast) with rows where rowmask is set forced to zero.  b may hold the rows of ONE sample (fewer rows than a:
+    positions shared by the batch) -- it is then read with a period and its gradient is the sum over the batch."""
 
     @staticmethod
     def forward(ctx, a, b, vec, rowmask):
         ctx.save_for_backward(rowmask)
         ctx.has = (b is not None, vec is not None)
         ctx.vdtype = vec.dtype if vec is not None else None
+        ctx.b_shape = tuple(b.shape) if (b is not None and b.numel() != a.numel()) else None
         return K.add_rowvec_mask(a, b, vec, rowmask)
 
     @staticmethod
@@ -500,7 +502,16 @@ class AddFn(torch.autograd.Function):
         (rowmask,) = ctx.saved_tensors
         g = K.add_rowvec_mask(dy, None, None, rowmask) if rowmask is not None else dy
         dvec = K.colsum(g, out_dtype=ctx.vdtype) if ctx.has[1] else None
-        return g, (g if ctx.has[0] else None), dvec, None
+        db = None
+        if ctx.has[0]:
+            if ctx.b_shape is None:
+                db = g
+            else:
+                nb = 1
+                for d in ctx.b_shape:
+                    nb *= d
+                db = K.batch_sum(g, g.numel() // nb).view(ctx.b_shape)
+        return g, db, dvec, None
 
 
 def dropout_add(x, residual, p, training):
@@ -520,8 +531,24 @@ def dropout_add(x, residual, p, training):
     return restore(AddFn.apply(x2d, r2d, None, None))
 
 
+def shared_rows(x):
+    """[1, T, D] base of a [B, T, D] tensor whose B samples are one and the same storage (a stride-0 `expand`: position embeddings of
+    arange- / grid-derived positions, which every built-in adaptor returns that way), else None."""
+    if x is not None and x.dim() == 3 and x.shape[0] > 1 and x.stride(0) == 0:
+        return x[:1]
+    return None
+
+
 def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+    """a [B, T, D] + b + vec: b is [B, T, D] or -- batch-shared -- [1, T, D] / a stride-0 expand of it (read once per sample, never
+    materialised B times; its gradient comes back summed over the batch)."""
     if b is not None:
+        base = shared_rows(b)
+        if base is not None and a.dim() == 3 and a.is_contiguous() and tuple(a.shape[1:]) == tuple(base.shape[1:]):
+            b = base
+        if b.shape[0] == 1 and a.dim() == 3 and a.shape[0] > 1 and a.is_contiguous() and tuple(a.shape[1:]) == tuple(b.shape[1:]):
+            m = rowmask.reshape(-1) if rowmask is not None else None
+            return AddFn.apply(a.view(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), vec, m).view(a.shape)
         b = like_layout(b, a)
     a2d, restore = rows_view(a)
     b2d = rows_view(b)[0] if b is not None else None
@@ -569,8 +596,11 @@ def cached_index(owner, key, make):
     (the tensor would belong to that graph's pool and only hold data after its replay)."""
     cache = owner.__dict__.setdefault("_ofa_index_cache", {})
     hit = cache.get(key)
-    if hit is not None and hit.device == next(owner.buffers()).device:
-        return hit
+    if hit is not None:
+        ref = next(owner.buffers(), None)
+        ref = ref if ref is not None else next(owner.parameters(), None)
+        if ref is None or hit.device == ref.device:
+            return hit
     t = make()
     if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
         if len(cache) >= 64:
@@ -652,15 +682,24 @@ _TOKEN_KEYED_CACHES.append(SegmentPlan._cache)
 
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, weight, padding_idx, plan_key=None):
+    def forward(ctx, ids, weight, padding_idx, plan_key=None, pad_mask_of=None):
         ctx.save_for_backward(ids)
         ctx.V, ctx.padding_idx = weight.shape[0], padding_idx
         ctx.weight_ref = weight
         ctx.plan_key = plan_key
-        return K.embedding_fwd(weight, ids)
+        ctx.with_mask = pad_mask_of is not None
+        if pad_mask_of is None:
+            return K.embedding_fwd(weight, ids)
+        out, mask = K.embedding_fwd(weight, ids, pad_mask_of)          # the ids' padding mask from the same pass
+        ctx.mark_non_differentiable(mask)
+        return out, mask
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
+        return EmbeddingFn._backward(ctx, dout) + (None,)
+
+    @staticmethod
+    def _backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         pad = -1 if ctx.padding_idx is None else ctx.padding_idx
         gw = _sink(ctx.weight_ref)
@@ -690,6 +729,11 @@ def embedding(ids, weight, padding_idx=None, plan_key=None):
     """F.embedding.  plan_key (hashable, optional): promises that every call with this key and shape looks up the SAME ids (a rel-pos
     bucket table slice) -- the gradient then uses a cached sort of the ids (SegmentPlan) instead of scanning them per table row."""
     return EmbeddingFn.apply(ids, weight, padding_idx, plan_key)
+
+
+def embedding_with_pad_mask(ids, weight, padding_idx, pad):
+    """(F.embedding(ids), ids == pad) in one launch (adaptor/text.py:108-125)."""
+    return EmbeddingFn.apply(ids, weight, padding_idx, None, int(pad))
 
 
 # ---------------------------------------------------------------------------------------------- attention

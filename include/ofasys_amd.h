@@ -262,6 +262,14 @@ int ofa_transpose_heads(const void* x, void* xt, int B, int T, int C, int Tpad, 
  * with the inverse index, scatters gradients back. */
 int ofa_gather_rows(const void* src, const int64_t* index, void* out, int64_t n, int D, int64_t src_rows, int dtype,
                     void* stream);
+/* The same gather over the VIRTUAL concatenation along the sequence of nparts <= 8 slot outputs (adaptor/general.py:245-282
+ * `torch.cat(tuple(x.embed ...), dim=1)`): index[r] = b * T + t addresses the concatenated [batch, T, D], T = sum lens; part k is its own
+ * contiguous [batch, lens[k], D] (srcs / lens: HOST arrays).  The concatenated tensor is never built.  ofa_scatter_rows_part is the
+ * backward for one part: out [batch, nk, D] row (b, j) = src[inverse[b * T + start + j]] or 0 (src: gradient of the packed rows). */
+int ofa_gather_rows_parts(const void* const* srcs, const int* lens, int nparts, const int64_t* index, void* out, int64_t n, int D,
+                          int64_t batch, int dtype, void* stream);
+int ofa_scatter_rows_part(const void* src, const int64_t* inverse, void* out, int64_t batch, int nk, int Ttot, int start, int D,
+                          int64_t src_rows, int dtype, void* stream);
 /* out[r, :] = weight[ids[r], :]  (F.embedding, adaptor/text.py:124-125); is_pad (optional, n bytes): is_pad[r] = ids[r] == pad_id -- the
  * padding mask the text adaptor derives from the same ids (adaptor/text.py:108-111), written by the same pass. */
 int ofa_embedding_fwd(const void* weight, const int64_t* ids, void* out, int64_t n, int D, int64_t V, uint8_t* is_pad, int64_t pad_id,
@@ -349,8 +357,10 @@ int ofa_bias_block_add_batch(void* bias, const void* values, int B, int A, int T
 int ofa_bias_block_slice(const void* dbias, void* dvalues, int B, int A, int T, int start, int n, int dtype, void* stream);
 
 /* ---- patch embedding (adaptor/image_patch_embed.py:59-73): im2col of non-overlapping p x p patches.
- * img [B,C,H,W] -> col [B*(H/p)*(W/p), Kpad] with K = C*p*p in (c,ph,pw) order (= Conv2d weight.view(D,-1)), zero pad. */
-int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype, void* stream);
+ * img [B,C,H,W] -> col [B*(lead + (H/p)*(W/p)), Kpad] with K = C*p*p in (c,ph,pw) order (= Conv2d weight.view(D,-1)), zero pad; every
+ * sample's rows start with `lead` all-zero rows (1: the class-token position, so that the projection and its weight gradient run over
+ * the [B, 1 + N, D] rows the adaptor returns and `torch.cat((cls_token, x))` (:71-73) never happens). */
+int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int lead, int dtype, void* stream);
 
 /* ---- criterion (engine/criterion/cross_entropy.py:27-67): fp32 log-softmax + NLL(sum, ignore_index) per row.
  * logits [rows, V] (ld elements); writes lse[rows] and row_loss[rows] (0 for ignored rows). */

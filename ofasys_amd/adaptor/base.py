@@ -123,7 +123,8 @@ class BaseAdaptor(torch.nn.Module):
         pos = output.pos_embed if (self.cfg.entangle_position_embedding and output.pos_embed is not None) else None
         typ = self.type_embedding.weight.view(-1) if (slot.is_src and self.type_embedding is not None) else None
         if pos is not None or typ is not None:
-            embed = ops.add_rowvec_mask(embed, pos, typ)                     # :170-173 in one pass
+            embed = ops.add_rowvec_mask(embed, pos, typ,                     # :170-173 in one pass
+                                        vec_param=self.type_embedding.weight if typ is not None else None)
         if self.cfg.scale_embedding_gradient != 1.0:
             # :174-176 `embed * a + embed.detach() * (1 - a)`: the value is unchanged, the gradient flowing back into the
             # embedding / position / type tables is multiplied by a

@@ -133,12 +133,11 @@ class OFAGeneralAdaptor(torch.nn.Module):
                 pos_embed = torch.cat(bases, dim=1).expand(pos_parts[0].shape[0], -1, -1)
             else:
                 pos_embed = torch.cat(tuple(pos_parts), dim=1)
-            output = AdaptorOutput(
-                torch.cat(tuple(x.embed for x in modality_outputs), dim=1),
-                torch.cat(tuple(x.masks for x in modality_outputs), dim=1),
-                pos_embed,
-                None,
-            )
+            # `lazy_embed_concat` (set by the stacks around their call when they will pack the rows): the slots' embeddings are handed on
+            # unconcatenated (ops.LazyCat) and the packed rows are gathered from them directly
+            embeds = tuple(x.embed for x in modality_outputs)
+            embed = ops.LazyCat(embeds) if getattr(self, "lazy_embed_concat", False) else torch.cat(embeds, dim=1)
+            output = AdaptorOutput(embed, torch.cat(tuple(x.masks for x in modality_outputs), dim=1), pos_embed, None)
         self.last_pos_shared = all(getattr(mo, "pos_shared", False) for mo in modality_outputs)    # (read by the stacks)
         if not self.cfg.use_self_attn_bias:
             return output
@@ -156,7 +155,7 @@ class OFAGeneralAdaptor(torch.nn.Module):
         per_sample = any(isinstance(v, _PerSample) for values in layer_values for v in values)
         shared = self.last_pos_shared and not per_sample
         output.pos_shared = shared
-        abs_pos_bias = self.build_abs_pos_bias(output.pos_embed[:1] if shared else output.pos_embed)
+        abs_pos_bias = self.build_abs_pos_bias(ops.first_sample(output.pos_embed) if shared else output.pos_embed)
         starts, s = [], 0
         for mo in modality_outputs:
             starts.append(s)

@@ -51,9 +51,9 @@ class ImagePatchEmbedAdaptor(BaseAdaptor):
         batch_size, _, height, width = image.shape
         assert height == self.image_size[0] and width == self.image_size[1], \
             f"Input image size ({height}*{width}) doesn't match model ({self.image_size[0]}*{self.image_size[1]})."
-        x = ops.patch_embed(image, self.proj.weight, self.proj.bias, self.patch_size[0])      # [B, N, D]
-        if self.cfg.add_cls_token:
-            x = torch.cat((self.cls_token.expand(batch_size, -1, -1).to(x.dtype), x), dim=1)
+        # [B, (1 +) N, D]: the class token (:71-73 concatenates it) is written by the projection op itself
+        x = ops.patch_embed(image, self.proj.weight, self.proj.bias, self.patch_size[0],
+                            cls_token=self.cls_token if self.cfg.add_cls_token else None)
         n = x.size(1)
         mask = ops.cached_index(self, ("nomask", batch_size, n), lambda: torch.zeros((batch_size, n), dtype=torch.bool, device=image.device))
         pos = ops.cached_index(self, ("arange", n), lambda: torch.arange(n, dtype=torch.long, device=image.device).unsqueeze(0))

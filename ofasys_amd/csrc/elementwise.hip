@@ -120,6 +120,55 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   }
 }
 
+// The same gather over the VIRTUAL concatenation of up to 8 slot outputs along the sequence (adaptor/general.py:245-282 `torch.cat(.., dim=1)`):
+// index[r] names a position b * T + t of the concatenated [B, T, D]; slot k holds the positions start[k] <= t < start[k+1] of every sample as
+// its own contiguous [B, n_k, D].  The packed rows are gathered straight from the slots' outputs: the concatenated tensor is never built.
+struct GatherParts { const void* src[8]; int start[9]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_parts_kernel(GatherParts gp, const int64_t* __restrict__ index, T* __restrict__ out,
+                                                                int64_t n, int D, int Ttot, int64_t batch) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = D / N;
+  const int64_t total = n * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    const int64_t id = index[r];
+    typename Vec<T>::type val = {};
+    if (id >= 0 && id < batch * Ttot) {
+      const int64_t b = id / Ttot;
+      const int t = (int)(id - b * Ttot);
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q)
+        if (q < gp.n && t >= gp.start[q]) k = q;
+      const int nk = gp.start[k + 1] - gp.start[k];
+      val = *reinterpret_cast<const typename Vec<T>::type*>((const T*)gp.src[k] + ((b * nk + (t - gp.start[k])) * D + c));
+    }
+    *reinterpret_cast<typename Vec<T>::type*>(out + r * D + c) = val;
+  }
+}
+
+// ... and its backward for ONE slot: out[b * nk + j] = inverse[b * T + start + j] >= 0 ? src[inverse[..]] : 0  (src: the packed-row gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_part_kernel(const T* __restrict__ src, const int64_t* __restrict__ inverse,
+                                                                T* __restrict__ out, int64_t batch, int nk, int Ttot, int start, int D,
+                                                                int64_t src_rows) {
+  constexpr int N = Vec<T>::N;
+  const int vpr = D / N;
+  const int64_t total = batch * nk * vpr;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * N;
+    const int64_t b = r / nk;
+    const int j = (int)(r - b * nk);
+    const int64_t id = inverse[b * Ttot + start + j];
+    typename Vec<T>::type val = {};
+    if (id >= 0 && id < src_rows) val = *reinterpret_cast<const typename Vec<T>::type*>(src + id * D + c);
+    *reinterpret_cast<typename Vec<T>::type*>(out + r * D + c) = val;
+  }
+}
+
 // narrow tables (rel-pos bias tables are [n_rel, heads], heads = 4..16): element-wise gather
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_fwd_scalar_kernel(const T* __restrict__ w, const int64_t* __restrict__ ids,
@@ -271,20 +320,23 @@ __global__ __launch_bounds__(256) void embedding_fold_kernel(const float* __rest
   }
 }
 
-// col[(b*nph*npw + ph*npw + pw)][c*p*p + i*p + j] = img[b][c][ph*p+i][pw*p+j]; columns K..Kpad-1 are zero.
+// col[(b*(lead + nph*npw) + lead + ph*npw + pw)][c*p*p + i*p + j] = img[b][c][ph*p+i][pw*p+j]; columns K..Kpad-1 are zero, and so are the
+// `lead` rows in front of every sample's patches (the class-token position of adaptor/image_patch_embed.py:71-73: the projection GEMM then
+// runs over the [B, 1 + N, D] rows the adaptor returns -- no concatenation -- and the weight-gradient GEMM over the same rows sees zeros there)
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const T* __restrict__ img, T* __restrict__ col, int B, int C, int H,
-                                                           int W, int p, int Kpad) {
+                                                           int W, int p, int Kpad, int lead) {
   const int nph = H / p, npw = W / p, K = C * p * p;
-  const int64_t total = (int64_t)B * nph * npw * Kpad;
+  const int64_t per = (int64_t)lead + (int64_t)nph * npw;
+  const int64_t total = (int64_t)B * per * Kpad;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int k = (int)(e % Kpad);
     const int64_t r = e / Kpad;
+    const int64_t b = r / per, rs = r % per - lead;
     float v = 0.f;
-    if (k < K) {
+    if (k < K && rs >= 0) {
       const int j = k % p, i = (k / p) % p, c = k / (p * p);
-      const int pw = (int)(r % npw), ph = (int)((r / npw) % nph);
-      const int64_t b = r / ((int64_t)npw * nph);
+      const int pw = (int)(rs % npw), ph = (int)(rs / npw);
       v = ld1<T>(img + ((b * C + c) * H + ph * p + i) * W + pw * p + j);
     }
     st1<T>(col + e, v);
@@ -484,6 +536,52 @@ extern "C" int ofa_gather_rows(const void* src, const int64_t* index, void* out,
   return check_launch("gather_rows");
 }
 
+extern "C" int ofa_gather_rows_parts(const void* const* srcs, const int* lens, int nparts, const int64_t* index, void* out, int64_t n, int D,
+                                     int64_t batch, int dtype, void* stream) {
+  OFA_DT_CHECK("gather_rows_parts");
+  OFA_REQUIRE(srcs && lens && index && out && nparts >= 1 && nparts <= 8 && n >= 0 && D > 0 && batch > 0, OFA_ERR_INVALID, "gather_rows_parts: bad argument");
+  OFA_REQUIRE(D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "gather_rows_parts: D=%d not vectorizable", D);
+  if (n == 0) return 0;
+  GatherParts gp;
+  gp.n = nparts;
+  gp.start[0] = 0;
+  for (int k = 0; k < 8; ++k) {
+    gp.src[k] = srcs[k < nparts ? k : 0];
+    if (k < nparts) {
+      OFA_REQUIRE(srcs[k] && lens[k] > 0 && !((uintptr_t)srcs[k] & 15), OFA_ERR_INVALID, "gather_rows_parts: part %d is NULL, empty or not 16-byte aligned", k);
+      gp.start[k + 1] = gp.start[k] + lens[k];
+    } else {
+      gp.start[k + 1] = gp.start[k];
+    }
+  }
+  const int Ttot = gp.start[nparts];
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((gather_rows_parts_kernel<float>), dim3(grid_for(n * D / 4)), dim3(256), 0, st, gp, index, (float*)out, n, D, Ttot, batch);
+  else if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((gather_rows_parts_kernel<bf16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, gp, index, (bf16_t*)out, n, D, Ttot, batch);
+  else
+    hipLaunchKernelGGL((gather_rows_parts_kernel<f16_t>), dim3(grid_for(n * D / 8)), dim3(256), 0, st, gp, index, (f16_t*)out, n, D, Ttot, batch);
+  return check_launch("gather_rows_parts");
+}
+
+extern "C" int ofa_scatter_rows_part(const void* src, const int64_t* inverse, void* out, int64_t batch, int nk, int Ttot, int start, int D,
+                                     int64_t src_rows, int dtype, void* stream) {
+  OFA_DT_CHECK("scatter_rows_part");
+  OFA_REQUIRE(src && inverse && out && batch > 0 && nk > 0 && start >= 0 && start + nk <= Ttot && D > 0 && src_rows > 0, OFA_ERR_INVALID,
+              "scatter_rows_part: bad argument");
+  OFA_REQUIRE(D % (dtype == OFA_F32 ? 4 : 8) == 0, OFA_ERR_UNSUPPORTED, "scatter_rows_part: D=%d not vectorizable", D);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t work = batch * nk * D / (dtype == OFA_F32 ? 4 : 8);
+  if (dtype == OFA_F32)
+    hipLaunchKernelGGL((scatter_rows_part_kernel<float>), dim3(grid_for(work)), dim3(256), 0, st, (const float*)src, inverse, (float*)out, batch, nk, Ttot, start, D, src_rows);
+  else if (dtype == OFA_BF16)
+    hipLaunchKernelGGL((scatter_rows_part_kernel<bf16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)src, inverse, (bf16_t*)out, batch, nk, Ttot, start, D, src_rows);
+  else
+    hipLaunchKernelGGL((scatter_rows_part_kernel<f16_t>), dim3(grid_for(work)), dim3(256), 0, st, (const f16_t*)src, inverse, (f16_t*)out, batch, nk, Ttot, start, D, src_rows);
+  return check_launch("scatter_rows_part");
+}
+
 // Narrow-table scatter-add with a PRECOMPUTED segment plan: the ids of a rel-pos bias lookup (bucket[i][j], adaptor/text.py:101-104,
 // image_resnet.py:116-128) are the same every step, a few hundred distinct values over 10^4..10^6 positions, so the positions are
 // sorted by id once on the host side of the op (order / seg_off / seg_row, cached per lookup) and one wave sums one segment:
@@ -610,22 +708,22 @@ extern "C" int ofa_embedding_bwd(const void* dout, const int64_t* ids, void* dwe
   return check_launch("embedding_fold");
 }
 
-extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int dtype,
+extern "C" int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int p, int Kpad, int lead, int dtype,
                                 void* stream) {
   OFA_DT_CHECK("im2col_patch");
-  OFA_REQUIRE(img && col && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= C * p * p, OFA_ERR_INVALID,
+  OFA_REQUIRE(img && col && B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && Kpad >= C * p * p && lead >= 0, OFA_ERR_INVALID,
               "im2col_patch: bad argument (H=%d W=%d p=%d Kpad=%d)", H, W, p, Kpad);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t total = (int64_t)B * (H / p) * (W / p) * Kpad;
+  const int64_t total = (int64_t)B * (lead + (int64_t)(H / p) * (W / p)) * Kpad;
   if (dtype == OFA_F32)
     hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)img, (float*)col,
-                       B, C, H, W, p, Kpad);
+                       B, C, H, W, p, Kpad, lead);
   else if (dtype == OFA_BF16)
     hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img,
-                       (bf16_t*)col, B, C, H, W, p, Kpad);
+                       (bf16_t*)col, B, C, H, W, p, Kpad, lead);
   else
     hipLaunchKernelGGL((im2col_patch_kernel<f16_t>), dim3(grid_for(total)), dim3(256), 0, st, (const f16_t*)img,
-                       (f16_t*)col, B, C, H, W, p, Kpad);
+                       (f16_t*)col, B, C, H, W, p, Kpad, lead);
   return check_launch("im2col_patch");
 }
 

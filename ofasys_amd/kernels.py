@@ -766,6 +766,28 @@ def gather_rows(src2d, index):
     return out
 
 
+def gather_rows_parts(parts, index):
+    """Packed rows of the virtual concatenation torch.cat(parts, dim=1) (parts: contiguous [B, n_k, D], <= 8 of them): index[r] = b * T + t."""
+    assert 1 <= len(parts) <= 8 and index.dtype == torch.int64 and index.is_contiguous()
+    B, D = parts[0].shape[0], parts[0].shape[2]
+    assert all(t.dim() == 3 and t.is_contiguous() and t.shape[0] == B and t.shape[2] == D and t.dtype == parts[0].dtype for t in parts)
+    out = torch.empty(index.numel(), D, dtype=parts[0].dtype, device=parts[0].device)
+    srcs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    lens = (ctypes.c_int * len(parts))(*[int(t.shape[1]) for t in parts])
+    lib().call("ofa_gather_rows_parts", ctypes.addressof(srcs), ctypes.addressof(lens), len(parts), ptr(index), ptr(out), index.numel(), D, B,
+               dtype_code(parts[0]), stream())
+    return out
+
+
+def scatter_rows_part(dpacked, inverse, B, nk, Ttot, start):
+    """[B, nk, D] gradient of one part: row (b, j) = dpacked[inverse[b * Ttot + start + j]] or 0."""
+    assert dpacked.dim() == 2 and dpacked.is_contiguous() and inverse.dtype == torch.int64 and inverse.is_contiguous()
+    D = dpacked.shape[1]
+    out = torch.empty(B, nk, D, dtype=dpacked.dtype, device=dpacked.device)
+    lib().call("ofa_scatter_rows_part", ptr(dpacked), ptr(inverse), ptr(out), B, nk, Ttot, start, D, dpacked.shape[0], dtype_code(dpacked), stream())
+    return out
+
+
 def embedding_bwd(dout, ids, V, padding_idx=-1, dweight=None):
     dout = dout.contiguous()
     ids = ids.contiguous()
@@ -788,11 +810,12 @@ def segment_rowsum(dout2d, plan, dweight, accumulate):
     return dweight
 
 
-def im2col_patch(img, p, Kpad):
+def im2col_patch(img, p, Kpad, lead=0):
+    """[B, C, H, W] -> [B * (lead + N), Kpad]: every sample's N patch rows behind `lead` zero rows."""
     img = img.contiguous()
     B, C, H, W = img.shape
-    col = torch.empty(B * (H // p) * (W // p), Kpad, dtype=img.dtype, device=img.device)
-    lib().call("ofa_im2col_patch", ptr(img), ptr(col), B, C, H, W, p, Kpad, dtype_code(img), stream())
+    col = torch.empty(B * (lead + (H // p) * (W // p)), Kpad, dtype=img.dtype, device=img.device)
+    lib().call("ofa_im2col_patch", ptr(img), ptr(col), B, C, H, W, p, Kpad, int(lead), dtype_code(img), stream())
     return col
 
 

@@ -92,7 +92,11 @@ class TransformerEncoder(nn.Module):
         the layers ("encoder_out" is then [rows, 1, C] packed rows and "encoder_padding_mask" the plan's segment tables)."""
         if len(slots) == 0:
             return None
-        adaptor_output = AdaptorOutput(*self.adaptor(slots))
+        self.adaptor.lazy_embed_concat = pack is not None       # packed rows are gathered from the slots' outputs: no concatenated [B,T,C]
+        try:
+            adaptor_output = AdaptorOutput(*self.adaptor(slots))
+        finally:
+            self.adaptor.lazy_embed_concat = False
         if pack is not None:
             _check_packable(self.cfg, return_all_hiddens or return_all_attention_weights)
             if self.cfg.use_self_attn_bias:
@@ -131,7 +135,7 @@ class TransformerEncoder(nn.Module):
         return {
             "encoder_out": [x],                                     # T x B x C
             "encoder_padding_mask": [adaptor_output.masks if pack is None else pack],   # B x T (packed: the plan)
-            "encoder_embedding": [adaptor_output.embed],            # B x T x C
+            "encoder_embedding": [adaptor_output.embed],            # B x T x C (packed mode, several slots: an ops.LazyCat of the slots' outputs)
             "encoder_states": encoder_states,
             "position_embeddings": [adaptor_output.pos_embed],      # B x T x C
             "position_embeddings_shared": [bool(getattr(self.adaptor, "last_pos_shared", False))],   # (every row identical: see SharedBias)
@@ -140,7 +144,7 @@ class TransformerEncoder(nn.Module):
 
     def reorder_encoder_out(self, encoder_out: Dict[str, List[Tensor]], new_order):
         def sel(key, dim):
-            return [] if len(encoder_out[key]) == 0 else [encoder_out[key][0].index_select(dim, new_order)]
+            return [] if len(encoder_out[key]) == 0 else [ops.materialize(encoder_out[key][0]).index_select(dim, new_order)]
         return {
             "encoder_out": sel("encoder_out", 1), "encoder_padding_mask": sel("encoder_padding_mask", 0),
             "encoder_embedding": sel("encoder_embedding", 0),
@@ -190,7 +194,7 @@ class TransformerDecoder(nn.Module):
         """abs position bias for cross attention -> [B,A,Tt,Ts] (model/transformer.py:280-299); shared (both position embeddings are
         the same for every batch row): built once from row 0 -> ops.SharedBias [A,Tt,Ts]."""
         if shared:
-            tgt_pos_embed, src_pos_embed = tgt_pos_embed[:1], src_pos_embed[:1]
+            tgt_pos_embed, src_pos_embed = ops.first_sample(tgt_pos_embed), ops.first_sample(src_pos_embed)
         pos_q = self.cross_pos_q_linear(tgt_pos_embed, alpha=self.adaptor.pos_scaling)
         pos_k = self.cross_pos_k_linear(src_pos_embed)
         b = ops.heads_matmul_nt(pos_q, pos_k, self.num_attention_heads)

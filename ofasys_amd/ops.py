@@ -490,18 +490,26 @@ class AddFn(torch.autograd.Function):
     positions shared by the batch) -- it is then read with a period and its gradient is the sum over the batch."""
 
     @staticmethod
-    def forward(ctx, a, b, vec, rowmask):
+    def forward(ctx, a, b, vec, rowmask, vec_param=None):
         ctx.save_for_backward(rowmask)
         ctx.has = (b is not None, vec is not None)
         ctx.vdtype = vec.dtype if vec is not None else None
         ctx.b_shape = tuple(b.shape) if (b is not None and b.numel() != a.numel()) else None
+        ctx.vec_param = vec_param                      # the parameter `vec` is a view of: its gradient goes straight to the arena
         return K.add_rowvec_mask(a, b, vec, rowmask)
 
     @staticmethod
     def backward(ctx, dy):
         (rowmask,) = ctx.saved_tensors
         g = K.add_rowvec_mask(dy, None, None, rowmask) if rowmask is not None else dy
-        dvec = K.colsum(g, out_dtype=ctx.vdtype) if ctx.has[1] else None
+        dvec = None
+        if ctx.has[1]:
+            gv = _sink(ctx.vec_param)
+            if gv is not None and gv.is_contiguous():
+                K.colsum(g, out=gv.view(-1), accumulate=True)
+                _sink_done(ctx.vec_param)
+            else:
+                dvec = K.colsum(g, out_dtype=ctx.vdtype)
         db = None
         if ctx.has[0]:
             if ctx.b_shape is None:
@@ -511,7 +519,7 @@ class AddFn(torch.autograd.Function):
                 for d in ctx.b_shape:
                     nb *= d
                 db = K.batch_sum(g, g.numel() // nb).view(ctx.b_shape)
-        return g, db, dvec, None
+        return g, db, dvec, None, None
 
 
 def dropout_add(x, residual, p, training):
@@ -535,25 +543,42 @@ def shared_rows(x):
     """[1, T, D] base of a [B, T, D] tensor whose B samples are one and the same storage (a stride-0 `expand`: position embeddings of
     arange- / grid-derived positions, which every built-in adaptor returns that way), else None."""
     if x is not None and x.dim() == 3 and x.shape[0] > 1 and x.stride(0) == 0:
+        # the tensor the expand was taken of, when autograd still knows it: going through `x[:1]` instead would make backward zero-fill
+        # a [B, T, D] gradient, copy one sample into it and sum it over the batch again
+        base = x._base
+        if (base is not None and base.dim() == 3 and base.shape[0] == 1 and tuple(base.shape[1:]) == tuple(x.shape[1:])
+                and base.data_ptr() == x.data_ptr() and base.stride()[1:] == x.stride()[1:]):
+            return base
         return x[:1]
     return None
 
 
-def add_rowvec_mask(a, b=None, vec=None, rowmask=None):
+def first_sample(x):
+    """x[:1] of a [B, T, D] tensor -- through the base of a batch-shared tensor when it is one (see shared_rows)."""
+    base = shared_rows(x)
+    return base if base is not None else x[:1]
+
+
+def add_rowvec_mask(a, b=None, vec=None, rowmask=None, vec_param=None):
     """a [B, T, D] + b + vec: b is [B, T, D] or -- batch-shared -- [1, T, D] / a stride-0 expand of it (read once per sample, never
-    materialised B times; its gradient comes back summed over the batch)."""
+    materialised B times; its gradient comes back summed over the batch).  vec_param: the parameter `vec` is a flat view of (its
+    gradient is then accumulated into the gradient arena by the op's own backward)."""
+    if vec_param is not None and not (vec is not None and vec.requires_grad and torch.is_grad_enabled() and _sink(vec_param) is not None):
+        vec_param = None                               # (no gradient arena: autograd carries the gradient as usual)
+    if vec_param is not None:
+        vec = vec.detach()                             # the gradient takes the direct route
     if b is not None:
         base = shared_rows(b)
         if base is not None and a.dim() == 3 and a.is_contiguous() and tuple(a.shape[1:]) == tuple(base.shape[1:]):
             b = base
         if b.shape[0] == 1 and a.dim() == 3 and a.shape[0] > 1 and a.is_contiguous() and tuple(a.shape[1:]) == tuple(b.shape[1:]):
             m = rowmask.reshape(-1) if rowmask is not None else None
-            return AddFn.apply(a.view(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), vec, m).view(a.shape)
+            return AddFn.apply(a.view(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), vec, m, vec_param).view(a.shape)
         b = like_layout(b, a)
     a2d, restore = rows_view(a)
     b2d = rows_view(b)[0] if b is not None else None
     m = rowmask.reshape(-1) if rowmask is not None else None
-    return restore(AddFn.apply(a2d, b2d, vec, m))
+    return restore(AddFn.apply(a2d, b2d, vec, m, vec_param))
 
 
 class DropPathFn(torch.autograd.Function):
@@ -771,9 +796,56 @@ class PackRowsFn(torch.autograd.Function):
         return K.gather_rows(dout.contiguous(), inverse), None, None
 
 
+class PackPartsFn(torch.autograd.Function):
+    """Packed rows of torch.cat(parts, dim=1) without the concatenation: one gather over the slots' own [B, n_k, D] outputs
+    (K.gather_rows_parts); backward hands every part its contiguous [B, n_k, D] gradient (K.scatter_rows_part)."""
+
+    @staticmethod
+    def forward(ctx, index, inverse, *parts):
+        ctx.save_for_backward(inverse)
+        ctx.lens = [int(t.shape[1]) for t in parts]
+        ctx.B = parts[0].shape[0]
+        return K.gather_rows_parts([t.contiguous() for t in parts], index)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (inverse,) = ctx.saved_tensors
+        d = dout.contiguous()
+        T, grads, s = sum(ctx.lens), [], 0
+        for i, n in enumerate(ctx.lens):
+            grads.append(K.scatter_rows_part(d, inverse, ctx.B, n, T, s) if ctx.needs_input_grad[2 + i] else None)
+            s += n
+        return (None, None) + tuple(grads)
+
+
+class LazyCat:
+    """torch.cat(parts, dim=1) that has not happened yet: what the general adaptor hands the encoder / decoder stacks as `embed` when
+    they asked for it (row packing: the packed rows are gathered from the parts directly).  `.materialize()` is the tensor."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        B, _, D = self.parts[0].shape
+        self.shape = torch.Size((B, sum(int(t.shape[1]) for t in self.parts), D))
+        self.dtype, self.device = self.parts[0].dtype, self.parts[0].device
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def materialize(self):
+        return torch.cat(tuple(self.parts), dim=1)
+
+
+def materialize(x):
+    return x.materialize() if isinstance(x, LazyCat) else x
+
+
 def pack_rows(x, index, inverse):
-    """x [B, T, D] (padded) -> [1, R, D] packed rows."""
+    """x [B, T, D] (padded; a tensor or a LazyCat of the slots' outputs) -> [1, R, D] packed rows."""
     B, T, D = x.shape
+    if isinstance(x, LazyCat):
+        if len(x.parts) <= 8 and D % 8 == 0 and all(t.is_cuda for t in x.parts):
+            return PackPartsFn.apply(index, inverse, *x.parts).view(1, -1, D)
+        x = x.materialize()
     return PackRowsFn.apply(x.reshape(B * T, D), index, inverse).view(1, -1, D)
 
 
@@ -1388,39 +1460,77 @@ def scale(x, fwd=1.0, bwd=None):
 
 # ---------------------------------------------------------------------------------------------- patch embedding
 class PatchEmbedFn(torch.autograd.Function):
-    """Conv2d(C, D, kernel=stride=p) as im2col + MFMA GEMM (adaptor/image_patch_embed.py:59-73).  img [B,C,H,W],
-    weight [D,C,p,p], bias [D] -> [B, (H/p)*(W/p), D].  The image itself gets no gradient (it is an input)."""
+    """Conv2d(C, D, kernel=stride=p) as im2col + MFMA GEMM, with the class token in place (adaptor/image_patch_embed.py:59-73).
+    img [B,C,H,W], weight [D,C,p,p], bias [D], cls [1,1,D] or None -> [B, (1 +) (H/p)*(W/p), D].  With a class token the im2col matrix
+    carries one all-zero row in front of every sample's patches: ONE GEMM writes the [B, 1 + N, D] result (the reference concatenates),
+    the class-token rows are then overwritten with the token, and in backward the weight gradient is ONE contraction over the same rows
+    (a zero row contributes nothing) of the incoming gradient as it is -- no slice, no copy.  The image gets no gradient (an input)."""
 
     @staticmethod
-    def forward(ctx, img, weight, bias, p):
+    def forward(ctx, img, weight, bias, cls, p):
         B, C, H, W = img.shape
         D = weight.shape[0]
         Kc = C * p * p
         Kpad = (Kc + 7) // 8 * 8
-        col = K.im2col_patch(img.to(weight.dtype), p, Kpad)
+        lead = 0 if cls is None else 1
+        col = K.im2col_patch(img.to(weight.dtype), p, Kpad, lead)
         wp = weight.reshape(D, Kc)
-        if Kpad != Kc:
-            wp2 = torch.zeros(D, Kpad, dtype=weight.dtype, device=weight.device)
-            wp2[:, :Kc].copy_(wp)
+        if Kpad != Kc:                                       # k-major operand rows are whole 16-byte vectors: pad the weight's K
+            wp2 = getattr(weight, "_ofa_kpad", None)         # (the zero tail is written once; every step copies the live columns)
+            if wp2 is None or wp2.shape != (D, Kpad) or wp2.dtype != weight.dtype or wp2.device != weight.device:
+                wp2 = weight.new_zeros(D, Kpad)
+                if not (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    weight._ofa_kpad = wp2
+            wp2[:, :Kc].copy_(wp.detach())
             wp = wp2
-        out = K.gemm(col, wp, False, True, bias=bias)
+        out = K.gemm(col, wp, False, True, bias=bias).view(B, lead + (H // p) * (W // p), D)
+        if cls is not None:
+            out[:, 0, :] = cls.reshape(1, D).to(out.dtype)   # (the GEMM left the bias there)
         ctx.save_for_backward(col)
-        ctx.meta = (weight.shape, Kc, Kpad, bias is not None)
-        return out.view(B, (H // p) * (W // p), D)
+        ctx.meta = (weight.shape, Kc, Kpad, lead)
+        ctx.refs = (weight, bias, cls)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         (col,) = ctx.saved_tensors
-        wshape, Kc, Kpad, has_bias = ctx.meta
-        d2 = dout.reshape(-1, dout.shape[-1])
-        d2 = d2 if d2.stride(-1) == 1 else d2.contiguous()
-        dw = K.gemm(d2, col, True, False)[:, :Kc].reshape(wshape)
-        db = K.colsum(d2, out_dtype=dout.dtype) if has_bias else None
-        return None, dw, db, None
+        wshape, Kc, Kpad, lead = ctx.meta
+        weight, bias, cls = ctx.refs
+        B, T, D = dout.shape
+        d2 = dout.reshape(B * T, D)
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        dw = db = dcls = None
+        gw = _sink(weight)
+        if gw is not None and gw.is_contiguous() and Kc % 4 == 0:
+            K.gemm(d2, col[:, :Kc], True, False, out=gw.view(wshape[0], Kc), accumulate=True)   # straight onto the arena gradient (ldb = Kpad)
+            _sink_done(weight)
+        else:
+            dw = K.gemm(d2, col, True, False)[:, :Kc].reshape(wshape)
+        first = dout[:, 0, :] if lead else None              # [B, D] rows (B * T * D apart): the class-token positions
+        if cls is not None:
+            gc = _sink(cls)
+            if gc is not None:
+                K.colsum(first, out=gc.view(-1), accumulate=True)
+                _sink_done(cls)
+            else:
+                dcls = K.colsum(first, out_dtype=dout.dtype).view(cls.shape)
+        if bias is not None:
+            gb = _sink(bias)
+            if gb is not None:
+                K.colsum(d2, out=gb, accumulate=True)
+                if lead:
+                    K.colsum(first, alpha=-1.0, out=gb, accumulate=True)               # the class-token rows never saw the bias
+                _sink_done(bias)
+            else:
+                db = K.colsum(d2, out_dtype=dout.dtype)
+                if lead:
+                    db = db - K.colsum(first, out_dtype=dout.dtype)
+        return None, dw, db, dcls, None
 
 
-def patch_embed(img, weight, bias, p):
-    return PatchEmbedFn.apply(img, weight, bias, p)
+def patch_embed(img, weight, bias, p, cls_token=None):
+    """[B, C, H, W] -> [B, N, D], or [B, 1 + N, D] with `cls_token` [1, 1, D] in front of every sample's patches."""
+    return PatchEmbedFn.apply(img, weight, bias, cls_token, p)
 
 
 # ---------------------------------------------------------------------------------------------- criterion

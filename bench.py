@@ -388,7 +388,64 @@ def self_launch(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def dp_selftest_child():
+    """Child process of `captured_collectives_ok` (one per rank, its own rendezvous): capture an async RCCL all-reduce the way the step
+    graph does (launched on a side handle inside the capture, waited for inside it), replay it twice on fresh data, check the sums."""
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="nccl", device_id=device)
+    a = torch.zeros(1 << 20, device=device, dtype=torch.bfloat16)
+    b = torch.zeros(3, device=device, dtype=torch.float64)
+    dist.all_reduce(a)                                               # communicator warm-up, eager
+    dist.all_reduce(b)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        h = dist.all_reduce(a, op=dist.ReduceOp.SUM, async_op=True)  # a gradient bucket: launched from inside "backward" ...
+        a2 = a * 1.0
+        h.wait()                                                     # ... waited for before the optimizer reads it
+        dist.all_reduce(b)                                           # the step's scalar exchange
+        out = a + a2 * 0.0
+    ok = True
+    for it in range(2):
+        a.fill_(float(rank + 1 + it))
+        b.fill_(float(rank + it))
+        g.replay()
+        torch.cuda.synchronize()
+        want_a = sum(r + 1 + it for r in range(world))
+        want_b = sum(r + it for r in range(world))
+        ok = ok and bool((out.float() == want_a).all()) and bool((b == want_b).all())
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 3)
+
+
+def captured_collectives_ok(world, rank, local_rank, timeout=180):
+    """Can THIS node replay RCCL collectives captured in a hipGraph with `world` ranks?  Asked of a CHILD process per rank (its own
+    rendezvous on MASTER_PORT + 1): a capture that fails cannot be retried in the process it failed in (trainer.TrainStep docstring), so
+    the question must not be asked in the process that then has to capture the real step.  Every rank's answer is folded (min) over
+    the bench's own process group by the caller.  VERDICT r4 item 7c: `--gpus N` must not die in its first capture."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the children rendezvous among themselves: rank 0's child hosts the store on the new port
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dp-selftest-child"], env=env, timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode != 0 and rank == 0:
+            sys.stderr.write("bench: captured-collective self-test failed (rc %d): %s\n" % (r.returncode, r.stderr.decode(errors="replace")[-600:]))
+        return r.returncode == 0
+    except subprocess.TimeoutExpired:
+        return False
+
+
 def main():
+    if "--dp-selftest-child" in sys.argv:
+        dp_selftest_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -450,12 +507,26 @@ def main():
         local_rank = int(os.environ["OFA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dp_selftest = None
     if world > 1:
+        want_full = args.backend == "nccl" and not args.no_graph and args.dp_graph in (None, "full")
+        if want_full and os.environ.get("OFA_BENCH_SKIP_DP_SELFTEST") != "1":
+            # BEFORE this process touches RCCL or captures anything: can captured collectives replay here?  (a child process per rank)
+            dp_selftest = captured_collectives_ok(world, rank, local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend="gloo")
         dist.all_reduce(torch.zeros(1, device=device))            # communicator warm-up (distributed/utils.py:240-241)
+        if dp_selftest is not None:
+            flag = torch.tensor([1.0 if dp_selftest else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)           # one rank's failure decides for all: the modes must agree
+            dp_selftest = bool(flag.item() > 0.5)
+            if not dp_selftest:
+                if rank == 0:
+                    sys.stderr.write("bench: captured RCCL collectives do not replay on this node -> dp_graph = split (two graphs around "
+                                     "an eager bucket-by-bucket all-reduce)\n")
+                args.dp_graph = "split"
 
     from ofasys_amd import kernels as K
     from ofasys_amd.trainer import TrainStep
@@ -533,7 +604,7 @@ def main():
         tot_alone = sum(alone)
         exp_ms = sum(exposed[1:]) / max(len(exposed) - 1, 1) if exposed else None
         dp = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
-              "dp_graph": trainer.dp_graph, "buckets": len(red.buckets), "bucket_bytes": red.bucket_sizes(),
+              "dp_graph": trainer.dp_graph, "captured_collective_selftest": dp_selftest, "buckets": len(red.buckets), "bucket_bytes": red.bucket_sizes(),
               "bucket_allreduce_ms_alone": alone, "allreduce_ms_alone_total": tot_alone,
               "buckets_launched_inside_backward": red.last_early, "launch_order": red.last_launch_order,
               "exposed_wait_ms_per_step": exp_ms,

@@ -477,3 +477,34 @@ def test_bench_two_ranks_rccl_full_graph():
     assert dp["world_size"] == 2 and dp["backend"] == "nccl" and dp["rccl_version"][0].isdigit()
     assert dp["launch_order"] == list(range(dp["buckets"])) and dp["buckets_launched_inside_backward"] >= 1
     assert all(t > 0 for t in dp["bucket_allreduce_ms_alone"])
+
+
+def test_bench_captured_collective_selftest_child_and_fallback_decision():
+    """bench.py asks a CHILD process per rank whether RCCL collectives captured in a hipGraph replay on this node before it captures the
+    real step (`captured_collectives_ok`; a failed capture cannot be retried in the process it failed in), and falls back to
+    dp_graph = split when any rank says no.  One GPU here: the child runs as a one-rank job (its RCCL communicator, its capture, two
+    replays on fresh data), and the parent-side helper returns False -- not an exception, not a hang -- when the child cannot work."""
+    import importlib.util
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dp-selftest-child"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    old = dict(os.environ)
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 1))
+        assert bench.captured_collectives_ok(1, 0, 0, timeout=300) is True
+        assert bench.captured_collectives_ok(1, 0, 99, timeout=300) is False          # a device that does not exist: the child fails, the parent survives
+    finally:
+        os.environ.clear()
+        os.environ.update(old)

@@ -617,3 +617,72 @@ def test_fan_out_backward_takes_the_pairwise_path_for_gradients_add_n_would_refu
     x.grad = None
     ((a * ga).sum() + (b.double() * gb).sum() + c.sum()).backward(inputs=[x])
     assert torch.allclose(g1, ga) and torch.allclose(x.grad, ga + gb.float() + 1.0, atol=1e-6)
+
+
+def _dp_four_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd.distributed import GradBucketReducer
+    from ofasys_amd.trainer import FlatParams
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(6)])
+    fp = FlatParams(layers)
+    red = GradBucketReducer(fp.params, fp.grad, fp.offsets, None, bucket_bytes=600)
+    grads, early, orders = [], [], []
+    # every rank pads its own batches: the structure key (shapes are part of it) repeats on rank 0 at once, on rank 1 every other step,
+    # on rank 2 every third step, never on rank 3 -- so in one and the same step some ranks launch buckets from inside backward
+    # (armed: structure learned) and others launch all of them at finish()
+    period = [1, 2, 3, 10 ** 6][rank]
+    for step in range(6):
+        fp.zero_grad()
+        red.begin_step(("len", step % period))
+        h = torch.randn(3 + rank, 16, generator=torch.Generator().manual_seed(100 * rank + step))      # uneven batch sizes too
+        for lin in layers:
+            h = torch.tanh(lin(h))
+        h.sum().backward()
+        red.finish()
+        grads.append(fp.grad.clone().numpy())
+        early.append(red.last_early)
+        orders.append(list(red.last_launch_order))
+    q.put((rank, grads, early, orders, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_dp_reducer_four_ranks_with_uneven_structures_per_rank():
+    """four gloo ranks whose step structures repeat at different rates, so that armed ranks (buckets launched from
+    inside backward) and learning ranks (everything at finish()) meet in the same step, with different batch sizes per rank.  The
+    sequence of collectives is the bucket index on every rank in every step, and every rank ends with the sum of the four gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp_four_rank_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(4)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nb = res[0][4]
+    assert nb >= 4
+    for rank, _, early, orders, _ in res:
+        assert all(o == list(range(nb)) for o in orders), (rank, orders)
+    assert max(res[0][2]) > 0 and res[3][2] == [0] * 6                     # rank 0 overlapped, rank 3 never could
+    assert any(res[0][2][s] > 0 and res[3][2][s] == 0 for s in range(6))   # ... in the SAME step
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(16, 16) for _ in range(6)]
+    for step in range(6):
+        for m in layers:
+            m.zero_grad()
+        for rank in range(4):
+            h = torch.randn(3 + rank, 16, generator=torch.Generator().manual_seed(100 * rank + step))
+            for lin in layers:
+                h = torch.tanh(lin(h))
+            h.sum().backward()
+        want = torch.cat([p.grad.reshape(-1) for m in layers for p in m.parameters()])
+        for rank in range(4):
+            g = torch.from_numpy(res[rank][1][step])
+            assert torch.allclose(g[: want.numel()], want, atol=1e-5), (rank, step)
+        assert all(np.array_equal(res[0][1][step], res[r][1][step]) for r in range(1, 4))

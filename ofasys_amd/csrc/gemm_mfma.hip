@@ -803,18 +803,19 @@ static void launch_big(const GemmArgs& g, int batch, int splits, int ksplit, flo
   hipLaunchKernelGGL(kern, grid, block, lds, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-// Which main loop runs a big tile: 0 = the compiler-scheduled lockstep loop (gemm_big_kernel), 21 = the ping-pong loop (gemm_pp.hip).
-// Measured on the step's products (profiles/round5_gemm_pp_ab.txt, bit-identical results): the two are level on the k-major / k-major
-// forward products (the loop is bound by what a K-tile moves, not by who issues it: profiles/round5_gemm_pp_ablate.txt); with an m-major
-// operand -- fragments are two transposing reads each: twice the LDS read instructions -- the ping-pong loop wins: grouped weight gradients of
-// an encoder layer 210 -> 194 us, the K = 9216 input gradient of the shared cross-attention k|v 182 -> 172 us.
+// Which main loop runs a big tile: 0 = the compiler-scheduled lockstep loop (gemm_big_kernel), 23 = the ping-pong loop (gemm_pp.hip).
+// Measured on the step's products (profiles/round5_gemm_pp_ab.txt, 7 interleaved rounds, bit-identical results): the two are level on the
+// k-major / k-major forward products at K = 768 (the loop is bound by what a K-tile moves, not by who issues it:
+// profiles/round5_gemm_pp_ablate.txt, round5_gemm_pp_timeline.txt); with an m-major operand -- fragments are two transposing reads each:
+// twice the LDS read instructions -- and a long contraction the ping-pong loop wins: grouped weight gradients of an encoder layer
+// 209 -> 182 us, input gradients at K = 2304 / 3072 / 9216: 49.2 -> 47.0, 60.9 -> 59.4, 178 -> 169 us.
 static int pp_variant(bool trans_a, bool trans_b, int K) {
 #ifdef OFA_DEBUG_SWITCHES
   const char* e = getenv("OFA_GEMM_PP");       // (read per call: tools/gemm_pp_ab.py flips it inside one process)
   if (e) return atoi(e);
 #endif
-  if (trans_a && !trans_b) return 21;
-  if (!trans_a && !trans_b && K >= 4096) return 21;
+  if (trans_a && !trans_b) return 23;
+  if (!trans_a && !trans_b && K >= 2048) return 23;
   return 0;
 }
 

@@ -313,14 +313,16 @@ static void launch_pp(const GemmArgs& g, int batch, int splits, int ksplit, floa
   hipLaunchKernelGGL(kern, grid, block, PP_LDS, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
-// variant: NKS * 10 + {1: staggered groups + s_setprio (the shipped form), 0: staggered, no priority, 2: lockstep (no stagger, no priority)};
-// + 1000 + 100 * NDL: only NDL LDS-DMA pieces per phase in the load segment; + 100 * ABL: timing-only ablations.  Everything but 21 exists in
-// the debug library only (tools/gemm_pp_ab.py, gemm_pp_ablate.py).
+// variant: 23 = the shipped form (two k-slices per phase, staggered groups, s_setprio around the MFMA segment, THREE of a phase's four LDS-DMA
+// pieces issued in its load segment and the fourth between the MFMAs: profiles/round5_gemm_pp_ab.txt).  Debug library only (tools/gemm_pp_ab.py,
+// gemm_pp_ablate.py): NKS * 10 + {1: staggered + s_setprio, 0: staggered, no priority, 2: lockstep (no stagger, no priority)}, all pieces in
+// the load segment; + 1000 + 100 * NDL: NDL pieces in the load segment; + 100 * ABL: timing-only ablations.
 template <int TM, bool AK, bool BKM, bool OF, bool F16>
 static bool launch_pp_variant(int variant, const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   switch (variant) {
-    case 21: launch_pp<TM, AK, BKM, OF, F16, 2, true, true>(g, batch, splits, ksplit, ws, st); return true;
+    case 23: launch_pp<TM, AK, BKM, OF, F16, 2, true, true, 0, 3>(g, batch, splits, ksplit, ws, st); return true;    // the shipped form
 #ifdef OFA_DEBUG_SWITCHES
+    case 21: launch_pp<TM, AK, BKM, OF, F16, 2, true, true>(g, batch, splits, ksplit, ws, st); return true;
     case 20: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 2, true, false>(g, batch, splits, ksplit, ws, st); return true; } return false;
     case 22: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 2, false, false>(g, batch, splits, ksplit, ws, st); return true; } return false;
     case 11: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 1, true, true>(g, batch, splits, ksplit, ws, st); return true; } return false;
@@ -372,17 +374,17 @@ bool gemm_pp_launch(int variant, const GemmArgs& g, int batch, int tm, int split
 }
 
 // Grouped weight gradients (ofa_gemm_group_tn) on the same loop: both operands m-major, 256 x 256 tiles
-template <bool F16, int NKS, bool STAGGER, bool PRIO>
+template <bool F16, int NKS, bool STAGGER, bool PRIO, int NDL = 4>
 __global__ __launch_bounds__(512) void gemm_group_tn_pp_kernel(GroupArgs ga) {
   GemmArgs g;
   int t, ks;
   const GroupItem& it = group_enter(ga, g, t, ks);
-  gemm_pp_body<4, false, false, false, F16, NKS, STAGGER, PRIO>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
+  gemm_pp_body<4, false, false, false, F16, NKS, STAGGER, PRIO, 0, NDL>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
 }
 
-template <bool F16, int NKS, bool STAGGER, bool PRIO>
+template <bool F16, int NKS, bool STAGGER, bool PRIO, int NDL = 4>
 static void launch_group_pp(const GroupArgs& ga, hipStream_t st) {
-  auto kern = gemm_group_tn_pp_kernel<F16, NKS, STAGGER, PRIO>;
+  auto kern = gemm_group_tn_pp_kernel<F16, NKS, STAGGER, PRIO, NDL>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
@@ -393,14 +395,17 @@ static void launch_group_pp(const GroupArgs& ga, hipStream_t st) {
 
 bool gemm_group_pp_launch(int variant, const GroupArgs& ga, bool f16, hipStream_t st) {
   switch (variant) {
-    case 21:
-      if (f16) launch_group_pp<true, 2, true, true>(ga, st);
-      else launch_group_pp<false, 2, true, true>(ga, st);
+    case 23:                                                                   // the shipped form
+      if (f16) launch_group_pp<true, 2, true, true, 3>(ga, st);
+      else launch_group_pp<false, 2, true, true, 3>(ga, st);
       return true;
 #ifdef OFA_DEBUG_SWITCHES
+    case 21: if (f16) return false; launch_group_pp<false, 2, true, true>(ga, st); return true;
     case 20: if (f16) return false; launch_group_pp<false, 2, true, false>(ga, st); return true;
     case 22: if (f16) return false; launch_group_pp<false, 2, false, false>(ga, st); return true;
     case 11: if (f16) return false; launch_group_pp<false, 1, true, true>(ga, st); return true;
+    case 1321: if (f16) return false; launch_group_pp<false, 2, true, true, 3>(ga, st); return true;   // (= 23)
+    case 1221: if (f16) return false; launch_group_pp<false, 2, true, true, 2>(ga, st); return true;
 #endif
     default: return false;
   }

@@ -113,13 +113,13 @@ print("forced tiles ok")
 """
 
 
-@pytest.mark.parametrize("pp", ["0", "21"])
+@pytest.mark.parametrize("pp", ["0", "23"])
 @pytest.mark.parametrize("tile", ["83", "84"])
 def test_gemm_eight_wave_tiles_forced(K, tile, pp):
     """Every product of the list on the eight-wave 192 x 256 / 256 x 256 kernels (gemm_big_kernel<3|4, 2, .., 2, 4>): ragged edges in M
     and N, all four operand layouts, column / row bias, alpha, fp32 output, accumulation, ldc > N.  OFA_GEMM_TILE exists in the DEBUG library only
     (libofasys_amd_dbg.so, OFASYS_AMD_LIB), hence the subprocess; the planner's own choice of these kernels is covered by test_gemm_big_tile.
-    pp = 21: the same products through the ping-pong main loop (csrc/gemm_pp.hip) in every layout it is built for -- the shipped planner
+    pp = 23: the same products through the ping-pong main loop (csrc/gemm_pp.hip) in every layout it is built for -- the shipped planner
     sends it the m-major-operand products only; pp = 0 forces the lockstep loop for all of them."""
     import os
     import subprocess
@@ -140,7 +140,7 @@ def test_gemm_ping_pong_loop_bit_identical_to_lockstep_loop():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_check.py"), "21"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_check.py"), "23", "21"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 mismatching products" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 

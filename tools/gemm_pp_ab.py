@@ -48,7 +48,7 @@ shapes = [
 ]
 if quick:
     shapes = [shapes[0], shapes[2], shapes[3], shapes[6], shapes[8], shapes[11]]
-NROUND, NL = 3, 20
+NROUND, NL = int(os.environ.get('AB_ROUNDS', '3')), 20
 print(f"# rounds {NROUND} x {NL} launches, median us; eq = bit-identical to the lockstep loop on the same tile", flush=True)
 for kind, M, N, Kk, tile, what in shapes:
     ta, tb = {"NT": (False, True), "NN": (False, False), "TN": (True, False)}[kind]

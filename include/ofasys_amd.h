@@ -82,7 +82,9 @@ int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, con
  * (Philox position offset + *offset_base).  Rounding points match the unfused kernels, results are bit-identical.
  * Backward: dy / dz = gradients of y / z (NULL = zero); dres = gradient of residual (== total gradient of y), dx = gradient
  * of x; ws: fp32 [5][ofa_join_bwd_slots()][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b and (want_dx_colsum) the
- * column sums of dx -- the bias gradient of the Linear that produced x -- for ofa_fold_batched. */
+ * column sums of dx -- the bias gradient of the Linear that produced x -- for ofa_fold_batched.
+ * residual == NULL (and dres == NULL in backward): y = dropout_p(LN_a(x)) -- the adaptor post-hook's `dropout(layernorm_embedding(embed))`
+ * (adaptor/base.py:178-182) in one pass instead of a LayerNorm and a dropout kernel. */
 int ofa_join_fwd(const void* x, const void* residual, const void* gamma_a, const void* beta_a, const void* gamma_b,
                  const void* beta_b, void* y, void* z, float* stats, int64_t rows, int cols, float eps, float p, uint64_t seed,
                  uint64_t offset, const int64_t* offset_base, int dtype, void* stream);

@@ -129,8 +129,15 @@ class BaseAdaptor(torch.nn.Module):
             # :174-176 `embed * a + embed.detach() * (1 - a)`: the value is unchanged, the gradient flowing back into the
             # embedding / position / type tables is multiplied by a
             embed = ops.scale(embed, 1.0, float(self.cfg.scale_embedding_gradient))
+        fused_dropout = False
         if self.layernorm_embedding is not None:
-            embed = self.layernorm_embedding(embed)
+            p_drop = float(self.dropout_module.p)
+            if embed.is_cuda and p_drop > 0 and (self.training or self.dropout_module.apply_during_inference):
+                # dropout(layernorm_embedding(embed)) (:178, :182) in ONE pass: the residual-join kernel without a residual
+                embed, _ = ops.residual_join(embed, None, self.layernorm_embedding, p_drop, True, None, eps=self.layernorm_embedding.eps)
+                fused_dropout = True
+            else:
+                embed = self.layernorm_embedding(embed)
         if self.layernorm_position is not None and output.pos_embed is not None:
             base = ops.shared_rows(output.pos_embed)
             if base is not None:
@@ -139,7 +146,7 @@ class BaseAdaptor(torch.nn.Module):
                 output.pos_embed = self.layernorm_position(base).expand_as(output.pos_embed)
             else:
                 output.pos_embed = self.layernorm_position(output.pos_embed)
-        output.embed = self.dropout_module(embed)
+        output.embed = embed if fused_dropout else self.dropout_module(embed)
         output.pos_shared = bool(self.pos_batch_invariant)
         if not output.self_attn_bias and self.cfg.use_self_attn_bias:
             output.self_attn_bias = []

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void join_fwd_kernel(const T* __restrict__ x, 
     rraw[i] = make_uint4(0, 0, 0, 0);
     if (c < cols) {
       load_vec<T>(x + row * cols + c, v[i]);
-      rraw[i] = *reinterpret_cast<const uint4*>(res + row * cols + c);
+      if (res) rraw[i] = *reinterpret_cast<const uint4*>(res + row * cols + c);     // (no residual: y = dropout(LN_a(x)), the adaptor post-hook)
     }
   }
   if (ga) {                                             // LN_a, two-pass statistics in registers
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* _
         for (int j = 0; j < N; ++j) g[j] = rnd<T>(rs * (dzv[j] * gB[j] - s1 - yh[j] * s2) + g[j]);   // LN_b input gradient + dy, rounded once
       }
     }
-    if (live) store_vec<T>(dres + e0, g);                 // gradient of the residual input == gradient of y
+    if (live && dres) store_vec<T>(dres + e0, g);         // gradient of the residual input == gradient of y
     if (rg.p > 0.f && live) {                             // dropout backward on the rounded gradient
       bool keep[N];
       keep_mask<N>(rng, off, e0, rg.p, keep);
@@ -350,7 +350,7 @@ extern "C" int ofa_join_fwd(const void* x, const void* residual, const void* gam
                             const void* beta_b, void* y, void* z, float* stats, int64_t rows, int cols, float eps, float p,
                             uint64_t seed, uint64_t offset, const int64_t* offset_base, int dtype, void* stream) {
   if (int rc = join_check(rows, cols, dtype, "join_fwd")) return rc;
-  OFA_REQUIRE(x && residual && y && stats && (!gamma_a == !beta_a) && (!gamma_b == !beta_b) && (!gamma_b || z) && p >= 0.f && p < 1.f,
+  OFA_REQUIRE(x && y && stats && (!gamma_a == !beta_a) && (!gamma_b == !beta_b) && (!gamma_b || z) && p >= 0.f && p < 1.f,
               OFA_ERR_INVALID, "join_fwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -391,7 +391,7 @@ extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const
                             const float* stats, void* dres, void* dx, float* ws, int64_t rows, int cols, float p, uint64_t seed,
                             uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream) {
   if (int rc = join_check(rows, cols, dtype, "join_bwd")) return rc;
-  OFA_REQUIRE(stats && dres && dx && ws && (!gamma_a || x) && (!gamma_b || (y && dz)) && (dy || dz), OFA_ERR_INVALID,
+  OFA_REQUIRE(stats && dx && ws && (!gamma_a || x) && (!gamma_b || (y && dz)) && (dy || dz), OFA_ERR_INVALID,
               "join_bwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;

@@ -1182,7 +1182,8 @@ def relu(x, gate=None):
 # ------------------------------------------------------------------ residual join (csrc/join.hip)
 def join_fwd(x, residual, ln_a, ln_b, eps, p, seed, offset, offset_base):
     """y = residual + dropout_p(LN_a(x)); z = LN_b(y).  ln_a / ln_b: (gamma, beta) or None.  Returns y, z (or None), stats."""
-    x, residual = x.contiguous(), residual.contiguous()
+    x = x.contiguous()
+    residual = residual.contiguous() if residual is not None else None       # None: y = dropout_p(LN_a(x))
     rows, cols = _rows_cols(x)
     y = torch.empty_like(x)
     z = torch.empty_like(x) if ln_b is not None else None
@@ -1194,13 +1195,13 @@ def join_fwd(x, residual, ln_a, ln_b, eps, p, seed, offset, offset_base):
     return y, z, stats
 
 
-def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None):
+def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None, want_dres=True):
     """grads = (dgamma_a, dbeta_a, dgamma_b, dbeta_b[, dx_colsum]) output tensors (accumulated into; None for an absent
     LayerNorm; dx_colsum: the bias gradient of the Linear that produced x, optional).
     Returns dres, dx.  The column partials are folded by `fold` (a FoldQueue) or immediately."""
     like = dy if dy is not None else dz
     rows, cols = _rows_cols(like)
-    dres, dx = torch.empty_like(like), torch.empty_like(like)
+    dres, dx = (torch.empty_like(like) if want_dres else None), torch.empty_like(like)
     ns = lib().cdll.ofa_join_bwd_slots(rows, cols, dtype_code(like))
     ws = torch.empty(5 * ns * cols, dtype=torch.float32, device=like.device)
     q = fold if fold is not None else FoldQueue()

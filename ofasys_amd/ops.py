@@ -296,6 +296,7 @@ class ResidualJoinFn(torch.autograd.Function):
         ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats)
         ctx.refs = (ba, bb, x_bias)
         ctx.rng = (p, seed, off, base)
+        ctx.has_res = r2d is not None
         ctx.set_materialize_grads(False)                    # an unused y (last layer of a stack) costs no zero fill
         if z is None:
             return y, None
@@ -321,7 +322,7 @@ class ResidualJoinFn(torch.autograd.Function):
         else:
             grads = tuple((torch.zeros_like(t) if t is not None else None) for t in params)
             fold = None
-        dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold)
+        dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold, want_dres=ctx.has_res)
         if xb_sink is not None:
             _sink_done(x_bias)
         elif x_bias is not None:
@@ -345,9 +346,11 @@ def residual_join(x, residual, ln_a, p, training, ln_b, eps=1e-5, x_bias=None):
     x_bias: bias Parameter of the Linear that produced x when that Linear was called with skip_bias_grad=True -- its
     gradient (column sums of dx) then comes out of the join's backward kernel."""
     x2d, restore = rows_view(x)
-    r2d, _ = rows_view(residual)
-    if r2d.shape != x2d.shape:
-        raise OfaError("residual_join: shape mismatch")
+    r2d = None
+    if residual is not None:                                # (None: y = dropout(LN_a(x)), the adaptor post-hook)
+        r2d, _ = rows_view(residual)
+        if r2d.shape != x2d.shape:
+            raise OfaError("residual_join: shape mismatch")
     wa, ba = (ln_a.weight, ln_a.bias) if ln_a is not None else (None, None)
     wb, bb = (ln_b.weight, ln_b.bias) if ln_b is not None else (None, None)
     y, z = ResidualJoinFn.apply(x2d, r2d, wa, ba, wb, bb, p if training else 0.0, eps, x_bias)

@@ -4,3 +4,4 @@ rocprofv3 --kernel-trace --stats -d /tmp/r5a -o p -- python $R/bench.py --steps 
 python $R/tools/prof_summary.py /tmp/r5a/p_results.db 24 90 --json $O/kernel_stats.json > $O/kernel_stats.txt 2>&1
 python $R/tools/prof_by_grid.py /tmp/r5a/p_results.db > $O/by_grid.txt 2>&1
 tail -3 $O/stats_run.log | cut -c1-300
+python $R/tools/prof_last_step.py /tmp/r5a/p_results.db > $O/last_step.txt 2>&1

@@ -48,15 +48,6 @@ __device__ __forceinline__ void pp_pin(u64x2& d) { asm volatile("" : "+v"(d)); }
 #define PP_T(x) do { } while (0)
 #endif
 
-// One LDS-DMA piece issued as inline asm: hipcc neither counts it on vmcnt nor treats it as a pending LDS write (it would put
-// `s_waitcnt vmcnt(0)` in front of the epilogue's LDS bounce while the NEXT tile's first K-tiles are in flight -- the whole point of the
-// persistent form).  M0 (the LDS destination) is written in the statement that uses it and restored (section 5.7 of the guide).
-__device__ __forceinline__ void pp_glds_asm(const bf16_t* src, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-}
-
 template <int N> __device__ __forceinline__ void pp_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -65,14 +56,9 @@ template <int N> __device__ __forceinline__ void pp_vmcnt() {
 // (t, ks, bz): output tile, K-slice and batch index of this workgroup; nsplit > 1 or to_ws: the raw fp32 tile goes to slab ks of ws
 // ABL (measurement builds of tools/gemm_pp_ab.py only, WRONG results): 1 no fragment reads, 2 no LDS-DMA, 4 no MFMAs inside the loop
 // NDL: LDS-DMA pieces of a phase issued in its LOAD segment; the others go between the MFMAs of its MFMA segment
-// PERSIST: the workgroup walks the tiles t, t + tstride, ... < ntiles (splits == 1): the next tile's first K-tiles are sent for in front of
-// the epilogue (into the LDS slots the epilogue's bounce does not use), so first-tile flight, store acknowledgement and re-dispatch are paid
-// once per workgroup instead of once per tile.  ASMDMA: LDS-DMA pieces as inline asm (required by PERSIST, see pp_glds_asm).
-template <int TM, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool F16, int NKS, bool STAGGER, bool PRIO, int ABL = 0, int NDL = 4,
-          bool PERSIST = false, bool ASMDMA = false>
+template <int TM, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool F16, int NKS, bool STAGGER, bool PRIO, int ABL = 0, int NDL = 4>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int tiles_n, int ksplit, float* __restrict__ ws, int t,
-                                             int ks, int bz, int nsplit, bool to_ws, int ntiles = 0, int tstride = 0) {
-  static_assert(!PERSIST || ASMDMA, "the persistent form needs the asm LDS-DMA");
+                                             int ks, int bz, int nsplit, bool to_ws) {
   constexpr int TN = 2, HM = 32 * TM, BM = 2 * HM, BN = 256;
   static_assert(A_KMAJ || HM == 128, "an m-major A half is 128 wide (swizzle)");
   static_assert(NKS == 1 || NKS == 2 || NKS == 4, "k-slices per phase");
@@ -86,33 +72,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
   const int tid_g = tid & 255;
   constexpr int GM = 8;
   const int gsz = GM * tiles_n;
+  const int gid = t / gsz, first_m = gid * GM;
+  const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int tm = first_m + (t % gsz) % rows_in_group, tn = (t % gsz) / rows_in_group;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int mg = m0 + grp * HM;                                 // first row of this group's half
   const bf16_t* A = (const bf16_t*)g.A + batch_off(bz, g.batch_inner, g.strideA, g.strideA2);
   const bf16_t* B = (const bf16_t*)g.B + batch_off(bz, g.batch_inner, g.strideB, g.strideB2);
   const int kbeg = ks * ksplit;
   const int kend = (kbeg + ksplit < g.K) ? kbeg + ksplit : g.K;
   const int nk = (kend - kbeg) / BK;                            // launcher guarantees whole K tiles
-  int m0, n0, mg;                                               // origin of the tile, first row of this group's half
-  const bf16_t* pa[NVA];
-  const bf16_t* pb[NVB];
-  int ka_next, kb_next;
-  auto enter_tile = [&](int tt) {                               // tile tt in XCD-chunked order: 8-row groups, column-major inside
-    const int lt = PERSIST ? xcd_remap(tt, ntiles) : tt;
-    const int gid = lt / gsz, first_m = gid * GM;
-    const int rows_in_group = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int tm = first_m + (lt % gsz) % rows_in_group, tn = (lt % gsz) / rows_in_group;
-    m0 = tm * BM;
-    n0 = tn * BN;
-    mg = m0 + grp * HM;
-    int tid_a = tid_g, tid_b = tid;
-    if constexpr (PERSIST) {                                    // (per-lane pointer parts are recomputed per tile, not kept live across the K loop)
-      asm volatile("" : "+v"(tid_a));
-      asm volatile("" : "+v"(tid_b));
-    }
-    glds_ptrs<HM, A_KMAJ, 256, NVA, true>(pa, A, g.lda, mg, g.M, kbeg, tid_a, g.a_krows);
-    glds_ptrs<BN, B_KMAJ, 512, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid_b, g.b_krows);
-    ka_next = kb_next = kbeg;
-  };
-  enter_tile(t);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -122,7 +91,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bf16_t* pa[NVA];
+  const bf16_t* pb[NVB];
+  glds_ptrs<HM, A_KMAJ, 256, NVA, true>(pa, A, g.lda, mg, g.M, kbeg, tid_g, g.a_krows);
+  glds_ptrs<BN, B_KMAJ, 512, NVB>(pb, B, g.ldb, n0, g.N, kbeg, tid, g.b_krows);
   const int64_t stepA = A_KMAJ ? BK : (int64_t)BK * g.lda, stepB = B_KMAJ ? BK : (int64_t)BK * g.ldb;
+  int ka_next = kbeg, kb_next = kbeg;
   // this wave's pieces of K-tile (ka_next / kb_next) into the A half at byte offset `slot` / the B slot at `slot`
   // piece i of this wave's share of K-tile (ka_next / kb_next) into the A half at byte offset `slot` / the B slot at `slot`
   auto dma_a_piece = [&](auto ic, uint32_t slot) {
@@ -132,8 +106,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
         glds_ptrs<HM, A_KMAJ, 256, NVA, true>(pa, A, g.lda, mg, g.M, ka_next, tid_g, g.a_krows);
     }
     unsigned char* d = smem_raw + slot + (uint32_t)grp * 16384u + (uint32_t)(wave_u & 3) * 1024u;
-    if constexpr (ASMDMA) pp_glds_asm(pa[i], (uint32_t)(uintptr_t)(d + i * 4096));
-    else __builtin_amdgcn_global_load_lds((gvoid_t*)pa[i], (lvoid_t*)(d + i * 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gvoid_t*)pa[i], (lvoid_t*)(d + i * 4096), 16, 0, 0);
     pa[i] += stepA;
     if constexpr (i == NVA - 1) ka_next += BK;
   };
@@ -144,8 +117,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
         glds_ptrs<BN, B_KMAJ, 512, NVB>(pb, B, g.ldb, n0, g.N, kb_next, tid, g.b_krows);
     }
     unsigned char* d = smem_raw + slot + (uint32_t)wave_u * 1024u;
-    if constexpr (ASMDMA) pp_glds_asm(pb[i], (uint32_t)(uintptr_t)(d + i * 8192));
-    else __builtin_amdgcn_global_load_lds((gvoid_t*)pb[i], (lvoid_t*)(d + i * 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gvoid_t*)pb[i], (lvoid_t*)(d + i * 8192), 16, 0, 0);
     pb[i] += stepB;
     if constexpr (i == NVB - 1) kb_next += BK;
   };
@@ -165,24 +137,15 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
   unsigned long long tl_acc0 = 0, tl_acc1 = 0, tl_acc2 = 0, tl_acc3 = 0, tl_acc4 = 0, tl_n = 0;
   const unsigned long long tl_begin = __builtin_amdgcn_s_memtime(), tl_rbegin = __builtin_amdgcn_s_memrealtime();
 #endif
-  // prologue of a tile, in the loop's issue order: b(0), a(0), b(1)
-  auto issue_prologue = [&]() {
+  if (nk > 0) {
+    // prologue, in the loop's issue order: b(0), a(0), b(1)
     dma_b(PP_B0);
     dma_a(PP_A0);
-    if (nk > 1) dma_b(PP_B0 + PP_SLOT);
-  };
-  if (nk > 0) issue_prologue();
-  for (;;) {                                                    // one pass unless PERSIST
-  if (nk > 0) {
-    if constexpr (!PERSIST) {
-      if (nk > 1) pp_vmcnt<NVB>();
-      else pp_vmcnt<0>();
+    if (nk > 1) {
+      dma_b(PP_B0 + PP_SLOT);
+      pp_vmcnt<NVB>();
     } else {
-      // everything: the prologue pieces, the previous tile's epilogue stores (issued behind them) -- and, for hipcc's own bookkeeping, the
-      // scratch reloads of the tile setup: the builtin form is the one its waitcnt pass sees, so that it does not re-wait (vmcnt(0)!) at the
-      // first use of a reloaded pointer INSIDE the K loop; the asm form is the one it cannot drop
       pp_vmcnt<0>();
-      __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     PP_SB;
     __builtin_amdgcn_s_barrier();
@@ -304,7 +267,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
   }
   PP_SB;
 #ifdef OFA_PP_TIMELINE
-  if ((tid & 255) == 0 && ws && !PERSIST) {
+  if ((tid & 255) == 0 && ws) {
     unsigned long long* o = (unsigned long long*)ws + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + grp) * 16;
     o[0] = tl_acc0; o[1] = tl_acc1; o[2] = tl_acc2; o[3] = tl_acc3; o[4] = tl_acc4; o[5] = tl_n;
     o[6] = __builtin_amdgcn_s_memtime() - tl_begin; o[7] = __builtin_amdgcn_s_memrealtime() - tl_rbegin;
@@ -312,54 +275,20 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& g, int tiles_m, int
   }
 #endif
   {
-    const int m_w = m0 + grp * HM, n_w = n0 + wn * TN * 32;     // (of the tile just finished)
-    bool more_tiles = false;
-    if constexpr (PERSIST) {
-      t += tstride;
-      more_tiles = t < ntiles;
-      if (more_tiles && nk > 0) {
-        // every fragment read of the finished tile is complete (barrier above): the next tile's first K-tiles go to A slot 0 and
-        // B slots 0 / 1 NOW and land under the epilogue, which bounces through the other 64 KiB (B slot 2 + A slot 1)
-        enter_tile(t);
-        issue_prologue();
-      }
-    }
-    int m_e = m_w, n_e = n_w, lane_e = lane;
-    if constexpr (PERSIST) {
-      // the epilogue sits inside the tile loop: without this, LICM hoists its ~50 address / bias registers above the K loop (spills)
-      asm volatile("" : "+s"(m_e), "+s"(n_e));
-      asm volatile("" : "+v"(lane_e));
-    }
     const bool split = to_ws || nsplit > 1;
-    constexpr int REGION = PERSIST ? 8192 : 16384;              // per wave: 8 x 16 KiB of the (now idle) stages, or 8 x 8 KiB beside the prefetch
-    unsigned char* wl = PERSIST ? smem_raw + (wave_u < 4 ? PP_B0 + 2 * PP_SLOT + (uint32_t)wave_u * 8192u : PP_A0 + PP_SLOT + (uint32_t)(wave_u - 4) * 8192u)
-                                : smem_raw + wave_u * REGION;
+    constexpr int REGION = 16384;                               // per wave: 8 x 16 KiB of the (now idle) stages
+    unsigned char* wl = smem_raw + wave_u * REGION;
+    const int m_w = m0 + grp * HM, n_w = n0 + wn * TN * 32;
     if (split) {
       const int64_t n4 = (g.N + 3) & ~3;
       float* wsb = ws + ((int64_t)bz * nsplit + ks) * g.M * n4;
-      epilogue_lds<TM, TN, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_e, n_e, lane_e);
+      epilogue_lds<TM, TN, true, true, F16>(g, acc, wl, REGION, wsb, n4, m_w, n_w, lane);
     } else {
       const int64_t coff = batch_off(bz, g.batch_inner, g.strideC, g.strideC2);
       void* Cb = OUT_F32 ? (void*)((float*)g.C + coff) : (void*)((bf16_t*)g.C + coff);
-      epilogue_lds<TM, TN, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_e, n_e, lane_e);
+      epilogue_lds<TM, TN, OUT_F32, false, F16>(g, acc, wl, REGION, Cb, g.ldc, m_w, n_w, lane);
     }
-    if (!more_tiles) break;
-    // next tile: fresh accumulators, the canonical slot state (A slot 0 / B slot 0 hold its K-tile 0), and every wave done with the bounce
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    {
-      int lane_f = lane;
-      asm volatile("" : "+v"(lane_f));
-      fax.init(lds0 + PP_A0 + (uint32_t)grp * 16384u, 0, lane_f);
-      faw.init(lds0 + PP_B0, wn * TN * 32, lane_f);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  }   // tile loop
 }
 
 template <int TM, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool F16, int NKS, bool STAGGER, bool PRIO, int ABL = 0, int NDL = 4>
@@ -368,27 +297,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g, int tiles_m, i
   tile_and_slice(tiles_m * tiles_n, t, ks);
   gemm_pp_body<TM, A_KMAJ, B_KMAJ, OUT_F32, F16, NKS, STAGGER, PRIO, ABL, NDL>(g, tiles_m, tiles_n, ksplit, ws, t, ks, (int)blockIdx.z,
                                                                         (int)gridDim.y, false);
-}
-
-// Persistent form: min(tiles, CUs) workgroups, each walks its tiles (splits == 1, one batch); see gemm_pp_body PERSIST
-template <int TM, bool A_KMAJ, bool B_KMAJ, bool OUT_F32, bool F16, int NDL>
-__global__ __launch_bounds__(512) void gemm_pp_persist_kernel(GemmArgs g, int tiles_m, int tiles_n, int ksplit, float* __restrict__ ws) {
-  gemm_pp_body<TM, A_KMAJ, B_KMAJ, OUT_F32, F16, 2, true, true, 0, NDL, true, true>(g, tiles_m, tiles_n, ksplit, ws, (int)blockIdx.x, 0, 0, 1, false,
-                                                                                     tiles_m * tiles_n, (int)gridDim.x);
-}
-
-template <int TM, bool AK, bool BKM, bool OF, bool F16, int NDL>
-static void launch_pp_persist(const GemmArgs& g, int ksplit, float* ws, hipStream_t st, int wgs) {
-  constexpr int BM = 64 * TM, BN = 256;
-  const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  auto kern = gemm_pp_persist_kernel<TM, AK, BKM, OF, F16, NDL>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    attr_done = true;
-  }
-  const int ntiles = tiles_m * tiles_n;
-  hipLaunchKernelGGL(kern, dim3(ntiles < wgs ? ntiles : wgs), dim3(512), PP_LDS, st, g, tiles_m, tiles_n, ksplit, ws);
 }
 
 template <int TM, bool AK, bool BKM, bool OF, bool F16, int NKS, bool STAGGER, bool PRIO, int ABL = 0, int NDL = 4>
@@ -415,14 +323,6 @@ static bool launch_pp_variant(int variant, const GemmArgs& g, int batch, int spl
     case 23: launch_pp<TM, AK, BKM, OF, F16, 2, true, true, 0, 3>(g, batch, splits, ksplit, ws, st); return true;    // the shipped form
 #ifdef OFA_DEBUG_SWITCHES
     case 21: launch_pp<TM, AK, BKM, OF, F16, 2, true, true>(g, batch, splits, ksplit, ws, st); return true;
-    case 33: case 34:                                                              // persistent walk over the tiles (experiment)
-      if constexpr (!F16 && AK) {
-        if (splits != 1 || batch != 1) return false;
-        if (variant == 33) launch_pp_persist<TM, AK, BKM, OF, F16, 3>(g, ksplit, ws, st, 256);
-        else launch_pp_persist<TM, AK, BKM, OF, F16, 4>(g, ksplit, ws, st, 256);
-        return true;
-      }
-      return false;
     case 20: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 2, true, false>(g, batch, splits, ksplit, ws, st); return true; } return false;
     case 22: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 2, false, false>(g, batch, splits, ksplit, ws, st); return true; } return false;
     case 11: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 1, true, true>(g, batch, splits, ksplit, ws, st); return true; } return false;

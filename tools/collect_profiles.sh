@@ -1,9 +1,9 @@
 #!/bin/bash
-# Evidence of a round (ROUND=<n>, default 4): kernel-trace stats of the bench commands (cfg-2 headline, cfg-2b, cfg-4), HBM PMC passes, MFMA / LDS PMC pass, microbenchmarks.
+# Evidence of a round (ROUND=<n>, default 5): kernel-trace stats of the bench commands (cfg-2 headline, cfg-2b, cfg-4), HBM PMC passes, MFMA / LDS PMC pass, microbenchmarks.
 # Run on the GPU box:  bash tools/collect_profiles.sh   (outputs under gpurun_out/profiles/, copied into profiles/ afterwards)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/profiles; mkdir -p $O
-N=${ROUND:-4}
+N=${ROUND:-5}
 cd /tmp && export TMPDIR=/tmp
 # 4 distinct batches x 3 set-up steps (2 eager + capture) + 2 warm-up + 10 timed = 24 train steps in the trace
 rocprofv3 --kernel-trace --stats -d /tmp/r${N}stats -o p -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-gemm 0 > $O/stats_run.log 2>&1
@@ -49,4 +49,6 @@ for w in cfg2 cfg2b cfg4; do python tools/native_glue_trace.py $w 2>&1 | grep -v
 timeout 300 tools/experiments/_build/adam_stream_bench > $O/round${N}_adam_stream_bench.txt 2>&1 || true
 (python tools/gemm_split_check.py; OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so OFA_GEMM_SPLIT_MIN_K=1000000 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_split_check.txt
 # what every parity test measures next to its bound (pytest -s prints MEASURED lines)
+ROUND=$N python tools/gemm_bench.py > /dev/null 2>&1 || true
+python tools/prof_last_step.py /tmp/r${N}stats/p_results.db > $O/round${N}_last_step_sequence.txt 2>&1 || true
 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "MEASURED|passed|failed" > $O/round${N}_parity_measured.txt

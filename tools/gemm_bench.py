@@ -81,7 +81,7 @@ except Exception as e:                                     # (the yard-stick mus
     lines.append(f"grouped weight gradients: not timed ({type(e).__name__}: {e})")
     print(lines[-1])
 
-rnd = os.environ.get("ROUND", "4")
+rnd = os.environ.get("ROUND", "5")
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles")
 os.makedirs(dst, exist_ok=True)
 with open(os.path.join(dst, f"round{rnd}_gemm_microbench.txt"), "w") as f:

@@ -79,19 +79,24 @@ int ofa_gelu_layernorm_bwd(const void* dy, const void* h, const void* gamma, con
 /* ---- residual join of a pre-LN sub-block (transformer_layer.py:167-208, 438-494), one pass each way:
  *   y = residual + dropout_p(LN_a(x)),  z = LN_b(y);   LN_a (gamma_a/beta_a) and LN_b (gamma_b/beta_b, z) are optional.
  * stats: fp32 [4][rows] = mean_a, rstd_a, mean_b, rstd_b (kept for the backward).  Dropout as ofa_dropout_add_fwd
- * (Philox position offset + *offset_base).  Rounding points match the unfused kernels, results are bit-identical.
+ * (Philox position offset + *offset_base).  Rounding points match the unfused kernels (y is bit-identical without LN_a; with it, and for
+ * every gradient, the row sums are grouped differently: fp32 rounding noise).
  * Backward: dy / dz = gradients of y / z (NULL = zero); dres = gradient of residual (== total gradient of y), dx = gradient
  * of x; ws: fp32 [5][ofa_join_bwd_slots()][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b and (want_dx_colsum) the
  * column sums of dx -- the bias gradient of the Linear that produced x -- for ofa_fold_batched.
  * residual == NULL (and dres == NULL in backward): y = dropout_p(LN_a(x)) -- the adaptor post-hook's `dropout(layernorm_embedding(embed))`
- * (adaptor/base.py:178-182) in one pass instead of a LayerNorm and a dropout kernel. */
+ * (adaptor/base.py:178-182) in one pass instead of a LayerNorm and a dropout kernel.
+ * keep_bits (optional, ofa_join_keep_bytes() bytes; 0 bytes: the shape has no such buffer, pass NULL): the forward leaves the dropout
+ * decisions there, one bit per element in the kernels' own lane order, and a backward given the same buffer reads them instead of running the
+ * Philox generator again (which is what bounds these kernels, not HBM); NULL on either side: the mask is regenerated, same bits. */
+int64_t ofa_join_keep_bytes(int64_t rows, int cols, int dtype);
 int ofa_join_fwd(const void* x, const void* residual, const void* gamma_a, const void* beta_a, const void* gamma_b,
-                 const void* beta_b, void* y, void* z, float* stats, int64_t rows, int cols, float eps, float p, uint64_t seed,
-                 uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
+                 const void* beta_b, void* y, void* z, float* stats, uint8_t* keep_bits, int64_t rows, int cols, float eps, float p,
+                 uint64_t seed, uint64_t offset, const int64_t* offset_base, int dtype, void* stream);
 int ofa_join_bwd_slots(int64_t rows, int cols, int dtype);
 int ofa_join_bwd(const void* dy, const void* dz, const void* x, const void* y, const void* gamma_a, const void* gamma_b,
-                 const float* stats, void* dres, void* dx, float* ws, int64_t rows, int cols, float p, uint64_t seed,
-                 uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream);
+                 const float* stats, const uint8_t* keep_bits, void* dres, void* dx, float* ws, int64_t rows, int cols, float p,
+                 uint64_t seed, uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream);
 
 /* ---- GEMM: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+bias) (+C).  Replaces F.linear / torch.bmm / matmul:
  * multihead_attention.py:199-217,308,338,346; transformer_layer.py:194,202; adaptor/general.py:223-243.

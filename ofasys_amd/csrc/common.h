@@ -166,6 +166,13 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 
 // ---------------------------------------------------------------- Philox4x32-10 (counter-based dropout masks)
+// 32 x 32 -> 64-bit product in ONE quarter-rate instruction (hipcc splits `(uint64_t)a * b` with a constant operand into v_mul_hi_u32 +
+// v_mul_lo_u32, two quarter-rate instructions: the generator is 40 such products per call and the residual-join kernels are bound by it)
+__device__ __forceinline__ uint64_t mul_wide(uint32_t k, uint32_t x) {
+  uint64_t r, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "s"(k), "v"(x));
+  return r;
+}
 struct Philox {
   uint32_t k0, k1;
   __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
@@ -174,8 +181,8 @@ struct Philox {
     uint32_t a = k0, b = k1;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      const uint64_t p0 = mul_wide(0xD2511F53u, c0), p1 = mul_wide(0xCD9E8D57u, c2);
+      const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
       c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       a += 0x9E3779B9u; b += 0xBB67AE85u;

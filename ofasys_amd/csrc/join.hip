@@ -328,6 +328,414 @@ __global__ __launch_bounds__(join_wpb(WPR) * 64) void join_bwd_kernel(const T* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row-per-wave forms: 16-bit rows of 256 * k columns (every embed_dim of the model families: 256 ... 1536).  The kernels above spend their time
+// in the VALU, not on HBM (a wave64 instruction holds a 16-lane SIMD for 4 cycles; per 768-column row they issue ~1000 (forward) / ~1200
+// (backward) of them, a third of it the Philox generator, with a quarter of the lanes idle in the second vector: 22 / 28 us for passes HBM
+// moves in 13 / 17 us).  Here a lane owns NF 8-element chunks plus, for an odd multiple of 256 columns, one 4-element tail chunk, so all 64
+// lanes work on every chunk; a row never leaves its wave (no LDS exchange, no block barrier); the forward kernel leaves one byte of keep bits
+// per (chunk, lane), so that the backward reads 1 / 16 of a pass instead of re-running the generator; the backward is persistent with the next
+// two rows in flight (the raw vectors, ~12 KB per wave).  Rounding points are those of the kernels above; the row statistics are summed in a
+// different lane grouping, means are sum * (1 / cols) and rstd is v_rsq_f32 (the split-row kernels divide and take 1 / sqrt: ~40 instructions
+// per row): fp32 rounding noise against them, and against csrc/layernorm.hip.
+template <int NF_, bool TAIL_> struct RowMap {
+  static constexpr int NF = NF_;
+  static constexpr bool TAIL = TAIL_;
+  static constexpr int EPL = NF * 8 + (TAIL ? 4 : 0);          // elements per lane
+  static constexpr int W = EPL / 2;                            // 32-bit words per lane
+  static constexpr int NCH = NF + (TAIL ? 1 : 0);              // chunks per lane
+  static constexpr int COLS = 64 * EPL;
+  static constexpr int TAIL0 = NF * 512;                       // first column of the tail chunks
+};
+
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo, float& hi) {
+  const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+
+template <typename M, typename T> __device__ __forceinline__ void row_load(const T* __restrict__ p, int lane, uint32_t (&w)[M::W]) {
+#pragma unroll
+  for (int i = 0; i < M::NF; ++i) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p + (i * 64 + lane) * 8);
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  if constexpr (M::TAIL) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + M::TAIL0 + lane * 4);
+    w[4 * M::NF] = v.x; w[4 * M::NF + 1] = v.y;
+  }
+}
+template <typename M, typename T> __device__ __forceinline__ void row_store(T* __restrict__ p, int lane, const uint32_t (&w)[M::W]) {
+#pragma unroll
+  for (int i = 0; i < M::NF; ++i)
+    *reinterpret_cast<uint4*>(p + (i * 64 + lane) * 8) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  if constexpr (M::TAIL) *reinterpret_cast<uint2*>(p + M::TAIL0 + lane * 4) = make_uint2(w[4 * M::NF], w[4 * M::NF + 1]);
+}
+template <typename M, typename T> __device__ __forceinline__ void row_unpack(const uint32_t (&w)[M::W], float (&v)[M::EPL]) {
+#pragma unroll
+  for (int k = 0; k < M::W; ++k) unpack2<T>(w[k], v[2 * k], v[2 * k + 1]);
+}
+// rounds v to the storage type: w = the packed row, v = what a reader of w sees
+template <typename M, typename T> __device__ __forceinline__ void row_round(float (&v)[M::EPL], uint32_t (&w)[M::W]) {
+#pragma unroll
+  for (int k = 0; k < M::W; ++k) {
+    w[k] = pack2<T>(v[2 * k], v[2 * k + 1]);
+    unpack2<T>(w[k], v[2 * k], v[2 * k + 1]);
+  }
+}
+// keep bits of the lane's chunks: bit j of kb[i] <- element j of chunk i survives (keep_mask's rule: the same Philox positions as every
+// other dropout kernel of the library)
+template <typename M> __device__ __forceinline__ void row_keep_bits(const Philox& rng, uint64_t off, int64_t row0, int lane, float p,
+                                                                    uint32_t (&kb)[M::NCH]) {
+#pragma unroll
+  for (int i = 0; i < M::NF; ++i) {
+    bool keep[8];
+    keep_mask<8>(rng, off, row0 + (i * 64 + lane) * 8, p, keep);
+    uint32_t b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b |= (keep[j] ? 1u : 0u) << j;
+    kb[i] = b;
+  }
+  if constexpr (M::TAIL) {
+    bool keep[4];
+    keep_mask<4>(rng, off, row0 + M::TAIL0 + lane * 4, p, keep);
+    uint32_t b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b |= (keep[j] ? 1u : 0u) << j;
+    kb[M::NF] = b;
+  }
+}
+// v <- keep ? v * scale : 0 over the lane's chunks
+template <typename M> __device__ __forceinline__ void row_drop(float (&v)[M::EPL], const uint32_t (&kb)[M::NCH], float scale) {
+#pragma unroll
+  for (int e = 0; e < M::EPL; ++e) v[e] = (kb[e >> 3] >> (e & 7)) & 1u ? v[e] * scale : 0.f;
+}
+template <typename M> __device__ __forceinline__ float row_sum(const float (&v)[M::EPL]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < M::EPL; ++e) s += v[e];
+  return s;
+}
+
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void join_fwd_row_kernel(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ ga,
+                                                           const T* __restrict__ ba, const T* __restrict__ gb, const T* __restrict__ bb,
+                                                           T* __restrict__ y, T* __restrict__ z, float* __restrict__ stats,
+                                                           uint8_t* __restrict__ keep_bits, int64_t rows, float eps, JoinRng rg) {
+  constexpr int EPL = M::EPL, W = M::W, cols = M::COLS;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t row0 = row * cols;
+  uint32_t xw[W], rw[W];
+  row_load<M, T>(x + row0, lane, xw);
+  if (res) {
+    row_load<M, T>(res + row0, lane, rw);
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) rw[k] = 0;
+  }
+  float v[EPL];
+  row_unpack<M, T>(xw, v);
+  if (ga) {                                             // LN_a, two-pass statistics in registers
+    const float mu = wave_sum(row_sum<M>(v)) * (1.0f / cols);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q += (v[e] - mu) * (v[e] - mu);
+    const float rs = __builtin_amdgcn_rsqf(wave_sum(q) * (1.0f / cols) + eps);
+    if (lane == 0) { stats[row] = mu; stats[rows + row] = rs; }
+    uint32_t gw[W], bw[W];
+    row_load<M, T>(ga, lane, gw);
+    row_load<M, T>(ba, lane, bw);
+    float g[EPL], b[EPL];
+    row_unpack<M, T>(gw, g);
+    row_unpack<M, T>(bw, b);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mu) * rs * g[e] + b[e];
+    row_round<M, T>(v, xw);                             // (the unfused LayerNorm stores its output: one rounding)
+  }
+  if (rg.p > 0.f) {
+    const uint64_t off = rg.offset + (rg.base ? (uint64_t)rg.base[0] : 0);
+    uint32_t kb[M::NCH];
+    row_keep_bits<M>(Philox(rg.seed), off, row0, lane, rg.p, kb);
+    row_drop<M>(v, kb, 1.0f / (1.0f - rg.p));
+    if (keep_bits) {
+#pragma unroll
+      for (int i = 0; i < M::NCH; ++i) keep_bits[(row * M::NCH + i) * 64 + lane] = (uint8_t)kb[i];
+    }
+  }
+  float r[EPL];
+  row_unpack<M, T>(rw, r);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) v[e] += r[e];
+  row_round<M, T>(v, xw);
+  row_store<M, T>(y + row0, lane, xw);
+  if (!gb) return;
+  const float mu = wave_sum(row_sum<M>(v)) * (1.0f / cols);            // LN_b of the (rounded) y
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) q += (v[e] - mu) * (v[e] - mu);
+  const float rs = __builtin_amdgcn_rsqf(wave_sum(q) * (1.0f / cols) + eps);
+  if (lane == 0) { stats[2 * rows + row] = mu; stats[3 * rows + row] = rs; }
+  uint32_t gw[W], bw[W];
+  row_load<M, T>(gb, lane, gw);
+  row_load<M, T>(bb, lane, bw);
+  float g[EPL], b[EPL];
+  row_unpack<M, T>(gw, g);
+  row_unpack<M, T>(bw, b);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mu) * rs * g[e] + b[e];
+#pragma unroll
+  for (int k = 0; k < W; ++k) xw[k] = pack2<T>(v[2 * k], v[2 * k + 1]);
+  row_store<M, T>(z + row0, lane, xw);
+}
+
+template <typename M> struct JoinRowRaw {                // one row as fetched: raw vectors, keep bytes, the four statistics
+  uint32_t dy[M::W], dz[M::W], y[M::W], x[M::W];
+  uint32_t kb[M::NCH];
+  float st[4];
+};
+
+// HAS_A / HAS_B / DROP: LN_a, LN_b, p > 0 as compile-time facts (as run-time flags every one of them costs register copies at the joins
+// of the row loop: a third more instructions per row)
+template <typename T, typename M, int WPB, int DIST, bool HAS_A, bool HAS_B, bool DROP>
+__global__ __launch_bounds__(WPB * 64) void join_bwd_row_kernel(const T* __restrict__ dy, const T* __restrict__ dz,
+                                                                        const T* __restrict__ x, const T* __restrict__ y,
+                                                                        const T* __restrict__ ga, const T* __restrict__ gb,
+                                                                        const float* __restrict__ stats,
+                                                                        const uint8_t* __restrict__ keep_bits, T* __restrict__ dres,
+                                                                        T* __restrict__ dx, float* __restrict__ ws, int64_t rows,
+                                                                        JoinRng rg, int want_xsum) {
+  constexpr int EPL = M::EPL, W = M::W, cols = M::COLS;
+  __shared__ float fold[WPB][cols];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t gAw[W], gBw[W];                               // the gammas stay packed (registers: three raw rows are in flight)
+  float acc[5][EPL];                                     // dgamma_a, dbeta_a, dgamma_b, dbeta_b, column sums of dx
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q][e] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < W; ++k) gAw[k] = gBw[k] = 0;
+  if constexpr (HAS_A) row_load<M, T>(ga, lane, gAw);
+  if constexpr (HAS_B) row_load<M, T>(gb, lane, gBw);
+  const float scale = DROP ? 1.0f / (1.0f - rg.p) : 1.0f;
+  const int64_t stride = (int64_t)gridDim.x * WPB;
+  const int64_t first = (int64_t)blockIdx.x * WPB + wib;
+  const int64_t niter = (rows + stride - 1) / stride;
+
+  auto fetch = [&](JoinRowRaw<M>& b, int64_t it) {
+    const int64_t row = it * stride + first;
+    if (row < rows) {                                     // (wave-uniform)
+      const int64_t row0 = row * cols;
+      if (dy) row_load<M, T>(dy + row0, lane, b.dy);
+      if constexpr (HAS_B) {
+        row_load<M, T>(dz + row0, lane, b.dz);
+        row_load<M, T>(y + row0, lane, b.y);
+        b.st[2] = stats[2 * rows + row];
+        b.st[3] = stats[3 * rows + row];
+      }
+      if constexpr (HAS_A) {
+        row_load<M, T>(x + row0, lane, b.x);
+        b.st[0] = stats[row];
+        b.st[1] = stats[rows + row];
+      }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int i = 0; i < M::NCH; ++i) b.kb[i] = keep_bits[(row * M::NCH + i) * 64 + lane];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // the loads stay HERE, two rows ahead of their use
+  };
+  auto process = [&](JoinRowRaw<M>& b, int64_t it) {
+    const int64_t row = it * stride + first;
+    if (row >= rows) return;
+    const int64_t row0 = row * cols;
+    float g[EPL];                                         // running gradient of this lane's columns
+    uint32_t w[W];
+    if (dy) {
+      row_unpack<M, T>(b.dy, g);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = 0.f;
+    }
+    if constexpr (HAS_B) {                                // LN_b backward
+      float dzv[EPL], yh[EPL], gB[EPL], s1 = 0.f, s2 = 0.f;
+      row_unpack<M, T>(b.dz, dzv);
+      row_unpack<M, T>(b.y, yh);
+      row_unpack<M, T>(gBw, gB);
+      const float mu = b.st[2], rs = b.st[3];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        yh[e] = (yh[e] - mu) * rs;
+        const float gy = dzv[e] * gB[e];
+        s1 += gy;
+        s2 += gy * yh[e];
+        acc[2][e] += dzv[e] * yh[e];
+        acc[3][e] += dzv[e];
+      }
+      s1 = wave_sum(s1) * (1.0f / cols);
+      s2 = wave_sum(s2) * (1.0f / cols);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = rs * (dzv[e] * gB[e] - s1 - yh[e] * s2) + g[e];   // LN_b input gradient + dy, rounded once
+      row_round<M, T>(g, w);
+      if (dres) row_store<M, T>(dres + row0, lane, w);
+    } else if (dres) {                                    // gradient of the residual input == gradient of y
+      row_store<M, T>(dres + row0, lane, b.dy);
+    }
+    if constexpr (DROP) {                                 // dropout backward on the rounded gradient
+      row_drop<M>(g, b.kb, scale);
+      row_round<M, T>(g, w);
+    }
+    if constexpr (HAS_A) {                                // LN_a backward
+      float xh[EPL], gA[EPL], s1 = 0.f, s2 = 0.f;
+      row_unpack<M, T>(b.x, xh);
+      row_unpack<M, T>(gAw, gA);
+      const float mu = b.st[0], rs = b.st[1];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        xh[e] = (xh[e] - mu) * rs;
+        const float gy = g[e] * gA[e];
+        s1 += gy;
+        s2 += gy * xh[e];
+        acc[0][e] += g[e] * xh[e];
+        acc[1][e] += g[e];
+      }
+      s1 = wave_sum(s1) * (1.0f / cols);
+      s2 = wave_sum(s2) * (1.0f / cols);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = rs * (g[e] * gA[e] - s1 - xh[e] * s2);
+#pragma unroll
+      for (int k = 0; k < W; ++k) w[k] = pack2<T>(g[2 * k], g[2 * k + 1]);
+    } else if (!DROP && !HAS_B) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) w[k] = b.dy[k];
+    }
+    row_store<M, T>(dx + row0, lane, w);
+    if (want_xsum) {                                      // gradient of the bias of the Linear that produced x
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[4][e] += g[e];
+    }
+  };
+
+  if constexpr (DIST == 2) {                                // two rows ahead
+    JoinRowRaw<M> b0, b1, b2;
+    fetch(b0, 0);
+    fetch(b1, 1);
+    for (int64_t it = 0; it < niter; it += 3) {
+      fetch(b2, it + 2); process(b0, it);
+      fetch(b0, it + 3); process(b1, it + 1);
+      fetch(b1, it + 4); process(b2, it + 2);
+    }
+  } else {                                                  // one row ahead
+    JoinRowRaw<M> b0, b1;
+    fetch(b0, 0);
+    for (int64_t it = 0; it < niter; it += 2) {
+      fetch(b1, it + 1); process(b0, it);
+      fetch(b0, it + 2); process(b1, it + 1);
+    }
+  }
+  // the block's waves -> one partial row per quantity
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    if ((q < 2 && !HAS_A) || (q >= 2 && q < 4 && !HAS_B) || (q == 4 && !want_xsum)) continue;
+#pragma unroll
+    for (int i = 0; i < M::NF; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fold[wib][(i * 64 + lane) * 8 + j] = acc[q][i * 8 + j];
+    if constexpr (M::TAIL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fold[wib][M::TAIL0 + lane * 4 + j] = acc[q][M::NF * 8 + j];
+    }
+    __syncthreads();
+    float* wq = ws + ((int64_t)q * gridDim.x + blockIdx.x) * cols;
+    for (int c = threadIdx.x; c < cols; c += WPB * 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < WPB; ++r) a += fold[r][c];
+      wq[c] = a;
+    }
+    __syncthreads();
+  }
+}
+
+// columns the row-per-wave kernels take (16-bit types); 0: the kernels above.  The backward holds three raw rows: up to 1024 columns.
+// One launch of the row-per-wave backward.  Waves per block / rows in flight ahead of the one being worked on, by what fits the registers of
+// the instantiation (measured, tools/join_bench.py): 8 waves (two per SIMD, 256 registers each) and two rows ahead; one row ahead where three
+// raw rows do not fit (768 columns with both LayerNorms, 1024 columns); 1024 columns with both LayerNorms: 4 waves (512 registers), two ahead.
+template <typename T, typename M, bool A, bool B, bool D, int WPB, int DIST, typename... Args>
+static void join_bwd_row_go(int nblk, hipStream_t st, Args... args) {
+  hipLaunchKernelGGL((join_bwd_row_kernel<T, M, WPB, DIST, A, B, D>), dim3(nblk), dim3(WPB * 64), 0, st, args...);
+}
+template <typename T, typename M, bool A, bool B, bool D, typename... Args>
+static void join_bwd_row_launch(int variant, int nblk, hipStream_t st, Args... args) {
+  constexpr bool AB = A && B;
+  constexpr int WPB = (M::EPL == 16 && AB) ? 4 : 8;
+  constexpr int DIST = M::EPL <= 8 ? 2 : (M::EPL == 12 ? (AB ? 1 : 2) : (AB ? 2 : 1));
+#ifdef OFA_DEBUG_SWITCHES
+  if (variant == 1) return join_bwd_row_go<T, M, A, B, D, 8, 1>(nblk, st, args...);
+  if (variant == 2) return join_bwd_row_go<T, M, A, B, D, 4, 2>(nblk, st, args...);
+  if (variant == 3) return join_bwd_row_go<T, M, A, B, D, 8, 2>(nblk, st, args...);
+#endif
+  join_bwd_row_go<T, M, A, B, D, WPB, DIST>(nblk, st, args...);
+}
+template <typename T, typename M, typename... Args>
+static void join_bwd_row_flags(bool a, bool b, bool d, int variant, int nblk, hipStream_t st, Args... args) {
+  switch ((a ? 4 : 0) | (b ? 2 : 0) | (d ? 1 : 0)) {
+    case 0: return join_bwd_row_launch<T, M, false, false, false>(variant, nblk, st, args...);
+    case 1: return join_bwd_row_launch<T, M, false, false, true>(variant, nblk, st, args...);
+    case 2: return join_bwd_row_launch<T, M, false, true, false>(variant, nblk, st, args...);
+    case 3: return join_bwd_row_launch<T, M, false, true, true>(variant, nblk, st, args...);
+    case 4: return join_bwd_row_launch<T, M, true, false, false>(variant, nblk, st, args...);
+    case 5: return join_bwd_row_launch<T, M, true, false, true>(variant, nblk, st, args...);
+    case 6: return join_bwd_row_launch<T, M, true, true, false>(variant, nblk, st, args...);
+    default: return join_bwd_row_launch<T, M, true, true, true>(variant, nblk, st, args...);
+  }
+}
+template <typename T>
+static void join_bwd_row_cols(int k, bool a, bool b, bool d, int variant, int nblk, hipStream_t st, const void* dy, const void* dz,
+                              const void* x, const void* y, const void* ga, const void* gb, const float* stats, const uint8_t* keep_bits,
+                              void* dres, void* dx, float* ws, int64_t rows, JoinRng rg, int want_xsum) {
+#define GO(NF, TAIL)                                                                                                                        \
+  join_bwd_row_flags<T, RowMap<NF, TAIL>>(a, b, d, variant, nblk, st, (const T*)dy, (const T*)dz, (const T*)x, (const T*)y, (const T*)ga, \
+                                          (const T*)gb, stats, keep_bits, (T*)dres, (T*)dx, ws, rows, rg, want_xsum)
+  switch (k) {
+    case 1: GO(0, true); break;
+    case 2: GO(1, false); break;
+    case 3: GO(1, true); break;
+    default: GO(2, false); break;
+  }
+#undef GO
+}
+
+// debug builds: OFA_JOIN_BWD = 0 (the split-row kernel) / 1, 2, 3 (row per wave: 8 waves one row ahead, 4 waves two ahead, 8 waves two ahead)
+// / anything else (row per wave, the shipped choice per instantiation); OFA_JOIN_FWD = 0 (split row) / 1 (row per wave)
+static int join_bwd_variant() {
+#ifdef OFA_DEBUG_SWITCHES
+  if (const char* e = getenv("OFA_JOIN_BWD")) return atoi(e);
+#endif
+  return 9;
+}
+static int join_fwd_variant() {
+#ifdef OFA_DEBUG_SWITCHES
+  if (const char* e = getenv("OFA_JOIN_FWD")) return atoi(e);
+#endif
+  return 1;
+}
+
+static int join_row_k(int cols, int dtype, bool backward) {
+  if (dtype == OFA_F32 || cols % 256 != 0 || !(backward ? join_bwd_variant() : join_fwd_variant())) return 0;
+  const int k = cols / 256;
+  return k >= 1 && k <= (backward ? 4 : 6) ? k : 0;
+}
+
 static int join_wpr(int cols, int n) {
   int wpr = 1;
   while (wpr < 8 && cols / wpr > 64 * n) wpr *= 2;
@@ -346,18 +754,53 @@ static int join_check(int64_t rows, int cols, int dtype, const char* what) {
 }  // namespace ofa
 using namespace ofa;
 
+// bytes of the keep-bit buffer the forward may leave for the backward (0: this shape recomputes the mask in the backward)
+extern "C" int64_t ofa_join_keep_bytes(int64_t rows, int cols, int dtype) {
+  const int k = join_row_k(cols, dtype, true);
+  return k ? rows * (int64_t)((k + 1) / 2) * 64 : 0;
+}
+
+#define JOIN_ROW_DISPATCH(k, CALL)              \
+  do {                                          \
+    switch (k) {                                \
+      case 1: CALL(0, true); break;             \
+      case 2: CALL(1, false); break;            \
+      case 3: CALL(1, true); break;             \
+      case 4: CALL(2, false); break;            \
+      case 5: CALL(2, true); break;             \
+      default: CALL(3, false); break;           \
+    }                                           \
+  } while (0)
+
 extern "C" int ofa_join_fwd(const void* x, const void* residual, const void* gamma_a, const void* beta_a, const void* gamma_b,
-                            const void* beta_b, void* y, void* z, float* stats, int64_t rows, int cols, float eps, float p,
-                            uint64_t seed, uint64_t offset, const int64_t* offset_base, int dtype, void* stream) {
+                            const void* beta_b, void* y, void* z, float* stats, uint8_t* keep_bits, int64_t rows, int cols, float eps,
+                            float p, uint64_t seed, uint64_t offset, const int64_t* offset_base, int dtype, void* stream) {
   if (int rc = join_check(rows, cols, dtype, "join_fwd")) return rc;
   OFA_REQUIRE(x && y && stats && (!gamma_a == !beta_a) && (!gamma_b == !beta_b) && (!gamma_b || z) && p >= 0.f && p < 1.f,
               OFA_ERR_INVALID, "join_fwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const JoinRng rg{p, seed, offset, offset_base};
+  dim3 grid(cdiv(rows, 4)), block(256);
+  if (const int k = join_row_k(cols, dtype, false)) {
+    uint8_t* kb = ofa_join_keep_bytes(rows, cols, dtype) ? keep_bits : nullptr;
+#define JOIN_FWD_ROW(NF, TAIL)                                                                                                      \
+  do {                                                                                                                              \
+    if (dtype == OFA_BF16)                                                                                                          \
+      hipLaunchKernelGGL((join_fwd_row_kernel<bf16_t, RowMap<NF, TAIL>>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)residual, \
+                         (const bf16_t*)gamma_a, (const bf16_t*)beta_a, (const bf16_t*)gamma_b, (const bf16_t*)beta_b, (bf16_t*)y,   \
+                         (bf16_t*)z, stats, kb, rows, eps, rg);                                                                     \
+    else                                                                                                                            \
+      hipLaunchKernelGGL((join_fwd_row_kernel<f16_t, RowMap<NF, TAIL>>), grid, block, 0, st, (const f16_t*)x, (const f16_t*)residual,  \
+                         (const f16_t*)gamma_a, (const f16_t*)beta_a, (const f16_t*)gamma_b, (const f16_t*)beta_b, (f16_t*)y,        \
+                         (f16_t*)z, stats, kb, rows, eps, rg);                                                                      \
+  } while (0)
+    JOIN_ROW_DISPATCH(k, JOIN_FWD_ROW);
+#undef JOIN_FWD_ROW
+    return check_launch("join_fwd");
+  }
   const int n = dtype == OFA_F32 ? 4 : 8;
   const int nv = cdiv(cols, 64 * n);
-  dim3 grid(cdiv(rows, 4)), block(256);
 #define JOIN_FWD(T, NV)                                                                                                  \
   hipLaunchKernelGGL((join_fwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)residual, (const T*)gamma_a,   \
                      (const T*)beta_a, (const T*)gamma_b, (const T*)beta_b, (T*)y, (T*)z, stats, rows, cols, eps, rg)
@@ -377,8 +820,13 @@ extern "C" int ofa_join_fwd(const void* x, const void* residual, const void* gam
 }
 
 extern "C" int ofa_join_bwd_slots(int64_t rows, int cols, int dtype) {
-  const int wpr = join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
-  const int rpb = join_wpb(wpr) / wpr;
+  int rpb;
+  if (join_row_k(cols, dtype, true)) {
+    rpb = 8;
+  } else {
+    const int wpr = join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
+    rpb = join_wpb(wpr) / wpr;
+  }
   int64_t nblk = (rows + rpb - 1) / rpb;
   return (int)(nblk < 1 ? 1 : (nblk > JOIN_BLOCKS ? JOIN_BLOCKS : nblk));
 }
@@ -387,15 +835,27 @@ extern "C" int ofa_join_bwd_slots(int64_t rows, int cols, int dtype) {
 // input; dx: gradient of x; ws: fp32 [5][ofa_join_bwd_slots][cols] partial rows of dgamma_a, dbeta_a, dgamma_b, dbeta_b and,
 // with want_dx_colsum, the column sums of dx (= the bias gradient of the Linear that produced x, so that Linear needs no
 // separate column-sum pass); fold with ofa_fold_batched; quantities that do not apply are not written.
+// keep_bits: what ofa_join_fwd left (ofa_join_keep_bytes() > 0 and p > 0), or NULL: the mask is regenerated.
 extern "C" int ofa_join_bwd(const void* dy, const void* dz, const void* x, const void* y, const void* gamma_a, const void* gamma_b,
-                            const float* stats, void* dres, void* dx, float* ws, int64_t rows, int cols, float p, uint64_t seed,
-                            uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype, void* stream) {
+                            const float* stats, const uint8_t* keep_bits, void* dres, void* dx, float* ws, int64_t rows, int cols,
+                            float p, uint64_t seed, uint64_t offset, const int64_t* offset_base, int want_dx_colsum, int dtype,
+                            void* stream) {
   if (int rc = join_check(rows, cols, dtype, "join_bwd")) return rc;
   OFA_REQUIRE(stats && dx && ws && (!gamma_a || x) && (!gamma_b || (y && dz)) && (dy || dz), OFA_ERR_INVALID,
               "join_bwd: bad argument");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const JoinRng rg{p, seed, offset, offset_base};
+  if (const int k = (p > 0.f && !keep_bits) ? 0 : join_row_k(cols, dtype, true)) {
+    const int nblk = ofa_join_bwd_slots(rows, cols, dtype);
+    if (dtype == OFA_BF16)
+      join_bwd_row_cols<bf16_t>(k, gamma_a, gamma_b, p > 0.f, join_bwd_variant(), nblk, st, dy, gamma_b ? dz : nullptr, x, y, gamma_a,
+                                gamma_b, stats, keep_bits, dres, dx, ws, rows, rg, want_dx_colsum);
+    else
+      join_bwd_row_cols<f16_t>(k, gamma_a, gamma_b, p > 0.f, join_bwd_variant(), nblk, st, dy, gamma_b ? dz : nullptr, x, y, gamma_a,
+                               gamma_b, stats, keep_bits, dres, dx, ws, rows, rg, want_dx_colsum);
+    return check_launch("join_bwd");
+  }
   const int wpr = join_wpr(cols, dtype == OFA_F32 ? 4 : 8);
   dim3 grid(ofa_join_bwd_slots(rows, cols, dtype)), block(64 * join_wpb(wpr));
 #define JOIN_BWD(T, WPR)                                                                                              \

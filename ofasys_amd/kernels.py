@@ -1181,21 +1181,24 @@ def relu(x, gate=None):
 
 # ------------------------------------------------------------------ residual join (csrc/join.hip)
 def join_fwd(x, residual, ln_a, ln_b, eps, p, seed, offset, offset_base):
-    """y = residual + dropout_p(LN_a(x)); z = LN_b(y).  ln_a / ln_b: (gamma, beta) or None.  Returns y, z (or None), stats."""
+    """y = residual + dropout_p(LN_a(x)); z = LN_b(y).  ln_a / ln_b: (gamma, beta) or None.  Returns y, z (or None), stats, keep_bits
+    (the dropout decisions for join_bwd, or None: this shape regenerates them)."""
     x = x.contiguous()
     residual = residual.contiguous() if residual is not None else None       # None: y = dropout_p(LN_a(x))
     rows, cols = _rows_cols(x)
     y = torch.empty_like(x)
     z = torch.empty_like(x) if ln_b is not None else None
     stats = torch.empty(4, rows, dtype=torch.float32, device=x.device)
+    nkeep = lib().cdll.ofa_join_keep_bytes(rows, cols, dtype_code(x)) if p > 0 else 0
+    keep = torch.empty(nkeep, dtype=torch.uint8, device=x.device) if nkeep else None
     ga, ba = ln_a if ln_a is not None else (None, None)
     gb, bb = ln_b if ln_b is not None else (None, None)
-    lib().call("ofa_join_fwd", ptr(x), ptr(residual), ptr(ga), ptr(ba), ptr(gb), ptr(bb), ptr(y), ptr(z), ptr(stats), rows, cols,
+    lib().call("ofa_join_fwd", ptr(x), ptr(residual), ptr(ga), ptr(ba), ptr(gb), ptr(bb), ptr(y), ptr(z), ptr(stats), ptr(keep), rows, cols,
                float(eps), float(p), seed, offset, ptr(offset_base), dtype_code(x), stream())
-    return y, z, stats
+    return y, z, stats, keep
 
 
-def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None, want_dres=True):
+def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, fold=None, want_dres=True, keep=None):
     """grads = (dgamma_a, dbeta_a, dgamma_b, dbeta_b[, dx_colsum]) output tensors (accumulated into; None for an absent
     LayerNorm; dx_colsum: the bias gradient of the Linear that produced x, optional).
     Returns dres, dx.  The column partials are folded by `fold` (a FoldQueue) or immediately."""
@@ -1210,7 +1213,7 @@ def join_bwd(dy, dz, x, y, ga, gb, stats, p, seed, offset, offset_base, grads, f
             q.add(ws, i * ns * cols, o, cols, cols, ns)
     want_xsum = len(grads) > 4 and grads[4] is not None
     lib().call("ofa_join_bwd", ptr(dy.contiguous() if dy is not None else None), ptr(dz.contiguous() if dz is not None else None),
-               ptr(x), ptr(y), ptr(ga), ptr(gb), ptr(stats), ptr(dres), ptr(dx), ptr(ws), rows, cols, float(p), seed, offset,
+               ptr(x), ptr(y), ptr(ga), ptr(gb), ptr(stats), ptr(keep), ptr(dres), ptr(dx), ptr(ws), rows, cols, float(p), seed, offset,
                ptr(offset_base), int(want_xsum), dtype_code(like), stream())
     if fold is None:
         q.flush()

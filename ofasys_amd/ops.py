@@ -291,9 +291,9 @@ class ResidualJoinFn(torch.autograd.Function):
         seed, off, base = (0, 0, None)
         if p > 0:
             seed, off, base = _Rng.reserve(x2d.numel(), x2d.device)
-        y, z, stats = K.join_fwd(x2d, r2d, (wa, ba) if wa is not None else None, (wb, bb) if wb is not None else None, eps,
-                                 p, seed, off, base)
-        ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats)
+        y, z, stats, keep = K.join_fwd(x2d, r2d, (wa, ba) if wa is not None else None, (wb, bb) if wb is not None else None, eps,
+                                       p, seed, off, base)
+        ctx.save_for_backward(x2d if wa is not None else None, y if wb is not None else None, wa, wb, stats, keep)
         ctx.refs = (ba, bb, x_bias)
         ctx.rng = (p, seed, off, base)
         ctx.has_res = r2d is not None
@@ -306,7 +306,7 @@ class ResidualJoinFn(torch.autograd.Function):
     def backward(ctx, dy, dz):
         if dy is None and dz is None:
             return (None,) * 9
-        x2d, y, wa, wb, stats = ctx.saved_tensors
+        x2d, y, wa, wb, stats, keep = ctx.saved_tensors
         ba, bb, x_bias = ctx.refs
         p, seed, off, base = ctx.rng
         if wb is None:
@@ -322,7 +322,7 @@ class ResidualJoinFn(torch.autograd.Function):
         else:
             grads = tuple((torch.zeros_like(t) if t is not None else None) for t in params)
             fold = None
-        dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold, want_dres=ctx.has_res)
+        dres, dx = K.join_bwd(dy, dz, x2d, y, wa, wb, stats, p, seed, off, base, grads, fold, want_dres=ctx.has_res, keep=keep)
         if xb_sink is not None:
             _sink_done(x_bias)
         elif x_bias is not None:

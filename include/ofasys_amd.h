@@ -121,7 +121,7 @@ int ofa_gemm_colstat(const void* A, const void* B, void* C, const void* bias, in
                      int64_t lda, int64_t ldb, int64_t ldc, float alpha, int flags, int dtype, void* ws, int64_t ws_bytes,
                      double* partial, int max_groups, int* groups, void* stream);
 
-/* ---- grouped weight-gradient products: up to 8 independent  slabs_p[s][m][n] = sum over K-slice s of a_p^T b_p  in ONE
+/* ---- grouped weight-gradient products: up to 16 independent  slabs_p[s][m][n] = sum over K-slice s of a_p^T b_p  in ONE
  * launch (256 x 256 eight-wave tiles).  The nn.Linear weight gradients of one Transformer layer (dW = dY^T X, what autograd
  * computes for transformer_layer.py:194,202 and multihead_attention.py:199-217,346) are 9-36 such tiles each: launched alone
  * each has to be cut into 3-7 short K-slices to occupy the chip; together they fill it with ~2 long slices each.

@@ -540,7 +540,7 @@ __device__ __forceinline__ void big_frag(u64x2& d, const BigAddr<R, KMAJ>& fa) {
 __host__ __device__ constexpr int big_read_after(int t, int nr) { return t < nr ? t : -1; }
 
 // Grouped weight-gradient launch (ofa_gemm_group_tn): argument block shared by gemm_mfma.hip and gemm_pp.hip
-constexpr int GROUP_MAX = 8;
+constexpr int GROUP_MAX = 16;                  // (two layers' worth of weight gradients: 2 x 6 for a decoder layer)
 struct GroupItem {
   const void* A; const void* B; float* ws;
   void* out; int64_t ldo; float alpha;     // out != nullptr: ONE K-slice, accumulated straight onto out (16-bit) in the epilogue
@@ -550,8 +550,12 @@ struct GroupItem {
 struct GroupArgs { GroupItem it[GROUP_MAX]; int n, total; };
 
 // The product, tile and K-slice of this workgroup of a grouped launch, and the product's argument block.  XCD chunks over the
-// flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2.
-__device__ __forceinline__ const GroupItem& group_enter(const GroupArgs& ga, GemmArgs& g, int& t, int& ks) {
+// flattened (item, slice, tile) order: the tiles of one slice of one product share operand panels in L2 -- which these products
+// depend on (a 256 x 256 tile of a 13312-row contraction reads 13.6 MB; unshared, 216 of them are 2.9 GB in ~320 us).  The round-5
+// experiment of giving every XCD 1 / 8 of EVERY product (equal work per XCD whatever the mix of contraction lengths) ran a decoder
+// pair 2.7 x slower and an encoder pair 20 % slower for exactly that reason; mixed-length groups are avoided by the caller instead
+// (ops._Wgrads flushes when the row count changes).
+__device__ __forceinline__ const GroupItem* group_enter(const GroupArgs& ga, GemmArgs& g, int& t, int& ks) {
   const int id = xcd_remap((int)blockIdx.x, ga.total);
   int p = 0;
   for (int q = 1; q < ga.n; ++q)
@@ -565,7 +569,7 @@ __device__ __forceinline__ const GroupItem& group_enter(const GroupArgs& ga, Gem
   const int ntiles = it.tiles_m * it.tiles_n, local = id - it.first;
   ks = local / ntiles;
   t = local - ks * ntiles;
-  return it;
+  return &it;
 }
 
 bool gemm_group_pp_launch(int variant, const GroupArgs& ga, bool f16, hipStream_t st);   // gemm_pp.hip

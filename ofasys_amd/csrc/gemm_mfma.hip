@@ -684,7 +684,9 @@ template <bool F16, bool W4 = false>
 __global__ __launch_bounds__(W4 ? 256 : 512) void gemm_group_tn_kernel(GroupArgs ga) {
   GemmArgs g;
   int t, ks;
-  const GroupItem& it = group_enter(ga, g, t, ks);
+  const GroupItem* itp = group_enter(ga, g, t, ks);
+  if (!itp) return;
+  const GroupItem& it = *itp;
   // (OUT_F32 = false: the non-slab epilogue of this instantiation is the 16-bit accumulate of a one-slice product)
   if constexpr (W4) gemm_big_body<4, 4, false, false, false, 2, 2, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
   else gemm_big_body<4, 2, false, false, false, 2, 4, F16>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
@@ -1006,18 +1008,55 @@ static bool group_item_ok(const ofa_gemm_group_item& it) {
   return true;
 }
 
-// K-slice length shared by the group: the shortest (in K tiles) for which the whole group is at most one round of 256
-// workgroups; every product is then cut into ceil(k / length) slices, so workgroups of long and short contractions run
-// about equally long.  A slice keeps >= 4 K tiles.
+// K-slice length shared by the group (every product is cut into ceil(k / length) slices; a slice keeps >= 4 K tiles): the candidate with the
+// shortest estimated time -- the finish time of the busiest XCD (an eighth of the flattened workgroup list, contiguous: group_enter), its
+// workgroups handed to its 32 CUs in order as they free up, plus what the slabs cost afterwards.  Constants from the cfg-2 traces
+// (profiles/round5_*): 1.5 us per K tile of a 256 x 256 workgroup, 6 us of prologue / epilogue / re-dispatch per workgroup (163 us for 104
+// K tiles, 317 us for 208), the fold launch moving (4 B per slab + old and new 16-bit gradient) per element at 4.1 TB/s (20.5 us for an encoder
+// layer's two-slab products, 26.8 us for a decoder layer's).  (Rounds 3-4: the shortest length with at most 256 workgroups in the group --
+// it never weighed the slabs against an idle sixth of the chip, and two layers' products in one launch need none.)
+static double group_time_us(const ofa_gemm_group_item* items, int n, int len) {
+  int steps[GROUP_MAX], count[GROUP_MAX], total = 0;
+  double slab_bytes = 0.0;
+  for (int p = 0; p < n; ++p) {
+    int sp = cdiv(items[p].k, len);
+    sp = sp > 32 ? 32 : sp;
+    const int ksplit = cdiv(cdiv(items[p].k, BK), sp) * BK;
+    sp = cdiv(items[p].k, ksplit);
+    steps[p] = ksplit / BK;
+    count[p] = cdiv(items[p].m, 256) * cdiv(items[p].n, 256) * sp;
+    total += count[p];
+    if (sp > 1) slab_bytes += ((double)sp * 4.0 + 4.0) * items[p].m * items[p].n;
+  }
+  double worst = 0.0;
+  for (int x = 0; x < 8; ++x) {                                             // xcd_remap: XCD x runs ids [lo, hi) of the flattened list
+    const int q = total >> 3, r = total & 7;
+    const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, hi = lo + q + (x < r ? 1 : 0);
+    double cu[32];
+    for (int c = 0; c < 32; ++c) cu[c] = 0.0;
+    int id = 0;
+    for (int p = 0; p < n; ++p)
+      for (int w = 0; w < count[p]; ++w, ++id) {
+        if (id < lo || id >= hi) continue;
+        int best = 0;
+        for (int c = 1; c < 32; ++c) best = cu[c] < cu[best] ? c : best;
+        cu[best] += 1.5 * steps[p] + 6.0;
+      }
+    for (int c = 0; c < 32; ++c) worst = cu[c] > worst ? cu[c] : worst;
+  }
+  return worst + (slab_bytes > 0.0 ? 2.0 + slab_bytes / 4.1e6 : 0.0);
+}
+
 static void group_plan(ofa_gemm_group_item* items, int n) {
   int kmax = 0;
   for (int p = 0; p < n; ++p) kmax = items[p].k > kmax ? items[p].k : kmax;
-  kmax = cdiv(kmax, BK) * BK;
-  int len = kmax;
-  for (int l = 4 * BK; l < kmax; l += BK) {
-    int64_t wgs = 0;
-    for (int p = 0; p < n; ++p) wgs += (int64_t)cdiv(items[p].m, 256) * cdiv(items[p].n, 256) * cdiv(items[p].k, l);
-    if (wgs <= 256) { len = l; break; }
+  const int tiles = cdiv(kmax, BK);
+  int len = tiles * BK;
+  double best = group_time_us(items, n, len);
+  for (int sp = 2; sp <= 32 && cdiv(tiles, sp) >= 4; ++sp) {               // the lengths at which the longest product gains a slice
+    const int l = cdiv(tiles, sp) * BK;
+    const double t = group_time_us(items, n, l);
+    if (t < best * 0.97) { best = t; len = l; }                             // (a tie goes to fewer slices: less slab traffic)
   }
   for (int p = 0; p < n; ++p) {
     int sp = cdiv(items[p].k, len);

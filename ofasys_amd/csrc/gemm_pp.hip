@@ -378,7 +378,9 @@ template <bool F16, int NKS, bool STAGGER, bool PRIO, int NDL = 4>
 __global__ __launch_bounds__(512) void gemm_group_tn_pp_kernel(GroupArgs ga) {
   GemmArgs g;
   int t, ks;
-  const GroupItem& it = group_enter(ga, g, t, ks);
+  const GroupItem* itp = group_enter(ga, g, t, ks);
+  if (!itp) return;
+  const GroupItem& it = *itp;
   gemm_pp_body<4, false, false, false, F16, NKS, STAGGER, PRIO, 0, NDL>(g, it.tiles_m, it.tiles_n, it.ksplit, it.ws, t, ks, 0, it.splits, it.out == nullptr);
 }
 

@@ -264,7 +264,7 @@ class _GroupItem(ctypes.Structure):     # ofa_gemm_group_item
                 ("splits", ctypes.c_int32), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64), ("out_alpha", ctypes.c_float)]
 
 
-GROUP_MAX = 8
+GROUP_MAX = 16
 GROUP_DIRECT = True      # (tests / A-B tools may clear it: every grouped product then goes through an fp32 slab and the fold)
 
 

@@ -146,20 +146,32 @@ def _fold():
     return q
 
 
-# Grouped weight gradients: the nn.Linear weight gradients of one Transformer layer (dW += dY^T X into the arena) are
-# collected while the layer's backward runs and launched together when its input gradient is produced (wgrad_boundary) --
-# one launch of 256 x 256 tiles with ~2 long K-slices per product instead of one launch of 3-7 short slices each
-# (kernels.gemm_group_tn).  The queue holds dY and X until then.
+# Grouped weight gradients: the nn.Linear weight gradients of a Transformer layer (dW += dY^T X into the arena) are
+# collected while the layer's backward runs and launched together at a layer boundary (wgrad_boundary) -- one launch of
+# 256 x 256 tiles (kernels.gemm_group_tn).  The queue holds dY and X until then.
+# A boundary launches the queue only once it holds about a chip's worth of tiles (FLUSH_TILES of the 256 workgroups one
+# round takes): a base-size layer is 108 (encoder) / 126 (decoder) tiles, so ONE layer per launch has to be cut into two
+# K-slices per product to occupy the chip -- fp32 slabs written by the kernel and read back by a fold launch (23-27 us per
+# layer on cfg-2, as long as two thirds of the decoder's grouped GEMM itself) -- while TWO layers are 216 / 252 workgroups
+# of one slice each, accumulated straight onto the arena gradients in the epilogue: no slab, no fold.
 class _Wgrads:
     enabled = True       # (tests / A-B tools may clear it: every weight gradient is then its own product)
     items = []           # (dy, x2d, out, alpha, weight)
     queued = False       # an end-of-backward flush is registered with the autograd engine
+    FLUSH_TILES = 128    # a boundary flushes a queue of more tiles than this (0: every boundary, rounds 3-4)
+
+
+def _queued_tiles():
+    return sum(((dy.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) for dy, x2d, _, _, _ in _Wgrads.items)
 
 
 def _wgrad(dy, x2d, gw, alpha, *weights):
     """gw += alpha * dy^T x2d (gw: the arena gradient of `weights` -- one weight, or several packed row-wise), then tell the
     reducer."""
     if _Wgrads.enabled and K.gemm_group_ok(dy, x2d, gw) and _flush_at_end_of_backward():
+        if _Wgrads.items and _Wgrads.items[0][0].shape[0] != dy.shape[0]:
+            flush_wgrads()       # one contraction length per launch: the workgroup -> XCD map is by count (csrc/gemm_core.h group_enter), a group
+                                 # mixing 13312-row and 3072-row products leaves some XCDs two rounds of long tiles and others idle
         _Wgrads.items.append((dy, x2d, gw, float(alpha), weights))
         if len(_Wgrads.items) == K.GROUP_MAX:
             flush_wgrads()
@@ -212,7 +224,9 @@ class _WgradBoundaryFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        flush_wgrads()
+        # (more than one more layer would not fit the group either: GROUP_MAX products)
+        if _queued_tiles() > _Wgrads.FLUSH_TILES or 2 * len(_Wgrads.items) > K.GROUP_MAX:
+            flush_wgrads()
         return dy
 
 

@@ -58,7 +58,9 @@ def test_gemm_group_plan_is_host_only():
     with pytest.raises(L.OfaError, match="gemm_group"):
         plan([(768, 768, 128)], L.F32)
     with pytest.raises(L.OfaError, match="gemm_group"):
-        plan([(256, 256, 64)] * 9)
+        plan([(256, 256, 64)] * 17)
+    # two base-size encoder layers in one group: a round of one-slice products (no slabs: ops._Wgrads.FLUSH_TILES)
+    assert plan([(768, 3072, 13312), (3072, 768, 13312), (2304, 768, 13312), (768, 768, 13312)] * 2) == [1] * 8
 
 
 def test_status_codes_not_asserts():

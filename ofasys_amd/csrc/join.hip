@@ -6,7 +6,9 @@
 // kernels forward (LayerNorm, dropout+add, LayerNorm) and three backward plus their small reduce launches, every one of
 // them a full pass over the [rows, C] activations; fused it is one pass each way.  Rounding points are kept where the
 // unfused kernels put them (LN_a output, y, the gradient of y, the dropout gradient are rounded to the storage dtype),
-// so the fused and the unfused compositions agree bit for bit.  HBM-bound: 4 (forward) / 6 (backward) row passes.
+// so the fused and the unfused compositions agree bit for bit (the split-row kernels below; the row-per-wave forms further down
+// sum the row statistics in another lane grouping).  4 (forward) / 6 (backward) row passes of HBM traffic -- but at ~1000 wave64
+// instructions per 768-column row these kernels are bound by the VALU before they are bound by HBM (round 5).
 #include "common.h"
 
 namespace ofa {

@@ -63,6 +63,15 @@ def test_gemm_group_plan_is_host_only():
     assert plan([(768, 3072, 13312), (3072, 768, 13312), (2304, 768, 13312), (768, 768, 13312)] * 2) == [1] * 8
 
 
+def test_shipped_join_backward_is_the_split_row_kernel():
+    """The row-per-wave residual-join BACKWARD is not shipped (it faults in the replayed cfg-2b graph: DESIGN.md section 8, round 5): the
+    shipped library must keep no dropout bits for it and size the partial rows for the split-row kernel."""
+    h = L.lib()
+    assert h.cdll.ofa_join_keep_bytes(13312, 768, L.BF16) == 0 and h.cdll.ofa_join_keep_bytes(100, 1024, L.F16) == 0
+    assert h.cdll.ofa_join_bwd_slots(13312, 768, L.BF16) == 256 and h.cdll.ofa_join_bwd_slots(1800, 768, L.BF16) == 256    # 6 rows per block
+    assert h.cdll.ofa_join_bwd_slots(60, 768, L.BF16) == 10
+
+
 def test_status_codes_not_asserts():
     h = L.lib()
     # argument validation happens before any launch, so it is observable without a GPU

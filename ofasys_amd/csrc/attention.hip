@@ -865,10 +865,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_sbias_f16_lds_kernel(AttnL a)
 // prefetched register sets of 32; and the transposed Q / dO fragments are read AFTER the S / dP MFMAs have been issued, into the
 // registers of the row-major fragments those MFMAs have consumed.
 constexpr int STAT_BYTES = 256;                            // per stage: lse[32] | delta[32] of the query block (fp32)
-__device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const float* __restrict__ delta_bh, int q0,
+// Rows of the block beyond the sample's T queries read row T - 1 (their scores are masked: the value is never used).  Without the clamp
+// the last block of a sample whose length is not a multiple of 32 read up to 31 floats past q_off + q_len -- for the LAST head of the
+// LAST sample of a packed batch that ends in the bucket's final rows, past the END of the [heads, Tpad] buffers: harmless wherever the
+// allocator had mapped memory behind them, a GPU memory access fault where the tensor closed a segment (round 5's cfg-2b graph fault;
+// found with tools/capture_audit.py --dump-before-replay + tools/r6/postmortem.py, profiles/round6_graph_fault_root_cause.txt).
+__device__ __forceinline__ void stat_dma(const float* __restrict__ lse_bh, const float* __restrict__ delta_bh, int q0, int T,
                                          unsigned char* __restrict__ lds_stat, int lane, int wave_u) {
   if (wave_u == 0) {                                       // lanes 0..31: lse[q0 + lane], lanes 32..63: delta[q0 + lane - 32]
-    const float* src = (lane < 32 ? lse_bh : delta_bh - 32) + q0 + lane;
+    int row = q0 + (lane & 31);
+    row = row < T ? row : T - 1;
+    const float* src = (lane < 32 ? lse_bh : delta_bh) + row;
     __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)lds_stat, 4, 0, 0);
   }
 }
@@ -1025,7 +1032,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
     if constexpr (BIAS == 3) bias_dma(bswz, qb_first, lds_bias);
     tile_dma(qbase, a.ldq, qb_first * 32, a.T, h * HD, lds, tid, wave_u);
     tile_dma(dobase, a.ldo, qb_first * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
-    stat_dma(lse_bh, delta_bh, qb_first * 32, lds_stat, lane, wave_u);
+    stat_dma(lse_bh, delta_bh, qb_first * 32, a.T, lds_stat, lane, wave_u);
   }
   ATT_SYNC();
   for (int qb = qb_first; qb < nqb; qb += 2) {
@@ -1035,7 +1042,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
         if constexpr (BIAS == 3) bias_dma(bswz, qb + 1, lds_bias + BIAS_STAGE_BYTES);
         tile_dma(qbase, a.ldq, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 1) * 32, a.T, h * HD, lds + TILE_BYTES + TILE_BYTES / 2, tid, wave_u);
-        stat_dma(lse_bh, delta_bh, (qb + 1) * 32, lds_stat + STAT_BYTES, lane, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 1) * 32, a.T, lds_stat + STAT_BYTES, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && qb * 32 + 31 < key0);
       if (need) {
@@ -1050,7 +1057,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
         if constexpr (BIAS == 3) bias_dma(bswz, qb + 2, lds_bias);
         tile_dma(qbase, a.ldq, (qb + 2) * 32, a.T, h * HD, lds, tid, wave_u);
         tile_dma(dobase, a.ldo, (qb + 2) * 32, a.T, h * HD, lds + TILE_BYTES / 2, tid, wave_u);
-        stat_dma(lse_bh, delta_bh, (qb + 2) * 32, lds_stat, lane, wave_u);
+        stat_dma(lse_bh, delta_bh, (qb + 2) * 32, a.T, lds_stat, lane, wave_u);
       }
       const bool need = live_wave && !(a.causal && (qb + 1) * 32 + 31 < key0);
       if (need) {

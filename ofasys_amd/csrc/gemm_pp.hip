@@ -299,18 +299,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g, int tiles_m, i
                                                                         (int)gridDim.y, false);
 }
 
+// 160 KiB of dynamic LDS needs the attribute on every DEVICE the kernel is launched on (the flag is a bit per device, not one per
+// process), and a refused attribute must not leave a launch that cannot start: false -> the planner's lockstep kernel.
+static bool pp_lds_attr(const void* kern, uint64_t& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (done >> dev & 1) return true;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  done |= 1ull << dev;
+  return true;
+}
+
 template <int TM, bool AK, bool BKM, bool OF, bool F16, int NKS, bool STAGGER, bool PRIO, int ABL = 0, int NDL = 4>
-static void launch_pp(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
+static bool launch_pp(const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   constexpr int BM = 64 * TM, BN = 256;
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   auto kern = gemm_pp_kernel<TM, AK, BKM, OF, F16, NKS, STAGGER, PRIO, ABL, NDL>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    attr_done = true;
-  }
+  static uint64_t attr_done = 0;   // per instantiation, one bit per device
+  if (!pp_lds_attr((const void*)kern, attr_done)) return false;    // (the caller falls back to the lockstep loop)
   dim3 grid(tiles_m * tiles_n, splits, batch), block(512);
   hipLaunchKernelGGL(kern, grid, block, PP_LDS, st, g, tiles_m, tiles_n, ksplit, ws);
+  return true;
 }
 
 // variant: 23 = the shipped form (two k-slices per phase, staggered groups, s_setprio around the MFMA segment, THREE of a phase's four LDS-DMA
@@ -320,7 +332,7 @@ static void launch_pp(const GemmArgs& g, int batch, int splits, int ksplit, floa
 template <int TM, bool AK, bool BKM, bool OF, bool F16>
 static bool launch_pp_variant(int variant, const GemmArgs& g, int batch, int splits, int ksplit, float* ws, hipStream_t st) {
   switch (variant) {
-    case 23: launch_pp<TM, AK, BKM, OF, F16, 2, true, true, 0, 3>(g, batch, splits, ksplit, ws, st); return true;    // the shipped form
+    case 23: return launch_pp<TM, AK, BKM, OF, F16, 2, true, true, 0, 3>(g, batch, splits, ksplit, ws, st);    // the shipped form
 #ifdef OFA_DEBUG_SWITCHES
     case 21: launch_pp<TM, AK, BKM, OF, F16, 2, true, true>(g, batch, splits, ksplit, ws, st); return true;
     case 20: if constexpr (!F16) { launch_pp<TM, AK, BKM, OF, F16, 2, true, false>(g, batch, splits, ksplit, ws, st); return true; } return false;
@@ -385,22 +397,18 @@ __global__ __launch_bounds__(512) void gemm_group_tn_pp_kernel(GroupArgs ga) {
 }
 
 template <bool F16, int NKS, bool STAGGER, bool PRIO, int NDL = 4>
-static void launch_group_pp(const GroupArgs& ga, hipStream_t st) {
+static bool launch_group_pp(const GroupArgs& ga, hipStream_t st) {
   auto kern = gemm_group_tn_pp_kernel<F16, NKS, STAGGER, PRIO, NDL>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    attr_done = true;
-  }
+  static uint64_t attr_done = 0;   // per instantiation, one bit per device
+  if (!pp_lds_attr((const void*)kern, attr_done)) return false;    // (the caller launches gemm_group_tn_kernel)
   hipLaunchKernelGGL(kern, dim3(ga.total), dim3(512), PP_LDS, st, ga);
+  return true;
 }
 
 bool gemm_group_pp_launch(int variant, const GroupArgs& ga, bool f16, hipStream_t st) {
   switch (variant) {
     case 23:                                                                   // the shipped form
-      if (f16) launch_group_pp<true, 2, true, true, 3>(ga, st);
-      else launch_group_pp<false, 2, true, true, 3>(ga, st);
-      return true;
+      return f16 ? launch_group_pp<true, 2, true, true, 3>(ga, st) : launch_group_pp<false, 2, true, true, 3>(ga, st);
 #ifdef OFA_DEBUG_SWITCHES
     case 21: if (f16) return false; launch_group_pp<false, 2, true, true>(ga, st); return true;
     case 20: if (f16) return false; launch_group_pp<false, 2, true, false>(ga, st); return true;

@@ -723,11 +723,11 @@ static int join_bwd_variant() {
 #ifdef OFA_DEBUG_SWITCHES
   if (const char* e = getenv("OFA_JOIN_BWD")) return atoi(e);
 #endif
-  // NOT shipped: the row-per-wave backward is correct in every eager comparison (tools/join_bench.py check, the GPU suite) and in the replayed
-  // cfg-2 graph, but the replayed cfg-2b graph (ResNet-101 + position bias, B = 32) dies with a GPU memory access fault whenever it is the
-  // backward kernel (any waves / rows-ahead form; the forward form is fine; eager is fine) -- not root-caused within the round's GPU budget.
-  // The split-row backward (Philox mask regenerated) stays the product's kernel; ofa_join_keep_bytes() is then 0 and no keep bits are kept.
-  return 0;
+  // Shipped since round 6.  (Round 5 held it back: the replayed cfg-2b graph died with a GPU memory access fault whenever this was the
+  // backward kernel.  The fault was not this kernel's: its keep-bit tensors moved the decoder self-attention's lse buffer to the end of an
+  // allocator segment, where an unclamped 32-row read of the dK/dV attention kernel -- csrc/attention.hip stat_dma, present since round 2 --
+  // crossed into unmapped memory: profiles/round6_graph_fault_root_cause.txt.)
+  return 9;
 }
 static int join_fwd_variant() {
 #ifdef OFA_DEBUG_SWITCHES

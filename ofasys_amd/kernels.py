@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from .lib import (BF16, F32, GEMM_ACCUM, GEMM_BIAS_COL, GEMM_BIAS_ROW, GEMM_FORCE_SIMPLE, GEMM_OUT_F32, OfaError,
-                  dtype_code, lib, ptr, stream)
+                  dptr, dtype_code, lib, ptr, stream)
 
 _ws_cache = {}
 
@@ -41,7 +41,7 @@ def copy_batched(pairs):
     for dst, src in pairs:
         if (src.dtype == dst.dtype and src.shape == dst.shape and src.device == dst.device and dst.is_cuda
                 and src.is_contiguous() and dst.is_contiguous()):
-            jobs.append((src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()))
+            jobs.append((dptr(src), dptr(dst), src.numel() * src.element_size()))
         else:
             dst.copy_(src, non_blocking=True)
     if jobs:
@@ -74,7 +74,7 @@ class FoldQueue:
             # concurrently, so two read-modify-writes of one output must not share a launch
             self.flush()
         self.outs.add(out.data_ptr())
-        self.jobs.append(_FoldJob(part.data_ptr() + part_off * 4, out.data_ptr(), cols, stride, nslots, int(accumulate),
+        self.jobs.append(_FoldJob(dptr(part) + part_off * 4, dptr(out), cols, stride, nslots, int(accumulate),
                                   float(alpha), dtype_code(out)))
         self.keep.append((part, out))
         self.bytes += nslots * stride * 4
@@ -283,7 +283,7 @@ def gemm_group_tn(products, fold):
     assert 1 <= len(products) <= GROUP_MAX
     arr = (_GroupItem * len(products))()
     for it, (dy, x, out, alpha) in zip(arr, products):
-        it.a, it.b, it.lda, it.ldb = dy.data_ptr(), x.data_ptr(), dy.stride(0), x.stride(0)
+        it.a, it.b, it.lda, it.ldb = dptr(dy), dptr(x), dy.stride(0), x.stride(0)
         it.m, it.n, it.k = dy.shape[1], x.shape[1], dy.shape[0]
     dt = dtype_code(products[0][0])
     lib().call("ofa_gemm_group_plan", ctypes.addressof(arr), len(products), dt)
@@ -300,11 +300,11 @@ def gemm_group_tn(products, fold):
                   and out.data_ptr() % 16 == 0 and out.data_ptr() not in direct_outs)     # (two read-modify-writes of one output
         if direct:                                                                         #  must not share a launch)
             direct_outs.add(out.data_ptr())
-            it.out, it.ldo, it.out_alpha = out.data_ptr(), out.stride(0), float(alpha)
+            it.out, it.ldo, it.out_alpha = dptr(out), out.stride(0), float(alpha)
             slabs.append(None)
         else:
             sl = torch.empty(it.splits * it.m * it.n, dtype=torch.float32, device=dy.device)
-            it.slabs = sl.data_ptr()
+            it.slabs = dptr(sl)
             slabs.append(sl)
     if _prof is not None:
         # roofline timing in situ (see gemm): the grouped launch alone; the fold of its K-slice slabs is a FoldQueue launch later on
@@ -509,12 +509,12 @@ def bias_build(abs_bias, starts=(), values=(), heads=None, want_out=True):
             vf, vi = (t.to(ref.dtype).contiguous() for t in v)
             keep += [vf, vi]
             n = vf.shape[0] * vi.shape[0]
-            slots.values[i], slots.values2[i], slots.inner[i] = vf.data_ptr(), vi.data_ptr(), vi.shape[0]
+            slots.values[i], slots.values2[i], slots.inner[i] = dptr(vf), dptr(vi), vi.shape[0]
         else:
             v = v.to(ref.dtype).contiguous()
             keep.append(v)
             n = v.shape[0]
-            slots.values[i], slots.values2[i], slots.inner[i] = v.data_ptr(), None, 0
+            slots.values[i], slots.values2[i], slots.inner[i] = dptr(v), None, 0
         slots.start[i], slots.n[i] = int(s), n
         ends.append(int(s) + n)
     slots.count = len(live)
@@ -772,7 +772,7 @@ def gather_rows_parts(parts, index):
     B, D = parts[0].shape[0], parts[0].shape[2]
     assert all(t.dim() == 3 and t.is_contiguous() and t.shape[0] == B and t.shape[2] == D and t.dtype == parts[0].dtype for t in parts)
     out = torch.empty(index.numel(), D, dtype=parts[0].dtype, device=parts[0].device)
-    srcs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+    srcs = (ctypes.c_void_p * len(parts))(*[dptr(t) for t in parts])
     lens = (ctypes.c_int * len(parts))(*[int(t.shape[1]) for t in parts])
     lib().call("ofa_gather_rows_parts", ctypes.addressof(srcs), ctypes.addressof(lens), len(parts), ptr(index), ptr(out), index.numel(), D, B,
                dtype_code(parts[0]), stream())
@@ -952,7 +952,7 @@ def add_n(tensors):
     if len(ts) == 1:
         return ts[0]
     out = torch.empty_like(ts[0])
-    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    arr = (ctypes.c_void_p * len(ts))(*[dptr(t) for t in ts])
     lib().call("ofa_add_n", ctypes.addressof(arr), len(ts), ptr(out), out.numel(), dtype_code(out), stream())
     return out
 

@@ -154,6 +154,12 @@ def _fold():
 # K-slices per product to occupy the chip -- fp32 slabs written by the kernel and read back by a fold launch (23-27 us per
 # layer on cfg-2, as long as two thirds of the decoder's grouped GEMM itself) -- while TWO layers are 216 / 252 workgroups
 # of one slice each, accumulated straight onto the arena gradients in the epilogue: no slab, no fold.
+# Cost of the deferral: the queue keeps one extra layer's dY / X operands alive until the next boundary -- per
+# encoder layer of cfg-2 rows x (2304 + 3 * 768 + 2 * 3072 + 768 ... ) = 13312 rows x 12288 columns x 2 B = 327 MB (cfg-5, OFA-large
+# at micro-batch 4: 1800 rows x 16384 x 2 B = 59 MB) of a 288 GB device -- and the weights of that layer report to the
+# data-parallel reducer (`_sink_done`) one layer later: a bucket's all-reduce starts at most one layer's backward (~0.3 ms of a
+# cfg-2 step) later than with a flush per layer; only the LAST bucket's delay is exposed, and that bucket ends with the embedding
+# gradients, which are final only at the very end of backward anyway.
 class _Wgrads:
     enabled = True       # (tests / A-B tools may clear it: every weight gradient is then its own product)
     items = []           # (dy, x2d, out, alpha, weight)
@@ -860,7 +866,10 @@ def pack_rows(x, index, inverse):
     """x [B, T, D] (padded; a tensor or a LazyCat of the slots' outputs) -> [1, R, D] packed rows."""
     B, T, D = x.shape
     if isinstance(x, LazyCat):
-        if len(x.parts) <= 8 and D % 8 == 0 and all(t.is_cuda for t in x.parts):
+        # (slots whose embeddings differ in dtype or batch -- an fp32 adaptor beside 16-bit text, which torch.cat would promote -- take
+        #  the materialised path: the parts gather reads every part as ONE dtype)
+        if len(x.parts) <= 8 and D % 8 == 0 and all(t.is_cuda and t.dtype == x.parts[0].dtype and t.shape[0] == B and t.dim() == 3
+                                                    for t in x.parts):
             return PackPartsFn.apply(index, inverse, *x.parts).view(1, -1, D)
         x = x.materialize()
     return PackRowsFn.apply(x.reshape(B * T, D), index, inverse).view(1, -1, D)
@@ -1754,7 +1763,7 @@ class Conv2dFn(torch.autograd.Function):
             g2 = gw.permute(0, 2, 3, 1)                                           # the GEMM's (kh, kw, c) order, unpadded
             gw = g2 if (g2.is_contiguous() and col.shape[1] == kh * kw * Cin) else None
         if gw is not None:                                                        # dW += dY^T X straight into the arena,
-            _wgrad(dy, col, gw.view(Cout, kh * kw * Cin), 1.0, weight)            # in groups of up to 8 products (flush_wgrads)
+            _wgrad(dy, col, gw.view(Cout, kh * kw * Cin), 1.0, weight)            # queued for a grouped launch (flush_wgrads)
             dw = None
         else:
             dw2 = K.gemm(dy, col, True, False)                                    # [Cout, Kpad]

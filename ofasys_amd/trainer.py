@@ -17,10 +17,12 @@ import warnings
 from typing import List
 
 import torch
+import torch.utils._python_dispatch          # noqa: F401  (TorchDispatchMode: the capture audit's view of torch-native ops)
 
 from . import kernels as K
 from . import ops
 from .distributed import GradBucketReducer, all_reduce_scalars
+from .lib import capture_audit
 
 
 class FlatParams:
@@ -135,6 +137,28 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
                 p.grad = self._view(self.grad, o, p)
                 p._ofa_grad = p.grad
+
+
+class _AtenAudit(torch.utils._python_dispatch.TorchDispatchMode):
+    """Shows the capture audit the tensor arguments of torch-native ops too (masks, cached index tensors consumed by aten indexing or
+    `cat`): the C ABI sees only its own arguments.  Thread-local, i.e. the forward pass and whatever backward work runs on the calling
+    thread; the autograd engine's device thread runs this package's Functions, whose launches the audit sees through lib.ptr()."""
+
+    def __init__(self, audit):
+        super().__init__()
+        self.audit = audit
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        for a in args:
+            if torch.is_tensor(a):
+                if a.is_cuda:
+                    self.audit.see(a)
+            elif isinstance(a, (list, tuple)):
+                for b in a:
+                    if torch.is_tensor(b) and b.is_cuda:
+                        self.audit.see(b)
+        self.audit.label("aten::" + getattr(func, "__name__", str(func)))
+        return func(*args, **(kwargs or {}))
 
 
 # Capture mode: other threads of the process (the RCCL watchdog of torch.distributed polls events) must not invalidate a
@@ -406,24 +430,47 @@ class TrainStep:
             self._pool = torch.cuda.graph_pool_handle()
         pool = self._pool
         entry = {"static": samples, "graphs": [], "mode": mode}
-        if self.world == 1 or mode == "full":
-            g = torch.cuda.CUDAGraph()
-            _KEEP_ALIVE.append(g)
-            with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
-                self._fwd_bwd(samples, overlap_reduce=self.world > 1, structure=structure)
-                if self.world > 1:
-                    self._reduce()
-                self._update()
-            entry["graphs"] = [g]
-        else:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            _KEEP_ALIVE.extend((ga, gb))
-            with torch.cuda.graph(ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
-                self._fwd_bwd(samples, overlap_reduce=False)
-            with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
-                self._update()
-            entry["graphs"] = [ga, gb]
+        # A captured kernel node holds raw addresses.  What the capture allocates lives in the graphs' private pool; everything older
+        # lives in the default pool and stays mapped only while Python holds it.  lib.capture_audit records every such tensor a
+        # C-ABI call of the capture addresses (and _AtenAudit the inputs of the forward's torch-native ops); the entry PINS them, so
+        # that no cache that later drops or regrows a tensor (ops.cached_index, SegmentPlan, a grown mask) can unmap memory a graph
+        # still reads -- the allocator flush at the entry of the NEXT capture would otherwise hand it back to the driver.
+        with capture_audit() as audit, _AtenAudit(audit):
+            if self.world == 1 or mode == "full":
+                g = torch.cuda.CUDAGraph()
+                _KEEP_ALIVE.append(g)
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                    self._fwd_bwd(samples, overlap_reduce=self.world > 1, structure=structure)
+                    if self.world > 1:
+                        self._reduce()
+                    self._update()
+                entry["graphs"] = [g]
+            else:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                _KEEP_ALIVE.extend((ga, gb))
+                with torch.cuda.graph(ga, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                    self._fwd_bwd(samples, overlap_reduce=False)
+                with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                    self._update()
+                entry["graphs"] = [ga, gb]
+        entry["audit"] = audit
+        if os.environ.get("OFA_CAPTURE_PINS", "1") != "0":          # (0: the audit tool's negative control -- reproduces a dangling pointer)
+            entry["pins"] = audit.tensors()
         return entry
+
+    def owned_tensors(self):
+        """Tensors whose lifetime is the step engine's / the model's own (what a capture may address without a pin)."""
+        own = list(self.model.parameters()) + list(self.model.buffers())
+        own += [self.fp.flat, self.fp.grad, self.master, self.exp_avg, self.exp_avg_sq, self._stats, self._gsq, self._gnorm_t,
+                self._step_t, self._lr_t, self._sched, self._seed, getattr(self, "_ls", None)]
+        own += list(ops._Rng.base.values())
+        return own
+
+    def audit_report(self, entry):
+        """[(first C-ABI call, shape, dtype, storage bytes)]: default-pool tensors the captured graphs of `entry` address that neither
+        the engine, the model nor the entry's static inputs own -- each one is kept alive by entry["pins"] only."""
+        own = self.owned_tensors() + [t for _, t in sample_tensors(entry["static"])]
+        return entry["audit"].foreign(own)
 
     def _replay(self, entry, samples):
         if samples is not entry["static"]:

@@ -271,3 +271,119 @@ def test_cfg3_two_task_step_resnet101():
     assert int(out["stats"][0]) == n
     assert abs(float(out["stats"][1]) - loss) <= 1e-3 * loss
     _check_grads(_arena_grads(tr, model), want)
+
+
+# ------------------------------------------------------------------------------------------------------------ cfg-2b
+def _cfg2b_structures(d, B, want=4, tries=16):
+    """Batches of bench.py's cfg-2b workload with `want` DISTINCT step structures (packed row buckets differ with the drawn lengths)."""
+    import bench
+    from ofasys_amd.trainer import sample_structure
+    seen, out = set(), []
+    for i in range(tries):
+        sample, ntok, lens = bench.make_batch(d, B, 252, 64, 97 * i, torch.device(DEV), "cfg2b", pack=True)
+        key = sample_structure([sample])
+        if key not in seen:
+            seen.add(key)
+            out.append((sample, lens))
+        if len(out) == want:
+            break
+    return out
+
+
+def test_cfg2b_benchmarked_step_packed_graph_vs_oracle():
+    """The reference's DEFAULT configuration as bench.py --workload cfg2b builds and steps it -- ResNet-101 trunk (train-mode
+    BatchNorm over the whole batch), position-biased attention, ragged row packing, bf16, B = 32, several batch structures each
+    with its own hipGraph in ONE memory pool -- against the oracle.  Every structure is captured, then all are replayed round-robin
+    twice (the allocator cache flushed in between: what a captured graph addresses must not depend on it); the LAST replay runs the
+    first batch, whose loss, sample size, clip norm and gradient norms are compared with the oracle on the same bf16 weights
+    (fp32 arithmetic, the padded shapes computed in full as the reference does).  This is the step that died with a GPU memory
+    access fault in round 5 (profiles/round6_graph_fault_root_cause.txt)."""
+    import bench
+    from ofasys_amd.trainer import TrainStep
+    B = 32
+    args = SimpleNamespace(arch="base", workload="cfg2b", dtype="bf16", dropout=0.0)      # dropout 0: the oracle has none
+    bench._HALF_NOW[0] = torch.bfloat16
+    model, d = bench.build(args, torch.device(DEV))
+    batches = _cfg2b_structures(d, B)
+    assert len(batches) >= 3, "the synthetic length distribution no longer produces several row buckets"
+    sample, (slens, tlens) = batches[0]
+    state = _state_from_model(model)
+    cfg = OConfig(**ARCH["base"], resnet_layers=(3, 4, 23), training=True)
+    img, src, prev = (s.value.detach().cpu() for s in sample["slots"])
+    target = sample["target"].cpu()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    params = oracle_params(state)
+    oslots = [OSlot("IMAGE", True, img.float(), None), OSlot("TEXT", True, src), OSlot("TEXT", False, prev)]
+    lg, _ = restate.model_forward(state, cfg, oslots)       # ONE pass over the whole batch: BatchNorm's statistics are the batch's
+    ref_loss, n = restate.cross_entropy(lg, target)
+    ref_loss.backward()
+    ref_loss, n = float(ref_loss), int(n)
+    want = {k: (None if p.grad is None else p.grad.detach()) for k, p in params.items()}
+    ref_logits = lg.detach()
+    del lg
+
+    tr = TrainStep(model, lr=0.0, clip_norm=0.0, use_graph=True, graph_warmup=1)
+    for s, _ in batches:                                     # one eager step + the capture (+ first replay) per structure
+        for _ in range(2):
+            tr.train_step([s])
+    torch.cuda.synchronize()
+    assert tr.captured_graphs() == len(batches)
+    foreign = [r for e in tr._graphs.values() if "graphs" in e for r in tr.audit_report(e)]
+    print(f"MEASURED cfg-2b capture audit: {len(foreign)} pinned default-pool tensors outside the engine's own (index / plan caches)")
+    for rnd in range(2):
+        torch.cuda.empty_cache()
+        order = batches[1:] + batches[:1] if rnd else batches
+        for s, _ in order:
+            out = tr.train_step([s])
+        torch.cuda.synchronize()
+    assert int(out["stats"][0]) == n == sum(tlens)
+    dev_loss = abs(float(out["stats"][1]) - ref_loss) / ref_loss
+    _measured("cfg-2b packed graph step (B = 32): loss deviation", dev_loss)
+    assert dev_loss <= 5e-3
+    got = _arena_grads(tr, model)
+    _bf16_grad_check(got, want, 4 * CFG2_GRAD_TOL, "cfg-2b packed graph step (B = 32):")
+    gn = np.sqrt(sum(float(g.double().pow(2).sum()) for g in want.values() if g is not None)) / n
+    _measured("cfg-2b packed graph step (B = 32): clip-norm deviation", abs(float(out["gnorm"]) - gn) / gn)
+    assert abs(float(out["gnorm"]) - gn) <= 2e-2 * gn
+    model.train()
+    with torch.no_grad():
+        logits = model(sample["slots"], pack=sample["pack"])[0].float().cpu()
+    idx = sample["pack"].dec_index.cpu()
+    rows = torch.nonzero(idx >= 0).squeeze(1)
+    ref_rows = ref_logits.reshape(-1, ref_logits.shape[-1])[idx[rows]]
+    _measured("cfg-2b packed forward (B = 32): logits max |diff| / max |logit|", rel_err(logits[0, rows], ref_rows))
+    assert rel_err(logits[0, rows], ref_rows) < 5e-2
+
+
+@pytest.mark.parametrize("pins", ["1", "0"])
+def test_cfg2b_replayed_graphs_survive_dropped_caches(pins, monkeypatch):
+    """The benchmarked cfg-2b step with dropout ON (the row-per-wave residual joins and their keep-bit tensors: the allocation pattern
+    that exposed round 5's fault): every structure captured, then -- between replays -- every clearable cache of the package is
+    dropped and the allocator cache flushed.  With pins (the product) the graphs cannot lose anything; without them (the negative
+    control) the run documents that today's dangling candidates share their allocator blocks with live tensors -- it must still be
+    finite, and a fault here would be the regression the pins exist for."""
+    import bench
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import TrainStep
+    from tools.capture_audit import drop_caches
+    monkeypatch.setenv("OFA_CAPTURE_PINS", pins)
+    args = SimpleNamespace(arch="base", workload="cfg2b", dtype="bf16", dropout=None)
+    bench._HALF_NOW[0] = torch.bfloat16
+    model, d = bench.build(args, torch.device(DEV))
+    ops.manual_seed(3)
+    batches = _cfg2b_structures(d, 32)
+    tr = TrainStep(model, lr=1e-4, clip_norm=1.0, use_graph=True)
+    for s, _ in batches:
+        for _ in range(tr.graph_warmup + 1):
+            tr.train_step([s])
+    torch.cuda.synchronize()
+    assert tr.captured_graphs() == len(batches)
+    losses = []
+    for rnd in range(3):
+        drop_caches(model)
+        for s, _ in batches:
+            out = tr.train_step([s])
+            torch.cuda.synchronize()
+            losses.append(float(out["stats"][1]) / max(float(out["stats"][0]), 1.0))
+    tr.check()
+    assert all(np.isfinite(v) and 5.0 < v < 12.0 for v in losses), losses

@@ -686,3 +686,54 @@ def test_dp_reducer_four_ranks_with_uneven_structures_per_rank():
             g = torch.from_numpy(res[rank][1][step])
             assert torch.allclose(g[: want.numel()], want, atol=1e-5), (rank, step)
         assert all(np.array_equal(res[0][1][step], res[r][1][step]) for r in range(1, 4))
+
+
+def test_pointer_audit_classifies_pins_by_pool_and_owner():
+    """lib.PointerAudit (the capture-time pointer audit) on a synthetic allocator snapshot: only tensors inside
+    default-pool segments are pinned, each once per storage, labelled with the first C-ABI call that used them; `foreign` leaves
+    out what the engine owns."""
+    from ofasys_amd.lib import PointerAudit
+
+    class FakeStorage:
+        def __init__(self, addr, nbytes):
+            self._a, self._n = addr, nbytes
+
+        def data_ptr(self):
+            return self._a
+
+        def nbytes(self):
+            return self._n
+
+    class FakeTensor:
+        is_cuda = True
+
+        def __init__(self, addr, shape=(4,), storage=None):
+            self._a, self.shape, self.dtype = addr, shape, torch.float32
+            self._s = storage or FakeStorage(addr, 16)
+
+        def data_ptr(self):
+            return self._a
+
+        def untyped_storage(self):
+            return self._s
+
+    snap = [{"address": 0x1000, "total_size": 0x1000, "segment_pool_id": (0, 0), "blocks": []},
+            {"address": 0x8000, "total_size": 0x2000, "segment_pool_id": (0, 1), "blocks": []},        # a graph's private pool
+            {"address": 0x4000, "total_size": 0x1000, "segment_pool_id": (0, 0), "blocks": []}]
+    au = PointerAudit.from_snapshot(snap)
+    assert au.in_default_pool(0x1000) and au.in_default_pool(0x1fff) and not au.in_default_pool(0x2000)
+    assert au.in_default_pool(0x4800) and not au.in_default_pool(0x8000) and not au.in_default_pool(0x0)
+    param = FakeTensor(0x1100)
+    cache = FakeTensor(0x4100, shape=(7, 7))
+    st = FakeStorage(0x4200, 64)
+    view_a, view_b = FakeTensor(0x4200, storage=st), FakeTensor(0x4210, storage=st)
+    priv = FakeTensor(0x8100)
+    for t in (param, cache, view_a):
+        au.see(t)
+    au.label("ofa_first")
+    for t in (view_b, priv, cache):
+        au.see(t)
+    au.label("ofa_second")
+    assert len(au.pins) == 3 and {id(t) for t in au.tensors()} == {id(param), id(cache), id(view_a)}
+    rep = au.foreign([param, None])
+    assert sorted(rep) == sorted([("ofa_first", (7, 7), "float32", 16), ("ofa_first", (4,), "float32", 64)])

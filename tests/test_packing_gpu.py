@@ -145,3 +145,31 @@ def test_packing_refuses_what_it_cannot_run():
     model, d = build_model(CASE, DEV, torch.float32)                         # fp32: no fused ragged attention kernel
     with pytest.raises(NotImplementedError, match="fused"):
         model(make_slots(vals, DEV), pack=plan)
+
+
+def test_ragged_attention_backward_reads_nothing_behind_lse_and_delta():
+    """Regression of round 5's replayed-graph fault (profiles/round6_graph_fault_root_cause.txt): the dK/dV kernel fetched the softmax
+    statistics of a whole 32-row query block, unclamped -- for the last head of a last sample that ends in the bucket's final rows,
+    up to 31 floats past the END of the [heads, rows] lse / delta buffers.  Here lse closes a freshly mapped allocator segment (the
+    next address is normally unmapped: an overrun kills the process with a GPU memory access fault) and the result must equal the
+    run with a roomy lse bit for bit."""
+    from ofasys_amd import kernels as K
+    from ofasys_amd.packing import Segments
+    heads, D, R = 4, 256, 64
+    lens = [24, 40]                                   # sample 1 = rows 24 .. 63: its second 32-row block spans rows 56 .. 87 > R
+    table = torch.tensor([[0, 24, 0, 24], [24, 40, 24, 40]], dtype=torch.int32, device=DEV)
+    seg = Segments(table, 2, R, R, 64, 64)
+    g = torch.Generator().manual_seed(5)
+    q, k, v, do = (torch.randn(1, R, D, generator=g).to(torch.bfloat16).to(DEV) for _ in range(4))
+    out, lse = K.attn_fwd(q, k, v, heads, 0.125, seg=seg)
+    ref = K.attn_bwd(q, k, v, out, do, lse, heads, 0.125, seg=seg)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                          # no cached block can serve the next request: it gets a segment of its own
+    big = torch.empty((12 << 20) + (2 << 20), dtype=torch.uint8, device=DEV)
+    n = lse.numel() * 4
+    tail = big[big.numel() - n:].view(torch.float32).view_as(lse)
+    tail.copy_(lse)
+    got = K.attn_bwd(q, k, v, out, do, tail, heads, 0.125, seg=seg)
+    torch.cuda.synchronize()
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a, b)

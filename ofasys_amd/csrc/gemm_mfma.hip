@@ -918,6 +918,27 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
     }
   }
   int splits = 1;
+  // Round 6: a k-major-A product with a very long contraction and a handful of output tiles (the vocabulary projection's input gradient,
+  // 1536 x 768 x 51328: 72 tiles of 128 x 128 in 6 K-slices ran at 15 % of peak, every tile re-reading its operand panels at 64 flop / B)
+  // takes the 256 x 256 tile cut into as many K-slices as fill ONE round of the 256 CUs: twice the flops per operand byte, ~57 K tiles per
+  // workgroup, fp32 slabs summed by the reduce launch (tools/gemm_bench.py, profiles/round6_gemm_microbench.txt).
+#ifdef OFA_DEBUG_SWITCHES
+  const bool big_split_on = !(getenv("OFA_GEMM_BIGSPLIT") && atoi(getenv("OFA_GEMM_BIGSPLIT")) == 0);
+#else
+  constexpr bool big_split_on = true;
+#endif
+  if (big_split_on && !big_tm && big_ok && !force_tile && !g.transA && batch == 1 && has_ws && g.K >= 8192) {
+    const int64_t t4 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256);
+    int s = t4 <= 64 ? (int)(256 / t4) : 1;
+    s = s > maxs ? maxs : s;
+    while (s > 1 && (int64_t)s * g.M * ((g.N + 3) & ~3) * 4 > ws_bytes) --s;
+    if (s >= 4) {
+      big_tm = 4;
+      wm = wn = 0;
+      tiles = t4;
+      splits = s;
+    }
+  }
   if (!big_tm && tiles < want && maxs > 1) {
     splits = (int)((want + tiles - 1) / tiles);
     if (splits > maxs) splits = maxs;

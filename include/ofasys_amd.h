@@ -206,6 +206,20 @@ int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, 
                  void* dv, void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo,
                  float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
 
+/* ofa_attn_bwd that also leaves the COLUMN SUMS of its outputs as fp32 partial rows for ofa_fold_batched -- the bias gradients of the
+ * q / k / v projections (multihead_attention.py:199-217: q_proj / k_proj / v_proj carry biases) and the gradient of c_attn (:342-345) --
+ * instead of a column-sum pass over dq / dk / dv and ofa_c_attn_grad afterwards.  One partial row per (sample, 128-row tile, wave):
+ * cs_q: [ofa_attn_cs_slots(B, T)][cs_ldq], columns [64 h, 64 h + 64) of a row written by one wave of the dQ workgroup of head h;
+ * cs_k, cs_v: [ofa_attn_cs_slots(B, S)][cs_ldk] likewise by the dK/dV kernel; cs_c: [ofa_attn_cs_slots(B, T)][heads], sum over the
+ * wave's 32 rows of delta / c_attn[h].  Any of them may be NULL.  Every partial row is written on every call (empty tiles of a ragged batch:
+ * zeros), the sums are over the fp32 values BEFORE their rounding to `dtype`, in a fixed order.  Ragged mode: B = the segment count, T / S = max_q / max_k. */
+int ofa_attn_cs_slots(int B, int rows);
+int ofa_attn_bwd_cs(const void* q, const void* k, const void* v, const void* dout, const void* bias, const uint8_t* kpm,
+                    const void* c_attn, int c_attn_dtype, const float* lse, float* delta, const void* out, void* dq, void* dk,
+                    void* dv, void* dbias, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo,
+                    float scale, int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, float* cs_q, int64_t cs_ldq,
+                    float* cs_k, float* cs_v, int64_t cs_ldk, float* cs_c, void* stream);
+
 /* ---- Attention with a batch-SHARED position bias.
  * The reference adds a dense bias [B*A, T, S] to the scores of every attention of its default configuration (use_self_attn_bias,
  * model/ofa.py:110-113; multihead_attention.py:308-311): abs-pos (pos_q_linear(pos) * pos_scaling) pos_k_linear(pos)^T per head
@@ -237,6 +251,13 @@ int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* 
                        const float* lse, float* delta, const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype,
                        float* ws, int64_t ws_bytes, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
                        int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream);
+/* ... with the column-sum partial rows of ofa_attn_bwd_cs */
+int ofa_attn_sbias_bwd_cs(const void* q, const void* k, const void* v, const void* dout, const void* bias, const void* bias_swz_row,
+                          const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype,
+                          const float* lse, float* delta, const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype,
+                          float* ws, int64_t ws_bytes, int B, int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale,
+                          int causal, const int32_t* seg, int rows_q, int rows_k, int dtype, float* cs_q, int64_t cs_ldq, float* cs_k,
+                          float* cs_v, int64_t cs_ldk, float* cs_c, void* stream);
 /* Batch chunks the dS-sum kernel of ofa_attn_sbias_bwd cuts B samples into (short sequences: the [128 x 64] tiles of the heads alone
  * would leave the chip idle).  1 and dbias_dtype == OFA_F32 or == dtype: it writes dbias_sum itself, ws may be NULL.  Otherwise ws must hold
  * n * heads * Tb * Sb floats (the chunks' partial sums, folded in chunk order -- and cast -- by ofa_fold_batched inside the call). */
@@ -373,6 +394,13 @@ int ofa_im2col_patch(const void* img, void* col, int B, int C, int H, int W, int
  * logits [rows, V] (ld elements); writes lse[rows] and row_loss[rows] (0 for ignored rows). */
 int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, float* lse, float* row_loss, int64_t rows,
                           int64_t V, int64_t ld, int64_t ignore_index, int dtype, void* stream);
+/* Both in ONE pass over the logits (one read, one write instead of two reads and a write): lse, row_loss AND
+ * dlogits = (softmax - onehot) * grad_scale[0] (grad_scale: device scalar known before the forward -- the backward seed or the loss
+ * scale; NULL = 1; zero for ignored rows and for columns V..ld-1).  16-bit logits of at most 65536 padded columns
+ * (ofa_cross_entropy_fwd_grad_ok != 0), the row is held in the registers of a 1024-thread block. */
+int ofa_cross_entropy_fwd_grad_ok(int64_t V, int64_t ld, int dtype);
+int ofa_cross_entropy_fwd_grad(const void* logits, const int64_t* target, const float* grad_scale, float* lse, float* row_loss,
+                               void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype, void* stream);
 /* dlogits = (softmax - onehot) * grad_scale[0] (device scalar), zero for ignored rows and for columns V..ld-1. */
 int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,
                           void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, int dtype,

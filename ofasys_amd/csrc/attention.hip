@@ -61,6 +61,14 @@ struct AttnL {
   // 32 x 32 block: see BiasSwz / csrc/bias.hip bias_build_kernel.  bias_nqt / bias_nkt: 32-row / 32-column tiles per head.
   const bf16_t* bias_sr; const bf16_t* bias_sc;
   int bias_nqt, bias_nkt;
+  // backward only, optional: fp32 partial rows of the COLUMN SUMS of dq / dk / dv (= the bias gradients of the q / k / v projections,
+  // multihead_attention.py:199-217) and of sum_t delta / c (= the gradient of c_attn, :342-345).  One partial row per (sample, 128-row
+  // tile, wave): wave w of workgroup (x, b * heads + h) of the dQ kernel writes columns [64 h, 64 h + 64) of row (b * nqt + x) * 4 + w of
+  // cs_q (row stride cs_ldq) and element ((b * nqt + x) * 4 + w) * heads + h of cs_c; the dK/dV kernel likewise rows
+  // (b * nkt + x) * 4 + w of cs_k / cs_v (row stride cs_ldk).  Every partial row is written by every call (empty tiles of a ragged batch
+  // write zeros); ofa_fold_batched sums them.
+  float* cs_q; float* cs_k; float* cs_v; float* cs_c;
+  int64_t cs_ldq, cs_ldk;
 };
 
 // Ragged mode: the rows between sample b's last row and sample b+1's first (alignment filler, and behind the last sample the
@@ -402,6 +410,50 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+
+// Column sums of the 32 x 64 block a wave holds in two accumulator tiles (lane (i, hi): row i of the block, columns
+// 32 dt + 8 (r >> 2) + 4 hi + (r & 3) for register r of tile dt), over the 32 rows, of the fp32 accumulators times `mul` (NOT re-rounded to
+// the 16-bit storage type: the sums differ from the column sums of the stored tensor by its rounding noise, ~2^-9 / sqrt(rows) relative --
+// emulating the rounding cost a third of this epilogue's instructions in kernels that are bound by VALU issue; rows with !row_ok count
+// as zero).  A transposing butterfly over the 32 lanes of each half: at every level a lane keeps the half of
+// its values selected by one bit of its lane number and adds the partner's copy of them -- 16 + 8 + 4 + 2 + 1 = 31 exchanges instead of
+// 32 x 5.  The levels run over lane bits 3, 2, 1, 0 as DPP operands of the add (row_mirror, row_half_mirror, quad_perm: partners that flip
+// the level's bit -- and lower ones, which later levels do not mind) and only the last, single exchange (bit 4: across 16-lane rows)
+// is a shuffle through the LDS crossbar: the first form (five ds_bpermute levels, then a workgroup-wide fold through LDS behind two
+// barriers) cost ~1 us per workgroup and sum (tools r6 attn_cs_bench: dK/dV at 32 x 12 x 448^2 +2.9 us per sum), as much as the column-sum
+// launches it replaced.  Fixed order: deterministic.  Lane l ends up with the sum of column col64(l).
+__device__ __forceinline__ int col64(int lane) {
+  const int i = lane & 31, hi = lane >> 5;
+  const int vidx = ((i & 15) << 1) | (i >> 4), dt = vidx >> 4, r = vidx & 15;
+  return dt * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+}
+template <int M, int CTRL> __device__ __forceinline__ void colsum_level(float (&v)[32], int lane, int bit) {
+  const bool up = (lane & bit) != 0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const float keep = up ? v[j + M] : v[j], give = up ? v[j] : v[j + M];
+    float got;
+    if constexpr (CTRL != 0) got = dpp_f<CTRL, 0xf>(0.f, give);
+    else got = __shfl_xor(give, 16, 64);
+    v[j] = keep + got;
+  }
+}
+template <bool F16>
+__device__ __forceinline__ float wave_colsum64(const f32x16 (&acc)[2], float mul, bool row_ok, int lane) {
+  float v[32];
+  const float m = row_ok ? mul : 0.f;                      // (one multiply per value is the scale AND the row mask)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[dt * 16 + r] = acc[dt][r] * m;
+  colsum_level<16, 0x140>(v, lane, 8);     // row_mirror:      lane i <-> 15 - i of its row of 16
+  colsum_level<8, 0x141>(v, lane, 4);      // row_half_mirror: i <-> 7 - i of its 8
+  colsum_level<4, 0x4E>(v, lane, 2);       // quad_perm [2,3,0,1]
+  colsum_level<2, 0xB1>(v, lane, 1);       // quad_perm [1,0,3,2]
+  colsum_level<1, 0>(v, lane, 16);         // lane i <-> i ^ 16
+  return v[0];
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int BUF, int BIAS, bool F16>   // BUF selects the double-buffer half at compile time (immediates); BIAS: 0 none, 1 dense, 2 swizzled
 __device__ __forceinline__ void fwd_block(const AttnL& a, const TileAddr& ta, const uint32_t* trx, const bf16x8 (&qf)[4],
@@ -718,7 +770,21 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
     seg_zero_fill(a.seg, a.B, b, h, false, a.rows_q, a.dq, a.ldq, nullptr, 0, tid, a.out ? a.delta + (int64_t)h * a.Tpad : nullptr);
     return;
   }
-  if (!seg_enter(a, b, bh, h, qb0, true)) return;
+  // partial row of the column sums (cs_q) / of sum delta / c (cs_c) this workgroup owns: (sample, query tile), see AttnL.  (Computed
+  // where it is used -- here for an empty tile, else behind the loop: nothing of it is live across the loop.)
+  const int b_sample = __builtin_amdgcn_readfirstlane(b);      // (seg_enter rebases b to 0; a scalar register across the loop)
+  auto cs_rows = [&](float*& csq, float*& csc) {              // this WAVE's partial row
+    const int64_t slot = ((int64_t)b_sample * (gridDim.x - (a.seg ? 1 : 0)) + blockIdx.x) * 4 + wave_u;
+    csq = a.cs_q ? a.cs_q + slot * a.cs_ldq + h * HD : nullptr;
+    csc = a.cs_c ? a.cs_c + slot * a.heads + h : nullptr;
+  };
+  if (!seg_enter(a, b, bh, h, qb0, true)) {
+    float *csq, *csc;
+    cs_rows(csq, csc);
+    if (csq) csq[lane] = 0.f;
+    if (csc && lane == 0) *csc = 0.f;
+    return;
+  }
   const int q0 = qb0 + wave * 32;
   const int qi = q0 + i;
   const int qrow = qi < a.T ? qi : a.T - 1;
@@ -845,6 +911,17 @@ __device__ __forceinline__ void attn_bwd_dq_body(AttnL a) {
       for (int qq = 0; qq < 4; ++qq)
         st4<F16>(op + dt * 32 + 8 * qq + 4 * hi, dqt[dt][4 * qq] * a.scale, dqt[dt][4 * qq + 1] * a.scale,
             dqt[dt][4 * qq + 2] * a.scale, dqt[dt][4 * qq + 3] * a.scale);
+  }
+  float *csq, *csc;
+  cs_rows(csq, csc);
+  if (csq || csc) {
+    // (the lane number afresh from the hardware: nothing may live across the loop for this epilogue -- three waves per SIMD, 168 registers)
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (csq) csq[col64(ln)] = wave_colsum64<F16>(dqt, a.scale, qi < a.T, ln);        // (uniform) bias gradient of the q projection
+    if (csc) {                                                                       // (uniform) gradient of c_attn
+      const float dsum = wave_sum((ln < 32 && qi < a.T) ? delta_q : 0.f);
+      if (ln == 0) *csc = dsum / head_scale(a, h);
+    }
   }
 }
 
@@ -986,7 +1063,20 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
     seg_zero_fill(a.seg, a.B, b, h, true, a.rows_k, a.dk, a.ldk, a.dv, a.ldk, tid);
     return;
   }
-  if (!seg_enter(a, b, bh, h, kb0, false)) return;
+  // partial rows of the column sums of dk / dv this workgroup owns: (sample, key tile), see AttnL (computed where they are used)
+  const int b_sample = __builtin_amdgcn_readfirstlane(b);      // (seg_enter rebases b to 0; a scalar register across the loop)
+  auto cs_rows = [&](float*& csk, float*& csv) {              // this WAVE's partial rows
+    const int64_t slot = ((int64_t)b_sample * (gridDim.x - (a.seg ? 1 : 0)) + blockIdx.x) * 4 + wave_u;
+    csk = a.cs_k ? a.cs_k + slot * a.cs_ldk + h * HD : nullptr;
+    csv = a.cs_v ? a.cs_v + slot * a.cs_ldk + h * HD : nullptr;
+  };
+  if (!seg_enter(a, b, bh, h, kb0, false)) {
+    float *csk, *csv;
+    cs_rows(csk, csv);
+    if (csk) csk[lane] = 0.f;
+    if (csv) csv[lane] = 0.f;
+    return;
+  }
   const int key0 = kb0 + wave * 32;
   const int ki = key0 + i;
   const int krow = ki < a.S ? ki : a.S - 1;
@@ -1079,6 +1169,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(AttnL a) {
             dkt[dt][4 * qq + 3] * a.scale);
         st4<F16>(dvp + d, dvt[dt][4 * qq] * c, dvt[dt][4 * qq + 1] * c, dvt[dt][4 * qq + 2] * c, dvt[dt][4 * qq + 3] * c);
       }
+  }
+  float *csk, *csv;
+  cs_rows(csk, csv);
+  if (csk || csv) {                                        // (uniform) bias gradients of the k / v projections
+    // (the lane number afresh from the hardware: the kernel is at its register limit inside the loop, nothing may live across it for this)
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (csk) csk[col64(ln)] = wave_colsum64<F16>(dkt, a.scale, ki < a.S, ln);
+    if (csv) csv[col64(ln)] = wave_colsum64<F16>(dvt, c, ki < a.S, ln);
   }
 }
 
@@ -1343,11 +1441,21 @@ extern "C" int ofa_attn_fwd(const void* q, const void* k, const void* v, const v
   return check_launch("attn_fwd");
 }
 
-extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+// the optional column-sum outputs of the backward kernels (AttnL::cs_*)
+struct AttnCs { float* q; int64_t ldq; float* k; float* v; int64_t ldk; float* c; };
+static int attn_cs_set(AttnL& a, const AttnCs& cs, int heads, const void* c_attn) {
+  OFA_REQUIRE((!cs.q || cs.ldq >= (int64_t)heads * HD) && ((!cs.k && !cs.v) || cs.ldk >= (int64_t)heads * HD), OFA_ERR_INVALID,
+              "attn_bwd: a column-sum partial row holds heads * 64 = %d floats (row strides %lld / %lld)", heads * HD, (long long)cs.ldq, (long long)cs.ldk);
+  OFA_REQUIRE(!cs.c || c_attn, OFA_ERR_INVALID, "attn_bwd: cs_c (partial sums of the c_attn gradient) without c_attn");
+  a.cs_q = cs.q; a.cs_k = cs.k; a.cs_v = cs.v; a.cs_c = cs.c; a.cs_ldq = cs.ldq; a.cs_ldk = cs.ldk;
+  return 0;
+}
+
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* dout, const void* bias,
                             const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
                             const void* out, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
                             int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
-                            int rows_k, int dtype, void* stream) {
+                            int rows_k, int dtype, void* stream, const AttnCs& cs) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   OFA_REQUIRE(!seg || (!bias && !kpm && !dbias && !((uintptr_t)seg & 15)), OFA_ERR_INVALID,
               "attn_bwd: the ragged (seg) mode takes no bias / key-padding mask / dbias and a 16-byte aligned table");
@@ -1362,6 +1470,7 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   a.rows_q = rows_q; a.rows_k = rows_k;
   a.bias_ld = S; a.bias_hs = (int64_t)T * S; a.bias_bs = (int64_t)heads * T * S;
   OFA_REQUIRE(!seg || (rows_q > 0 && rows_k > 0 && Tpad >= rows_q), OFA_ERR_INVALID, "attn_bwd: ragged mode needs rows_q / rows_k and Tpad >= rows_q");
+  if (int rc = attn_cs_set(a, cs, heads, c_attn)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
   auto dq_kern = dtype == OFA_F16 ? (bias ? attn_bwd_dq_bias_f16_lds_kernel : attn_bwd_dq_f16_lds_kernel) : (bias ? attn_bwd_dq_bias_lds_kernel : attn_bwd_dq_lds_kernel);
@@ -1372,6 +1481,27 @@ extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const v
   auto kv_kern = dtype == OFA_F16 ? (bias ? attn_bwd_dkv_bias_f16_lds_kernel : attn_bwd_dkv_f16_lds_kernel) : (bias ? attn_bwd_dkv_bias_lds_kernel : attn_bwd_dkv_lds_kernel);
   hipLaunchKernelGGL(kv_kern, kv_grid, dim3(256), 4 * TILE_BYTES + 2 * STAT_BYTES, st, a);
   return check_launch("attn_bwd_dkv");
+}
+
+extern "C" int ofa_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+                            const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                            const void* out, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
+                            int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
+                            int rows_k, int dtype, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, bias, kpm, c_attn, c_attn_dtype, lse, delta, out, dq, dk, dv, dbias, B, heads, T, S, Tpad, ldq, ldk, ldo,
+                       scale, causal, seg, rows_q, rows_k, dtype, stream, AttnCs{});
+}
+
+extern "C" int ofa_attn_cs_slots(int B, int rows) { return B * cdiv(rows, 128) * 4; }   // one partial row per wave of a (sample, tile) workgroup
+
+extern "C" int ofa_attn_bwd_cs(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+                               const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                               const void* out, void* dq, void* dk, void* dv, void* dbias, int B, int heads, int T, int S, int Tpad,
+                               int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal, const int32_t* seg, int rows_q,
+                               int rows_k, int dtype, float* cs_q, int64_t cs_ldq, float* cs_k, float* cs_v, int64_t cs_ldk, float* cs_c,
+                               void* stream) {
+  return attn_bwd_impl(q, k, v, dout, bias, kpm, c_attn, c_attn_dtype, lse, delta, out, dq, dk, dv, dbias, B, heads, T, S, Tpad, ldq, ldk, ldo,
+                       scale, causal, seg, rows_q, rows_k, dtype, stream, AttnCs{cs_q, cs_ldq, cs_k, cs_v, cs_ldk, cs_c});
 }
 
 
@@ -1420,11 +1550,11 @@ extern "C" int ofa_attn_sbias_chunks(int B, int heads, int Tb, int Sb) {
 
 // bias: the row-major [heads, Tb, Sb] tensor (read by the batch-sum kernel only: may be NULL when dbias_sum is);
 // bias_swz_row / bias_swz_col: its two swizzled images (ofa_bias_build)
-extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+static int attn_sbias_bwd_impl(const void* q, const void* k, const void* v, const void* dout, const void* bias,
                                   const void* bias_swz_row, const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
                                   const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype, float* ws, int64_t ws_bytes, int B,
                                   int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
-                                  const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream) {
+                                  const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream, const AttnCs& cs) {
   if (int rc = attnl_check(B, heads, T, S, Tpad, ldq, ldk, ldo, dtype)) return rc;
   if (int rc = sbias_check(bias_swz_row, Tb, Sb, T, S, seg)) return rc;
   OFA_REQUIRE(bias_swz_col && !((uintptr_t)bias_swz_col & 15) && (bias || !dbias_sum), OFA_ERR_INVALID,
@@ -1442,6 +1572,7 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
   a.rows_q = rows_q; a.rows_k = rows_k;
   a.bias_ld = Sb; a.bias_hs = (int64_t)Tb * Sb; a.bias_bs = 0;
   a.bias_sr = (const bf16_t*)bias_swz_row; a.bias_sc = (const bf16_t*)bias_swz_col; a.bias_nqt = cdiv(Tb, 32); a.bias_nkt = cdiv(Sb, 32);
+  if (int rc = attn_cs_set(a, cs, heads, c_attn)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const dim3 q_grid(cdiv(T, 128) + (seg ? 1 : 0), B * heads);
   auto dq_kern = dtype == OFA_F16 ? attn_bwd_dq_sbias_f16_lds_kernel : attn_bwd_dq_sbias_lds_kernel;
@@ -1474,6 +1605,26 @@ extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, c
     ofa_fold_job job{ws, dbias_sum, (int64_t)heads * Tb * Sb, (int64_t)heads * Tb * Sb, nchunk, 0, 1.0f, dbias_dtype};
     return ofa_fold_batched(&job, 1, stream);
   }
+}
+
+extern "C" int ofa_attn_sbias_bwd(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+                                  const void* bias_swz_row, const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                                  const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype, float* ws, int64_t ws_bytes, int B,
+                                  int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
+                                  const int32_t* seg, int rows_q, int rows_k, int dtype, void* stream) {
+  return attn_sbias_bwd_impl(q, k, v, dout, bias, bias_swz_row, bias_swz_col, Tb, Sb, kpm, c_attn, c_attn_dtype, lse, delta, out, dq, dk, dv, dbias_sum,
+                             dbias_dtype, ws, ws_bytes, B, heads, T, S, Tpad, ldq, ldk, ldo, scale, causal, seg, rows_q, rows_k, dtype, stream, AttnCs{});
+}
+
+extern "C" int ofa_attn_sbias_bwd_cs(const void* q, const void* k, const void* v, const void* dout, const void* bias,
+                                     const void* bias_swz_row, const void* bias_swz_col, int Tb, int Sb, const uint8_t* kpm, const void* c_attn, int c_attn_dtype, const float* lse, float* delta,
+                                     const void* out, void* dq, void* dk, void* dv, void* dbias_sum, int dbias_dtype, float* ws, int64_t ws_bytes, int B,
+                                     int heads, int T, int S, int Tpad, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
+                                     const int32_t* seg, int rows_q, int rows_k, int dtype, float* cs_q, int64_t cs_ldq, float* cs_k, float* cs_v,
+                                     int64_t cs_ldk, float* cs_c, void* stream) {
+  return attn_sbias_bwd_impl(q, k, v, dout, bias, bias_swz_row, bias_swz_col, Tb, Sb, kpm, c_attn, c_attn_dtype, lse, delta, out, dq, dk, dv, dbias_sum,
+                             dbias_dtype, ws, ws_bytes, B, heads, T, S, Tpad, ldq, ldk, ldo, scale, causal, seg, rows_q, rows_k, dtype, stream,
+                             AttnCs{cs_q, cs_ldq, cs_k, cs_v, cs_ldk, cs_c});
 }
 
 #ifdef OFA_ATTN_TIMELINE

@@ -84,6 +84,90 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   }
 }
 
+// Forward AND gradient in one pass over the logits (16-bit types, V <= 65536): the [rows, V] logits of the vocabulary projection
+// (158 MB at cfg-2: 1536 decoder rows x 51265) were read by ce_fwd, read again and written as a gradient by ce_bwd -- 53 + 65 us.  The
+// criterion is the LAST node of the forward graph and its upstream gradient is a scalar the caller knows before the forward runs (the
+// backward seed 1, or the loss scale), so one kernel can do both: a 1024-thread block holds its whole row in registers (NV x 8 elements
+// per thread), reduces max / sum-exp (waves by shuffles, the 16 waves through LDS), and writes lse, the row's loss and
+// dlogits = (softmax - onehot) * grad_scale from the same registers: one read, one write.  Same arithmetic per element as
+// ce_fwd_kernel / ce_bwd_kernel (expf(x - lse)); the reduction tree is 1024 wide instead of 256, so lse may differ in its last bit.
+template <typename T, int NV>
+__global__ __launch_bounds__(1024) void ce_fwd_grad_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           const float* __restrict__ gscale, float* __restrict__ lse,
+                                                           float* __restrict__ row_loss, T* __restrict__ dlogits, int64_t V, int64_t ld,
+                                                           int64_t ignore_index) {
+  constexpr int N = Vec<T>::N;
+  static_assert(N == 8, "16-bit element types");
+  __shared__ float sm[16], ss[16];
+  const int64_t row = blockIdx.x;
+  const T* x = logits + row * ld;
+  const int64_t nvec = ld / N;                           // ld is a multiple of the vector width (launch precondition)
+  uint4 raw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t v = threadIdx.x + (int64_t)i * 1024;
+    raw[i] = v < nvec ? *reinterpret_cast<const uint4*>(x + v * N) : make_uint4(0, 0, 0, 0);
+  }
+  float m = -INFINITY, s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t c0 = (threadIdx.x + (int64_t)i * 1024) * N;
+    if (c0 >= V) continue;
+    float a[N];
+    unpack16<T>(raw[i], a);
+    if (c0 + N <= V) {
+      float lm = a[0];
+#pragma unroll
+      for (int j = 1; j < N; ++j) lm = fmaxf(lm, a[j]);
+      const float mm = fmaxf(m, lm);
+      float acc = s * expf(m - mm);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += expf(a[j] - mm);
+      m = mm;
+      s = acc;
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (c0 + j < V) online_merge(m, s, a[j], 1.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    online_merge(m, s, m2, s2);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[wave] = m; ss[wave] = s; }
+  __syncthreads();
+  float M = sm[0], S = ss[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) online_merge(M, S, sm[w], ss[w]);       // (every thread: the same 16 values in the same order)
+  const float l = M + logf(S);
+  const int64_t t = target[row];
+  const bool ignored = t == ignore_index;
+  if (threadIdx.x == 0) {
+    lse[row] = l;
+    row_loss[row] = ignored ? 0.f : l - ld1<T>(x + t);
+  }
+  const float g = gscale ? gscale[0] : 1.0f;
+  T* dx = dlogits + row * ld;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t v = threadIdx.x + (int64_t)i * 1024;
+    if (v >= nvec) continue;
+    float a[N], o[N];
+    unpack16<T>(raw[i], a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int64_t c = v * N + j;
+      float d = 0.f;
+      if (!ignored && c < V) d = (expf(a[j] - l) - (c == t ? 1.f : 0.f)) * g;
+      o[j] = d;
+    }
+    store_vec<T>(dx + v * N, o);
+  }
+}
+
 // ---- label-smoothed cross entropy (engine/criterion/label_smoothed_cross_entropy.py:62-191), fused with the
 // log-softmax: per non-ignored row
 //     nll = lse - x[t];   smooth = sum_{v allowed} (lse - x[v]);   eps_i = eps / (Vc - 1 [+1e-6 with constraints])
@@ -468,6 +552,40 @@ extern "C" int ofa_cross_entropy_fwd(const void* logits, const int64_t* target, 
   else
     hipLaunchKernelGGL((ce_fwd_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, st, (const f16_t*)logits, target, lse, row_loss, V, ld, ignore_index);
   return check_launch("cross_entropy_fwd");
+}
+
+// the whole row lives in the block's registers: NV vectors of 8 per thread, 1024 threads
+template <typename T>
+static bool ce_fwd_grad_launch(const T* logits, const int64_t* target, const float* gs, float* lse, float* row_loss, T* dlogits,
+                               int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, hipStream_t st) {
+  const int64_t per_thread = (ld / 8 + 1023) / 1024;
+#define CE_FG(NV) hipLaunchKernelGGL((ce_fwd_grad_kernel<T, NV>), dim3((unsigned)rows), dim3(1024), 0, st, logits, target, gs, lse, row_loss, dlogits, V, ld, ignore_index)
+  if (per_thread <= 1) CE_FG(1);
+  else if (per_thread <= 2) CE_FG(2);
+  else if (per_thread <= 4) CE_FG(4);
+  else if (per_thread <= 7) CE_FG(7);
+  else if (per_thread <= 8) CE_FG(8);
+  else return false;
+#undef CE_FG
+  return true;
+}
+
+extern "C" int ofa_cross_entropy_fwd_grad_ok(int64_t V, int64_t ld, int dtype) {
+  return (dtype == OFA_BF16 || dtype == OFA_F16) && V > 0 && ld >= V && ld % 8 == 0 && ld <= 8 * 1024 * 8;
+}
+
+extern "C" int ofa_cross_entropy_fwd_grad(const void* logits, const int64_t* target, const float* grad_scale, float* lse,
+                                          float* row_loss, void* dlogits, int64_t rows, int64_t V, int64_t ld, int64_t ignore_index,
+                                          int dtype, void* stream) {
+  OFA_REQUIRE(ofa_cross_entropy_fwd_grad_ok(V, ld, dtype), OFA_ERR_UNSUPPORTED,
+              "cross_entropy_fwd_grad: 16-bit logits of at most 65536 (padded) columns, ld a multiple of 8 (V=%lld ld=%lld dtype=%d)", (long long)V, (long long)ld, dtype);
+  OFA_REQUIRE(rows >= 0 && logits && target && lse && row_loss && dlogits, OFA_ERR_INVALID, "cross_entropy_fwd_grad: bad argument");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool ok = dtype == OFA_BF16 ? ce_fwd_grad_launch<bf16_t>((const bf16_t*)logits, target, grad_scale, lse, row_loss, (bf16_t*)dlogits, rows, V, ld, ignore_index, st)
+                                    : ce_fwd_grad_launch<f16_t>((const f16_t*)logits, target, grad_scale, lse, row_loss, (f16_t*)dlogits, rows, V, ld, ignore_index, st);
+  OFA_REQUIRE(ok, OFA_ERR_UNSUPPORTED, "cross_entropy_fwd_grad: row too long");
+  return check_launch("cross_entropy_fwd_grad");
 }
 
 extern "C" int ofa_cross_entropy_bwd(const void* logits, const int64_t* target, const float* lse, const float* grad_scale,

@@ -587,10 +587,30 @@ def attn_fwd(q, k, v, heads, scale, bias=None, kpm=None, c_attn=None, causal=Fal
     return out, lse
 
 
+def attn_cs_slots(B, T, seg=None, k_side=False):
+    """Partial rows of the column sums the attention backward kernels leave per call (ofa_attn_bwd_cs): one per (sample, 128-row tile)."""
+    if seg is not None:
+        B, T = seg.batch, (seg.max_k if k_side else seg.max_q)
+    return lib().cdll.ofa_attn_cs_slots(int(B), int(T))
+
+
+def _cs_args(cs, heads):
+    """cs = dict(q=, k=, v=, c=): fp32 2-D views [slots, heads * 64] (row stride free, k and v the same; c: [slots, heads] contiguous)."""
+    q, k, v, c = cs.get("q"), cs.get("k"), cs.get("v"), cs.get("c")
+    for t in (q, k, v):
+        assert t is None or (t.dtype == torch.float32 and t.stride(1) == 1 and t.shape[1] == heads * 64)
+    assert c is None or (c.dtype == torch.float32 and c.is_contiguous() and c.shape[1] == heads)
+    assert k is None or v is None or k.stride(0) == v.stride(0)
+    kv = k if k is not None else v
+    return (ptr(q), q.stride(0) if q is not None else 0, ptr(k), ptr(v), kv.stride(0) if kv is not None else 0, ptr(c))
+
+
 def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=None, causal=False, need_dbias=False,
-             outs=None, seg=None, bias_shared=False, dbias_dtype=torch.float32):
+             outs=None, seg=None, bias_shared=False, dbias_dtype=torch.float32, cs=None):
     """outs=(dq, dk, dv): caller-provided gradient views with the SAME row strides as q / k (e.g. column slices of one
-    packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place."""
+    packed [B,T,3D] buffer next to a packed qkv input) -- the kernels write them in place.
+    cs: optional dict of fp32 partial-row buffers (see _cs_args / attn_cs_slots) that receive the column sums of dq / dk / dv and
+    the per-head sums of delta / c_attn -- the projections' bias gradients and the c_attn gradient, finished by the FoldQueue."""
     q, ldq = _rows3(q)
     k, v, ldk = _same_ld(k, v)
     dout, ldo = _rows3(dout)
@@ -621,6 +641,8 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         dq = torch.empty(B, T, D, dtype=q.dtype, device=q.device)     # (ragged mode: the kernels zero the filler rows)
         dk = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
         dv = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+    csa = _cs_args(cs, heads) if cs else ()
+    fn = "ofa_attn_bwd_cs" if cs else "ofa_attn_bwd"
     if bias_shared:
         # dbias (when asked for): fp32 [heads, Tb, Sb] = the sum over the batch of dS, from the batch-walking third kernel
         bias = _shared_bias(bias, heads, q)
@@ -640,20 +662,20 @@ def attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=None, kpm=None, c_attn=
         else:
             dims = (B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale), int(causal), None, 0, 0)
             kp = ptr(kpm)
-        lib().call("ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(swz_row), ptr(swz_col), Tb, Sb, kp, ptr(c_attn),
-                   _c_dtype(c_attn), ptr(lse),
+        lib().call("ofa_attn_sbias_bwd_cs" if cs else "ofa_attn_sbias_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(swz_row),
+                   ptr(swz_col), Tb, Sb, kp, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                    ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), dtype_code(dbias) if dbias is not None else F32, ptr(ws),
-                   ws_bytes, *dims, dtype_code(q), stream())
+                   ws_bytes, *dims, dtype_code(q), *csa, stream())
         return dq, dk, dv, dbias, delta
     if seg is not None:
         assert B == 1 and bias is None and kpm is None and not need_dbias and seg.rows_q == T and seg.rows_k == S
-        lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
+        lib().call(fn, ptr(q), ptr(k), ptr(v), ptr(dout), None, None, ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                    ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), None, seg.batch, heads, seg.max_q, seg.max_k, Tpad, ldq, ldk, ldo,
-                   float(scale), int(causal), ptr(seg.table), T, S, dtype_code(q), stream())
+                   float(scale), int(causal), ptr(seg.table), T, S, dtype_code(q), *csa, stream())
         return dq, dk, dv, None, delta
-    lib().call("ofa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
+    lib().call(fn, ptr(q), ptr(k), ptr(v), ptr(dout), ptr(bias), ptr(kpm), ptr(c_attn), _c_dtype(c_attn), ptr(lse),
                ptr(delta), ptr(out), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, heads, T, S, Tpad, ldq, ldk, ldo, float(scale),
-               int(causal), None, 0, 0, dtype_code(q), stream())
+               int(causal), None, 0, 0, dtype_code(q), *csa, stream())
     return dq, dk, dv, dbias, delta
 
 
@@ -836,6 +858,22 @@ def cross_entropy_fwd(logits2d, target, V, ignore_index):
     lib().call("ofa_cross_entropy_fwd", ptr(logits2d), ptr(target), ptr(lse), ptr(row_loss), rows, V, ld, ignore_index,
                dtype_code(logits2d), stream())
     return lse, row_loss
+
+
+def cross_entropy_fwd_grad_ok(logits2d, V):
+    return logits2d.is_cuda and bool(lib().cdll.ofa_cross_entropy_fwd_grad_ok(int(V), int(logits2d.stride(0)), dtype_code(logits2d)))
+
+
+def cross_entropy_fwd_grad(logits2d, target, grad_scale, V, ignore_index):
+    """lse, row_loss AND dlogits = (softmax - onehot) * grad_scale[0] in one pass over the logits (ofa_cross_entropy_fwd_grad):
+    grad_scale is the fp32 device scalar the backward pass will be seeded with (None: 1)."""
+    rows, ld = logits2d.shape[0], logits2d.stride(0)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    dlogits = torch.empty(rows, ld, dtype=logits2d.dtype, device=logits2d.device)
+    lib().call("ofa_cross_entropy_fwd_grad", ptr(logits2d), ptr(target), ptr(grad_scale), ptr(lse), ptr(row_loss), ptr(dlogits), rows, V,
+               ld, ignore_index, dtype_code(logits2d), stream())
+    return lse, row_loss, dlogits
 
 
 def cross_entropy_bwd(logits2d, target, lse, grad_scale, V, ignore_index, dlogits=None):

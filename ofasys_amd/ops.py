@@ -944,6 +944,42 @@ def _packed_grads(ws, gview, grad_packed_fn, inputs=()):
     return outs
 
 
+class _AttnCs:
+    """Partial-row buffers of one attention backward call (kernels.attn_bwd cs=): bufs = the dict handed to the kernels, bias_ws /
+    c_ws = the fp32 buffers to register with the FoldQueue (None: that gradient takes the separate-pass route), ns = partial rows."""
+    __slots__ = ("bufs", "bias_ws", "c_ws", "ns")
+
+
+def _attn_cs_begin(gb, c_ref, B, T, S, seg, heads, dev, packed_kvq=False, want_q=True):
+    """-> (_AttnCs or None, FoldQueue).  gb: the arena gradient of the call's packed bias ([3D] k|v|q for packed_kvq, else [D] of the q
+    projection) or None; c_ref: the c_attn Parameter whose gradient is wanted (or None).  Only inside a backward pass with a FoldQueue,
+    and only for gradients that live contiguously in the arena."""
+    fq = _fold()
+    if fq is None:
+        return None, None
+    D = heads * 64
+    gc = _sink(c_ref) if c_ref is not None else None
+    use_b = gb is not None and gb.is_contiguous() and want_q
+    use_c = gc is not None and gc.is_contiguous()
+    ns = K.attn_cs_slots(B, T, seg)
+    if packed_kvq and K.attn_cs_slots(B, S, seg, k_side=True) != ns:
+        use_b = False                                    # (self-attention: the same tiles on both sides -- anything else keeps the pass)
+    if not (use_b or use_c):
+        return None, None
+    cs = _AttnCs()
+    cs.ns, cs.bufs, cs.bias_ws, cs.c_ws = ns, {}, None, None
+    if use_b:
+        cs.bias_ws = torch.empty(ns, 3 * D if packed_kvq else D, dtype=torch.float32, device=dev)
+        if packed_kvq:
+            cs.bufs.update(k=cs.bias_ws[:, 0:D], v=cs.bias_ws[:, D:2 * D], q=cs.bias_ws[:, 2 * D:3 * D])
+        else:
+            cs.bufs["q"] = cs.bias_ws
+    if use_c:
+        cs.c_ws = torch.empty(ns, heads, dtype=torch.float32, device=dev)
+        cs.bufs["c"] = cs.c_ws
+    return cs, fq
+
+
 class PackedSelfAttentionFn(torch.autograd.Function):
     """Self-attention core with ONE packed k|v|q projection (N = 3D) in front of the fused attention kernels
     (multihead_attention.py:199-346 up to, not including, out_proj).  The attention backward writes dk|dv|dq as column
@@ -976,18 +1012,34 @@ class PackedSelfAttentionFn(torch.autograd.Function):
         k, v, q = kvq[:, :, 0:D], kvq[:, :, D:2 * D], kvq[:, :, 2 * D:3 * D]
         dkvq = torch.empty_like(kvq)                                   # (ragged mode: the kernels zero the filler rows)
         need_dbias = bias is not None and ctx.needs_input_grad[7]
+        # the bias gradients (column sums of dk | dv | dq) and the c_attn gradient come out of the backward kernels' epilogues as partial
+        # rows for the FoldQueue when the gradients live in the arena: no pass over dkvq, no c_attn_grad launch
+        want_c = c_attn is not None and ctx.needs_input_grad[9]
+        cs, fq = _attn_cs_begin(pack.get("gb"), ctx.c_ref if want_c else None, B, T, T, ctx.seg, heads, kvq.device, packed_kvq=True)
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=causal, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
-                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]))
+                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dkvq[:, :, 2 * D:3 * D], dkvq[:, :, 0:D], dkvq[:, :, D:2 * D]),
+                                           cs=cs.bufs if cs else None)
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         d2 = dkvq.view(B * T, D3)
         dx = K.gemm(d2, W, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         gws = _packed_wgrads((wk, wv, wq), pack.get("gw"), d2, x2d)
-        gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
-                            lambda o, acc, f: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype, fold=f), (d2,))
         dc = None
-        if c_attn is not None and ctx.needs_input_grad[9]:
+        if cs and cs.bias_ws is not None:
+            fq.add(cs.bias_ws, 0, pack.get("gb"), D3, D3, cs.ns, 1.0, True)
+            for w in (bk, bv, bq):
+                _sink_done(w)
+            gbs = [None] * 3
+        else:
+            gbs = _packed_grads((bk, bv, bq), pack.get("gb"),
+                                lambda o, acc, f: K.colsum(d2, out=o, accumulate=acc, out_dtype=d2.dtype, fold=f), (d2,))
+        if cs and cs.c_ws is not None:
+            fq.add(cs.c_ws, 0, _sink(ctx.c_ref), heads, heads, cs.ns, 1.0, True)
+            _sink_done(ctx.c_ref)
+        elif want_c:
             dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
+        if cs:
+            fq.flush_if_large()
         return (dx, *gws, *gbs, dbias, None, dc, None, None, None, None, None)
 
 
@@ -1004,6 +1056,7 @@ class CrossKVShared:
         self.enc2d = enc_rows
         self.kv_all = K.gemm(enc_rows, pack["w"], False, True, bias=pack["b"])          # [rows, L * 2D]
         self.dkv_all = None
+        self.cs_all = None                                  # fp32 partial rows of colsum(dkv_all), written by the dK/dV kernels (dkv_cs)
         self.done = 0
         self.users = set()                                  # layers whose fused attention reads its slice (registered in forward)
 
@@ -1020,6 +1073,18 @@ class CrossKVShared:
         lo = layer * 2 * self.D
         return self.dkv_all[:, lo:lo + 2 * self.D].view(B, S, 2 * self.D)
 
+    def dkv_cs(self, layer, ns):
+        """Layer `layer`'s (k, v) column slices of the stack-wide partial rows of colsum(dkv_all) [ns, L * 2D] (fp32) -- every layer's
+        dK/dV kernel writes its own slice, finish() registers ONE fold -- or None when the bias gradient takes the separate pass."""
+        gb = self.pack.get("gb")
+        if len(self.users) != self.L or _fold() is None or gb is None or not gb.is_contiguous():
+            return None
+        if self.cs_all is None:
+            self.cs_all = torch.empty(ns, self.L * 2 * self.D, dtype=torch.float32, device=self.kv_all.device)
+        assert self.cs_all.shape[0] == ns
+        lo = layer * 2 * self.D
+        return self.cs_all[:, lo:lo + self.D], self.cs_all[:, lo + self.D:lo + 2 * self.D]
+
     def finish(self, need_dx):
         """After the last participating layer's slice has been written: d enc, d W_all, d b_all.  A layer that did not take part
         (it needed the attention weights: exact tier, own projection, own gradients) contributes zeros here."""
@@ -1032,7 +1097,12 @@ class CrossKVShared:
         L, D = self.L, self.D
         if len(self.users) == L:                            # every layer took part: ONE weight-gradient product, ONE column sum
             _wgrad(self.dkv_all, self.enc2d, p["gw"], 1.0, *p["params"][:2 * L])
-            K.colsum(self.dkv_all, out=p["gb"], accumulate=True, out_dtype=self.dkv_all.dtype, fold=_fold())
+            fq = _fold()
+            if self.cs_all is not None and fq is not None:
+                fq.add(self.cs_all, 0, p["gb"], L * 2 * D, L * 2 * D, self.cs_all.shape[0], 1.0, True)
+                fq.flush_if_large()
+            else:
+                K.colsum(self.dkv_all, out=p["gb"], accumulate=True, out_dtype=self.dkv_all.dtype, fold=fq)
         else:
             # a layer that kept its own projection already owns (and may already be all-reducing) its gradient rows: touch only
             # the participating layers' slices
@@ -1096,15 +1166,31 @@ class PackedCrossAttentionFn(torch.autograd.Function):
         k, v = kv[:, :, 0:D], kv[:, :, D:2 * D]
         dq = torch.empty_like(q)                                       # (ragged mode: the kernels zero the filler rows)
         need_dbias = bias is not None and ctx.needs_input_grad[8]
+        # bias gradients / c_attn gradient from the backward kernels' epilogues (see PackedSelfAttentionFn.backward); the k | v side of a
+        # stack-wide projection goes into CrossKVShared's partial rows, folded once by finish()
+        want_c = c_attn is not None and ctx.needs_input_grad[10]
+        cs, fq = _attn_cs_begin(_sink(bq), ctx.c_ref if want_c else None, B, T, S, ctx.seg, heads, q.device)
+        kv_cs = None
+        if shared_kv is not None:
+            kv_cs = shared_kv.dkv_cs(ctx.layer, K.attn_cs_slots(B, S, ctx.seg, k_side=True))
+        bufs = dict(cs.bufs) if cs else {}
+        if kv_cs is not None:
+            bufs.update(k=kv_cs[0], v=kv_cs[1])
         _, _, _, dbias, delta = K.attn_bwd(q, k, v, out, dout, lse, heads, scale, bias=bias, kpm=kpm, c_attn=c_attn,
                                            causal=False, need_dbias=need_dbias, seg=ctx.seg, bias_shared=ctx.bias_shared,
-                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]))
+                                           dbias_dtype=_dbias_dtype(bias, ctx.bias_shared), outs=(dq, dkv[:, :, 0:D], dkv[:, :, D:2 * D]),
+                                           cs=bufs or None)
         dbias = _shared_dbias(dbias, bias, ctx.bias_shared)
         dq2 = dq.view(B * T, D)
         dxq = K.gemm(dq2, wq, False, False).view(B, T, D) if ctx.needs_input_grad[0] else None
         gq = _packed_wgrads((wq,), _sink(wq), dq2, xq2)
-        gbq = _packed_grads((bq,), _sink(bq), lambda o, acc, f: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype, fold=f),
-                            (dq2,))
+        if cs and cs.bias_ws is not None:
+            fq.add(cs.bias_ws, 0, _sink(bq), D, D, cs.ns, 1.0, True)
+            _sink_done(bq)
+            gbq = [None]
+        else:
+            gbq = _packed_grads((bq,), _sink(bq), lambda o, acc, f: K.colsum(dq2, out=o, accumulate=acc, out_dtype=dq2.dtype, fold=f),
+                                (dq2,))
         if shared_kv is not None:
             # the slice is written; layer 0 -- the last cross-attention backward of the stack -- closes the shared projection
             shared_kv.done += 1
@@ -1120,8 +1206,13 @@ class PackedCrossAttentionFn(torch.autograd.Function):
             gbs = _packed_grads((bk, bv), pack.get("gb"),
                                 lambda o, acc, f: K.colsum(dkv2, out=o, accumulate=acc, out_dtype=dkv2.dtype, fold=f), (dkv2,))
         dc = None
-        if c_attn is not None and ctx.needs_input_grad[10]:
+        if cs and cs.c_ws is not None:
+            fq.add(cs.c_ws, 0, _sink(ctx.c_ref), heads, heads, cs.ns, 1.0, True)
+            _sink_done(ctx.c_ref)
+        elif want_c:
             dc = _c_attn_grad(delta, ctx.c_ref, B, heads, T)
+        if cs:
+            fq.flush_if_large()
         return (dxq, dxkv, gws[0], gws[1], gq[0], gbs[0], gbs[1], gbq[0], dbias, None, dc, None, None, None, None, None, None)
 
 
@@ -1565,7 +1656,10 @@ class CrossEntropyFn(torch.autograd.Function):
     (engine/criterion/cross_entropy.py:27-67).  logits: [..., V] view of storage whose row stride is a multiple of 8."""
 
     @staticmethod
-    def forward(ctx, logits, target, ignore_index):
+    def forward(ctx, logits, target, ignore_index, seed=None):
+        """seed: the fp32 device scalar the caller WILL hand to `loss.backward(seed)` (trainer.TrainStep: its constant ones tensor).
+        With it the logits' gradient is computed by the forward kernel from the row it already holds (one pass over the logits
+        instead of three); backward returns it when it is handed that very tensor, and otherwise takes the two-kernel route."""
         V = logits.shape[-1]
         if logits.is_contiguous():
             l2d = logits.reshape(-1, V)
@@ -1580,22 +1674,40 @@ class CrossEntropyFn(torch.autograd.Function):
             store[:, :V].copy_(l2d)
             l2d = store[:, :V]
         t = target.reshape(-1).contiguous()
+        ctx.ignore_index, ctx.shape = ignore_index, logits.shape
+        ctx.seed = ctx.pre = None
+        if (seed is not None and ctx.needs_input_grad[0] and seed.dtype == torch.float32 and seed.numel() == 1 and seed.device == l2d.device
+                and K.cross_entropy_fwd_grad_ok(l2d, V)):
+            lse, row_loss, d = K.cross_entropy_fwd_grad(l2d, t, seed, V, ignore_index)
+            ctx.seed, ctx.pre = seed, d                  # (the logits themselves are not kept: nothing reads them again)
+            ctx.save_for_backward(t, lse)
+            ctx.l2d = l2d                                # kept only for the fallback below (a view of the projection's output)
+            return K.sum_f32(row_loss)
         lse, row_loss = K.cross_entropy_fwd(l2d, t, V, ignore_index)
         ctx.save_for_backward(l2d, t, lse)
-        ctx.ignore_index, ctx.shape = ignore_index, logits.shape
         return K.sum_f32(row_loss)
 
     @staticmethod
     def backward(ctx, dloss):
+        if ctx.pre is not None:
+            t, lse = ctx.saved_tensors
+            d, seed, l2d = ctx.pre, ctx.seed, ctx.l2d
+            ctx.pre = ctx.seed = ctx.l2d = None
+            V = ctx.shape[-1]
+            if dloss.data_ptr() == seed.data_ptr() and dloss.dtype == seed.dtype:
+                return d[:, :V].view(ctx.shape), None, None, None
+            gs = dloss.reshape(1).float().contiguous()   # seeded with something else after all: the two-kernel route
+            d = K.cross_entropy_bwd(l2d, t, lse, gs, V, ctx.ignore_index, dlogits=d)
+            return d[:, :V].view(ctx.shape), None, None, None
         l2d, t, lse = ctx.saved_tensors
         V = l2d.shape[1]
         gs = dloss.reshape(1).float().contiguous()
         d = K.cross_entropy_bwd(l2d, t, lse, gs, V, ctx.ignore_index)
-        return d[:, :V].view(ctx.shape), None, None
+        return d[:, :V].view(ctx.shape), None, None, None
 
 
-def cross_entropy_sum(logits, target, ignore_index):
-    return CrossEntropyFn.apply(logits, target, ignore_index)
+def cross_entropy_sum(logits, target, ignore_index, seed=None):
+    return CrossEntropyFn.apply(logits, target, ignore_index, seed)
 
 
 def _ce_rows(logits):

@@ -362,7 +362,10 @@ class TrainStep:
                 loss, _, n = ops.label_smoothed_cross_entropy(logits, target, self.pad, self.label_smoothing,
                                                               self.constraint_range, cm, self.drop_worst_ratio)
             else:
-                loss = ops.cross_entropy_sum(logits, target, self.pad)
+                # (the backward seed is known here: the criterion kernel writes the logits' gradient in its one pass over them)
+                if self.loss_scale_cfg is None and (self._seed is None or self._seed.device != logits.device):
+                    self._seed = torch.ones((), dtype=torch.float32, device=logits.device)
+                loss = ops.cross_entropy_sum(logits, target, self.pad, seed=self._seed if self.loss_scale_cfg is None else None)
                 n = None
                 if loss.is_cuda and loss.dtype == torch.float32 and target.is_contiguous() and target.dtype == torch.int64:
                     # [sample_size, loss_sum, ntokens] += (non-pad targets, loss, non-pad targets) in one launch

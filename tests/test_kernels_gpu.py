@@ -566,6 +566,82 @@ def test_fused_attention(K, B, heads, T, S, causal, use_bias, use_kpm):
         assert rel(dq2, dq) < 1e-3 and rel(dk2, dk) < 1e-3 and rel(dv2, dv) < 1e-3
 
 
+def _cs_bufs(K, B, T, S, heads, seg=None, ld_extra=0):
+    D = heads * 64
+    nq, nk = K.attn_cs_slots(B, T, seg), K.attn_cs_slots(B, S, seg, k_side=True)
+    wq = torch.full((nq, D + ld_extra), float("nan"), device=DEV)          # (every partial row must be written: NaN would survive)
+    wkv = torch.full((nk, 2 * D + ld_extra), float("nan"), device=DEV)
+    wc = torch.full((nq, heads), float("nan"), device=DEV)
+    return dict(q=wq[:, :D], k=wkv[:, :D], v=wkv[:, D:2 * D], c=wc)
+
+
+def _cs_check(cs, dq, dk, dv, delta_rows, c):
+    """The partial rows sum to the column sums of the stored tensors up to their 16-bit rounding noise (the kernels sum the fp32 values
+    before rounding: |error| ~ 2^-9 |x| sqrt(rows) per column) and to sum(delta) / c."""
+    for name, g in (("q", dq), ("k", dk), ("v", dv)):
+        g2 = g.float().reshape(-1, g.shape[-1])
+        want = g2.sum(0)
+        got = cs[name].sum(0)
+        assert torch.isfinite(got).all(), name
+        noise = 2.0 ** -9 * g2.pow(2).sum(0).sqrt()                    # one sigma of the summed rounding errors, per column
+        assert ((got - want).abs() <= 4 * noise + 1e-3 * want.abs().max()).all(), name
+    want_c = delta_rows / c
+    got_c = cs["c"].sum(0)
+    assert (got_c - want_c).abs().max() <= 1e-3 * want_c.abs().max().clamp_min(1.0)
+
+
+@pytest.mark.parametrize("B,heads,T,S,causal,use_kpm,shared", [(2, 4, 200, 200, False, False, False), (3, 2, 130, 77, False, True, False),
+                                                             (2, 2, 96, 96, True, False, False), (2, 3, 257, 300, False, False, True),
+                                                             (1, 12, 448, 448, False, False, False)])
+def test_attention_backward_column_sums(K, B, heads, T, S, causal, use_kpm, shared):
+    """ofa_attn_bwd_cs / ofa_attn_sbias_bwd_cs: the bias gradients of the q / k / v projections and the c_attn gradient as partial rows
+    out of the backward kernels' epilogues; dq / dk / dv themselves are bit-identical to the plain call."""
+    torch.manual_seed(11)
+    D = heads * 64
+    q, k, v = (torch.randn(B, n, D, device=DEV).bfloat16() for n in (T, S, S))
+    dout = torch.randn(B, T, D, device=DEV).bfloat16()
+    kpm = None
+    if use_kpm:
+        kpm = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        kpm[-1, S - 9:] = True
+    bias = (0.5 * torch.randn(heads, T, S, device=DEV)).bfloat16() if shared else None
+    c = (1 + 0.2 * torch.randn(heads, device=DEV)).float()
+    kw = dict(bias=bias, kpm=kpm, c_attn=c, causal=causal, bias_shared=shared)
+    out, lse = K.attn_fwd(q, k, v, heads, 0.125, **kw)
+    ref = K.attn_bwd(q, k, v, out, dout, lse, heads, 0.125, **kw)
+    cs = _cs_bufs(K, B, T, S, heads, ld_extra=8)
+    got = K.attn_bwd(q, k, v, out, dout, lse, heads, 0.125, cs=cs, **kw)
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a, b)
+    delta_rows = got[4].view(B, heads, -1)[:, :, :T].sum((0, 2))
+    _cs_check(cs, got[0], got[1], got[2], delta_rows, c)
+
+
+def test_attention_backward_column_sums_ragged(K):
+    """... in ragged mode: tiles beyond a sample's length write zero rows, filler rows count as zeros."""
+    from ofasys_amd.packing import Segments
+    heads, D = 4, 256
+    qlens, klens = [150, 24, 300, 1], [40, 260, 129, 7]
+    qo = [0, 160, 192, 512]; ko = [0, 64, 352, 512]
+    Rq, Rk = 576, 576
+    table = torch.tensor([[qo[i], qlens[i], ko[i], klens[i]] for i in range(4)], dtype=torch.int32, device=DEV)
+    seg = Segments(table, 4, Rq, Rk, max(qlens), max(klens))
+    g = torch.Generator().manual_seed(5)
+    q, do = (torch.randn(1, Rq, D, generator=g).to(torch.bfloat16).to(DEV) for _ in range(2))
+    k, v = (torch.randn(1, Rk, D, generator=g).to(torch.bfloat16).to(DEV) for _ in range(2))
+    c = (1 + 0.2 * torch.randn(heads, generator=g)).to(DEV)
+    out, lse = K.attn_fwd(q, k, v, heads, 0.125, seg=seg, c_attn=c)
+    ref = K.attn_bwd(q, k, v, out, do, lse, heads, 0.125, seg=seg, c_attn=c)
+    cs = _cs_bufs(K, 1, Rq, Rk, heads, seg=seg)
+    assert cs["q"].shape[0] == 4 * 3 * 4 and cs["k"].shape[0] == 4 * 3 * 4           # (sample, tile, wave)
+    got = K.attn_bwd(q, k, v, out, do, lse, heads, 0.125, seg=seg, c_attn=c, cs=cs)
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a, b)
+    delta = got[4].view(heads, -1)
+    rows = torch.cat([torch.arange(qo[i], qo[i] + qlens[i]) for i in range(4)]).to(DEV)
+    _cs_check(cs, got[0], got[1], got[2], delta[:, rows].sum(1), c)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_elementwise(K, dtype):
     torch.manual_seed(6)
@@ -673,6 +749,50 @@ def test_cross_entropy(K, dtype, V):
     assert rel(d[:, :V], lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
     if ld > V:
         assert float(d[:, V:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V,ld", [(204, 208), (1001, 1024), (8192, 8192), (20011, 20032), (51265, 51328), (65536, 65536)])
+def test_cross_entropy_forward_and_gradient_in_one_pass(K, dtype, V, ld):
+    """ofa_cross_entropy_fwd_grad against the two-kernel route: lse to the last bits (a 1024- instead of a 256-wide reduction tree), the
+    same row losses, the same gradient up to one rounding of the 16-bit output; ignored rows and padding columns are zeros."""
+    torch.manual_seed(9 + V)
+    rows = 41
+    store = (torch.randn(rows, ld, device=DEV) * 3).to(dtype)
+    target = torch.randint(0, V, (rows,), device=DEV)
+    target[::5] = 1
+    gs = torch.tensor([0.37], device=DEV)
+    assert K.cross_entropy_fwd_grad_ok(store[:, :V], V)
+    lse, row_loss = K.cross_entropy_fwd(store, target, V, 1)
+    d = K.cross_entropy_bwd(store, target, lse, gs, V, 1)
+    lse2, row_loss2, d2 = K.cross_entropy_fwd_grad(store[:, :V], target, gs, V, 1)
+    assert (lse2 - lse).abs().max() <= 4e-6 * lse.abs().max()
+    assert (row_loss2 - row_loss).abs().max() <= 4e-6 * lse.abs().max()
+    assert float(row_loss2[::5].abs().max()) == 0.0 and float(d2[::5].float().abs().max()) == 0.0
+    assert rel(d2, d) < 1e-2 and (d2.float() - d.float()).abs().max() <= 2.0 ** -7 * d.float().abs().max()
+    if ld > V:
+        assert float(d2[:, V:].float().abs().max()) == 0.0
+    assert not K.cross_entropy_fwd_grad_ok(torch.empty(2, 65544, device=DEV, dtype=dtype), 65540)       # longer than a block's registers
+    assert not K.cross_entropy_fwd_grad_ok(torch.empty(2, 64, device=DEV), 64)                           # fp32: the two-kernel route
+
+
+def test_cross_entropy_function_hands_back_the_forward_gradient_only_for_the_promised_seed():
+    from ofasys_amd import ops
+    torch.manual_seed(3)
+    V, rows = 1001, 19
+    store = (torch.randn(rows, 1008, device=DEV) * 2).bfloat16()
+    target = torch.randint(0, V, (rows,), device=DEV)
+    target[3] = 1
+    seed = torch.ones((), device=DEV)
+    grads = []
+    for mode in ("plain", "seeded", "other"):
+        x = store[:, :V].clone().requires_grad_(True)       # (a dense [rows, V] tensor: the function pads it itself)
+        loss = ops.cross_entropy_sum(x, target, 1, seed=None if mode == "plain" else seed)
+        loss.backward(seed if mode != "other" else torch.full((), 2.0, device=DEV))
+        grads.append((float(loss), x.grad.float()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-5 * abs(grads[0][0]) and abs(grads[0][0] - grads[2][0]) <= 1e-5 * abs(grads[0][0])
+    assert rel(grads[1][1], grads[0][1]) < 1e-2
+    assert rel(grads[2][1], 2 * grads[0][1]) < 1e-2          # seeded with something else after all: the fallback scales correctly
 
 
 def test_adam_and_sumsq(K):

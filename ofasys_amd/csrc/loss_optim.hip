@@ -90,28 +90,36 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
 // backward seed 1, or the loss scale), so one kernel can do both: a 1024-thread block holds its whole row in registers (NV x 8 elements
 // per thread), reduces max / sum-exp (waves by shuffles, the 16 waves through LDS), and writes lse, the row's loss and
 // dlogits = (softmax - onehot) * grad_scale from the same registers: one read, one write.  Same arithmetic per element as
-// ce_fwd_kernel / ce_bwd_kernel (expf(x - lse)); the reduction tree is 1024 wide instead of 256, so lse may differ in its last bit.
+// dlogits = (softmax - onehot) * grad_scale from the same registers: one read, one write.  Exponentials by v_exp_f32 (1 ulp), a 1024-wide
+// reduction tree: lse and the probabilities agree with ce_fwd_kernel / ce_bwd_kernel to fp32 rounding, not bit for bit.
 template <typename T, int NV>
-__global__ __launch_bounds__(1024) void ce_fwd_grad_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
-                                                           const float* __restrict__ gscale, float* __restrict__ lse,
-                                                           float* __restrict__ row_loss, T* __restrict__ dlogits, int64_t V, int64_t ld,
-                                                           int64_t ignore_index) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void ce_fwd_grad_kernel(
+    const T* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ gscale, float* __restrict__ lse,
+    float* __restrict__ row_loss, T* __restrict__ dlogits, int V, int ld, int64_t ignore_index) {
+  // (two blocks per CU -- 64 registers -- so that one block's loads and stores overlap the other's arithmetic: with one, 141 us at cfg-2
+  // against 118 for the two kernels it replaces.  32-bit indices and scalar-base + 32-bit-offset addressing keep it there.)
   constexpr int N = Vec<T>::N;
   static_assert(N == 8, "16-bit element types");
+  // exponentials as ONE v_exp_f32 behind an FMA (2^(x log2 e - m log2 e), 1 ulp): the library expf the two-kernel route uses is ~12
+  // instructions, and with two exponentials per logit (one for the sum, one for the probability) that arithmetic, not HBM, set the time
+  constexpr float L2E = 1.4426950408889634f;
+  auto ex2 = [](float v) { return __builtin_amdgcn_exp2f(v); };
   __shared__ float sm[16], ss[16];
   const int64_t row = blockIdx.x;
-  const T* x = logits + row * ld;
-  const int64_t nvec = ld / N;                           // ld is a multiple of the vector width (launch precondition)
+  const char* xb = reinterpret_cast<const char*>(logits + row * ld);       // (uniform: scalar registers)
+  char* db = reinterpret_cast<char*>(dlogits + row * ld);
+  const int nvec = ld / N;                               // ld is a multiple of the vector width (launch precondition)
+  const int tid = threadIdx.x;
   uint4 raw[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int64_t v = threadIdx.x + (int64_t)i * 1024;
-    raw[i] = v < nvec ? *reinterpret_cast<const uint4*>(x + v * N) : make_uint4(0, 0, 0, 0);
+    const int v = tid + i * 1024;
+    raw[i] = v < nvec ? *reinterpret_cast<const uint4*>(xb + (uint32_t)v * 16u) : make_uint4(0, 0, 0, 0);
   }
   float m = -INFINITY, s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int64_t c0 = (threadIdx.x + (int64_t)i * 1024) * N;
+    const int c0 = (tid + i * 1024) * N;
     if (c0 >= V) continue;
     float a[N];
     unpack16<T>(raw[i], a);
@@ -119,10 +127,10 @@ __global__ __launch_bounds__(1024) void ce_fwd_grad_kernel(const T* __restrict__
       float lm = a[0];
 #pragma unroll
       for (int j = 1; j < N; ++j) lm = fmaxf(lm, a[j]);
-      const float mm = fmaxf(m, lm);
-      float acc = s * expf(m - mm);
+      const float mm = fmaxf(m, lm), mk = -mm * L2E;
+      float acc = s * ex2(fmaf(m, L2E, mk));             // (m == -inf on the first vector: 2^-inf = 0)
 #pragma unroll
-      for (int j = 0; j < N; ++j) acc += expf(a[j] - mm);
+      for (int j = 0; j < N; ++j) acc += ex2(fmaf(a[j], L2E, mk));
       m = mm;
       s = acc;
     } else {
@@ -131,40 +139,45 @@ __global__ __launch_bounds__(1024) void ce_fwd_grad_kernel(const T* __restrict__
         if (c0 + j < V) online_merge(m, s, a[j], 1.f);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-    online_merge(m, s, m2, s2);
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sm[wave] = m; ss[wave] = s; }
+  // max first, then ONE rescale per partial sum: the pairwise online merges of ce_fwd_kernel (two expf each, six shuffle levels and
+  // fifteen serial merges of the wave results) were this block's critical path -- nothing else runs on the CU while it reduces
+  const float mw = wave_max(m);
+  const float sw = wave_sum(mw == -INFINITY ? 0.f : s * ex2((m - mw) * L2E));
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { sm[wave] = mw; ss[wave] = sw; }
   __syncthreads();
-  float M = sm[0], S = ss[0];
+  float M = sm[0];
 #pragma unroll
-  for (int w = 1; w < 16; ++w) online_merge(M, S, sm[w], ss[w]);       // (every thread: the same 16 values in the same order)
+  for (int w = 1; w < 16; ++w) M = fmaxf(M, sm[w]);
+  float S = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) S += ss[w] * ex2((sm[w] - M) * L2E);   // (every thread: the same 16 values in the same order)
   const float l = M + logf(S);
-  const int64_t t = target[row];
-  const bool ignored = t == ignore_index;
-  if (threadIdx.x == 0) {
+  const int64_t t64 = target[row];
+  const bool ignored = t64 == ignore_index;
+  const int t = (t64 >= 0 && t64 < V) ? (int)t64 : -1;
+  if (tid == 0) {
     lse[row] = l;
-    row_loss[row] = ignored ? 0.f : l - ld1<T>(x + t);
+    row_loss[row] = ignored ? 0.f : l - ld1<T>(reinterpret_cast<const T*>(xb) + t64);
   }
-  const float g = gscale ? gscale[0] : 1.0f;
-  T* dx = dlogits + row * ld;
+  const float g = ignored ? 0.f : (gscale ? gscale[0] : 1.0f);
+  const float lk = -l * L2E;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int64_t v = threadIdx.x + (int64_t)i * 1024;
+    const int v = tid + i * 1024;
     if (v >= nvec) continue;
     float a[N], o[N];
     unpack16<T>(raw[i], a);
+    const int c0 = v * N;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const int64_t c = v * N + j;
       float d = 0.f;
-      if (!ignored && c < V) d = (expf(a[j] - l) - (c == t ? 1.f : 0.f)) * g;
+      if (!ignored && c0 + j < V) d = (ex2(fmaf(a[j], L2E, lk)) - (c0 + j == t ? 1.f : 0.f)) * g;
       o[j] = d;
     }
-    store_vec<T>(dx + v * N, o);
+    uint4 w;
+    w.x = pack2<T>(o[0], o[1]); w.y = pack2<T>(o[2], o[3]); w.z = pack2<T>(o[4], o[5]); w.w = pack2<T>(o[6], o[7]);
+    *reinterpret_cast<uint4*>(db + (uint32_t)v * 16u) = w;
   }
 }
 
@@ -559,7 +572,7 @@ template <typename T>
 static bool ce_fwd_grad_launch(const T* logits, const int64_t* target, const float* gs, float* lse, float* row_loss, T* dlogits,
                                int64_t rows, int64_t V, int64_t ld, int64_t ignore_index, hipStream_t st) {
   const int64_t per_thread = (ld / 8 + 1023) / 1024;
-#define CE_FG(NV) hipLaunchKernelGGL((ce_fwd_grad_kernel<T, NV>), dim3((unsigned)rows), dim3(1024), 0, st, logits, target, gs, lse, row_loss, dlogits, V, ld, ignore_index)
+#define CE_FG(NV) hipLaunchKernelGGL((ce_fwd_grad_kernel<T, NV>), dim3((unsigned)rows), dim3(1024), 0, st, logits, target, gs, lse, row_loss, dlogits, (int)V, (int)ld, ignore_index)
   if (per_thread <= 1) CE_FG(1);
   else if (per_thread <= 2) CE_FG(2);
   else if (per_thread <= 4) CE_FG(4);

@@ -94,6 +94,20 @@ class FoldQueue:
         self.outs = set()
 
 
+class ImmediateFold:
+    """The FoldQueue's `add` for a caller whose partial rows are already written and that has no queue to defer to (gradients consumed
+    from inside backward: data-parallel bucket all-reduces): one fold launch per job, same arithmetic and summation order."""
+
+    def add(self, part, part_off, out, cols, stride, nslots, alpha=1.0, accumulate=True, flush_ok=True):
+        assert part.dtype == torch.float32 and out.is_contiguous()
+        job = (_FoldJob * 1)(_FoldJob(dptr(part) + part_off * 4, dptr(out), cols, stride, nslots, int(accumulate), float(alpha),
+                                      dtype_code(out)))
+        lib().call("ofa_fold_batched", ctypes.addressof(job), 1, stream())
+
+    def flush_if_large(self):
+        pass
+
+
 def _u8(mask):
     """bool/uint8 mask as a contiguous uint8 tensor without a copy when possible."""
     mask = mask.contiguous()

@@ -951,12 +951,10 @@ class _AttnCs:
 
 
 def _attn_cs_begin(gb, c_ref, B, T, S, seg, heads, dev, packed_kvq=False, want_q=True):
-    """-> (_AttnCs or None, FoldQueue).  gb: the arena gradient of the call's packed bias ([3D] k|v|q for packed_kvq, else [D] of the q
-    projection) or None; c_ref: the c_attn Parameter whose gradient is wanted (or None).  Only inside a backward pass with a FoldQueue,
-    and only for gradients that live contiguously in the arena."""
-    fq = _fold()
-    if fq is None:
-        return None, None
+    """-> (_AttnCs or None, FoldQueue or ImmediateFold).  gb: the arena gradient of the call's packed bias ([3D] k|v|q for packed_kvq, else
+    [D] of the q projection) or None; c_ref: the c_attn Parameter whose gradient is wanted (or None).  Only for gradients that live
+    contiguously in the arena -- with or without a FoldQueue, so that a step computes the same bits whichever way its reductions run."""
+    fq = _fold() or K.ImmediateFold()                    # (no queue: gradients are consumed inside backward -- fold right behind the kernels)
     D = heads * 64
     gc = _sink(c_ref) if c_ref is not None else None
     use_b = gb is not None and gb.is_contiguous() and want_q
@@ -1077,7 +1075,7 @@ class CrossKVShared:
         """Layer `layer`'s (k, v) column slices of the stack-wide partial rows of colsum(dkv_all) [ns, L * 2D] (fp32) -- every layer's
         dK/dV kernel writes its own slice, finish() registers ONE fold -- or None when the bias gradient takes the separate pass."""
         gb = self.pack.get("gb")
-        if len(self.users) != self.L or _fold() is None or gb is None or not gb.is_contiguous():
+        if len(self.users) != self.L or gb is None or not gb.is_contiguous():
             return None
         if self.cs_all is None:
             self.cs_all = torch.empty(ns, self.L * 2 * self.D, dtype=torch.float32, device=self.kv_all.device)
@@ -1098,9 +1096,10 @@ class CrossKVShared:
         if len(self.users) == L:                            # every layer took part: ONE weight-gradient product, ONE column sum
             _wgrad(self.dkv_all, self.enc2d, p["gw"], 1.0, *p["params"][:2 * L])
             fq = _fold()
-            if self.cs_all is not None and fq is not None:
-                fq.add(self.cs_all, 0, p["gb"], L * 2 * D, L * 2 * D, self.cs_all.shape[0], 1.0, True)
-                fq.flush_if_large()
+            if self.cs_all is not None:
+                fq2 = fq or K.ImmediateFold()
+                fq2.add(self.cs_all, 0, p["gb"], L * 2 * D, L * 2 * D, self.cs_all.shape[0], 1.0, True)
+                fq2.flush_if_large()
             else:
                 K.colsum(self.dkv_all, out=p["gb"], accumulate=True, out_dtype=self.dkv_all.dtype, fold=fq)
         else:

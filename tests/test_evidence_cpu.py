@@ -26,8 +26,9 @@ def test_bench_lines_follow_the_contract_and_their_profiles_exist():
     for suffix in ("", "_cfg2b", "_cfg4") + (("_cfg3", "_cfg5") if r >= 4 else ()):
         d = _line(f"round{r}_bench{suffix}.json")
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                    "dtype", "data", "config", "roofline") + (("cpu_baseline",) if (suffix == "" or r < 5) else ()):
-            assert key in d, (suffix, key)        # (round 5: the other workloads' final lines were taken with --no-cpu-baseline, the GPU budget was gone)
+                    "dtype", "data", "config", "roofline") + (("cpu_baseline",) if (suffix == "" or r != 5) else ()) + \
+                (("source_id",) if r >= 6 else ()):
+            assert key in d, (suffix, key)        # (round 5 ONLY: the other workloads' final lines were taken with --no-cpu-baseline, the GPU budget was gone)
         assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["higher_is_better"] is True and "synthetic" in d["data"]
         assert "workload" in d["config"] and "model" not in d["config"]
         assert "tokens/sec" in base["metric"] and d["metric"].startswith("multimodal tokens/sec") and d["unit"] == "tokens/s"
@@ -43,6 +44,18 @@ def test_bench_lines_follow_the_contract_and_their_profiles_exist():
         assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), src
         stats = json.load(open(os.path.join(ROOT, src)))
         assert abs(stats["__meta__"]["total_ms_per_step"] - roof["rocprof"]["all_kernels_ms_per_step"]) < 1e-6
+        if r >= 6:
+            # ONE build: the line, the kernel trace it prices the GEMM family on and the PMC pass behind `traffic` / `hbm` carry the same
+            # source id (tools/build_id.py); bench.py refuses a summary of other sources (round 5's line quoted a mid-round PMC pass)
+            assert stats["__meta__"]["source_id"] == d["source_id"], (suffix, "kernel trace of other sources")
+            assert f"round{r}_" in src, (suffix, src)
+            tsrc = roof["traffic_source"]
+            if suffix in ("", "_cfg2b"):
+                assert roof["traffic"] is not None and tsrc.startswith(f"profiles/round{r}_pmc_traffic"), (suffix, tsrc)
+                pmc = json.load(open(os.path.join(ROOT, tsrc.split(" ")[0])))
+                assert pmc["__meta__"]["source_id"] == d["source_id"], (suffix, "PMC pass of other sources")
+            else:
+                assert roof["traffic"] is None or tsrc.startswith(f"profiles/round{r}_"), (suffix, tsrc)
         assert os.path.exists(os.path.join(ROOT, src.replace(".json", ".txt")))
         # the profiler's time of the GEMM family (which also holds the split-K reduces and slab folds) agrees with the in-situ events
         # (which bracket the GEMM launches alone) within 20 %; 30 % for the multi-task steps, whose small micro-batches put a larger

@@ -1,6 +1,8 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE): average per launch, gfx950 correction
 (FETCH_SIZE counts 64 B per 128-B request: doubled) as MI355X_MICROARCH.md section HBM prescribes; both are in KiB."""
-import sqlite3, sys, json, collections
+import sqlite3, sys, json, collections, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_id import source_id
 def load(db, counter):
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -37,6 +39,7 @@ for i, (tot, k, n, fe, wr) in enumerate(rows):
     res[k] = {"launches": n, "fetch_bytes_per_launch": fe, "write_bytes_per_launch": wr}
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # train steps the profiled command ran (warm-up + timed)
 total = sum(r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) for r in res.values())
-res["__meta__"] = {"steps": steps, "total_bytes": total, "bytes_per_step": total / steps if steps else None}
+res["__meta__"] = {"steps": steps, "total_bytes": total, "bytes_per_step": total / steps if steps else None,
+                   "source_id": source_id()}      # the sources the profiled command ran on (tools/build_id.py)
 print(f"all kernels: {total/1e9:.2f} GB over {steps} steps" + (f" = {total/steps/1e9:.2f} GB/step" if steps else ""))
 json.dump(res, open(sys.argv[3], "w"), indent=1)

@@ -31,25 +31,22 @@ class Dictionary:
         return self.indices.get(sym, self.unk_index)
 
     def add_symbol(self, word, n=1, overwrite=False, check=True):
-        if word in self.indices and not overwrite:
-            idx = self.indices[word]
-            self.count[idx] += n
-            return idx
-        idx = len(self.symbols)
-        self.indices[word] = idx
+        """Index of `word`, appended at the end when it is new (or `overwrite`: a second entry shadows the first in the lookup, the
+        reference's semantics for duplicate lines of a dictionary file); a known word only has its count raised by n."""
+        known = self.indices.get(word)
+        if known is not None and not overwrite:
+            self.count[known] += n
+            return known
         self.symbols.append(word)
         self.count.append(n)
-        return idx
+        self.indices[word] = len(self.symbols) - 1
+        return self.indices[word]
 
     def get_start_end_idx(self, prefix: str):
-        """[start, end) of the symbols carrying `prefix` (preprocessor/dictionary.py:66-74)."""
-        start, end = -1, -2
-        for i, token in enumerate(self.symbols):
-            if token.startswith(prefix):
-                if start < 0:
-                    start = i
-                end = i
-        return start, end + 1
+        """[start, end) spanned by the symbols carrying `prefix` -- first and last occurrence, whatever lies between them; (-1, -1)
+        when there is none (the contract of preprocessor/dictionary.py:66-74: the `<bin>_` / `<code>_` ranges of the vocabulary)."""
+        hits = [i for i, token in enumerate(self.symbols) if token.startswith(prefix)]
+        return (hits[0], hits[-1] + 1) if hits else (-1, -1)
 
     def encode_line(self, line, add_if_not_exist=True, append_eos=True, reverse_order=False):
         """Whitespace-split symbols -> int32 ids (preprocessor/dictionary.py:322-347)."""

@@ -688,6 +688,92 @@ def test_dp_reducer_four_ranks_with_uneven_structures_per_rank():
         assert all(np.array_equal(res[0][1][step], res[r][1][step]) for r in range(1, 4))
 
 
+def _dp_sharded_worker(rank, world, port, q):
+    """Two steps of a toy data-parallel training loop in BOTH exchange forms on the same ranks: all-reduce -> every rank updates the
+    whole arena, and reduce-scatter -> every rank updates the pieces it owns -> all-gather.  The update is an elementwise stand-in for
+    ofa_adam_step (a function of parameter, gradient, two moments and a global clip coefficient from the gradient norm)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ofasys_amd.distributed import GradBucketReducer
+    from ofasys_amd.trainer import FlatParams
+    out = {}
+    for shard in (False, True):
+        torch.manual_seed(0)
+        layers = torch.nn.ModuleList([torch.nn.Linear(12, 12) for _ in range(5)] + [torch.nn.Linear(12, 7)])
+        fp = FlatParams(layers)
+        red = GradBucketReducer(fp.params, fp.grad, fp.offsets, None, bucket_bytes=700, shard=shard)
+        assert len(red.buckets) >= 3
+        red.overlap = False        # every bucket at finish(): the gradients are rounded to integers between backward and the exchange
+        m, v = torch.zeros_like(fp.flat), torch.zeros_like(fp.flat)
+        norms = []
+        for step in range(3):
+            fp.zero_grad()
+            red.begin_step("s")
+            # integer-valued data: every sum below is exact in fp32, so the two forms must agree BIT FOR BIT whatever order a
+            # collective adds the ranks in
+            h = torch.randint(-2, 3, (4, 12), generator=torch.Generator().manual_seed(17 * rank + step)).float()
+            for lin in layers:
+                h = torch.tanh(lin(h))
+            (h.sum() * 256).backward()
+            with torch.no_grad():
+                fp.grad.round_()                             # integer-valued gradients on every rank BEFORE the exchange
+            red.finish()
+            owned = red.owned_ranges()
+            gsq = torch.zeros(1, dtype=torch.float64)        # (fp64: sums of squares of integers stay exact in any order)
+            for lo, hi, counted in owned:
+                if counted:
+                    gsq += fp.grad[lo:hi].double().pow(2).sum()
+            if shard:
+                dist.all_reduce(gsq)
+            norms.append(float(gsq))
+            coef = 1.0 / max(float(gsq.sqrt()), 1.0)
+            with torch.no_grad():
+                for lo, hi, _ in owned:
+                    g = fp.grad[lo:hi] * coef
+                    m[lo:hi].mul_(0.5).add_(g, alpha=0.5)
+                    v[lo:hi].mul_(0.75).add_(g * g, alpha=0.25)
+                    fp.flat[lo:hi].sub_(0.125 * m[lo:hi] / (v[lo:hi].sqrt() + 1.0))
+                    fp.flat[lo:hi].mul_(8).round_().div_(8)             # keep the parameters on a grid: the next step's sums stay exact
+            red.gather_params(fp.flat)
+        cover = sorted((lo, hi) for r in range(world) for b in range(len(red.buckets))
+                       for lo, hi in [red.piece(b, r)[:2], (red.piece(b, r)[2], red.buckets[b][1])] if hi > lo) if shard else None
+        out[shard] = (fp.flat.clone().numpy(), norms, cover, fp.numel, [(lo, hi) for lo, hi, _ in owned])
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_exchange_equals_all_reduce_form(world):
+    """reduce_scatter_tensor -> owners update 1 / world of the arena -> all_gather_into_tensor over arena slices
+    (GradBucketReducer(shard=True)) against the all-reduce form, 2 and 4 gloo ranks: the same parameters on every rank and in both
+    forms, bit for bit; the same global gradient norm; the ranks' pieces and the replicated tails tile the arena exactly once."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 1000 + world
+    procs = [ctx.Process(target=_dp_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = res[0][False]
+    for r in range(world):
+        for shard in (False, True):
+            flat, norms, cover, numel, owned = res[r][shard]
+            assert np.array_equal(flat, ref[0]), (r, shard)
+            assert norms == ref[1], (r, shard, norms, ref[1])
+        assert len(res[r][True][4]) > len(res[r][False][4]) == 1
+    cover, numel = res[0][True][2], res[0][True][3]
+    pieces = sorted(set(cover))
+    # every rank's piece once, every tail `world` times (replicated): as a set, a partition of [0, numel)
+    assert pieces[0][0] == 0 and pieces[-1][1] == numel and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    assert float(np.abs(ref[0]).sum()) > 0 and ref[1][0] > 0
+
+
 def test_pointer_audit_classifies_pins_by_pool_and_owner():
     """lib.PointerAudit (the capture-time pointer audit) on a synthetic allocator snapshot: only tensors inside
     default-pool segments are pinned, each once per storage, labelled with the first C-ABI call that used them; `foreign` leaves

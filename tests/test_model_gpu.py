@@ -431,6 +431,36 @@ def test_two_graph_replay_path_of_data_parallel_steps():
     assert l0 == l1 and torch.equal(m0, m1)
 
 
+def test_sharded_optimizer_step_on_one_rank_follows_the_default_step():
+    """TrainStep(shard_optimizer=True) (reduce-scatter -> owners update their pieces of the arena -> all-gather; multi-rank arithmetic:
+    tests/test_host_logic_cpu.py, 2 and 4 gloo ranks) on the one GPU there is: the rank owns every piece, so the step runs the
+    piecewise sum of squares / Adam launches over the bucket pieces and tails and must follow the default step -- same losses, the
+    master parameters within the fp32 rounding of a norm summed piece by piece -- eagerly and as a replayed graph."""
+    from ofasys_amd import ops
+    from ofasys_amd.trainer import TrainStep
+    case = CASES["tiny_multislot"]
+    vals, target = case_inputs(case)
+    runs = []
+    for shard, graph in ((False, False), (True, False), (True, True)):
+        model, d = build_model(case, DEV, torch.bfloat16)
+        tr = TrainStep(model, lr=1e-3, clip_norm=1.0, use_graph=graph, graph_warmup=1, shard_optimizer=shard, bucket_bytes=1 << 16)
+        if shard:
+            assert len(tr.reducer.buckets) > 3 and len(tr.reducer.owned_ranges()) >= len(tr.reducer.buckets)
+            spans = sorted((lo, hi) for lo, hi, _ in tr.reducer.owned_ranges())
+            assert spans[0][0] == 0 and spans[-1][1] == tr.fp.numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        batch = {"slots": make_slots(vals, DEV, torch.bfloat16), "target": target.to(DEV)}
+        ops.manual_seed(5)
+        losses = [float(tr.train_step([batch])["stats"][1]) for _ in range(5)]
+        torch.cuda.synchronize()
+        runs.append((losses, tr.master.clone(), tr.fp.flat.float().clone()))
+    (l0, m0, p0), (l1, m1, p1), (l2, m2, p2) = runs
+    assert l1 == l2 and torch.equal(m1, m2) and torch.equal(p1, p2)                 # eager == replayed graph, bit for bit
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-3 * abs(a)
+    assert float((m0 - m1).abs().max()) <= 1e-2 * 5 * 1e-3                          # five Adam steps of <= lr each
+    assert float((m0 - m1).abs().mean()) <= 1e-4 * 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ incremental decoding
 def _incremental_hip(dtype):
     """The scenario of oracle/incremental_case.py through the HIP model: encoder once, beams, KV-cache steps, reorder."""

@@ -20,6 +20,10 @@
 //   * skinny outputs (wgrad: M,N ~ 768..3072, K = tokens) use split-K into an fp32 workspace + a reduce/epilogue
 //     kernel (deterministic, no atomics).
 // Roofline: MFMA-bound; algorithmic flops = 2*M*N*K.
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "gemm_core.h"
 
 namespace ofa {
@@ -674,6 +678,64 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_big_kernel(GemmArgs g, in
                                                                 (int)gridDim.y, false);
 }
 
+// Two tile heights in ONE launch, against round quantisation.  The big-tile grid is counted in rounds of the 256 CUs: the FFN's first
+// product (13312 x 3072 x 768) is 624 tiles of 256 x 256 = 2.44 rounds and takes three (76 us where the loop's own rate says 62; the
+// vendor kernel, which balances with stream-K, 68).  Here the first `rows_big` row tiles are 256 rows high and the remaining rows are cut
+// into `rows_small` tiles of 192 -- 16 x 12 + 48 x 12 = 768 workgroups = exactly three per CU, 4/5 of them the short kind -- chosen by
+// gemm_plan from a simulation of the dispatch (mixed_time_us).  Every XCD gets an eighth of EACH kind (the hardware deals workgroups to
+// the XCDs round-robin; a contiguous eighth of a list sorted by height would give two XCDs all the tall tiles), tall ones first.  Same
+// main loop, same per-element summation order as gemm_big_kernel: bit-identical results.  k-major A only (an m-major A half is 128 wide).
+template <bool B_KMAJ, bool OUT_F32, bool F16>
+__global__ __launch_bounds__(512) void gemm_big_mixed_kernel(GemmArgs g, int tiles_n, int rows_big, int rows_small) {
+  const int nbig = rows_big * tiles_n, nsmall = rows_small * tiles_n;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  auto lo = [](int n, int x) { const int q = n >> 3, r = n & 7; return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; };
+  const int b0 = lo(nbig, xcd), nb = lo(nbig, xcd + 1) - b0, s0 = lo(nsmall, xcd), ns = lo(nsmall, xcd + 1) - s0;
+  if (local < nb) {
+    gemm_big_body<4, 2, true, B_KMAJ, OUT_F32, 2, 4, F16>(g, rows_big, tiles_n, g.K, nullptr, b0 + local, 0, 0, 1, false);
+  } else if (local - nb < ns) {
+    const int64_t r0 = (int64_t)rows_big * 256;                          // the short tiles start below the tall ones
+    g.A = (const bf16_t*)g.A + r0 * g.lda;
+    g.C = OUT_F32 ? (void*)((float*)g.C + r0 * g.ldc) : (void*)((bf16_t*)g.C + r0 * g.ldc);
+    g.M -= (int)r0;
+    gemm_big_body<3, 2, true, B_KMAJ, OUT_F32, 2, 4, F16>(g, rows_small, tiles_n, g.K, nullptr, s0 + local - nb, 0, 0, 1, false);
+  }
+}
+
+// estimated time of that launch: per XCD its eighth of the tall and of the short tiles, handed to its 32 CUs in order as they free up
+// (tile times from gemm_plan's fitted model: K-steps x 1.45 + 7.6 us for 256 x 256, x 1.13 + 6.5 for 192 x 256)
+static double mixed_time_us(int nbig, int nsmall, int nk) {
+  const double t4 = nk * 1.45 + 7.6, t3 = nk * 1.13 + 6.5;
+  double worst = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    auto lo = [](int n, int x_) { const int q = n >> 3, r = n & 7; return x_ < r ? x_ * (q + 1) : r * (q + 1) + (x_ - r) * q; };
+    const int nb = lo(nbig, x + 1) - lo(nbig, x), ns = lo(nsmall, x + 1) - lo(nsmall, x);
+    double cu[32];
+    for (int c = 0; c < 32; ++c) cu[c] = 0.0;
+    for (int i = 0; i < nb + ns; ++i) {
+      int best = 0;
+      for (int c = 1; c < 32; ++c) best = cu[c] < cu[best] ? c : best;
+      cu[best] += i < nb ? t4 : t3;
+    }
+    for (int c = 0; c < 32; ++c) worst = cu[c] > worst ? cu[c] : worst;
+  }
+  return worst;
+}
+
+template <bool BKM, bool OF, bool F16>
+static void launch_big_mixed(const GemmArgs& g, int rows_big, int rows_small, hipStream_t st) {
+  const int tiles_n = cdiv(g.N, 256), nbig = rows_big * tiles_n, nsmall = rows_small * tiles_n;
+  const size_t lds = 4 * (size_t)256 * BK * sizeof(bf16_t);
+  auto kern = gemm_big_mixed_kernel<BKM, OF, F16>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int per_xcd = cdiv(nbig, 8) + cdiv(nsmall, 8);              // (an XCD's list is at most this long; shorter lists leave idle workgroups)
+  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(512), lds, st, g, tiles_n, rows_big, rows_small);
+}
+
 // Grouped weight-gradient products (ofa_gemm_group_tn): up to GROUP_MAX independent  slabs_p[s] = A_p^T B_p over K-slice s
 // in ONE launch of 256 x 256 eight-wave tiles.  A layer's weight gradients are each 9-36 such tiles: alone, a product has
 // to be cut into 3-7 K-slices of 128 x 128 tiles to occupy the chip (short K loops, per-tile overheads every ~30 K-steps,
@@ -832,7 +894,7 @@ static void launch_big_shape(const GemmArgs& g, int batch, int tm, int splits, i
   launch_big<4, 2, AK, BKM, OF, 2, 4, F16>(g, batch, splits, ksplit, ws, st);                              // 128 x 64 per wave
 }
 
-struct GemmPlan { int wm, wn, big_tm, splits, ksplit, K; };
+struct GemmPlan { int wm, wn, big_tm, splits, ksplit, K, mixed_a, mixed_b; };   // mixed_a / mixed_b: row tiles of 256 / 192 (gemm_big_mixed_kernel), 0 / 0: not used
 
 // tile / split-K plan of one product (shared by the launcher and ofa_gemm_splits, which tells a caller that defers the
 // split-K reduce how many partial slabs the launch will write)
@@ -949,7 +1011,54 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
     ksplit = cdiv(cdiv(g.K, splits), BK) * BK;
     splits = cdiv(g.K, ksplit);
   }
-  return GemmPlan{wm, wn, big_tm, splits, ksplit, g.K};
+  // Round 6: two tile heights in one launch (gemm_big_mixed_kernel) where the plan above leaves a partly filled round: k-major A, one
+  // K-slice, no batch, plain epilogue (the column statistics and the row bias index rows of the whole product).  The candidates
+  // (a tall row tiles, the rest short) are simulated once per shape; the choice has to beat the plan's own estimate by 3 % (scratch gemm_mixed_bench, MI355X, replayed graphs:
+  // 13312 x 3072 x 768 NT 76.5 -> 68.5 us, its NN twin 78.3 -> 68.6, 13312 x 9216 x 768 201 -> 192; no other product of the step is taken).
+  int mixed_a = 0, mixed_b = 0;
+#ifdef OFA_DEBUG_SWITCHES
+  const int mixed_mode = getenv("OFA_GEMM_MIXED") ? atoi(getenv("OFA_GEMM_MIXED")) : -1;     // 0: never, 1: whenever eligible, -1: the model decides
+#else
+  constexpr int mixed_mode = -1;
+#endif
+  if (mixed_mode != 0 && big_ok && !force_tile && !g.transA && batch == 1 && splits == 1 && !g.colstat && !(g.flags & OFA_GEMM_BIAS_ROW) &&
+      g.M >= 1024 && g.N >= 512 && g.K >= 4 * BK && pp_variant(false, g.transB != 0, g.K) == 0) {
+    struct Key { int M, N, K, tb; };
+    struct Val { int a, b; double t; };
+    static std::mutex mu;
+    static std::vector<std::pair<Key, Val>> cache;
+    const int nk = g.K / BK, tiles_n = cdiv(g.N, 256);
+    Val best{0, 0, 1e30};
+    bool hit = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto& e : cache)
+        if (e.first.M == g.M && e.first.N == g.N && e.first.K == g.K && e.first.tb == g.transB) { best = e.second; hit = true; break; }
+    }
+    if (!hit) {
+      const int amax = g.M / 256;
+      for (int a = 1; a <= amax; ++a) {
+        const int rest = g.M - a * 256;
+        if (rest <= 0) break;
+        const int b = cdiv(rest, 192);
+        const double t = mixed_time_us(a * tiles_n, b * tiles_n, nk);
+        if (t < best.t) best = Val{a, b, t};
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (cache.size() < 256) cache.push_back({Key{g.M, g.N, g.K, g.transB}, best});
+    }
+    // the plan's own estimate, by the same model
+    double cur;
+    if (big_tm == 4) cur = (double)cdiv(tiles, 256) * (nk * 1.45 + 7.6);
+    else if (big_tm == 3) cur = (double)cdiv(tiles, 256) * (nk * 1.13 + 6.5);
+    else cur = (double)cdiv(tiles, (wm == 2 && wn == 2) ? 512 : 1024) * (nk * (g.transB ? 1.0 : 0.90) + 4.2);
+    const bool modelled = (wm == 2 && wn == 2) || big_tm;               // (the plans the time model above covers)
+    if (best.a > 0 && best.b > 0 && (mixed_mode == 1 || (modelled && best.t < 0.97 * cur))) {
+      mixed_a = best.a;
+      mixed_b = best.b;
+    }
+  }
+  return GemmPlan{wm, wn, big_tm, splits, ksplit, g.K, mixed_a, mixed_b};
 }
 
 int gemm_mfma_splits(const GemmArgs& g, int batch, int64_t ws_bytes) { return gemm_plan(g, batch, ws_bytes > 0, ws_bytes).splits; }
@@ -981,6 +1090,13 @@ int gemm_mfma_launch(const GemmArgs& g_in, int batch, void* ws, int64_t ws_bytes
   g.K = pl.K;
   const int wm = pl.wm, wn = pl.wn, big_tm = pl.big_tm, splits = pl.splits, ksplit = pl.ksplit;
   const bool ak = !g.transA, bk = g.transB != 0, of = (g.flags & OFA_GEMM_OUT_F32) != 0;
+  if (pl.mixed_a > 0) {                                     // (k-major A, one K-slice, no batch: gemm_plan)
+    if (bk) { if (of) { if (f16) launch_big_mixed<true, true, true>(g, pl.mixed_a, pl.mixed_b, st); else launch_big_mixed<true, true, false>(g, pl.mixed_a, pl.mixed_b, st); }
+              else { if (f16) launch_big_mixed<true, false, true>(g, pl.mixed_a, pl.mixed_b, st); else launch_big_mixed<true, false, false>(g, pl.mixed_a, pl.mixed_b, st); } }
+    else { if (of) { if (f16) launch_big_mixed<false, true, true>(g, pl.mixed_a, pl.mixed_b, st); else launch_big_mixed<false, true, false>(g, pl.mixed_a, pl.mixed_b, st); }
+           else { if (f16) launch_big_mixed<false, false, true>(g, pl.mixed_a, pl.mixed_b, st); else launch_big_mixed<false, false, false>(g, pl.mixed_a, pl.mixed_b, st); } }
+    return check_launch("gemm_big_mixed");
+  }
 #define GEMM_DISPATCH(AK, BKM, OF)                                                                      \
   do {                                                                                                  \
     if (f16) {                                                                                          \

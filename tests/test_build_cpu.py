@@ -47,6 +47,7 @@ def _kernel_meta(src, tmp_path):
     ("gemm_mfma.hip", r"gemm_mfma_kernelILi2ELi2ELb[01]ELb[01]ELb0ELb1E", 0),   # 128x128 LDS-DMA kernels, bf16 out
     ("gemm_mfma.hip", r"gemm_ring_kernelILi[12]ELi[12]ELb[01]ELb[01]ELb0E", 0),  # 4-stage ring kernels, bf16 out
     ("gemm_mfma.hip", r"gemm_group_tn_kernel", 0),                               # grouped weight gradients (256 accumulator registers live)
+    ("gemm_mfma.hip", r"gemm_big_mixed_kernel", 0),                              # 256- and 192-row tiles in one launch (round 6): both bodies in one kernel
     # the ping-pong loop (round 5): 128 accumulator + 48 fragment registers per wave, two waves per SIMD -- a spilled register inside its
     # load / MFMA segments would also put scratch traffic on the vmcnt counter the loop's LDS-DMA waits are counted on
     ("gemm_pp.hip", r"gemm_pp_kernel", 0),

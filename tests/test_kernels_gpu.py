@@ -132,6 +132,53 @@ def test_gemm_eight_wave_tiles_forced(K, tile, pp):
     assert r.returncode == 0 and "forced tiles ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_MIXED_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from ofasys_amd import kernels as K
+torch.manual_seed(12)
+def run(a, b, tb, mode, **kw):
+    os.environ["OFA_GEMM_MIXED"] = mode
+    return K.gemm(a, b, False, tb, **kw)
+n = 0
+for M, N, K_ in [(13312, 3072, 768), (12800, 3072, 768), (13001, 3080, 768), (2048, 9216, 256), (1100, 520, 1024), (5000, 1024, 512)]:
+    for tb in (True, False):
+        a = torch.randn(M, K_, device="cuda").bfloat16()
+        b = torch.randn((N, K_) if tb else (K_, N), device="cuda").bfloat16()
+        bias = torch.randn(N, device="cuda").bfloat16()
+        ref = a.float() @ (b.float().t() if tb else b.float())
+        plain = run(a, b, tb, "0", bias=bias, alpha=0.5)
+        mixed = run(a, b, tb, "1", bias=bias, alpha=0.5)
+        assert torch.equal(plain, mixed), (M, N, K_, tb)
+        assert float((mixed.float() - (ref + bias.float()) * 0.5).abs().max()) <= 1e-2 * float(ref.abs().max()), (M, N, K_, tb)
+        f0, f1 = run(a, b, tb, "0", out_f32=True), run(a, b, tb, "1", out_f32=True)
+        assert torch.equal(f0, f1), (M, N, K_, tb, "f32")
+        acc0 = torch.ones(M, N, device="cuda", dtype=torch.bfloat16); acc1 = acc0.clone()
+        run(a, b, tb, "0", out=acc0, accumulate=True); run(a, b, tb, "1", out=acc1, accumulate=True)
+        assert torch.equal(acc0, acc1), (M, N, K_, tb, "acc")
+        wide = torch.zeros(M, N + 24, device="cuda", dtype=torch.bfloat16)         # ldc > N: nothing outside the view is written
+        run(a, b, tb, "1", out=wide[:, :N])
+        assert float(wide[:, N:].abs().max()) == 0.0, (M, N, K_, tb, "ldc")
+        n += 1
+print("mixed tiles ok", n)
+"""
+
+
+def test_gemm_mixed_tile_heights_bit_identical_to_plain_plan(K):
+    """gemm_big_mixed_kernel (256- and 192-row tiles in one launch against round quantisation, csrc/gemm_mfma.hip) forced wherever it is
+    eligible (OFA_GEMM_MIXED=1, debug library) against the plain plan (=0): bit-identical outputs -- k-major and m-major B, column bias,
+    alpha, fp32 output, 16-bit accumulation, ldc > N, ragged M and N -- and correct against an fp32 product."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "ofasys_amd", "libofasys_amd_dbg.so")
+    assert os.path.exists(dbg), "the debug library (planner overrides compiled in) is not built: make -C ofasys_amd/csrc debug"
+    r = subprocess.run([sys.executable, "-c", _MIXED_SCRIPT, root], env=dict(os.environ, OFASYS_AMD_LIB=dbg), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "mixed tiles ok 12" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_gemm_ping_pong_loop_bit_identical_to_lockstep_loop():
     """tools/gemm_pp_check.py: every product (K = 1 .. 7 tiles and long, ragged M / N, NT / NN / TN, bias / alpha / accumulate, batched, ragged
     weight-gradient row counts, the grouped launch) through the ping-pong loop and through the lockstep loop on the same tile, compared bit

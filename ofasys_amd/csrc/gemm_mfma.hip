@@ -1184,7 +1184,36 @@ static double group_time_us(const ofa_gemm_group_item* items, int n, int len) {
   return worst + (slab_bytes > 0.0 ? 2.0 + slab_bytes / 4.1e6 : 0.0);
 }
 
+// (memoised on the group's shapes: the simulation below costs ~10 ms of host time per call, 7 calls per eager cfg-2 step -- a replayed
+//  graph never sees it, an eager step was host-bound on it; found by tools/gemm_bench.py timing the grouped launch at 5.3 ms in round 6)
+static int group_plan_len(const ofa_gemm_group_item* items, int n);
 static void group_plan(ofa_gemm_group_item* items, int n) {
+  struct Key { int n; int mnk[GROUP_MAX][3]; };
+  static std::mutex mu;
+  static std::vector<std::pair<Key, int>> cache;
+  Key key{};
+  key.n = n;
+  for (int p = 0; p < n; ++p) { key.mnk[p][0] = items[p].m; key.mnk[p][1] = items[p].n; key.mnk[p][2] = items[p].k; }
+  int len = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : cache)
+      if (!memcmp(&e.first, &key, sizeof(Key))) { len = e.second; break; }
+  }
+  if (len < 0) {
+    len = group_plan_len(items, n);
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() < 512) cache.push_back({key, len});
+  }
+  for (int p = 0; p < n; ++p) {
+    int sp = cdiv(items[p].k, len);
+    sp = sp > 32 ? 32 : sp;
+    const int ksplit = cdiv(cdiv(items[p].k, BK), sp) * BK;
+    items[p].splits = cdiv(items[p].k, ksplit);
+  }
+}
+
+static int group_plan_len(const ofa_gemm_group_item* items, int n) {
   int kmax = 0;
   for (int p = 0; p < n; ++p) kmax = items[p].k > kmax ? items[p].k : kmax;
   const int tiles = cdiv(kmax, BK);
@@ -1195,12 +1224,7 @@ static void group_plan(ofa_gemm_group_item* items, int n) {
     const double t = group_time_us(items, n, l);
     if (t < best * 0.97) { best = t; len = l; }                             // (a tie goes to fewer slices: less slab traffic)
   }
-  for (int p = 0; p < n; ++p) {
-    int sp = cdiv(items[p].k, len);
-    sp = sp > 32 ? 32 : sp;
-    const int ksplit = cdiv(cdiv(items[p].k, BK), sp) * BK;
-    items[p].splits = cdiv(items[p].k, ksplit);
-  }
+  return len;
 }
 
 extern "C" int ofa_gemm_group_plan(ofa_gemm_group_item* items, int n, int dtype) {

@@ -53,5 +53,10 @@ timeout 300 tools/experiments/_build/adam_stream_bench > $O/round${N}_adam_strea
 (T 300 python tools/gemm_split_check.py; OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so OFA_GEMM_SPLIT_MIN_K=1000000 T 300 python tools/gemm_split_check.py) 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_split_check.txt
 # what every parity test measures next to its bound (pytest -s prints MEASURED lines)
 ROUND=$N T 600 python tools/gemm_bench.py > /dev/null 2>&1 || true
+# round 6: the mixed-height plan, the fused criterion, the attention column-sum epilogues, the decoder-side products in a replayed graph
+OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so T 600 python tools/gemm_mixed_bench.py 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_mixed_bench.txt
+T 300 python tools/ce_bench.py 2>&1 | grep -v amdgpu.ids > $O/round${N}_ce_bench.txt
+T 300 python tools/attn_cs_bench.py 2>&1 | grep -v amdgpu.ids > $O/round${N}_attn_cs_bench.txt
+OFASYS_AMD_LIB=$R/ofasys_amd/libofasys_amd_dbg.so T 300 python tools/gemm_small_graph.py 2>&1 | grep -v amdgpu.ids > $O/round${N}_gemm_small_graph.txt
 python tools/prof_last_step.py /tmp/r${N}stats/p_results.db > $O/round${N}_last_step_sequence.txt 2>&1 || true
 T 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "MEASURED|passed|failed" > $O/round${N}_parity_measured.txt

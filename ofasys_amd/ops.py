@@ -122,7 +122,7 @@ def defer_reductions(flag):
 def drop_pending():
     """Forget queued weight gradients and folds without launching them: the start of a step, so that what a backward pass that
     raised left behind is not added to the next step's gradients."""
-    _Wgrads.items, _Wgrads.queued, _Fold.queued = [], False, False
+    _Wgrads.items, _Wgrads.fillers, _Wgrads.queued, _Fold.queued = [], [], False, False
     if _Fold.queue is not None:
         _Fold.queue.__init__()
 
@@ -160,25 +160,51 @@ def _fold():
 # data-parallel reducer (`_sink_done`) one layer later: a bucket's all-reduce starts at most one layer's backward (~0.3 ms of a
 # cfg-2 step) later than with a flush per layer; only the LAST bucket's delay is exposed, and that bucket ends with the embedding
 # gradients, which are final only at the very end of backward anyway.
+# FILLERS (round 6).  A pair of encoder layers is 216 workgroups of ONE round of the 256 CUs: 40 CUs idle for 315 us, three times per
+# cfg-2 step -- while the weight gradient of the stack-wide cross-attention k|v projection (CrossKVShared: [L * 2D, D] over the same
+# 13312 encoder rows, 108 tiles) ran as a launch of its own, 209 us, flushed ALONE out of the queue by the first decoder-side product
+# behind it (another contraction length).  A product queued as a filler is cut into chunks of <= FILLER_TILES tiles (row blocks of the
+# weight) that wait on the side; every group that leaves room in its round takes chunks of its own contraction length along: 216 + 36
+# = 252 workgroups, the round costs what it cost, and the 209 us launch is gone.  Only while gradients are not consumed inside backward
+# (no overlapped bucket all-reduces: a filler's parameters report to the reducer when its LAST chunk has been launched, which would
+# hold back every bucket behind theirs).
 class _Wgrads:
     enabled = True       # (tests / A-B tools may clear it: every weight gradient is then its own product)
-    items = []           # (dy, x2d, out, alpha, weight)
+    items = []           # (dy, x2d, out, alpha, weights, filler record or None)
+    fillers = []         # chunks waiting for room: (dy view, x2d, out view, alpha, (), record); record = [chunks left, weights]
     queued = False       # an end-of-backward flush is registered with the autograd engine
     FLUSH_TILES = 128    # a boundary flushes a queue of more tiles than this (0: every boundary, rounds 3-4)
+    FILLER_TILES = 40    # tiles per filler chunk (a group of two base-size encoder layers leaves 256 - 216 = 40)
+    use_fillers = True   # (A/B tools may clear it)
+
+
+def _tiles_of(dy, x2d):
+    return ((dy.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256)
 
 
 def _queued_tiles():
-    return sum(((dy.shape[1] + 255) // 256) * ((x2d.shape[1] + 255) // 256) for dy, x2d, _, _, _ in _Wgrads.items)
+    return sum(_tiles_of(it[0], it[1]) for it in _Wgrads.items)
 
 
-def _wgrad(dy, x2d, gw, alpha, *weights):
+def _wgrad(dy, x2d, gw, alpha, *weights, filler=False):
     """gw += alpha * dy^T x2d (gw: the arena gradient of `weights` -- one weight, or several packed row-wise), then tell the
-    reducer."""
+    reducer.  filler: nobody needs this gradient before the end of backward and later groups of the same contraction length are
+    expected -- it may ride along with them in chunks (see _Wgrads)."""
     if _Wgrads.enabled and K.gemm_group_ok(dy, x2d, gw) and _flush_at_end_of_backward():
+        tn = (x2d.shape[1] + 255) // 256
+        if (filler and _Wgrads.use_fillers and _Fold.queue is not None and gw.dim() == 2 and dy.shape[1] % 256 == 0
+                and tn <= _Wgrads.FILLER_TILES and _tiles_of(dy, x2d) > _Wgrads.FILLER_TILES):
+            rows = max(1, _Wgrads.FILLER_TILES // tn) * 256                      # weight rows per chunk
+            record = [0, weights]
+            for r0 in range(0, dy.shape[1], rows):
+                r1 = min(r0 + rows, dy.shape[1])
+                _Wgrads.fillers.append((dy[:, r0:r1], x2d, gw[r0:r1], float(alpha), (), record))
+                record[0] += 1
+            return
         if _Wgrads.items and _Wgrads.items[0][0].shape[0] != dy.shape[0]:
             flush_wgrads()       # one contraction length per launch: the workgroup -> XCD map is by count (csrc/gemm_core.h group_enter), a group
                                  # mixing 13312-row and 3072-row products leaves some XCDs two rounds of long tiles and others idle
-        _Wgrads.items.append((dy, x2d, gw, float(alpha), weights))
+        _Wgrads.items.append((dy, x2d, gw, float(alpha), weights, None))
         if len(_Wgrads.items) == K.GROUP_MAX:
             flush_wgrads()
         return
@@ -201,14 +227,32 @@ def _flush_at_end_of_backward():
 def _end_of_backward():
     _Wgrads.queued = False
     flush_wgrads()
+    while _Wgrads.fillers:                           # chunks no group had room for: groups of their own, by contraction length
+        rows = _Wgrads.fillers[0][0].shape[0]
+        take = [f for f in _Wgrads.fillers if f[0].shape[0] == rows][:K.GROUP_MAX]
+        _Wgrads.fillers = [f for f in _Wgrads.fillers if all(f is not t for t in take)]
+        _Wgrads.items = take
+        flush_wgrads(fill=False)
 
 
-def flush_wgrads():
+def flush_wgrads(fill=True):
     items, _Wgrads.items = _Wgrads.items, []
     if not items:
         return
+    if fill and _Wgrads.fillers:
+        # room left in the group's round of 256 workgroups: filler chunks of the same contraction length ride along
+        rows, tiles = items[0][0].shape[0], sum(_tiles_of(it[0], it[1]) for it in items)
+        rest = []
+        for f in _Wgrads.fillers:
+            t = _tiles_of(f[0], f[1])
+            if f[0].shape[0] == rows and tiles + t <= 256 and len(items) < K.GROUP_MAX:
+                items.append(f)
+                tiles += t
+            else:
+                rest.append(f)
+        _Wgrads.fillers = rest
     if len(items) == 1:
-        dy, x2d, gw, alpha, _ = items[0]
+        dy, x2d, gw, alpha = items[0][:4]
         K.gemm(dy, x2d, True, False, alpha=alpha, out=gw, accumulate=True, fold=_fold())
     else:
         fold = _fold()
@@ -221,6 +265,11 @@ def flush_wgrads():
     for it in items:
         for w in it[4]:
             _sink_done(w)
+        if it[5] is not None:                        # a filler chunk: its parameters are complete with the LAST chunk
+            it[5][0] -= 1
+            if it[5][0] == 0:
+                for w in it[5][1]:
+                    _sink_done(w)
 
 
 class _WgradBoundaryFn(torch.autograd.Function):
@@ -1094,7 +1143,8 @@ class CrossKVShared:
         dx = K.gemm(self.dkv_all, p["w"], False, False) if need_dx else None
         L, D = self.L, self.D
         if len(self.users) == L:                            # every layer took part: ONE weight-gradient product, ONE column sum
-            _wgrad(self.dkv_all, self.enc2d, p["gw"], 1.0, *p["params"][:2 * L])
+            # (a filler: the encoder layers' groups, whose backward starts right behind this node, take it along in their idle CUs)
+            _wgrad(self.dkv_all, self.enc2d, p["gw"], 1.0, *p["params"][:2 * L], filler=True)
             fq = _fold()
             if self.cs_all is not None:
                 fq2 = fq or K.ImmediateFold()

@@ -972,7 +972,10 @@ static GemmPlan gemm_plan(GemmArgs g, int batch, bool has_ws, int64_t ws_bytes) 
       }
     } else {
       const double f4 = (double)t4 / (double)(cdiv(t4, 256) * 256) * ((double)g.M / (cdiv(g.M, 256) * 256)) * ((double)g.N / (cdiv(g.N, 256) * 256));
-      if (f4 >= 0.7 && (g.K >= 4096 || t4 <= 256)) big_tm = 4;
+      // (round 6: also several well-filled rounds over a medium contraction -- the vocabulary projection's weight gradient, 51272 x 768
+      //  over 1536 decoder rows, 603 tiles = 2.36 rounds: 156 us on 128 x 128 tiles, whose transposing fragment reads the time model
+      //  above flatters, 131 us here)
+      if (f4 >= 0.7 && (g.K >= 4096 || t4 <= 256 || g.K >= 1024)) big_tm = 4;
     }
     if (big_tm) {
       wm = wn = 0;
